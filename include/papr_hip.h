@@ -1,0 +1,158 @@
+/*
+ * papr_hip.h -- C ABI of libpapr_hip.so: the MI355X (gfx950) PAPR per-ray render path.
+ *
+ * The reference (zvict/papr) has no FFI: its hot path is eager PyTorch inside
+ * models/model.py, models/attn.py and models/mlp.py.  Each entry point below replaces the
+ * group of reference lines it cites; INTEGRATION.md shows the ctypes binding that a
+ * maintainer of the reference would add to call them.
+ *
+ * Conventions
+ *   - plain device pointers + sizes, fp32 row-major, int32 indices; no torch / C++ types.
+ *   - every call enqueues work on `stream` (a hipStream_t passed as void*) and returns
+ *     immediately; 0 = ok, non-zero = error (text via papr_last_error()).
+ *   - no internal allocation, no global state: scratch is passed in by the caller; the
+ *     *_workspace_bytes helpers say how much.
+ *   - "ld" arguments are row strides in floats and must be multiples of 4 (16-byte rows).
+ */
+#ifndef PAPR_HIP_H
+#define PAPR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* papr_stream_t;
+
+enum { PAPR_ACT_NONE = 0, PAPR_ACT_RELU = 1, PAPR_ACT_LEAKY_RELU = 2 /* slope 0.2 */ };
+
+int papr_abi_version(void);
+const char* papr_last_error(void);
+
+/* ------------------------------------------------------------------------------------
+ * K1  ray -> k nearest points           replaces PAPR._calculate_global_distances
+ *                                        (models/model.py:258-283): R x P distance tensors + topk.
+ * points (P,3); rays_o (N,3); rays_d (R,3) with R = N * rays_per_image; ray r belongs to image
+ * r / rays_per_image.  Distance = | v - d (v.d)/(d.d+eps) |, v = p - o, d used as given.
+ * out_idx (R,k) int32, ascending distance, ties broken towards the smaller point index;
+ * out_dist (R,k) or NULL.  Requires 1 <= k <= 64 and k <= P.
+ * workspace: papr_ray_knn_workspace_bytes(R) bytes.
+ */
+size_t papr_ray_knn_workspace_bytes(int64_t R);
+int papr_ray_knn(const float* points, int64_t P, const float* rays_o, const float* rays_d, int64_t R,
+                 int64_t rays_per_image, int k, float eps, int32_t* out_idx, float* out_dist,
+                 void* workspace, papr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * K2  gather + ray geometry + positional encoding
+ *     replaces points[idx] / pc_feats[idx] (models/model.py:330,431-435), _calculate_distances
+ *     (models/model.py:285-310), _get_kqv (:396-437), posenc (models/utils.py:232-242) and the
+ *     torch.cat in Embeddings.forward (models/attn.py:173-191).
+ * Row layouts (raw, before any LayerNorm), M = R*k rows for key/value, R rows for the query:
+ *   key  = [pe(p, L_key[0]), pe(s, L_key[1]), pe(u, L_key[2]), feats if key_has_feats]
+ *   qry  = [pe(d, L_qry)]
+ *   val  = [pe(s, L_val[0]), pe(u, L_val[1]), feats if val_has_feats]
+ *   pe(x)[c*(with_self+2L) + ...] = x_c, sin(f^0 m x_c), cos(f^0 m x_c), sin(f^1 m x_c), ...
+ * Padding columns up to ld_* are written as zero.
+ */
+typedef struct {
+    int32_t k;              /* neighbours per ray */
+    int32_t feat_dim;       /* width of pc_feats */
+    int32_t L_key[3];
+    int32_t L_qry;
+    int32_t L_val[2];
+    int32_t with_self;      /* embed_type 1 -> 1, embed_type 2 -> 0 */
+    int32_t key_has_feats;  /* geoms.point_feats.use_ink */
+    int32_t val_has_feats;  /* geoms.point_feats.use_inv */
+    float pe_factor, pe_mult, eps;
+    int32_t ld_key, ld_qry, ld_val;
+} papr_feature_desc;
+
+int papr_feature_widths(const papr_feature_desc* d, int32_t* key_w, int32_t* qry_w, int32_t* val_w);
+
+int papr_build_features_fwd(const papr_feature_desc* d, const float* points, const float* pc_feats,
+                            const float* rays_o, const float* rays_d, int64_t R, int64_t rays_per_image,
+                            const int32_t* idx, float* key, float* qry, float* val,
+                            float* sel_points /* (R,k,3) or NULL */, papr_stream_t stream);
+
+/* Backward of K2: d_key / d_val are gradients w.r.t. the raw rows above.  Accumulates (atomic
+ * adds) into d_points (P,3) and d_pc_feats (P,feat_dim); the caller zeroes them.  The key's pe(p)
+ * block receives no gradient (points.detach(), models/model.py:405). */
+int papr_build_features_bwd(const papr_feature_desc* d, const float* points, const float* rays_o,
+                            const float* rays_d, int64_t R, int64_t rays_per_image, const int32_t* idx,
+                            const float* d_key, const float* d_val, float* d_points, float* d_pc_feats,
+                            papr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Row standardisation  y = (x - mean) / (std_unbiased + eps)      (the non-affine core of the
+ * reference LayerNorm, models/attn.py:39-42; the a_2/b_2 affine is folded into the next Linear by
+ * the host).  stats (rows,2) receives {1/(std+eps), std}.  x and y may alias.  width <= 1024.
+ */
+int papr_rownorm_fwd(const float* x, int64_t rows, int width, int ld, float eps, float* y, float* stats,
+                     papr_stream_t stream);
+int papr_rownorm_bwd(const float* dy, const float* y, const float* stats, int64_t rows, int width, int ld,
+                     float eps, float* dx, papr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * K3  embedding MLP chain on MFMA      replaces MLP.forward (models/mlp.py:47-59) and its autograd.
+ * Layer i computes out_i = act_i(in_i W_i^T + b_i), in_0 = x, in_i = out_{i-1}; a layer with
+ * n_skip > 0 consumes [in_i, x[:, :n_skip]] (skip_layers re-concatenation, models/mlp.py:54-55) and
+ * its weight holds the n_in columns first and the skip columns from column `skip_col` on.
+ * Weights are (n_out, ldw) row-major with zero padding; n_in and n_skip are padded to multiples of 4.
+ */
+typedef struct {
+    const float* weight;    /* (n_out, ldw) */
+    const float* weight_t;  /* (n_in_total, ldwt) transpose, needed by papr_mlp_bwd only */
+    const float* bias;      /* (n_out) or NULL */
+    int32_t n_in, n_out, ldw, ldwt;
+    int32_t n_skip, skip_col;
+    int32_t act;
+} papr_layer;
+
+/* outs[i] : (M, ld_out[i]) buffer of layer i's output.  For training pass distinct buffers (they are
+ * the saved activations); for inference two ping-pong buffers may be reused. */
+int papr_mlp_fwd(const papr_layer* layers, int n_layers, const float* x, int ldx, int64_t M,
+                 float* const* outs, const int32_t* ld_out, papr_stream_t stream);
+
+/* Backward.  d_out: gradient w.r.t. the last layer's output (M, ld_out[n-1]); it is consumed
+ * (overwritten).  scratch0/scratch1: two (M, max width) buffers.  d_weight[i] (n_out, ldw) and
+ * d_bias[i] (n_out) are overwritten.  d_x (M, ldx) or NULL when the input needs no gradient.
+ * workspace: papr_mlp_bwd_workspace_bytes() bytes (split-K slabs of the weight-gradient GEMMs). */
+size_t papr_mlp_bwd_workspace_bytes(void);
+int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float* x, int ldx, int64_t M,
+                 float* const* outs, const int32_t* ld_out, float* d_out, float* scratch0, float* scratch1,
+                 int ld_scratch, float* const* d_weight, float* const* d_bias, float* d_x,
+                 void* workspace, papr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * K4  attention tail        replaces attention("scaled-dot") + score_act (models/attn.py:217-225)
+ *                           and the softmax / renormalise / weighted sum of models/model.py:519-534.
+ * kp (R*k, ld_kp): W_k K + b_k rows;  qp (R, ld_qp): W_q Q + b_q rows;  v (R*k, ld_v), C columns.
+ * scores (R,k) = act(qp.kp_j / sqrt(d_model));  z = [scores * influ[idx], bkg_score];
+ * attn (R,k+1) = softmax(z);  fused (R,C) = sum_j attn_j / (sum_{j<k} attn_j if normalize) * v_j.
+ */
+typedef struct {
+    int32_t k, d_model, C;
+    int32_t ld_kp, ld_qp, ld_v;
+    int32_t score_act;
+    int32_t normalize;
+    float bkg_score;
+} papr_tail_desc;
+
+int papr_attn_tail_fwd(const papr_tail_desc* d, const float* kp, const float* qp, const float* v,
+                       const float* influ, const int32_t* idx, int64_t R, float* scores, float* attn,
+                       float* fused, papr_stream_t stream);
+
+/* d_v rows are overwritten; d_kp rows are overwritten; d_qp (R, ld_qp) overwritten;
+ * d_influ (P) accumulated with atomic adds (caller zeroes). */
+int papr_attn_tail_bwd(const papr_tail_desc* d, const float* kp, const float* qp, const float* v,
+                       const float* influ, const int32_t* idx, int64_t R, const float* scores,
+                       const float* attn, const float* d_fused, const float* d_attn, float* d_kp,
+                       float* d_qp, float* d_v, float* d_influ, papr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PAPR_HIP_H */

@@ -1,0 +1,14 @@
+#include "papr_common.h"
+#include <stdarg.h>
+
+static thread_local char g_err[512] = "";
+
+void papr_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* papr_last_error(void) { return g_err; }
+extern "C" int papr_abi_version(void) { return 1; }

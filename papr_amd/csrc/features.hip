@@ -1,0 +1,271 @@
+// K2: gather the k selected points of every ray, decompose p - o into the along-ray part s and the
+// perpendicular part u, and write the positionally-encoded key / query / value input rows.
+//
+// Replaces (reference): points[idx] / pc_feats[idx] (models/model.py:330,431-435),
+// _calculate_distances + normalize_vector (models/model.py:285-310, models/utils.py:255-257),
+// the feature lists of _get_kqv (models/model.py:396-437), posenc (models/utils.py:232-242) and the
+// concatenations of Embeddings.forward (models/attn.py:173-191) -- about forty eager kernels and
+// ~0.8 GB of temporaries per 25,600-ray step -- with one pass that reads 12+4 B per pair and writes
+// each row exactly once.
+//
+// One thread owns one (ray, neighbour) pair.  sin/cos use the full-range ocml sincosf: arguments
+// reach 2^5 * |x| ~ 1.6e3 rad, so the fast hardware approximations are not an option for parity.
+// The backward pass recomputes the encodings (cheaper than saving 2 x M x 78 floats) and folds
+// d/dx [x, sin(f x), cos(f x)] = [1, f cos(f x), -f sin(f x)] and the geometry Jacobian into a
+// single atomic scatter onto the point gradients.
+#include "papr_common.h"
+
+namespace {
+
+struct FeatParams {
+    papr_feature_desc d;
+    int key_w, qry_w, val_w;
+};
+
+__device__ __forceinline__ int pe_width(int L, int with_self) { return 3 * (with_self + 2 * L); }
+
+// write pe(x) for one 3-vector at dst (stride 1), returns number of floats written
+__device__ __forceinline__ int write_pe(float* __restrict__ dst, const float x[3], int L, int with_self,
+                                        float factor, float mult) {
+    const int per = with_self + 2 * L;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float* o = dst + c * per;
+        if (with_self) *o++ = x[c];
+        float f = 1.0f;
+        for (int i = 0; i < L; ++i) {
+            float s, co;
+            sincosf((f * x[c]) * mult, &s, &co);
+            o[2 * i] = s;
+            o[2 * i + 1] = co;
+            f *= factor;
+        }
+    }
+    return 3 * per;
+}
+
+struct RayGeom {
+    float ox, oy, oz;   // origin
+    float rx, ry, rz;   // re-normalised direction r = d / (|d| + eps)
+    float rr;           // r.r + eps
+};
+
+__device__ __forceinline__ RayGeom load_ray(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                            long r, long rays_per_image, float eps) {
+    RayGeom g;
+    long n = r / rays_per_image;
+    g.ox = rays_o[n * 3 + 0]; g.oy = rays_o[n * 3 + 1]; g.oz = rays_o[n * 3 + 2];
+    float dx = rays_d[r * 3 + 0], dy = rays_d[r * 3 + 1], dz = rays_d[r * 3 + 2];
+    // torch.norm: sqrt(fma(z,z, fma(y,y, x*x))) (measured against torch CPU)
+    float nrm = sqrtf(__builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx))) + eps;
+    g.rx = dx / nrm; g.ry = dy / nrm; g.rz = dz / nrm;
+    g.rr = ((g.rx * g.rx + g.ry * g.ry) + g.rz * g.rz) + eps;
+    return g;
+}
+
+__global__ __launch_bounds__(256) void features_fwd_kernel(FeatParams fp, const float* __restrict__ points,
+                                                           const float* __restrict__ pc_feats,
+                                                           const float* __restrict__ rays_o,
+                                                           const float* __restrict__ rays_d, long R,
+                                                           long rays_per_image, const int* __restrict__ idx,
+                                                           float* __restrict__ key, float* __restrict__ val,
+                                                           float* __restrict__ sel_points) {
+    const papr_feature_desc& d = fp.d;
+    long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long M = R * d.k;
+    if (m >= M) return;
+    long r = m / d.k;
+    RayGeom g = load_ray(rays_o, rays_d, r, rays_per_image, d.eps);
+    int pi = idx[m];
+    float p[3] = {points[pi * 3 + 0], points[pi * 3 + 1], points[pi * 3 + 2]};
+    if (sel_points) { sel_points[m * 3 + 0] = p[0]; sel_points[m * 3 + 1] = p[1]; sel_points[m * 3 + 2] = p[2]; }
+    float vx = p[0] - g.ox, vy = p[1] - g.oy, vz = p[2] - g.oz;
+    float t = ((vx * g.rx + vy * g.ry) + vz * g.rz) / g.rr;
+    float s[3] = {g.rx * t, g.ry * t, g.rz * t};
+    float u[3] = {vx - s[0], vy - s[1], vz - s[2]};
+
+    float* krow = key + m * d.ld_key;
+    int c = 0;
+    c += write_pe(krow + c, p, d.L_key[0], d.with_self, d.pe_factor, d.pe_mult);
+    c += write_pe(krow + c, s, d.L_key[1], d.with_self, d.pe_factor, d.pe_mult);
+    c += write_pe(krow + c, u, d.L_key[2], d.with_self, d.pe_factor, d.pe_mult);
+    const float* frow = pc_feats ? pc_feats + (long)pi * d.feat_dim : nullptr;
+    if (d.key_has_feats)
+        for (int j = 0; j < d.feat_dim; ++j) krow[c++] = frow[j];
+    for (; c < d.ld_key; ++c) krow[c] = 0.f;
+
+    float* vrow = val + m * d.ld_val;
+    c = 0;
+    // pe(s), pe(u) are shared with the key when the orders agree; recomputing keeps the kernel simple
+    c += write_pe(vrow + c, s, d.L_val[0], d.with_self, d.pe_factor, d.pe_mult);
+    c += write_pe(vrow + c, u, d.L_val[1], d.with_self, d.pe_factor, d.pe_mult);
+    if (d.val_has_feats)
+        for (int j = 0; j < d.feat_dim; ++j) vrow[c++] = frow[j];
+    for (; c < d.ld_val; ++c) vrow[c] = 0.f;
+}
+
+__global__ __launch_bounds__(256) void query_fwd_kernel(FeatParams fp, const float* __restrict__ rays_d, long R,
+                                                        float* __restrict__ qry) {
+    const papr_feature_desc& d = fp.d;
+    long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    float dv[3] = {rays_d[r * 3 + 0], rays_d[r * 3 + 1], rays_d[r * 3 + 2]};
+    float* q = qry + r * d.ld_qry;
+    int c = write_pe(q, dv, d.L_qry, d.with_self, d.pe_factor, d.pe_mult);
+    for (; c < d.ld_qry; ++c) q[c] = 0.f;
+}
+
+// gradient of the loss w.r.t. a 3-vector x from the gradient of pe(x)
+__device__ __forceinline__ void pe_grad(const float* __restrict__ g, const float x[3], int L, int with_self,
+                                        float factor, float mult, float out[3]) {
+    const int per = with_self + 2 * L;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float* gc = g + c * per;
+        float acc = 0.f;
+        if (with_self) acc = *gc++;
+        float f = 1.0f;
+        for (int i = 0; i < L; ++i) {
+            float s, co;
+            sincosf((f * x[c]) * mult, &s, &co);
+            acc += (f * mult) * (gc[2 * i] * co - gc[2 * i + 1] * s);
+            f *= factor;
+        }
+        out[c] += acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void features_bwd_kernel(FeatParams fp, const float* __restrict__ points,
+                                                           const float* __restrict__ rays_o,
+                                                           const float* __restrict__ rays_d, long R,
+                                                           long rays_per_image, const int* __restrict__ idx,
+                                                           const float* __restrict__ d_key,
+                                                           const float* __restrict__ d_val,
+                                                           float* __restrict__ d_points) {
+    const papr_feature_desc& d = fp.d;
+    long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long M = R * d.k;
+    if (m >= M) return;
+    long r = m / d.k;
+    RayGeom g = load_ray(rays_o, rays_d, r, rays_per_image, d.eps);
+    int pi = idx[m];
+    float vx = points[pi * 3 + 0] - g.ox, vy = points[pi * 3 + 1] - g.oy, vz = points[pi * 3 + 2] - g.oz;
+    float t = ((vx * g.rx + vy * g.ry) + vz * g.rz) / g.rr;
+    float s[3] = {g.rx * t, g.ry * t, g.rz * t};
+    float u[3] = {vx - s[0], vy - s[1], vz - s[2]};
+    float gs[3] = {0.f, 0.f, 0.f}, gu[3] = {0.f, 0.f, 0.f};
+    if (d_key) {
+        const float* kr = d_key + m * d.ld_key + pe_width(d.L_key[0], d.with_self);  // skip pe(p): detached
+        pe_grad(kr, s, d.L_key[1], d.with_self, d.pe_factor, d.pe_mult, gs);
+        pe_grad(kr + pe_width(d.L_key[1], d.with_self), u, d.L_key[2], d.with_self, d.pe_factor, d.pe_mult, gu);
+    }
+    if (d_val) {
+        const float* vr = d_val + m * d.ld_val;
+        pe_grad(vr, s, d.L_val[0], d.with_self, d.pe_factor, d.pe_mult, gs);
+        pe_grad(vr + pe_width(d.L_val[0], d.with_self), u, d.L_val[1], d.with_self, d.pe_factor, d.pe_mult, gu);
+    }
+    // s = r t, u = v - r t, t = (v.r)/(r.r+eps)  =>  dL/dv = gu + r * (r.(gs - gu)) / (r.r+eps)
+    float w = (g.rx * (gs[0] - gu[0]) + g.ry * (gs[1] - gu[1]) + g.rz * (gs[2] - gu[2])) / g.rr;
+    unsafeAtomicAdd(d_points + pi * 3 + 0, gu[0] + g.rx * w);
+    unsafeAtomicAdd(d_points + pi * 3 + 1, gu[1] + g.ry * w);
+    unsafeAtomicAdd(d_points + pi * 3 + 2, gu[2] + g.rz * w);
+}
+
+// scatter-add of the un-encoded per-point feature block: 4 columns per thread
+__global__ __launch_bounds__(256) void feats_scatter_kernel(const float* __restrict__ grad, int ld, int col0,
+                                                            int feat_dim, const int* __restrict__ idx, long M,
+                                                            float* __restrict__ d_pc_feats) {
+    const int groups = feat_dim / 4;
+    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= M * groups) return;
+    long m = e / groups;
+    int c = (int)(e - m * groups) * 4;
+    const float* src = grad + m * ld + col0 + c;
+    float* dst = d_pc_feats + (long)idx[m] * feat_dim + c;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) unsafeAtomicAdd(dst + j, src[j]);
+}
+
+int fill_params(const papr_feature_desc* d, FeatParams* fp) {
+    fp->d = *d;
+    fp->key_w = 0;
+    for (int i = 0; i < 3; ++i) fp->key_w += 3 * (d->with_self + 2 * d->L_key[i]);
+    if (d->key_has_feats) fp->key_w += d->feat_dim;
+    fp->qry_w = 3 * (d->with_self + 2 * d->L_qry);
+    fp->val_w = 0;
+    for (int i = 0; i < 2; ++i) fp->val_w += 3 * (d->with_self + 2 * d->L_val[i]);
+    if (d->val_has_feats) fp->val_w += d->feat_dim;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int papr_feature_widths(const papr_feature_desc* d, int32_t* key_w, int32_t* qry_w, int32_t* val_w) {
+    PAPR_REQUIRE(d, "papr_feature_widths: null descriptor");
+    FeatParams fp;
+    fill_params(d, &fp);
+    if (key_w) *key_w = fp.key_w;
+    if (qry_w) *qry_w = fp.qry_w;
+    if (val_w) *val_w = fp.val_w;
+    return 0;
+}
+
+static int check_desc(const papr_feature_desc* d, const FeatParams& fp, const char* who) {
+    PAPR_REQUIRE(d->k >= 1, "%s: k must be >= 1", who);
+    PAPR_REQUIRE(d->ld_key >= fp.key_w && d->ld_qry >= fp.qry_w && d->ld_val >= fp.val_w,
+                 "%s: row strides (%d,%d,%d) smaller than widths (%d,%d,%d)", who, d->ld_key, d->ld_qry, d->ld_val,
+                 fp.key_w, fp.qry_w, fp.val_w);
+    PAPR_REQUIRE(d->ld_key % 4 == 0 && d->ld_qry % 4 == 0 && d->ld_val % 4 == 0, "%s: row strides must be multiples of 4", who);
+    PAPR_REQUIRE(!(d->key_has_feats || d->val_has_feats) || d->feat_dim % 4 == 0, "%s: feat_dim must be a multiple of 4", who);
+    return 0;
+}
+
+extern "C" int papr_build_features_fwd(const papr_feature_desc* d, const float* points, const float* pc_feats,
+                                       const float* rays_o, const float* rays_d, int64_t R, int64_t rays_per_image,
+                                       const int32_t* idx, float* key, float* qry, float* val, float* sel_points,
+                                       papr_stream_t stream) {
+    PAPR_REQUIRE(d && points && rays_o && rays_d && idx && key && qry && val, "papr_build_features_fwd: null pointer");
+    FeatParams fp;
+    fill_params(d, &fp);
+    if (int e = check_desc(d, fp, "papr_build_features_fwd")) return e;
+    PAPR_REQUIRE(pc_feats || !(d->key_has_feats || d->val_has_feats), "papr_build_features_fwd: pc_feats required");
+    if (R <= 0) return 0;
+    hipStream_t s = as_stream(stream);
+    long M = R * d->k;
+    features_fwd_kernel<<<dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s>>>(fp, points, pc_feats, rays_o, rays_d, R,
+                                                                             rays_per_image, idx, key, val, sel_points);
+    PAPR_CHECK_LAUNCH("features_fwd");
+    query_fwd_kernel<<<dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s>>>(fp, rays_d, R, qry);
+    PAPR_CHECK_LAUNCH("query_fwd");
+    return 0;
+}
+
+extern "C" int papr_build_features_bwd(const papr_feature_desc* d, const float* points, const float* rays_o,
+                                       const float* rays_d, int64_t R, int64_t rays_per_image, const int32_t* idx,
+                                       const float* d_key, const float* d_val, float* d_points, float* d_pc_feats,
+                                       papr_stream_t stream) {
+    PAPR_REQUIRE(d && points && rays_o && rays_d && idx && d_points, "papr_build_features_bwd: null pointer");
+    FeatParams fp;
+    fill_params(d, &fp);
+    if (int e = check_desc(d, fp, "papr_build_features_bwd")) return e;
+    if (R <= 0) return 0;
+    hipStream_t s = as_stream(stream);
+    long M = R * d->k;
+    features_bwd_kernel<<<dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s>>>(fp, points, rays_o, rays_d, R,
+                                                                             rays_per_image, idx, d_key, d_val, d_points);
+    PAPR_CHECK_LAUNCH("features_bwd");
+    if (d_pc_feats) {
+        long n = M * (d->feat_dim / 4);
+        if (d->val_has_feats && d_val) {
+            feats_scatter_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(
+                d_val, d->ld_val, fp.val_w - d->feat_dim, d->feat_dim, idx, M, d_pc_feats);
+            PAPR_CHECK_LAUNCH("feats_scatter(val)");
+        }
+        if (d->key_has_feats && d_key) {
+            feats_scatter_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(
+                d_key, d->ld_key, fp.key_w - d->feat_dim, d->feat_dim, idx, M, d_pc_feats);
+            PAPR_CHECK_LAUNCH("feats_scatter(key)");
+        }
+    }
+    return 0;
+}

@@ -1,0 +1,450 @@
+// K3: the embedding MLPs as MFMA-tiled GEMMs over the (ray, neighbour) rows.
+//
+// Replaces MLP.forward (reference models/mlp.py:47-59: nn.Linear + ReLU/LeakyReLU chains of
+// FeedForward, models/attn.py:113-117, and w_k / w_q, models/attn.py:217-218) and the autograd
+// backward of those layers.  Two kernels carry all of it:
+//
+//   gemm_nt : C[m][n] = epi( sum_k A[m][k] * W[n][k] )      forward layers and data-gradients
+//             (the data-gradient uses the transposed weight so that both run the same kernel)
+//   gemm_tn : dW[n][k] = sum_m G[m][n] * X[m][k]             weight gradients, reduction over the
+//             512,000 rows split across the chip (one slab per workgroup, then a slab reduction)
+//
+// fp32 parity mode: v_mfma_f32_32x32x2_f32 (exact fp32 products and accumulation, 256 FLOP/clk/CU,
+// 157 TFLOP/s peak).  An MFMA of this type occupies the matrix pipe for 64 cycles and needs only one
+// VGPR per operand, so LDS bandwidth is irrelevant; what matters is that every SIMD always has an
+// MFMA to issue.  gemm_nt therefore runs two 4-wave workgroups per CU (<=256 VGPRs, 55 KB LDS each):
+// while one is in its global->LDS hand-over or its epilogue, the other keeps the matrix pipe busy.
+//
+// LDS layout for gemm_nt: row-major [rows][32 + 4] fp32 (144-byte rows).  A lane reads 4 consecutive
+// k with one ds_read_b128 and feeds them to 4 successive MFMAs: lanes 0-31 take k..k+3, lanes 32-63
+// take k+4..k+7, so one 16-byte read per operand feeds 256 cycles of matrix work, and the 36-float
+// pitch maps the 16 lanes of a read group onto 16 distinct 4-bank slots (conflict-free).
+#include "papr_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;        // k-slab per stage
+constexpr int PITCH = BK + 4; // LDS row pitch (floats)
+
+struct NTArgs {
+    const float* A;  long lda;  int K1;
+    const float* A2; long lda2; int K2;
+    const float* W;  int ldw;   int wcol2;
+    const float* bias;
+    const float* mask_src; long ld_mask;
+    int act;          // forward: activation; dgrad: activation whose derivative masks the result
+    int dgrad;        // 0: C = act(acc + bias)   1: C = acc * act'(mask_src)
+    int accumulate;   // C += ...
+    float* C; long ldc;
+    long M; int N;
+};
+
+template <int BM, int BN, int TM, int TN>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NTArgs p) {
+    constexpr int WN = BN / (32 * TN);          // waves along n
+    constexpr int WM = BM / (32 * TM);          // waves along m
+    static_assert(WM * WN == 4, "four waves per workgroup");
+    constexpr int A_LD = BM / 32;               // float4 loads per thread for the A slab
+    constexpr int W_LD = BN / 32;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                  // [BM][PITCH]
+    float* Ws = smem + BM * PITCH;     // [BN][PITCH]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const long m0 = (long)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+
+    const int nt1 = (p.K1 + BK - 1) / BK;
+    const int nt2 = p.A2 ? (p.K2 + BK - 1) / BK : 0;
+    const int nt = nt1 + nt2;
+
+    float4 ra[A_LD], rw[W_LD];
+
+    auto load_slab = [&](int kt) {
+        const float* src; long ld; int klim, k0, wcol;
+        if (kt < nt1) { src = p.A; ld = p.lda; klim = p.K1; k0 = kt * BK; wcol = k0; }
+        else { src = p.A2; ld = p.lda2; klim = p.K2; k0 = (kt - nt1) * BK; wcol = p.wcol2 + k0; }
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            int f = tid + 256 * i;
+            int row = f >> 3, kq = (f & 7) * 4;
+            long m = m0 + row;
+            ra[i] = (m < p.M && k0 + kq < klim) ? *reinterpret_cast<const float4*>(src + m * ld + k0 + kq)
+                                                : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < W_LD; ++i) {
+            int f = tid + 256 * i;
+            int row = f >> 3, kq = (f & 7) * 4;
+            int n = n0 + row;
+            rw[i] = (n < p.N && k0 + kq < klim) ? *reinterpret_cast<const float4*>(p.W + (long)n * p.ldw + wcol + kq)
+                                                : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_slab = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            int f = tid + 256 * i;
+            *reinterpret_cast<float4*>(As + (f >> 3) * PITCH + (f & 7) * 4) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < W_LD; ++i) {
+            int f = tid + 256 * i;
+            *reinterpret_cast<float4*>(Ws + (f >> 3) * PITCH + (f & 7) * 4) = rw[i];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const float* a_base = As + (wm * TM * 32 + (lane & 31)) * PITCH + 4 * (lane >> 5);
+    const float* w_base = Ws + (wn * TN * 32 + (lane & 31)) * PITCH + 4 * (lane >> 5);
+
+    load_slab(0);
+    store_slab();
+    __syncthreads();
+    for (int kt = 0; kt < nt; ++kt) {
+        if (kt + 1 < nt) load_slab(kt + 1);
+#pragma unroll
+        for (int kb = 0; kb < BK; kb += 8) {
+            float4 af[TM], wf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(a_base + i * 32 * PITCH + kb);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const float4*>(w_base + j * 32 * PITCH + kb);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, wf[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, wf[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, wf[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, wf[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+        if (kt + 1 < nt) {
+            store_slab();
+            __syncthreads();
+        }
+    }
+
+    // epilogue: D[row = (e&3) + 8*(e>>2) + 4*(lane>>5)][col = lane&31]
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
+        if (col >= p.N) continue;
+        const float b = (!p.dgrad && p.bias) ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                long row = m0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                if (row >= p.M) continue;
+                float v = acc[i][j][e];
+                if (p.dgrad) {
+                    if (p.mask_src) v *= papr_act_grad(p.mask_src[row * p.ld_mask + col], p.act);
+                } else {
+                    v = papr_act(v + b, p.act);
+                }
+                float* dst = p.C + row * p.ldc + col;
+                if (p.accumulate) v += *dst;
+                *dst = v;
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int TM, int TN>
+int launch_nt(const NTArgs& a, hipStream_t s) {
+    dim3 grid((unsigned)((a.M + BM - 1) / BM), (unsigned)((a.N + BN - 1) / BN));
+    size_t lds = (size_t)(BM + BN) * PITCH * sizeof(float);
+    gemm_nt_kernel<BM, BN, TM, TN><<<grid, dim3(256), lds, s>>>(a);
+    PAPR_CHECK_LAUNCH("gemm_nt");
+    return 0;
+}
+
+int gemm_nt(const NTArgs& a, hipStream_t s) {
+    PAPR_REQUIRE(a.K1 % 4 == 0 && a.lda % 4 == 0 && a.ldw % 4 == 0, "gemm_nt: K1/lda/ldw must be multiples of 4 (%d,%ld,%d)", a.K1, a.lda, a.ldw);
+    PAPR_REQUIRE(!a.A2 || (a.K2 % 4 == 0 && a.lda2 % 4 == 0 && a.wcol2 % 4 == 0), "gemm_nt: segment-2 sizes must be multiples of 4");
+    if (a.M <= 0 || a.N <= 0) return 0;
+    if (a.N > 128) return launch_nt<128, 256, 4, 2>(a, s);
+    if (a.N > 64) return launch_nt<128, 128, 2, 2>(a, s);
+    if (a.N > 32) return launch_nt<256, 64, 2, 2>(a, s);
+    return launch_nt<256, 32, 2, 1>(a, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// gemm_tn: slab[s][n][k] = sum_{m in slice s} G[m][n] * X[m][k]   (N, K <= 256), bias slab = col sums of G
+// 512 threads = 8 waves as 2 (n) x 4 (k); each wave owns a 128 x 64 corner of the 256 x 256 tile.
+constexpr int TN_ROWS = 32;   // m rows per stage
+constexpr int SLAB = 256;     // output tile edge
+
+struct TNArgs {
+    const float* G; long ldg; int N;
+    const float* X; long ldx; int K;
+    long M; long rows_per_slice;
+    float* slab;       // [S][256][256]
+    float* bias_slab;  // [S][256]
+};
+
+__global__ __launch_bounds__(512, 2) void gemm_tn_kernel(TNArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Gs = smem;                     // [32][256]
+    float* Xs = smem + TN_ROWS * SLAB;    // [32][256]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wn = wave >> 2, wk = wave & 3;     // wave's corner: n in [128 wn, +128), k in [64 wk, +64)
+    const long mbeg = (long)blockIdx.x * p.rows_per_slice;
+    long mend = mbeg + p.rows_per_slice;
+    if (mend > p.M) mend = p.M;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    float colsum = 0.f;
+
+    // staging map: 32 rows x 64 float4 per operand = 2048 float4 -> 4 per thread per operand
+    float4 rg[4], rx[4];
+    auto load_stage = [&](long mb) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int f = tid + 512 * i;
+            int row = f >> 6, c = (f & 63) * 4;
+            long m = mb + row;
+            rg[i] = (m < mend && c < p.N) ? *reinterpret_cast<const float4*>(p.G + m * p.ldg + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rx[i] = (m < mend && c < p.K) ? *reinterpret_cast<const float4*>(p.X + m * p.ldx + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int f = tid + 512 * i;
+            *reinterpret_cast<float4*>(Gs + (f >> 6) * SLAB + (f & 63) * 4) = rg[i];
+            *reinterpret_cast<float4*>(Xs + (f >> 6) * SLAB + (f & 63) * 4) = rx[i];
+        }
+    };
+
+    const float* g_base = Gs + (lane >> 5) * SLAB + wn * 128 + (lane & 31);
+    const float* x_base = Xs + (lane >> 5) * SLAB + wk * 64 + (lane & 31);
+    const bool n_live = wn * 128 < p.N, k_live = wk * 64 < p.K;
+
+    if (mbeg < mend) {
+        load_stage(mbeg);
+        store_stage();
+    }
+    __syncthreads();
+    for (long mb = mbeg; mb < mend; mb += TN_ROWS) {
+        const bool more = mb + TN_ROWS < mend;
+        if (more) load_stage(mb + TN_ROWS);
+        if (n_live && k_live) {
+#pragma unroll 4
+            for (int mm = 0; mm < TN_ROWS; mm += 2) {
+                float gf[4], xf[2];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) gf[i] = g_base[mm * SLAB + i * 32];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) xf[j] = x_base[mm * SLAB + j * 32];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(gf[i], xf[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (tid < SLAB) {
+#pragma unroll 8
+            for (int mm = 0; mm < TN_ROWS; ++mm) colsum += Gs[mm * SLAB + tid];
+        }
+        __syncthreads();
+        if (more) {
+            store_stage();
+            __syncthreads();
+        }
+    }
+
+    float* out = p.slab + (long)blockIdx.x * SLAB * SLAB;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int k = wk * 64 + j * 32 + (lane & 31);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                int n = wn * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                out[n * SLAB + k] = acc[i][j][e];
+            }
+        }
+    if (tid < SLAB) p.bias_slab[(long)blockIdx.x * SLAB + tid] = colsum;
+}
+
+// dW[n][k] (ld) = sum_s slab[s][n][k] ;  db[n] = sum_s bias_slab[s][n]
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bias_slab,
+                                                          int S, int N, int K, float* __restrict__ dW, int ldw,
+                                                          float* __restrict__ db) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;   // one float4 of the 256x256 tile
+    if (e < SLAB * SLAB / 4) {
+        int n = e >> 6, k = (e & 63) * 4;
+        if (n < N && k < K) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int s = 0; s < S; ++s) {
+                float4 v = *reinterpret_cast<const float4*>(slab + (long)s * SLAB * SLAB + n * SLAB + k);
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+            float* dst = dW + (long)n * ldw + k;
+            dst[0] = acc.x;
+            if (k + 1 < K) dst[1] = acc.y;
+            if (k + 2 < K) dst[2] = acc.z;
+            if (k + 3 < K) dst[3] = acc.w;
+        }
+    }
+    if (db && e < N) {
+        float acc = 0.f;
+        for (int s = 0; s < S; ++s) acc += bias_slab[(long)s * SLAB + e];
+        db[e] = acc;
+    }
+}
+
+constexpr int MAX_SLICES = 256;
+
+// dW (N x K, leading dim ldw) = G^T X ; db = column sums of G (optional)
+int gemm_tn(const float* G, long ldg, int N, const float* X, long ldx, int K, long M, float* dW, int ldw, float* db,
+            void* workspace, hipStream_t s) {
+    PAPR_REQUIRE(N <= SLAB && K <= SLAB, "gemm_tn: N=%d, K=%d exceed %d", N, K, SLAB);
+    PAPR_REQUIRE(N % 4 == 0 && K % 4 == 0 && ldg % 4 == 0 && ldx % 4 == 0, "gemm_tn: sizes must be multiples of 4");
+    if (M <= 0) return 0;
+    long stages = (M + TN_ROWS - 1) / TN_ROWS;
+    int S = (int)(stages < MAX_SLICES ? stages : MAX_SLICES);
+    long rows_per_slice = ((stages + S - 1) / S) * TN_ROWS;
+    S = (int)((M + rows_per_slice - 1) / rows_per_slice);
+    TNArgs a;
+    a.G = G; a.ldg = ldg; a.N = N; a.X = X; a.ldx = ldx; a.K = K; a.M = M; a.rows_per_slice = rows_per_slice;
+    a.slab = static_cast<float*>(workspace);
+    a.bias_slab = a.slab + (size_t)MAX_SLICES * SLAB * SLAB;
+    gemm_tn_kernel<<<dim3(S), dim3(512), 2 * TN_ROWS * SLAB * sizeof(float), s>>>(a);
+    PAPR_CHECK_LAUNCH("gemm_tn");
+    slab_reduce_kernel<<<dim3(SLAB * SLAB / 4 / 256), dim3(256), 0, s>>>(a.slab, a.bias_slab, S, N, K, dW, ldw, db);
+    PAPR_CHECK_LAUNCH("slab_reduce");
+    return 0;
+}
+
+// in-place g *= act'(y)
+__global__ __launch_bounds__(256) void act_grad_kernel(float* g, long ldg, const float* __restrict__ y, long ldy, long M,
+                                                       int N, int act) {
+    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= M * N) return;
+    long m = e / N;
+    int n = (int)(e - m * N);
+    g[m * ldg + n] *= papr_act_grad(y[m * ldy + n], act);
+}
+
+}  // namespace
+
+extern "C" size_t papr_mlp_bwd_workspace_bytes(void) {
+    return (size_t)MAX_SLICES * (SLAB * SLAB + SLAB) * sizeof(float);
+}
+
+extern "C" int papr_mlp_fwd(const papr_layer* layers, int n_layers, const float* x, int ldx, int64_t M,
+                            float* const* outs, const int32_t* ld_out, papr_stream_t stream) {
+    PAPR_REQUIRE(layers && x && outs && ld_out && n_layers >= 1, "papr_mlp_fwd: bad arguments");
+    hipStream_t s = as_stream(stream);
+    for (int i = 0; i < n_layers; ++i) {
+        const papr_layer& L = layers[i];
+        PAPR_REQUIRE(L.weight && outs[i], "papr_mlp_fwd: layer %d has null weight/output", i);
+        PAPR_REQUIRE(ld_out[i] >= L.n_out, "papr_mlp_fwd: layer %d output stride %d < %d", i, ld_out[i], L.n_out);
+        NTArgs a = {};
+        a.A = i == 0 ? x : outs[i - 1];
+        a.lda = i == 0 ? ldx : ld_out[i - 1];
+        a.K1 = L.n_in;
+        if (L.n_skip > 0) { a.A2 = x; a.lda2 = ldx; a.K2 = L.n_skip; a.wcol2 = L.skip_col; }
+        a.W = L.weight; a.ldw = L.ldw; a.bias = L.bias; a.act = L.act;
+        a.C = outs[i]; a.ldc = ld_out[i]; a.M = M; a.N = L.n_out;
+        if (int e = gemm_nt(a, s)) return e;
+    }
+    return 0;
+}
+
+extern "C" int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float* x, int ldx, int64_t M,
+                            float* const* outs, const int32_t* ld_out, float* d_out, float* scratch0, float* scratch1,
+                            int ld_scratch, float* const* d_weight, float* const* d_bias, float* d_x, void* workspace,
+                            papr_stream_t stream) {
+    PAPR_REQUIRE(layers && x && outs && ld_out && d_out && d_weight && d_bias && workspace && n_layers >= 1,
+                 "papr_mlp_bwd: bad arguments");
+    PAPR_REQUIRE(n_layers == 1 || (scratch0 && scratch1), "papr_mlp_bwd: scratch buffers required");
+    hipStream_t s = as_stream(stream);
+    bool any_skip = false;
+    for (int i = 0; i < n_layers; ++i) any_skip |= layers[i].n_skip > 0;
+    if (d_x && any_skip) {
+        hipError_t e = hipMemsetAsync(d_x, 0, (size_t)M * ldx * sizeof(float), s);
+        PAPR_REQUIRE(e == hipSuccess, "papr_mlp_bwd: memset failed");
+    }
+    // gradient w.r.t. the last layer's pre-activation
+    float* g = d_out;
+    long ldg = ld_out[n_layers - 1];
+    {
+        const papr_layer& L = layers[n_layers - 1];
+        if (L.act != PAPR_ACT_NONE) {
+            long n = (long)M * L.n_out;
+            act_grad_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(g, ldg, outs[n_layers - 1], ldg, M, L.n_out, L.act);
+            PAPR_CHECK_LAUNCH("act_grad");
+        }
+    }
+    for (int i = n_layers - 1; i >= 0; --i) {
+        const papr_layer& L = layers[i];
+        const float* in = i == 0 ? x : outs[i - 1];
+        long ld_in = i == 0 ? ldx : ld_out[i - 1];
+        PAPR_REQUIRE(d_weight[i], "papr_mlp_bwd: layer %d has null d_weight", i);
+        // weight / bias gradients
+        if (int e = gemm_tn(g, ldg, L.n_out, in, ld_in, L.n_in, M, d_weight[i], L.ldw, d_bias[i], workspace, s)) return e;
+        if (L.n_skip > 0)
+            if (int e = gemm_tn(g, ldg, L.n_out, x, ldx, L.n_skip, M, d_weight[i] + L.skip_col, L.ldw, nullptr, workspace, s)) return e;
+        // data gradients
+        if (L.n_skip > 0 && d_x) {
+            PAPR_REQUIRE(L.weight_t, "papr_mlp_bwd: layer %d needs weight_t", i);
+            NTArgs a = {};
+            a.A = g; a.lda = ldg; a.K1 = L.n_out;
+            a.W = L.weight_t + (long)L.skip_col * L.ldwt; a.ldw = L.ldwt;
+            a.dgrad = 1; a.accumulate = 1;
+            a.C = d_x; a.ldc = ldx; a.M = M; a.N = L.n_skip;
+            if (int e = gemm_nt(a, s)) return e;
+        }
+        if (i > 0) {
+            PAPR_REQUIRE(L.weight_t, "papr_mlp_bwd: layer %d needs weight_t", i);
+            float* gnext = (g == scratch0) ? scratch1 : scratch0;
+            NTArgs a = {};
+            a.A = g; a.lda = ldg; a.K1 = L.n_out;
+            a.W = L.weight_t; a.ldw = L.ldwt;
+            a.dgrad = 1; a.act = layers[i - 1].act; a.mask_src = outs[i - 1]; a.ld_mask = ld_out[i - 1];
+            a.C = gnext; a.ldc = ld_scratch; a.M = M; a.N = L.n_in;
+            PAPR_REQUIRE(ld_scratch >= L.n_in, "papr_mlp_bwd: scratch stride %d < %d", ld_scratch, L.n_in);
+            if (int e = gemm_nt(a, s)) return e;
+            g = gnext;
+            ldg = ld_scratch;
+        } else if (d_x) {
+            PAPR_REQUIRE(L.weight_t, "papr_mlp_bwd: layer 0 needs weight_t");
+            NTArgs a = {};
+            a.A = g; a.lda = ldg; a.K1 = L.n_out;
+            a.W = L.weight_t; a.ldw = L.ldwt;
+            a.dgrad = 1; a.accumulate = any_skip ? 1 : 0;
+            a.C = d_x; a.ldc = ldx; a.M = M; a.N = L.n_in;
+            if (int e = gemm_nt(a, s)) return e;
+        }
+    }
+    return 0;
+}

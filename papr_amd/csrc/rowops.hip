@@ -1,0 +1,253 @@
+// Row-wise kernels of the render path: the LayerNorm core and the fused attention tail (K4).
+// Both are HBM-streaming: one wave64 per row / per ray, 16-byte lane loads, shuffle reductions.
+#include "papr_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// y = (x - mean) / (std_unbiased + eps)      reference LayerNorm core, models/attn.py:39-42
+// One wave per row; a lane holds up to VPL = 16 elements (width <= 1024), strided by 64 so that
+// global accesses are coalesced.
+constexpr int MAX_VPL = 16;
+
+template <int VPL>
+__global__ __launch_bounds__(256) void rownorm_fwd_kernel(const float* x, long rows, int width, int ld, float eps,
+                                                          float* y, float* __restrict__ stats) {
+    const int lane = threadIdx.x & 63;
+    long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * ld;
+    float v[VPL];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        int c = lane + 64 * i;
+        v[i] = c < width ? xr[c] : 0.f;
+        sum += v[i];
+    }
+    float mean = wave_sum(sum) / (float)width;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        int c = lane + 64 * i;
+        float dlt = c < width ? v[i] - mean : 0.f;
+        v[i] = dlt;
+        ss += dlt * dlt;
+    }
+    float sigma = sqrtf(wave_sum(ss) / (float)(width - 1));
+    float rinv = 1.0f / (sigma + eps);
+    float* yr = y + row * ld;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        int c = lane + 64 * i;
+        if (c < width) yr[c] = v[i] * rinv;
+    }
+    if (lane == 0) { stats[row * 2 + 0] = rinv; stats[row * 2 + 1] = sigma; }
+}
+
+// dx_i = rinv (dy_i - mean(dy)) - y_i * (sum_j dy_j y_j) / ((n-1) sigma)
+template <int VPL>
+__global__ __launch_bounds__(256) void rownorm_bwd_kernel(const float* dy, const float* __restrict__ y,
+                                                          const float* __restrict__ stats, long rows, int width,
+                                                          int ld, float* dx) {
+    const int lane = threadIdx.x & 63;
+    long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* gr = dy + row * ld;
+    const float* yr = y + row * ld;
+    float g[VPL], yy[VPL];
+    float sg = 0.f, sgy = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        int c = lane + 64 * i;
+        g[i] = c < width ? gr[c] : 0.f;
+        yy[i] = c < width ? yr[c] : 0.f;
+        sg += g[i];
+        sgy += g[i] * yy[i];
+    }
+    sg = wave_sum(sg) / (float)width;
+    sgy = wave_sum(sgy);
+    float rinv = stats[row * 2 + 0], sigma = stats[row * 2 + 1];
+    float coef = sigma > 0.f ? sgy / ((float)(width - 1) * sigma) : 0.f;
+    float* dr = dx + row * ld;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        int c = lane + 64 * i;
+        if (c < width) dr[c] = rinv * (g[i] - sg) - yy[i] * coef;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4 attention tail.  One wave per ray.  Lane j < k owns neighbour j's score / attention weight,
+// lane k owns the background token; the d_model-long dot products are 16-byte-per-lane row reads
+// reduced with wave shuffles; the C-wide weighted sum puts one output channel on each lane.
+// Reference: models/attn.py:217-225 (+:54) and models/model.py:519-534.
+
+__device__ __forceinline__ float bcast(float v, int src) { return __shfl(v, src, 64); }
+
+__global__ __launch_bounds__(256) void tail_fwd_kernel(papr_tail_desc d, const float* __restrict__ kp,
+                                                       const float* __restrict__ qp, const float* __restrict__ v,
+                                                       const float* __restrict__ influ, const int* __restrict__ idx,
+                                                       long R, float* __restrict__ scores, float* __restrict__ attn,
+                                                       float* __restrict__ fused) {
+    const int lane = threadIdx.x & 63;
+    long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int k = d.k;
+    const float inv_sqrt_d = 1.0f / sqrtf((float)d.d_model);
+    const float* q = qp + r * d.ld_qp;
+    float my_score = 0.f;
+    for (int j = 0; j < k; ++j) {
+        const float* kr = kp + (r * k + j) * d.ld_kp;
+        float part = 0.f;
+        for (int c = lane * 4; c < d.d_model; c += 256) {
+            float4 a = *reinterpret_cast<const float4*>(q + c);
+            float4 b = *reinterpret_cast<const float4*>(kr + c);
+            part += (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w);
+        }
+        float dot = wave_sum(part);
+        if (lane == j) my_score = dot;
+    }
+    float z = -INFINITY;
+    if (lane < k) {
+        float sc = papr_act(my_score * inv_sqrt_d, d.score_act);
+        scores[r * k + lane] = sc;
+        z = sc * influ[idx[r * k + lane]];
+    } else if (lane == k) {
+        z = d.bkg_score;
+    }
+    float zmax = wave_max(z);
+    float e = lane <= k ? expf(z - zmax) : 0.f;
+    float denom = wave_sum(e);
+    float a = e / denom;
+    if (lane <= k) attn[r * (k + 1) + lane] = a;
+    float top = lane < k ? a : 0.f;
+    if (d.normalize) top = top / wave_sum(top);
+    for (int c = lane; c < d.C; c += 64) {
+        float acc = 0.f;
+        for (int j = 0; j < k; ++j) acc += bcast(top, j) * v[(r * k + j) * d.ld_v + c];
+        fused[r * d.C + c] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void tail_bwd_kernel(papr_tail_desc d, const float* __restrict__ kp,
+                                                       const float* __restrict__ qp, const float* __restrict__ v,
+                                                       const float* __restrict__ influ, const int* __restrict__ idx,
+                                                       long R, const float* __restrict__ scores,
+                                                       const float* __restrict__ attn, const float* __restrict__ d_fused,
+                                                       const float* __restrict__ d_attn, float* __restrict__ d_kp,
+                                                       float* __restrict__ d_qp, float* __restrict__ d_v,
+                                                       float* __restrict__ d_influ) {
+    const int lane = threadIdx.x & 63;
+    long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int k = d.k;
+    const float inv_sqrt_d = 1.0f / sqrtf((float)d.d_model);
+    float a = lane <= k ? attn[r * (k + 1) + lane] : 0.f;
+    float top = lane < k ? a : 0.f;
+    float tsum = 1.f;
+    if (d.normalize) { tsum = wave_sum(top); top = top / tsum; }
+    // d_top_j = d_fused . v_j ;  d_v_j = top_j d_fused     (channels across lanes)
+    float my_dtop = 0.f;
+    for (int j = 0; j < k; ++j) {
+        float part = 0.f;
+        float tj = bcast(top, j);
+        for (int c = lane; c < d.ld_v; c += 64) {   // padding columns of d_v are written as zero
+            float gf = c < d.C ? d_fused[r * d.C + c] : 0.f;
+            float vv = c < d.C ? v[(r * k + j) * d.ld_v + c] : 0.f;
+            part += gf * vv;
+            d_v[(r * k + j) * d.ld_v + c] = tj * gf;
+        }
+        float dt = wave_sum(part);
+        if (lane == j) my_dtop = dt;
+    }
+    float da = (d_attn && lane <= k) ? d_attn[r * (k + 1) + lane] : 0.f;
+    if (d.normalize) {
+        float corr = wave_sum(my_dtop * top);  // lanes >= k contribute 0
+        if (lane < k) da += (my_dtop - corr) / tsum;
+    } else if (lane < k) {
+        da += my_dtop;
+    }
+    float dz = a * (da - wave_sum(da * a));  // softmax backward over the k+1 tokens
+    float sc = lane < k ? scores[r * k + lane] : 0.f;
+    int pi = lane < k ? idx[r * k + lane] : 0;
+    float w = lane < k ? influ[pi] : 0.f;
+    float ddot = 0.f;
+    if (lane < k) {
+        unsafeAtomicAdd(d_influ + pi, dz * sc);
+        ddot = dz * w * papr_act_grad(sc, d.score_act) * inv_sqrt_d;
+    }
+    // d_qp = sum_j ddot_j kp_j ;  d_kp_j = ddot_j qp
+    const float* q = qp + r * d.ld_qp;
+    for (int c = lane * 4; c < d.d_model; c += 256) {
+        float4 qv = *reinterpret_cast<const float4*>(q + c);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < k; ++j) {
+            float gj = bcast(ddot, j);
+            float4 kv = *reinterpret_cast<const float4*>(kp + (r * k + j) * d.ld_kp + c);
+            acc.x += gj * kv.x; acc.y += gj * kv.y; acc.z += gj * kv.z; acc.w += gj * kv.w;
+            *reinterpret_cast<float4*>(d_kp + (r * k + j) * d.ld_kp + c) = make_float4(gj * qv.x, gj * qv.y, gj * qv.z, gj * qv.w);
+        }
+        *reinterpret_cast<float4*>(d_qp + r * d.ld_qp + c) = acc;
+    }
+}
+
+}  // namespace
+
+extern "C" int papr_rownorm_fwd(const float* x, int64_t rows, int width, int ld, float eps, float* y, float* stats,
+                                papr_stream_t stream) {
+    PAPR_REQUIRE(x && y && stats, "papr_rownorm_fwd: null pointer");
+    PAPR_REQUIRE(width >= 2 && width <= 64 * MAX_VPL && ld >= width, "papr_rownorm_fwd: width %d / ld %d unsupported", width, ld);
+    if (rows <= 0) return 0;
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    if (width <= 256) rownorm_fwd_kernel<4><<<grid, block, 0, as_stream(stream)>>>(x, rows, width, ld, eps, y, stats);
+    else rownorm_fwd_kernel<MAX_VPL><<<grid, block, 0, as_stream(stream)>>>(x, rows, width, ld, eps, y, stats);
+    PAPR_CHECK_LAUNCH("rownorm_fwd");
+    return 0;
+}
+
+extern "C" int papr_rownorm_bwd(const float* dy, const float* y, const float* stats, int64_t rows, int width, int ld,
+                                float eps, float* dx, papr_stream_t stream) {
+    (void)eps;
+    PAPR_REQUIRE(dy && y && stats && dx, "papr_rownorm_bwd: null pointer");
+    PAPR_REQUIRE(width >= 2 && width <= 64 * MAX_VPL && ld >= width, "papr_rownorm_bwd: width %d / ld %d unsupported", width, ld);
+    if (rows <= 0) return 0;
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    if (width <= 256) rownorm_bwd_kernel<4><<<grid, block, 0, as_stream(stream)>>>(dy, y, stats, rows, width, ld, dx);
+    else rownorm_bwd_kernel<MAX_VPL><<<grid, block, 0, as_stream(stream)>>>(dy, y, stats, rows, width, ld, dx);
+    PAPR_CHECK_LAUNCH("rownorm_bwd");
+    return 0;
+}
+
+static int check_tail(const papr_tail_desc* d, const char* who) {
+    PAPR_REQUIRE(d, "%s: null descriptor", who);
+    PAPR_REQUIRE(d->k >= 1 && d->k <= 63, "%s: k=%d outside [1,63]", who, d->k);
+    PAPR_REQUIRE(d->d_model % 4 == 0 && d->ld_kp % 4 == 0 && d->ld_qp % 4 == 0, "%s: d_model and strides must be multiples of 4", who);
+    PAPR_REQUIRE(d->ld_kp >= d->d_model && d->ld_qp >= d->d_model && d->ld_v >= d->C, "%s: strides too small", who);
+    return 0;
+}
+
+extern "C" int papr_attn_tail_fwd(const papr_tail_desc* d, const float* kp, const float* qp, const float* v,
+                                  const float* influ, const int32_t* idx, int64_t R, float* scores, float* attn,
+                                  float* fused, papr_stream_t stream) {
+    if (int e = check_tail(d, "papr_attn_tail_fwd")) return e;
+    PAPR_REQUIRE(kp && qp && v && influ && idx && scores && attn && fused, "papr_attn_tail_fwd: null pointer");
+    if (R <= 0) return 0;
+    tail_fwd_kernel<<<dim3((unsigned)((R + 3) / 4)), dim3(256), 0, as_stream(stream)>>>(*d, kp, qp, v, influ, idx, R, scores, attn, fused);
+    PAPR_CHECK_LAUNCH("tail_fwd");
+    return 0;
+}
+
+extern "C" int papr_attn_tail_bwd(const papr_tail_desc* d, const float* kp, const float* qp, const float* v,
+                                  const float* influ, const int32_t* idx, int64_t R, const float* scores,
+                                  const float* attn, const float* d_fused, const float* d_attn, float* d_kp,
+                                  float* d_qp, float* d_v, float* d_influ, papr_stream_t stream) {
+    if (int e = check_tail(d, "papr_attn_tail_bwd")) return e;
+    PAPR_REQUIRE(kp && qp && v && influ && idx && scores && attn && d_fused && d_kp && d_qp && d_v && d_influ,
+                 "papr_attn_tail_bwd: null pointer");
+    if (R <= 0) return 0;
+    tail_bwd_kernel<<<dim3((unsigned)((R + 3) / 4)), dim3(256), 0, as_stream(stream)>>>(
+        *d, kp, qp, v, influ, idx, R, scores, attn, d_fused, d_attn, d_kp, d_qp, d_v, d_influ);
+    PAPR_CHECK_LAUNCH("tail_bwd");
+    return 0;
+}

@@ -1,0 +1,122 @@
+"""ctypes binding of libpapr_hip.so (include/papr_hip.h).
+
+There is deliberately no fallback: if the library is missing or a call fails this raises.
+torch is imported first so that the HIP runtime torch already loaded (soname libamdhip64.so.7)
+is the one the library binds to -- device pointers and streams are shared with torch.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libpapr_hip.so")
+
+ACT = {"none": 0, "relu": 1, "leakyrelu": 2}
+
+EXPORTS = [
+    "papr_abi_version", "papr_last_error", "papr_ray_knn_workspace_bytes", "papr_ray_knn",
+    "papr_feature_widths", "papr_build_features_fwd", "papr_build_features_bwd",
+    "papr_rownorm_fwd", "papr_rownorm_bwd", "papr_mlp_bwd_workspace_bytes", "papr_mlp_fwd", "papr_mlp_bwd",
+    "papr_attn_tail_fwd", "papr_attn_tail_bwd",
+]
+
+
+class FeatureDesc(C.Structure):
+    _fields_ = [("k", C.c_int32), ("feat_dim", C.c_int32), ("L_key", C.c_int32 * 3), ("L_qry", C.c_int32),
+                ("L_val", C.c_int32 * 2), ("with_self", C.c_int32), ("key_has_feats", C.c_int32),
+                ("val_has_feats", C.c_int32), ("pe_factor", C.c_float), ("pe_mult", C.c_float), ("eps", C.c_float),
+                ("ld_key", C.c_int32), ("ld_qry", C.c_int32), ("ld_val", C.c_int32)]
+
+
+class Layer(C.Structure):
+    _fields_ = [("weight", C.c_void_p), ("weight_t", C.c_void_p), ("bias", C.c_void_p),
+                ("n_in", C.c_int32), ("n_out", C.c_int32), ("ldw", C.c_int32), ("ldwt", C.c_int32),
+                ("n_skip", C.c_int32), ("skip_col", C.c_int32), ("act", C.c_int32)]
+
+
+class TailDesc(C.Structure):
+    _fields_ = [("k", C.c_int32), ("d_model", C.c_int32), ("C", C.c_int32), ("ld_kp", C.c_int32),
+                ("ld_qp", C.c_int32), ("ld_v", C.c_int32), ("score_act", C.c_int32), ("normalize", C.c_int32),
+                ("bkg_score", C.c_float)]
+
+
+_lib = None
+
+
+def library_present():
+    return os.path.exists(LIB_PATH)
+
+
+def lib():
+    """The loaded library (loads on first use; raises if it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("papr_amd: %s is missing -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback for the render path)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
+    L.papr_abi_version.restype = C.c_int
+    L.papr_last_error.restype = C.c_char_p
+    L.papr_ray_knn_workspace_bytes.restype = C.c_size_t
+    L.papr_ray_knn_workspace_bytes.argtypes = [i64]
+    L.papr_ray_knn.argtypes = [vp, i64, vp, vp, i64, i64, i32, f32, vp, vp, vp, vp]
+    L.papr_feature_widths.argtypes = [C.POINTER(FeatureDesc), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.papr_build_features_fwd.argtypes = [C.POINTER(FeatureDesc), vp, vp, vp, vp, i64, i64, vp, vp, vp, vp, vp, vp]
+    L.papr_build_features_bwd.argtypes = [C.POINTER(FeatureDesc), vp, vp, vp, i64, i64, vp, vp, vp, vp, vp, vp]
+    L.papr_rownorm_fwd.argtypes = [vp, i64, i32, i32, f32, vp, vp, vp]
+    L.papr_rownorm_bwd.argtypes = [vp, vp, vp, i64, i32, i32, f32, vp, vp]
+    L.papr_mlp_bwd_workspace_bytes.restype = C.c_size_t
+    L.papr_mlp_fwd.argtypes = [C.POINTER(Layer), i32, vp, i32, i64, C.POINTER(vp), C.POINTER(C.c_int32), vp]
+    L.papr_mlp_bwd.argtypes = [C.POINTER(Layer), i32, vp, i32, i64, C.POINTER(vp), C.POINTER(C.c_int32), vp, vp, vp,
+                               i32, C.POINTER(vp), C.POINTER(vp), vp, vp, vp]
+    L.papr_attn_tail_fwd.argtypes = [C.POINTER(TailDesc), vp, vp, vp, vp, vp, i64, vp, vp, vp, vp]
+    L.papr_attn_tail_bwd.argtypes = [C.POINTER(TailDesc), vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    for name in EXPORTS:
+        getattr(L, name)  # every declared entry point must resolve
+    _check_single_hip_runtime()
+    _lib = L
+    return L
+
+
+def _check_single_hip_runtime():
+    seen = set()
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                if "libamdhip64" in line:
+                    seen.add(line.split()[-1])
+    except OSError:
+        return
+    if len(seen) > 1:
+        raise RuntimeError("papr_amd: two HIP runtimes are mapped (%s); device pointers would not be shared" % sorted(seen))
+
+
+def check(code, what):
+    if code != 0:
+        raise RuntimeError("%s failed (%d): %s" % (what, code, lib().papr_last_error().decode()))
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a contiguous fp32/int32 CUDA tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "papr_amd.hip.ptr: need a contiguous device tensor"
+    return C.c_void_p(t.data_ptr())
+
+
+def ptr_array(tensors):
+    arr = (C.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = None if t is None else t.data_ptr()
+    return arr
+
+
+def i32_array(vals):
+    return (C.c_int32 * len(vals))(*vals)

@@ -1,0 +1,402 @@
+"""Host-side orchestration of the HIP render path (kNN -> features -> embedding MLPs -> attention tail).
+
+`RenderPath` owns the static geometry of the path (widths, paddings, layer tables) derived from the
+config; `render_rays` is the differentiable entry point used by `papr_amd.model.PAPR`.  All device
+work goes through libpapr_hip.so (papr_amd/hip.py); torch is used for memory, streams and for the
+tiny weight preparation (LayerNorm-affine folding, zero padding, transposes), which keeps those
+pieces inside ordinary autograd.
+
+Reference call sites this file stands in for: PAPR._get_points / _get_kqv / evaluate / forward
+(models/model.py:312-333, 396-437, 462-545) and ProximityAttention.forward (models/attn.py:241-252).
+"""
+import ctypes as C
+
+import torch
+import torch.nn.functional as F
+
+from . import hip
+
+
+def _pad4(n):
+    return (n + 3) // 4 * 4
+
+
+def _pad32(n):
+    return (n + 31) // 32 * 32
+
+
+class MlpSpec:
+    """Static description of one embedding MLP (reference models/mlp.py:12-45 as configured by
+    models/attn.py:152-163)."""
+
+    def __init__(self, name, d_in, ecfg):
+        self.name = name
+        self.d_in = d_in
+        self.ld_in = _pad4(d_in)
+        self.n_layer = int(ecfg["n_ff_layer"])
+        self.width = int(ecfg["d_ff"])
+        self.d_out = int(ecfg["d_ff_out"])
+        self.norm = ecfg["norm"]
+        self.skip_layers = list(ecfg.get("skip_layers", []) or [])
+        for key in ("half_layers", "residual_layers"):
+            if ecfg.get(key):
+                raise NotImplementedError("papr_amd: %s.%s is not supported by the HIP path" % (name, key))
+        if ecfg.get("use_wn", False):
+            raise NotImplementedError("papr_amd: weight-norm (%s.use_wn) is not supported by the HIP path" % name)
+        if ecfg.get("residual_ff", False) and d_in == self.d_out:
+            raise NotImplementedError("papr_amd: %s.residual_ff is not supported by the HIP path" % name)
+        if float(ecfg.get("dropout_ff", 0.0)) != 0.0:
+            raise NotImplementedError("papr_amd: %s.dropout_ff > 0 is not supported by the HIP path" % name)
+        if self.norm not in ("layernorm", "none"):
+            raise ValueError("Invalid attention norm type")
+        for a in (ecfg["ff_act"], ecfg["ff_last_act"]):
+            if a.lower() not in hip.ACT:
+                raise NotImplementedError("papr_amd: activation '%s' (%s) has no HIP epilogue (relu/leakyrelu/none)" % (a, name))
+        self.act = hip.ACT[ecfg["ff_act"].lower()]
+        self.last_act = hip.ACT[ecfg["ff_last_act"].lower()]
+        if self.width % 4 or self.width > 256 or self.d_out > 256:
+            raise NotImplementedError("papr_amd: %s widths must be multiples of 4 and <= 256" % name)
+        # per-layer geometry
+        self.layers = []
+        for i in range(self.n_layer):
+            n_in = self.ld_in if i == 0 else self.width
+            n_out = self.d_out if i == self.n_layer - 1 else self.width
+            skip = i in self.skip_layers
+            self.layers.append(dict(n_in=n_in, n_out=n_out, n_out_pad=_pad32(n_out) if i == self.n_layer - 1 else n_out,
+                                    raw_in=(self.d_in if i == 0 else self.width), skip=skip,
+                                    act=self.last_act if i == self.n_layer - 1 else self.act))
+        self.ld_out = [l["n_out_pad"] for l in self.layers]
+
+
+def prepare_mlp_weights(spec, weights, biases, ln_in=None):
+    """Reference-shaped Linear parameters -> effective, padded weights for the kernels (differentiable).
+
+    ln_in = (a_2, b_2) of the input LayerNorm: the kernels only standardise rows, the affine part is
+    folded here:  W (a * xh + b) + c = (W * a) xh + (W b + c).
+    """
+    eff_w, eff_b = [], []
+    for i, (w, b) in enumerate(zip(weights, biases)):
+        L = spec.layers[i]
+        main = w[:, :L["raw_in"]]
+        extra = w[:, L["raw_in"]:] if L["skip"] else None
+        if ln_in is not None:
+            a, sh = ln_in
+            if i == 0:
+                b = b + main @ sh
+                main = main * a
+            if extra is not None:
+                b = b + extra @ sh
+                extra = extra * a
+        main = F.pad(main, (0, L["n_in"] - main.shape[1]))
+        if extra is not None:
+            extra = F.pad(extra, (0, spec.ld_in - extra.shape[1]))
+            main = torch.cat([main, extra], dim=1)
+        if L["n_out_pad"] != L["n_out"]:
+            main = F.pad(main, (0, 0, 0, L["n_out_pad"] - L["n_out"]))
+            b = F.pad(b, (0, L["n_out_pad"] - L["n_out"]))
+        eff_w.append(main.contiguous())
+        eff_b.append(b.contiguous())
+    return eff_w, eff_b
+
+
+def _layer_table(spec, ws, bs, wts=None):
+    tab = (hip.Layer * spec.n_layer)()
+    for i, L in enumerate(spec.layers):
+        t = tab[i]
+        t.weight = ws[i].data_ptr()
+        t.weight_t = wts[i].data_ptr() if wts is not None else None
+        t.bias = bs[i].data_ptr()
+        t.n_in, t.n_out = L["n_in"], L["n_out_pad"]
+        t.ldw = ws[i].shape[1]
+        t.ldwt = wts[i].shape[1] if wts is not None else 0
+        t.n_skip = spec.ld_in if L["skip"] else 0
+        t.skip_col = L["n_in"] if L["skip"] else 0
+        t.act = L["act"]
+    return tab
+
+
+def mlp_forward(spec, ws, bs, x, M, keep=True):
+    """Run the chain; returns the list of layer outputs (all kept, or two ping-pong buffers)."""
+    dev = x.device
+    if keep:
+        outs = [torch.empty((M, ld), device=dev, dtype=torch.float32) for ld in spec.ld_out]
+    else:
+        pool = [torch.empty(M * max(spec.ld_out), device=dev, dtype=torch.float32) for _ in range(2)]
+        outs = [pool[i & 1][:M * ld].view(M, ld) for i, ld in enumerate(spec.ld_out)]
+    tab = _layer_table(spec, ws, bs)
+    hip.check(hip.lib().papr_mlp_fwd(tab, spec.n_layer, hip.ptr(x), x.shape[1], M, hip.ptr_array(outs),
+                                     hip.i32_array(spec.ld_out), hip.stream_ptr()), "papr_mlp_fwd")
+    return outs
+
+
+_ws_cache = {}
+
+
+def _bwd_workspace(dev):
+    key = (dev.type, dev.index)
+    if key not in _ws_cache:
+        n = hip.lib().papr_mlp_bwd_workspace_bytes()
+        _ws_cache[key] = torch.empty(n // 4, device=dev, dtype=torch.float32)
+    return _ws_cache[key]
+
+
+def mlp_backward(spec, ws, bs, x, M, outs, d_out, scratch, need_dx):
+    """Returns (d_ws, d_bs, d_x or None).  d_out is consumed."""
+    dev = x.device
+    wts = [w.t().contiguous() for w in ws]
+    tab = _layer_table(spec, ws, bs, wts)
+    d_ws = [torch.empty_like(w) for w in ws]
+    d_bs = [torch.empty_like(b) for b in bs]
+    d_x = torch.empty_like(x) if need_dx else None
+    hip.check(hip.lib().papr_mlp_bwd(tab, spec.n_layer, hip.ptr(x), x.shape[1], M, hip.ptr_array(outs),
+                                     hip.i32_array(spec.ld_out), hip.ptr(d_out), hip.ptr(scratch[0]), hip.ptr(scratch[1]),
+                                     scratch[0].shape[1], hip.ptr_array(d_ws), hip.ptr_array(d_bs), hip.ptr(d_x),
+                                     hip.ptr(_bwd_workspace(dev)), hip.stream_ptr()), "papr_mlp_bwd")
+    return d_ws, d_bs, d_x
+
+
+def rownorm_(x, width, eps):
+    """In-place row standardisation; returns stats (rows,2)."""
+    stats = torch.empty((x.shape[0], 2), device=x.device, dtype=torch.float32)
+    hip.check(hip.lib().papr_rownorm_fwd(hip.ptr(x), x.shape[0], width, x.shape[1], eps, hip.ptr(x), hip.ptr(stats),
+                                         hip.stream_ptr()), "papr_rownorm_fwd")
+    return stats
+
+
+def rownorm_bwd_(dy, y, stats, width, eps):
+    """In-place: dy <- gradient w.r.t. the un-normalised rows."""
+    hip.check(hip.lib().papr_rownorm_bwd(hip.ptr(dy), hip.ptr(y), hip.ptr(stats), y.shape[0], width, y.shape[1], eps,
+                                         hip.ptr(dy), hip.stream_ptr()), "papr_rownorm_bwd")
+    return dy
+
+
+def ray_knn(points, rays_o, rays_d, rays_per_image, k, eps, want_dist=False):
+    """points (P,3), rays_o (N,3), rays_d (R,3) -> idx (R,k) int32 [, dist (R,k)]  (no gradient)."""
+    R = rays_d.shape[0]
+    dev = points.device
+    idx = torch.empty((R, k), device=dev, dtype=torch.int32)
+    dist = torch.empty((R, k), device=dev, dtype=torch.float32) if want_dist else None
+    ws = torch.empty(hip.lib().papr_ray_knn_workspace_bytes(R) // 4, device=dev, dtype=torch.float32)
+    hip.check(hip.lib().papr_ray_knn(hip.ptr(points), points.shape[0], hip.ptr(rays_o), hip.ptr(rays_d), R, rays_per_image,
+                                     k, eps, hip.ptr(idx), hip.ptr(dist), hip.ptr(ws), hip.stream_ptr()), "papr_ray_knn")
+    return (idx, dist) if want_dist else idx
+
+
+class RenderPath:
+    """Static plan of the per-ray path for one configuration."""
+
+    def __init__(self, cfg):
+        a = cfg["models"]["attn"]
+        e = a["embed"]
+        pf = cfg["geoms"]["point_feats"]
+        if a["k_type"] != 1:
+            raise ValueError("Invalid key type")
+        if a["q_type"] != 1:
+            raise ValueError("Invalid query type")
+        if a["v_type"] != 1:
+            raise ValueError("Invalid value type")
+        if e["embed_type"] not in (1, 2):
+            raise ValueError("Unknown embedding type: {}".format(e["embed_type"]))
+        if pf["use_inq"]:
+            raise NotImplementedError("papr_amd: geoms.point_feats.use_inq is not supported (it does not broadcast in the reference either)")
+        self.eps = float(cfg["eps"])
+        self.k_cfg = int(cfg["geoms"]["points"]["select_k"])
+        self.feat_dim = int(pf["dim"])
+        self.use_feats = bool(pf["use_ink"] or pf["use_inv"])
+        self.d_model = int(a["d_model"])
+        self.score_act = a["score_act"].lower()
+        if self.score_act not in hip.ACT:
+            raise NotImplementedError("papr_amd: score_act '%s' has no HIP implementation" % self.score_act)
+        self.bkg_score = float(cfg["geoms"]["background"]["constant"])
+        self.normalize = bool(cfg["models"]["normalize_topk_attn"])
+        with_self = 1 if e["embed_type"] == 1 else 0
+        w = lambda Ls: sum(3 * (with_self + 2 * L) for L in Ls)
+        self.key_w = w(e["k_L"]) + (self.feat_dim if pf["use_ink"] else 0)
+        self.qry_w = w(e["q_L"])
+        self.val_w = w(e["v_L"]) + (self.feat_dim if pf["use_inv"] else 0)
+        self.key = MlpSpec("key", self.key_w, e["key"])
+        self.qry = MlpSpec("query", self.qry_w, e["query"])
+        self.val = MlpSpec("value", self.val_w, e["value"])
+        if self.val.norm != "none":
+            raise NotImplementedError("papr_amd: value.norm must be 'none' (the out-norm affine has no following layer to fold into)")
+        if self.key.norm != self.qry.norm:
+            raise NotImplementedError("papr_amd: key.norm and query.norm must agree")
+        self.kq_norm = self.key.norm == "layernorm"
+        self.C = self.val.d_out
+        # single-layer "MLPs" for w_k / w_q so that they share the GEMM drivers
+        one = lambda name, d_in: MlpSpec(name, d_in, dict(n_ff_layer=1, d_ff=self.d_model, d_ff_out=self.d_model, norm="none",
+                                                          ff_act="none", ff_last_act="none"))
+        if self.d_model % 4 or self.d_model > 256:
+            raise NotImplementedError("papr_amd: d_model must be a multiple of 4 and <= 256")
+        self.wk = one("w_k", self.key.d_out)
+        self.wq = one("w_q", self.qry.d_out)
+        d = hip.FeatureDesc()
+        d.feat_dim = self.feat_dim
+        d.L_key = (C.c_int32 * 3)(*e["k_L"])
+        d.L_qry = e["q_L"][0]
+        d.L_val = (C.c_int32 * 2)(*e["v_L"])
+        d.with_self = with_self
+        d.key_has_feats = int(bool(pf["use_ink"]))
+        d.val_has_feats = int(bool(pf["use_inv"]))
+        d.pe_factor, d.pe_mult, d.eps = float(e["pe_factor"]), float(e["pe_mult_factor"]), self.eps
+        d.ld_key, d.ld_qry, d.ld_val = self.key.ld_in, self.qry.ld_in, self.val.ld_in
+        self.fdesc = d
+
+    # -------------------------------------------------------------------------------------------
+    def feature_desc(self, k):
+        d = hip.FeatureDesc()
+        C.memmove(C.byref(d), C.byref(self.fdesc), C.sizeof(d))
+        d.k = k
+        return d
+
+    def tail_desc(self, k):
+        t = hip.TailDesc()
+        t.k, t.d_model, t.C = k, self.d_model, self.C
+        t.ld_kp, t.ld_qp, t.ld_v = self.wk.ld_out[0], self.wq.ld_out[0], self.val.ld_out[-1]
+        t.score_act = hip.ACT[self.score_act]
+        t.normalize = int(self.normalize)
+        t.bkg_score = self.bkg_score
+        return t
+
+    def select(self, points, rays_o, rays_d, rays_per_image):
+        """Neighbour indices (R,k_eff) int32: kNN, or every point when select_k >= P or < 0
+        (reference models/model.py:326-329)."""
+        P = points.shape[0]
+        k = self.k_cfg
+        if k >= P or k < 0:
+            R = rays_d.shape[0]
+            return torch.arange(P, device=points.device, dtype=torch.int32).expand(R, P).contiguous()
+        if k > 63:
+            raise NotImplementedError("papr_amd: select_k=%d > 63 is not supported by the HIP kernels" % k)
+        return ray_knn(points, rays_o, rays_d, rays_per_image, k, self.eps)
+
+
+class _RenderFn(torch.autograd.Function):
+    """fused (R,C), attn (R,k+1) = path(points, pc_feats, influ, effective weights; rays, idx)."""
+
+    @staticmethod
+    def forward(ctx, plan, rays_o, rays_d, rays_per_image, idx, points, pc_feats, influ, n_k, n_q, n_v, *wb):
+        lib = hip.lib()
+        R, k = idx.shape
+        M = R * k
+        if k > 63:
+            raise NotImplementedError("papr_amd: %d neighbours per ray > 63 is not supported by the HIP kernels" % k)
+        dev = points.device
+        keep = ctx.needs_input_grad[5] or ctx.needs_input_grad[6] or ctx.needs_input_grad[7] or any(ctx.needs_input_grad[11:])
+        # unpack effective weights: key MLP, w_k, query MLP, w_q, value MLP  (each: weights then biases)
+        it = iter(wb)
+        take = lambda n: [next(it) for _ in range(n)]
+        kw, kb = take(n_k), take(n_k)
+        wkw, wkb = take(1), take(1)
+        qw, qb = take(n_q), take(n_q)
+        wqw, wqb = take(1), take(1)
+        vw, vb = take(n_v), take(n_v)
+
+        fd = plan.feature_desc(k)
+        key_in = torch.empty((M, plan.key.ld_in), device=dev, dtype=torch.float32)
+        qry_in = torch.empty((R, plan.qry.ld_in), device=dev, dtype=torch.float32)
+        val_in = torch.empty((M, plan.val.ld_in), device=dev, dtype=torch.float32)
+        sel = torch.empty((M, 3), device=dev, dtype=torch.float32)
+        feats = pc_feats if plan.use_feats else None
+        hip.check(lib.papr_build_features_fwd(C.byref(fd), hip.ptr(points), hip.ptr(feats), hip.ptr(rays_o), hip.ptr(rays_d), R,
+                                              rays_per_image, hip.ptr(idx), hip.ptr(key_in), hip.ptr(qry_in), hip.ptr(val_in),
+                                              hip.ptr(sel), hip.stream_ptr()), "papr_build_features_fwd")
+        eps = plan.eps
+        kst = qst = kst2 = qst2 = None
+        if plan.kq_norm:
+            kst = rownorm_(key_in, plan.key_w, eps)
+            qst = rownorm_(qry_in, plan.qry_w, eps)
+        k_outs = mlp_forward(plan.key, kw, kb, key_in, M, keep)
+        q_outs = mlp_forward(plan.qry, qw, qb, qry_in, R, keep)
+        K, Q = k_outs[-1], q_outs[-1]
+        if plan.kq_norm:
+            kst2 = rownorm_(K, plan.key.d_out, eps)
+            qst2 = rownorm_(Q, plan.qry.d_out, eps)
+        kp = mlp_forward(plan.wk, wkw, wkb, K, M, True)[0]
+        qp = mlp_forward(plan.wq, wqw, wqb, Q, R, True)[0]
+        v_outs = mlp_forward(plan.val, vw, vb, val_in, M, keep)
+        V = v_outs[-1]
+        td = plan.tail_desc(k)
+        scores = torch.empty((R, k), device=dev, dtype=torch.float32)
+        attn = torch.empty((R, k + 1), device=dev, dtype=torch.float32)
+        fused = torch.empty((R, plan.C), device=dev, dtype=torch.float32)
+        hip.check(lib.papr_attn_tail_fwd(C.byref(td), hip.ptr(kp), hip.ptr(qp), hip.ptr(V), hip.ptr(influ), hip.ptr(idx), R,
+                                         hip.ptr(scores), hip.ptr(attn), hip.ptr(fused), hip.stream_ptr()), "papr_attn_tail_fwd")
+        ctx.plan, ctx.rpi, ctx.n = plan, rays_per_image, (n_k, n_q, n_v)
+        ctx.mark_non_differentiable(sel)
+        if keep:
+            ctx.saved = dict(rays_o=rays_o, rays_d=rays_d, idx=idx, points=points, influ=influ, key_in=key_in, qry_in=qry_in,
+                             val_in=val_in, kst=kst, qst=qst, kst2=kst2, qst2=qst2, k_outs=k_outs, q_outs=q_outs,
+                             v_outs=v_outs, kp=kp, qp=qp, scores=scores, attn=attn, wb=wb, P=points.shape[0],
+                             feat_shape=None if pc_feats is None else pc_feats.shape)
+        return fused, attn, sel
+
+    @staticmethod
+    def backward(ctx, d_fused, d_attn, _d_sel):
+        lib = hip.lib()
+        plan, s = ctx.plan, ctx.saved
+        n_k, n_q, n_v = ctx.n
+        idx = s["idx"]
+        R, k = idx.shape
+        M = R * k
+        dev = idx.device
+        eps = plan.eps
+        it = iter(s["wb"])
+        take = lambda n: [next(it) for _ in range(n)]
+        kw, kb = take(n_k), take(n_k)
+        wkw, wkb = take(1), take(1)
+        qw, qb = take(n_q), take(n_q)
+        wqw, wqb = take(1), take(1)
+        vw, vb = take(n_v), take(n_v)
+        K, Q, V = s["k_outs"][-1], s["q_outs"][-1], s["v_outs"][-1]
+
+        td = plan.tail_desc(k)
+        d_kp = torch.empty_like(s["kp"])
+        d_qp = torch.empty_like(s["qp"])
+        d_V = torch.empty_like(V)
+        d_influ = torch.zeros((s["P"], 1), device=dev, dtype=torch.float32)
+        d_fused = d_fused.contiguous()
+        d_attn = d_attn.contiguous() if d_attn is not None else None
+        hip.check(lib.papr_attn_tail_bwd(C.byref(td), hip.ptr(s["kp"]), hip.ptr(s["qp"]), hip.ptr(V), hip.ptr(s["influ"]), hip.ptr(idx),
+                                         R, hip.ptr(s["scores"]), hip.ptr(s["attn"]), hip.ptr(d_fused), hip.ptr(d_attn), hip.ptr(d_kp),
+                                         hip.ptr(d_qp), hip.ptr(d_V), hip.ptr(d_influ), hip.stream_ptr()), "papr_attn_tail_bwd")
+        wmax = max(plan.key.width, plan.qry.width, plan.val.width, plan.key.ld_in, plan.val.ld_in, plan.d_model)
+        scratch = [torch.empty((M, wmax), device=dev, dtype=torch.float32) for _ in range(2)]
+        # key branch
+        d_wk, d_wkb, d_K = mlp_backward(plan.wk, wkw, wkb, K, M, [s["kp"]], d_kp, scratch, True)
+        if plan.kq_norm:
+            rownorm_bwd_(d_K, K, s["kst2"], plan.key.d_out, eps)
+        need_pts = ctx.needs_input_grad[5]
+        d_kw, d_kb, d_key = mlp_backward(plan.key, kw, kb, s["key_in"], M, s["k_outs"], d_K, scratch, need_pts)
+        if plan.kq_norm and d_key is not None:
+            rownorm_bwd_(d_key, s["key_in"], s["kst"], plan.key_w, eps)
+        # query branch (the ray directions need no gradient)
+        qscratch = [t[:R] for t in scratch]
+        d_wq, d_wqb, d_Q = mlp_backward(plan.wq, wqw, wqb, Q, R, [s["qp"]], d_qp, qscratch, True)
+        if plan.kq_norm:
+            rownorm_bwd_(d_Q, Q, s["qst2"], plan.qry.d_out, eps)
+        d_qw, d_qb, _ = mlp_backward(plan.qry, qw, qb, s["qry_in"], R, s["q_outs"], d_Q, qscratch, False)
+        # value branch
+        need_val_dx = need_pts or ctx.needs_input_grad[6]
+        d_vw, d_vb, d_val = mlp_backward(plan.val, vw, vb, s["val_in"], M, s["v_outs"], d_V, scratch, need_val_dx)
+        # gather / geometry / encoding backward
+        d_points = d_feats = None
+        if need_pts or ctx.needs_input_grad[6]:
+            d_points = torch.zeros((s["P"], 3), device=dev, dtype=torch.float32)
+            d_feats = torch.zeros(s["feat_shape"], device=dev, dtype=torch.float32) if plan.use_feats else None
+            fd = plan.feature_desc(k)
+            hip.check(lib.papr_build_features_bwd(C.byref(fd), hip.ptr(s["points"]), hip.ptr(s["rays_o"]), hip.ptr(s["rays_d"]), R,
+                                                  ctx.rpi, hip.ptr(idx), hip.ptr(d_key), hip.ptr(d_val), hip.ptr(d_points),
+                                                  hip.ptr(d_feats), hip.stream_ptr()), "papr_build_features_bwd")
+        ctx.saved = None
+        grads_wb = d_kw + d_kb + d_wk + d_wkb + d_qw + d_qb + d_wq + d_wqb + d_vw + d_vb
+        return (None, None, None, None, None, d_points, d_feats, d_influ, None, None, None) + tuple(grads_wb)
+
+
+def render_rays(plan, rays_o, rays_d, rays_per_image, idx, points, pc_feats, influ, weights):
+    """weights: dict with key/wk/query/wq/value -> (list of W, list of b) already prepared for the kernels."""
+    kw, kb = weights["key"]
+    qw, qb = weights["query"]
+    vw, vb = weights["value"]
+    flat = kw + kb + weights["wk"][0] + weights["wk"][1] + qw + qb + weights["wq"][0] + weights["wq"][1] + vw + vb
+    return _RenderFn.apply(plan, rays_o, rays_d, rays_per_image, idx, points, pc_feats, influ, len(kw), len(qw), len(vw), *flat)

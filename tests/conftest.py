@@ -1,0 +1,58 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+for p in (ROOT, GOLDEN):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a ROCm device (MI355X); run with -m gpu")
+
+
+def pytest_collection_modifyitems(config, items):
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no ROCm device visible")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+SMALL = {"geoms": {"points": {"init_num": 1000}}}
+TINY = {"geoms": {"points": {"init_num": 1000, "select_k": 12}},
+        "models": {"use_renderer": False, "attn": {"d_model": 64, "embed": {
+            "k_L": [4, 4, 4], "q_L": [4], "v_L": [4, 4],
+            "key": {"d_ff": 64, "d_ff_out": 64, "n_ff_layer": 3},
+            "query": {"d_ff": 64, "d_ff_out": 64, "n_ff_layer": 3},
+            "value": {"d_ff": 64, "d_ff_out": 3, "n_ff_layer": 4}}}}}
+PARITY = {"use_amp": False, "training": {"losses": {"mse": 1.0, "lpips": 0.0, "lpips_alex": 0.0}}}
+
+CASES = {
+    "chair1k": ("nerfsyn/chair.yml", SMALL, dict(n_img=1, hw=16, seed=0)),
+    "lego1k": ("nerfsyn/lego.yml", SMALL, dict(n_img=1, hw=16, seed=0)),
+    "tiny_norender": ("nerfsyn/chair.yml", TINY, dict(n_img=2, hw=8, seed=4)),
+}
+
+
+def case_cfg(tag):
+    from papr_amd.config import load_config, deep_merge
+    scene, over, _ = CASES[tag]
+    cfg = load_config(scene, overrides=over)
+    return deep_merge(cfg, PARITY)
+
+
+def case_rays(tag):
+    from formula import synth_rays
+    r = CASES[tag][2]
+    return synth_rays(r["n_img"], r["hw"], r["hw"], seed=r["seed"])

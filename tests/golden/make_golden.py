@@ -1,0 +1,260 @@
+"""Generate the golden fixtures by running the REFERENCE (zvict/papr, pure Python) on CPU.
+
+Run only in the build container:   python tests/golden/make_golden.py
+It needs /root/reference (read-only) and writes tests/golden/*.npz / *.json.  Nothing from
+the reference is copied: the fixtures hold seeded inputs and the reference's numeric outputs.
+
+Process-local shims: stub modules for lpips/torchvision/imageio (absent,
+never touched by the render path) and an lr_scheduler wrapper that swallows the `verbose=`
+keyword removed from recent torch.
+"""
+import copy
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import yaml
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+sys.path.insert(0, HERE)
+sys.path.insert(0, REF)
+for name in ["lpips", "torchvision", "torchvision.models", "imageio"]:
+    sys.modules[name] = types.ModuleType(name)
+sys.modules["torchvision"].models = sys.modules["torchvision.models"]
+import torch.optim.lr_scheduler as ls  # noqa: E402
+
+for n in ["LinearLR", "CosineAnnealingLR", "ExponentialLR", "StepLR", "SequentialLR"]:
+    c = getattr(ls, n)
+    o = c.__init__
+    c.__init__ = (lambda o: lambda self, *a, verbose=None, **k: o(self, *a, **k))(o)
+
+from utils import DictAsMember, update_dict, setup_seed  # noqa: E402  (reference utils.py)
+from models import get_model, get_loss  # noqa: E402
+from models.utils import posenc as ref_posenc  # noqa: E402
+from models.attn import LayerNorm as RefLayerNorm  # noqa: E402
+import train as ref_train  # noqa: E402
+
+from formula import formula_fill, synth_rays, uniform_points  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def load_cfg(scene, **over):
+    cfg = yaml.safe_load(open(REF + "/configs/default.yml"))
+    update_dict(cfg, yaml.safe_load(open(REF + "/configs/" + scene)))
+    cfg["use_amp"] = False
+    cfg["training"]["losses"] = {"mse": 1.0, "lpips": 0.0, "lpips_alex": 0.0}
+    update_dict(cfg, over)
+    return cfg
+
+
+def build(cfg):
+    setup_seed(1)
+    model = get_model(DictAsMember(copy.deepcopy(cfg)), "cpu")
+    formula_fill(model.state_dict())
+    return model
+
+
+def stats(t):
+    t = t.detach().double()
+    return np.array([t.sum().item(), t.abs().sum().item(), t.norm().item(), t.abs().max().item()])
+
+
+def npf(t):
+    return t.detach().cpu().numpy()
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrs)
+    print("wrote", name, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
+# ----------------------------------------------------------------------------------- G1/G2
+def g1_g2():
+    g = torch.Generator().manual_seed(11)
+    x = torch.cat([torch.randn(40, 3, generator=g) * 5.0,
+                   torch.tensor([[50.0, -49.5, 0.0], [1e-3, -1e-4, 12.0], [33.3, 41.7, -38.9]])])
+    out = {"x": npf(x)}
+    for L in (4, 6):
+        out["pe_L%d" % L] = npf(ref_posenc(x, L, 2.0, False, 1.0))
+        out["pe_L%d_noself" % L] = npf(ref_posenc(x, L, 2.0, True, 1.0))
+    for width in (39, 117, 256):
+        ln = RefLayerNorm(width, 1e-6)
+        xx = torch.randn(16, width, generator=g) * 3.0 + 0.5
+        with torch.no_grad():
+            ln.a_2.copy_(torch.rand(width, generator=g) + 0.5)
+            ln.b_2.copy_(torch.rand(width, generator=g) - 0.5)
+        out["ln%d_x" % width] = npf(xx)
+        out["ln%d_a" % width] = npf(ln.a_2)
+        out["ln%d_b" % width] = npf(ln.b_2)
+        out["ln%d_y" % width] = npf(ln(xx))
+    save("g12_posenc_layernorm.npz", **out)
+
+
+# ----------------------------------------------------------------------------------- G3/G4
+def g3_g4(model):
+    out = {}
+    # (a) reference cube init, P=1000, 16x16 rays
+    pts = model.points.detach()
+    ro, rd, c2w = synth_rays(1, 16, 16, seed=0)
+    with torch.no_grad():
+        idx = model._calculate_global_distances(ro, rd, pts)
+        _, _, proj, D = model._calculate_distances(ro, rd, pts[idx], c2w)
+    out.update(a_points=npf(pts), a_idx=np.sort(npf(idx), axis=-1).astype(np.int32),
+               a_proj=npf(proj), a_D=npf(D), a_idx_raw=npf(idx).astype(np.int32))
+    # (b) P=10000 uniform cloud, 32x32 rays (inputs regenerated from seeds in the tests)
+    pts_b = uniform_points(10000, 12.0, seed=5)
+    ro, rd, _ = synth_rays(1, 32, 32, seed=3)
+    with torch.no_grad():
+        idx = model._calculate_global_distances(ro, rd, pts_b)
+    out.update(b_idx=np.sort(npf(idx), axis=-1).astype(np.int32), b_points_sum=stats(pts_b))
+    # (c) two images (two origins), 8x8 rays each, lattice cloud
+    ro, rd, _ = synth_rays(2, 8, 8, seed=7)
+    with torch.no_grad():
+        idx = model._calculate_global_distances(ro, rd, pts)
+    out.update(c_idx=np.sort(npf(idx), axis=-1).astype(np.int32))
+    # (d) un-normalised directions (the selection step must not renormalise)
+    ro, rd, _ = synth_rays(1, 8, 8, seed=9)
+    rd = rd * 1.7
+    with torch.no_grad():
+        idx = model._calculate_global_distances(ro, rd, pts)
+        _, _, proj, D = model._calculate_distances(ro, rd, pts[idx], None)
+    out.update(d_idx=np.sort(npf(idx), axis=-1).astype(np.int32), d_proj=npf(proj), d_D=npf(D),
+               d_idx_raw=npf(idx).astype(np.int32))
+    save("g34_knn_geometry.npz", **out)
+
+
+# ----------------------------------------------------------------------------------- G5-G7
+def model_case(tag, cfg, n_img=1, hw=16, ray_seed=0, keep_rows=64):
+    model = build(cfg)
+    ro, rd, c2w = synth_rays(n_img, hw, hw, seed=ray_seed)
+    out = {"points": npf(model.points)}
+    with torch.no_grad():
+        fused, attn = model.evaluate(ro, rd, c2w)
+        idx = model.select_k_ind.clone()
+    # intermediates of the attention block on the reference's own neighbour order
+    pts_sel, _ = model._get_points(ro, rd, c2w)
+    key, query, value, kx, qx, vx = model._get_kqv(ro, rd, pts_sel, c2w, idx)
+    with torch.no_grad():
+        k, q, v, scores = model.proximity_attn(key, query, value, kx, qx, vx)
+    kk = idx.shape[-1]
+    out.update(idx_raw=npf(idx).astype(np.int32),
+               fused=npf(fused.squeeze(-2)), attn=npf(attn.squeeze(-1)),
+               K_head=npf(k[:8]), Q_head=npf(q[:32, 0]), V_head=npf(v[:keep_rows]),
+               scores=npf(scores.reshape(-1, kk)),
+               K_stats=stats(k), Q_stats=stats(q), V_stats=stats(v))
+    # forward + gradients of mean((rgb-0.5)^2)
+    model.clear_grad()
+    rgb = model(ro, rd, c2w)
+    loss = torch.mean((rgb - 0.5) ** 2)
+    loss.backward()
+    out.update(rgb=npf(rgb), loss=np.array(loss.item()))
+    full = ("points", "points_influ_scores", "pc_feats", "bkg_feats",
+            "proximity_attn.embed.embed_k.innorm.a_2", "proximity_attn.embed.embed_k.innorm.b_2",
+            "proximity_attn.embed.embed_k.outnorm.a_2", "proximity_attn.embed.embed_q.outnorm.b_2",
+            "proximity_attn.embed.embed_k.mlp.model.1.weight", "proximity_attn.embed.embed_v.mlp.model.1.weight",
+            "proximity_attn.embed.embed_q.mlp.model.1.weight", "proximity_attn.embed.embed_v.mlp.model.11.weight",
+            "proximity_attn.attention_layer.w_q.bias", "proximity_attn.attention_layer.w_k.bias")
+    names, gstats = [], []
+    for name, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        names.append(name)
+        gstats.append(stats(p.grad))
+        if name in full or p.dim() == 1:
+            out["grad/" + name] = npf(p.grad)
+    out["grad_names"] = np.array(names)
+    out["grad_stats"] = np.stack(gstats)
+    save("g567_%s.npz" % tag, **out)
+    return model
+
+
+def g7_trajectory(cfg):
+    """Three reference train_step calls (models/model.py:439-460 + train.py:155-179)."""
+    model = build(cfg)
+    ro, rd, c2w = synth_rays(1, 16, 16, seed=0)
+    g = torch.Generator().manual_seed(21)
+    tgt = torch.rand((1, 16, 16, 3), generator=g)
+
+    class DS:
+        def get_c2w(self, i):
+            return c2w[0]
+
+    loss_fn = get_loss(cfg["training"]["losses"])
+    args = DictAsMember(copy.deepcopy(cfg))
+    losses = []
+    for step in range(3):
+        loss, _ = ref_train.train_step(step + 1, model, "cpu", DS(), ([0], None, tgt, rd, ro), loss_fn, args)
+        losses.append(loss)
+    sd = model.state_dict()
+    names = [n for n in sd if sd[n].is_floating_point()]
+    save("g7_trajectory.npz", losses=np.array(losses, dtype=np.float64), target=npf(tgt),
+         points_after=npf(sd["points"]), influ_after=npf(sd["points_influ_scores"]),
+         names=np.array(names), stats_after=np.stack([stats(sd[n]) for n in names]),
+         attn_lr=np.array(model.attn_lr), pts_lr=np.array(model.pts_lr))
+    print("trajectory", losses)
+
+
+def g8_manifest(model):
+    sd = model.state_dict()
+    man = {k: [list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in sd.items()}
+    man["__optimizers__"] = sorted(model.optimizers.keys())
+    n_attn = sum(p.numel() for p in model.proximity_attn.parameters())
+    n_rend = sum(p.numel() for p in model.renderer.parameters())
+    man["__counts__"] = {"attn": n_attn, "renderer": n_rend}
+    json.dump(man, open(os.path.join(HERE, "g8_manifest.json"), "w"), indent=0, sort_keys=True)
+    print("wrote g8_manifest.json", n_attn, n_rend)
+
+
+def g9_dp(cfg):
+    """2-image batch == mean of the two single-image gradients (the 2-rank DP oracle)."""
+    model = build(cfg)
+    ro, rd, c2w = synth_rays(2, 16, 16, seed=13)
+    g = torch.Generator().manual_seed(22)
+    tgt = torch.rand((2, 16, 16, 3), generator=g)
+    out = {"target": npf(tgt)}
+
+    def grads(sl):
+        model.clear_grad()
+        for p in model.parameters():
+            p.grad = None
+        rgb = model(ro[sl], rd[sl], c2w[sl])
+        loss = torch.mean((rgb - tgt[sl]) ** 2)
+        loss.backward()
+        return loss.item(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    for tag, sl in (("both", slice(0, 2)), ("img0", slice(0, 1)), ("img1", slice(1, 2))):
+        loss, gr = grads(sl)
+        out[tag + "/loss"] = np.array(loss)
+        out[tag + "/points"] = npf(gr["points"])
+        out[tag + "/influ"] = npf(gr["points_influ_scores"])
+        out[tag + "/wq_bias"] = npf(gr["proximity_attn.attention_layer.w_q.bias"])
+        out[tag + "/outc_bias"] = npf(gr["renderer.outc.conv.bias"])
+        names = sorted(gr)
+        out[tag + "/names"] = np.array(names)
+        out[tag + "/stats"] = np.stack([stats(gr[n]) for n in names])
+    save("g9_dp.npz", **out)
+
+
+if __name__ == "__main__":
+    small = {"geoms": {"points": {"init_num": 1000}}}
+    cfg1 = load_cfg("nerfsyn/chair.yml", **small)
+    g1_g2()
+    m = model_case("chair1k", cfg1)
+    g3_g4(m)
+    g8_manifest(build(load_cfg("nerfsyn/chair.yml")))
+    model_case("lego1k", load_cfg("nerfsyn/lego.yml", **small))
+    tiny = {"geoms": {"points": {"init_num": 1000, "select_k": 12}},
+            "models": {"use_renderer": False, "attn": {"d_model": 64, "embed": {
+                "k_L": [4, 4, 4], "q_L": [4], "v_L": [4, 4],
+                "key": {"d_ff": 64, "d_ff_out": 64, "n_ff_layer": 3},
+                "query": {"d_ff": 64, "d_ff_out": 64, "n_ff_layer": 3},
+                "value": {"d_ff": 64, "d_ff_out": 3, "n_ff_layer": 4}}}}}
+    model_case("tiny_norender", load_cfg("nerfsyn/chair.yml", **tiny), n_img=2, hw=8, ray_seed=4)
+    g7_trajectory(cfg1)
+    g9_dp(cfg1)

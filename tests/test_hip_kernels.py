@@ -1,0 +1,317 @@
+"""Kernel-level parity: every C-ABI entry point of libpapr_hip.so against the CPU oracle.
+
+All tests here need an MI355X (`-m gpu`).  Tolerances are fp32 round-off scaled to the magnitudes
+involved; index work (kNN) is compared exactly against the reference's golden index sets.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, case_cfg
+from formula import synth_rays, uniform_points
+from oracle import papr_oracle as O
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def test_library_loads_on_device():
+    from papr_amd import hip
+    assert hip.lib().papr_abi_version() == 1
+
+
+# ------------------------------------------------------------------------------------------- K1
+def _knn(points, ro, rd, k, eps=1e-6):
+    from papr_amd import ops
+    N, H, W, _ = rd.shape
+    idx, dist = ops.ray_knn(points.to(dev()), ro.to(dev()), rd.reshape(-1, 3).contiguous().to(dev()), H * W, k, eps, want_dist=True)
+    torch.cuda.synchronize()
+    return idx.cpu(), dist.cpu()
+
+
+def _check_knn(points, ro, rd, k, ref_sorted_sets):
+    idx, dist = _knn(points, ro, rd, k)
+    got = np.sort(idx.numpy(), -1)
+    ref = ref_sorted_sets.reshape(-1, k)
+    mism = (got != ref).any(-1)
+    # distances as the oracle computes them for the returned indices: must be ascending and equal
+    feat = O.ray_point_distance(points, ro, rd, 1e-6).reshape(-1, points.shape[0])
+    d_or = torch.gather(feat, 1, idx.long())
+    assert torch.all(d_or[:, 1:] >= d_or[:, :-1] - 1e-6), "kernel output not sorted by distance"
+    np.testing.assert_allclose(dist.numpy(), d_or.numpy(), rtol=2e-6, atol=1e-6)
+    if mism.any():
+        # a different set is only acceptable at an exact distance tie with the reference's k-th neighbour
+        kth_ref = torch.gather(feat, 1, T(ref).long()).max(-1).values
+        kth_got = d_or.max(-1).values
+        assert torch.equal(kth_ref[T(mism)], kth_got[T(mism)]), "kNN sets differ on %d rays (not ties)" % mism.sum()
+    return int(mism.sum())
+
+
+def test_knn_lattice_cloud_matches_reference_sets():
+    g = golden("g34_knn_geometry.npz")
+    pts = T(g["a_points"])
+    ro, rd, _ = synth_rays(1, 16, 16, seed=0)
+    assert _check_knn(pts, ro, rd, 20, g["a_idx"]) == 0
+
+
+def test_knn_10k_uniform_cloud_matches_reference_sets():
+    g = golden("g34_knn_geometry.npz")
+    pts = uniform_points(10000, 12.0, seed=5)
+    ro, rd, _ = synth_rays(1, 32, 32, seed=3)
+    assert _check_knn(pts, ro, rd, 20, g["b_idx"]) == 0
+
+
+def test_knn_two_origins_and_unnormalised_directions():
+    g = golden("g34_knn_geometry.npz")
+    pts = T(g["a_points"])
+    ro, rd, _ = synth_rays(2, 8, 8, seed=7)
+    assert _check_knn(pts, ro, rd, 20, g["c_idx"]) == 0
+    ro, rd, _ = synth_rays(1, 8, 8, seed=9)
+    assert _check_knn(pts, ro, rd * 1.7, 20, g["d_idx"]) == 0
+
+
+@pytest.mark.parametrize("P,k,hw", [(64, 64, 5), (65, 1, 3), (257, 7, 9), (30000, 20, 40), (1000, 33, 7)])
+def test_knn_ragged_sizes_against_oracle(P, k, hw):
+    pts = uniform_points(P, 12.0, seed=P + k)
+    ro, rd, _ = synth_rays(1, hw, hw, seed=P)
+    ref, _ = O.knn_select(pts, ro, rd, k, 1e-6)
+    _check_knn(pts, ro, rd, k, np.sort(ref.numpy(), -1))
+
+
+def test_knn_duplicate_points_tie_break_is_lowest_index():
+    pts = uniform_points(500, 12.0, seed=1)
+    pts = torch.cat([pts, pts[:100]])            # exact duplicates -> exact ties
+    ro, rd, _ = synth_rays(1, 6, 6, seed=2)
+    idx, dist = _knn(pts, ro, rd, 10)
+    assert torch.all(dist[:, 1:] >= dist[:, :-1])
+    feat = O.ray_point_distance(pts, ro, rd, 1e-6).reshape(-1, pts.shape[0])
+    kth = feat.topk(10, largest=False).values.max(-1).values
+    np.testing.assert_allclose(dist.max(-1).values.numpy(), kth.numpy(), rtol=2e-6)
+    # among equal distances the smaller point index comes first
+    same = dist[:, 1:] == dist[:, :-1]
+    assert torch.all(idx[:, 1:][same] > idx[:, :-1][same])
+
+
+def test_knn_rejects_bad_k():
+    from papr_amd import ops
+    pts = uniform_points(100, 1.0, seed=0).to(dev())
+    ro, rd, _ = synth_rays(1, 2, 2)
+    with pytest.raises(RuntimeError):
+        ops.ray_knn(pts, ro.to(dev()), rd.reshape(-1, 3).to(dev()), 4, 65, 1e-6)
+
+
+# ------------------------------------------------------------------------------------------- K2
+def _plan(tag):
+    from papr_amd.ops import RenderPath
+    cfg = case_cfg(tag)
+    return cfg, RenderPath(cfg)
+
+
+@pytest.mark.parametrize("tag", ["chair1k", "tiny_norender"])
+def test_features_forward_match_oracle(tag):
+    from papr_amd import hip
+    g = golden("g567_%s.npz" % tag)
+    cfg, plan = _plan(tag)
+    from conftest import case_rays
+    ro, rd, _ = case_rays(tag)
+    idx = T(g["idx_raw"]).long()
+    P = g["points"].shape[0]
+    st = {"points": T(g["points"]), "pc_feats": torch.randn(P, 64, generator=torch.Generator().manual_seed(3))}
+    key_o, qry_o, val_o, sel_o, _, _ = O.build_inputs(st, cfg, ro, rd, idx)
+    R, k = idx.reshape(-1, idx.shape[-1]).shape
+    fd = plan.feature_desc(k)
+    d = dev()
+    key = torch.empty((R * k, plan.key.ld_in), device=d)
+    qry = torch.empty((R, plan.qry.ld_in), device=d)
+    val = torch.empty((R * k, plan.val.ld_in), device=d)
+    sel = torch.empty((R * k, 3), device=d)
+    hip.check(hip.lib().papr_build_features_fwd(C.byref(fd), hip.ptr(st["points"].to(d)), hip.ptr(st["pc_feats"].to(d)),
+                                                hip.ptr(ro.to(d)), hip.ptr(rd.reshape(-1, 3).contiguous().to(d)), R, rd.shape[1] * rd.shape[2],
+                                                hip.ptr(idx.reshape(R, k).int().to(d)), hip.ptr(key), hip.ptr(qry), hip.ptr(val),
+                                                hip.ptr(sel), hip.stream_ptr()), "features_fwd")
+    torch.cuda.synchronize()
+    kw, qw, vw = plan.key_w, plan.qry_w, plan.val_w
+    assert torch.equal(sel.cpu(), sel_o.reshape(-1, 3))
+    # x, s, u reproduce the reference bit for bit; sin/cos differ by libm (<= 2 ulp of 1.0)
+    np.testing.assert_allclose(key.cpu()[:, :kw].numpy(), key_o.reshape(-1, kw).numpy(), rtol=0, atol=5e-7)
+    np.testing.assert_allclose(qry.cpu()[:, :qw].numpy(), qry_o.reshape(-1, qw).numpy(), rtol=0, atol=5e-7)
+    np.testing.assert_allclose(val.cpu()[:, :vw].numpy(), val_o.reshape(-1, vw).numpy(), rtol=0, atol=5e-7)
+    assert torch.all(key.cpu()[:, kw:] == 0) and torch.all(val.cpu()[:, vw:] == 0) and torch.all(qry.cpu()[:, qw:] == 0)
+    per = 1 + 2 * cfg["models"]["attn"]["embed"]["k_L"][1]
+    raw_cols = [3 * per + c * per for c in range(3)]     # the un-encoded s components inside the key row
+    assert torch.equal(key.cpu()[:, raw_cols], key_o.reshape(-1, kw)[:, raw_cols]), "s = r t must be bit-exact"
+
+
+def test_features_backward_matches_autograd():
+    from papr_amd import hip
+    tag = "chair1k"
+    g = golden("g567_%s.npz" % tag)
+    cfg, plan = _plan(tag)
+    from conftest import case_rays
+    ro, rd, _ = case_rays(tag)
+    idx = T(g["idx_raw"]).long()
+    P = g["points"].shape[0]
+    gen = torch.Generator().manual_seed(5)
+    st = {"points": T(g["points"]).clone().requires_grad_(True),
+          "pc_feats": torch.randn(P, 64, generator=gen).requires_grad_(True)}
+    key_o, _, val_o, _, _, _ = O.build_inputs(st, cfg, ro, rd, idx)
+    gk = torch.randn(key_o.shape, generator=gen)
+    gv = torch.randn(val_o.shape, generator=gen)
+    (key_o * gk).sum().add((val_o * gv).sum()).backward()
+    R, k = idx.reshape(-1, idx.shape[-1]).shape
+    d = dev()
+    fd = plan.feature_desc(k)
+    gk_p = torch.zeros((R * k, plan.key.ld_in)); gk_p[:, :plan.key_w] = gk.reshape(R * k, -1)
+    gv_p = torch.zeros((R * k, plan.val.ld_in)); gv_p[:, :plan.val_w] = gv.reshape(R * k, -1)
+    d_pts = torch.zeros((P, 3), device=d)
+    d_f = torch.zeros((P, 64), device=d)
+    hip.check(hip.lib().papr_build_features_bwd(C.byref(fd), hip.ptr(st["points"].detach().to(d)), hip.ptr(ro.to(d)),
+                                                hip.ptr(rd.reshape(-1, 3).contiguous().to(d)), R, rd.shape[1] * rd.shape[2],
+                                                hip.ptr(idx.reshape(R, k).int().to(d)), hip.ptr(gk_p.to(d)), hip.ptr(gv_p.to(d)),
+                                                hip.ptr(d_pts), hip.ptr(d_f), hip.stream_ptr()), "features_bwd")
+    torch.cuda.synchronize()
+    ref = st["points"].grad
+    np.testing.assert_allclose(d_pts.cpu().numpy(), ref.numpy(), rtol=0, atol=2e-4 * ref.abs().max().item())
+    np.testing.assert_allclose(d_f.cpu().numpy(), st["pc_feats"].grad.numpy(), rtol=0, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------- row norm
+@pytest.mark.parametrize("rows,width,ld", [(1000, 117, 120), (37, 39, 40), (513, 256, 256), (5, 600, 600)])
+def test_rownorm_forward_backward(rows, width, ld):
+    from papr_amd import ops
+    gen = torch.Generator().manual_seed(rows)
+    x = torch.randn(rows, width, generator=gen) * 3 + 0.7
+    x.requires_grad_(True)
+    ones, zeros = torch.ones(width), torch.zeros(width)
+    y_ref = O.custom_layernorm(x, ones, zeros, 1e-6)
+    gy = torch.randn(rows, width, generator=gen)
+    (y_ref * gy).sum().backward()
+    xp = torch.zeros(rows, ld); xp[:, :width] = x.detach()
+    xd = xp.to(dev())
+    stats = ops.rownorm_(xd, width, 1e-6)
+    np.testing.assert_allclose(xd.cpu()[:, :width].numpy(), y_ref.detach().numpy(), rtol=0, atol=3e-6)
+    gp = torch.zeros(rows, ld); gp[:, :width] = gy
+    gd = gp.to(dev())
+    ops.rownorm_bwd_(gd, xd, stats, width, 1e-6)
+    np.testing.assert_allclose(gd.cpu()[:, :width].numpy(), x.grad.numpy(), rtol=0, atol=3e-5 * x.grad.abs().max().item())
+
+
+# ------------------------------------------------------------------------------------------- K3
+def _ref_mlp(x, ws, bs, acts, skips, d_in):
+    h = x
+    for i, (w, b) in enumerate(zip(ws, bs)):
+        if i in skips:
+            h = torch.cat([h, x], -1)
+        h = torch.nn.functional.linear(h, w, b)
+        if acts[i] == "relu":
+            h = torch.relu(h)
+        elif acts[i] == "leakyrelu":
+            h = torch.nn.functional.leaky_relu(h, 0.2)
+    return h
+
+
+@pytest.mark.parametrize("M,d_in,width,d_out,n,act,skips", [
+    (1000, 117, 256, 256, 5, "relu", []),
+    (777, 142, 256, 32, 8, "leakyrelu", [5]),
+    (129, 39, 64, 3, 4, "relu", []),
+    (4100, 142, 128, 64, 3, "relu", [1]),
+    (33, 27, 256, 256, 2, "none", []),
+])
+def test_mlp_forward_backward_vs_torch(M, d_in, width, d_out, n, act, skips):
+    from papr_amd import ops
+    gen = torch.Generator().manual_seed(M)
+    ecfg = dict(n_ff_layer=n, d_ff=width, d_ff_out=d_out, norm="none", ff_act=act, ff_last_act="none", skip_layers=skips)
+    spec = ops.MlpSpec("t", d_in, ecfg)
+    ws, bs = [], []
+    for i in range(n):
+        fi = (d_in if i == 0 else width) + (d_in if i in skips else 0)
+        fo = d_out if i == n - 1 else width
+        ws.append(((torch.rand(fo, fi, generator=gen) * 2 - 1) * (6.0 / (fi + fo)) ** 0.5).requires_grad_(True))
+        bs.append(((torch.rand(fo, generator=gen) * 2 - 1) * 0.1).requires_grad_(True))
+    x = (torch.randn(M, d_in, generator=gen)).requires_grad_(True)
+    y_ref = _ref_mlp(x, ws, bs, [act] * (n - 1) + ["none"], skips, d_in)
+    gy = torch.randn(M, d_out, generator=gen)
+    (y_ref * gy).sum().backward()
+
+    d = dev()
+    wd = [w.detach().to(d).requires_grad_(True) for w in ws]
+    bd = [b.detach().to(d).requires_grad_(True) for b in bs]
+    ew, eb = ops.prepare_mlp_weights(spec, wd, bd)
+    xp = torch.zeros(M, spec.ld_in); xp[:, :d_in] = x.detach()
+    xd = xp.to(d)
+    outs = ops.mlp_forward(spec, [w.detach() for w in ew], [b.detach() for b in eb], xd, M, keep=True)
+    y = outs[-1].cpu()[:, :d_out]
+    np.testing.assert_allclose(y.numpy(), y_ref.detach().numpy(), rtol=0, atol=2e-5 * max(1.0, y_ref.abs().max().item()))
+    # inference mode (ping-pong buffers) gives the same numbers
+    outs2 = ops.mlp_forward(spec, [w.detach() for w in ew], [b.detach() for b in eb], xd, M, keep=False)
+    assert torch.equal(outs2[-1].cpu(), outs[-1].cpu())
+    gp = torch.zeros(M, spec.ld_out[-1]); gp[:, :d_out] = gy
+    wmax = max(width, spec.ld_in, spec.ld_out[-1])
+    scratch = [torch.empty((M, wmax), device=d) for _ in range(2)]
+    d_ws, d_bs, d_x = ops.mlp_backward(spec, [w.detach() for w in ew], [b.detach() for b in eb], xd, M, outs, gp.to(d), scratch, True)
+    torch.cuda.synchronize()
+    # chain the gradients of the effective weights back to the reference-shaped parameters
+    torch.autograd.backward(ew + eb, d_ws + d_bs)
+    for i in range(n):
+        sw = ws[i].grad.abs().max().item() + 1e-12
+        np.testing.assert_allclose(wd[i].grad.cpu().numpy(), ws[i].grad.numpy(), rtol=0, atol=3e-5 * sw, err_msg="dW%d" % i)
+        sb = bs[i].grad.abs().max().item() + 1e-12
+        np.testing.assert_allclose(bd[i].grad.cpu().numpy(), bs[i].grad.numpy(), rtol=0, atol=3e-5 * sb, err_msg="db%d" % i)
+    sx = x.grad.abs().max().item()
+    np.testing.assert_allclose(d_x.cpu()[:, :d_in].numpy(), x.grad.numpy(), rtol=0, atol=3e-5 * sx)
+
+
+# ------------------------------------------------------------------------------------------- K4
+@pytest.mark.parametrize("R,k,d_model,Cc,act,normalize", [(300, 20, 256, 32, "relu", True), (65, 12, 64, 3, "relu", True),
+                                                          (17, 1, 256, 32, "none", False), (40, 63, 128, 32, "leakyrelu", True)])
+def test_attention_tail_forward_backward(R, k, d_model, Cc, act, normalize):
+    from papr_amd import hip
+    gen = torch.Generator().manual_seed(R * k)
+    P = 500
+    kp = (torch.randn(R, k, d_model, generator=gen) * 0.7).requires_grad_(True)
+    qp = (torch.randn(R, 1, d_model, generator=gen) * 0.7).requires_grad_(True)
+    ldv = (Cc + 31) // 32 * 32
+    v = torch.randn(R, k, Cc, generator=gen).requires_grad_(True)
+    influ = (torch.rand(P, 1, generator=gen) * 1.2 - 0.2).requires_grad_(True)
+    idx = torch.randint(0, P, (R, k), generator=gen)
+    bkg = 3.0
+    sc = torch.matmul(qp, kp.transpose(-2, -1)).squeeze(1) / d_model ** 0.5
+    sc = O._act(sc, act)
+    fused_ref, attn_ref = O.attention_tail(sc, influ[idx].squeeze(-1), v, bkg, normalize)
+    gf = torch.randn(R, Cc, generator=gen)
+    ga = torch.randn(R, k + 1, generator=gen)
+    ((fused_ref * gf).sum() + (attn_ref * ga).sum()).backward()
+
+    d = dev()
+    td = hip.TailDesc()
+    td.k, td.d_model, td.C, td.ld_kp, td.ld_qp, td.ld_v = k, d_model, Cc, d_model, d_model, ldv
+    td.score_act, td.normalize, td.bkg_score = hip.ACT[act], int(normalize), bkg
+    kpd = kp.detach().reshape(R * k, d_model).to(d)
+    qpd = qp.detach().reshape(R, d_model).to(d)
+    vp = torch.zeros(R * k, ldv); vp[:, :Cc] = v.detach().reshape(R * k, Cc)
+    vd = vp.to(d)
+    infd, idxd = influ.detach().to(d), idx.int().to(d)
+    scores = torch.empty((R, k), device=d); attn = torch.empty((R, k + 1), device=d); fused = torch.empty((R, Cc), device=d)
+    hip.check(hip.lib().papr_attn_tail_fwd(C.byref(td), hip.ptr(kpd), hip.ptr(qpd), hip.ptr(vd), hip.ptr(infd), hip.ptr(idxd), R,
+                                           hip.ptr(scores), hip.ptr(attn), hip.ptr(fused), hip.stream_ptr()), "tail_fwd")
+    np.testing.assert_allclose(scores.cpu().numpy(), sc.detach().numpy(), rtol=0, atol=5e-6)
+    np.testing.assert_allclose(attn.cpu().numpy(), attn_ref.detach().numpy(), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(fused.cpu().numpy(), fused_ref.detach().numpy(), rtol=0, atol=1e-5)
+    d_kp = torch.empty_like(kpd); d_qp = torch.empty_like(qpd); d_v = torch.empty_like(vd)
+    d_inf = torch.zeros((P, 1), device=d)
+    hip.check(hip.lib().papr_attn_tail_bwd(C.byref(td), hip.ptr(kpd), hip.ptr(qpd), hip.ptr(vd), hip.ptr(infd), hip.ptr(idxd), R,
+                                           hip.ptr(scores), hip.ptr(attn), hip.ptr(gf.to(d)), hip.ptr(ga.to(d)), hip.ptr(d_kp),
+                                           hip.ptr(d_qp), hip.ptr(d_v), hip.ptr(d_inf), hip.stream_ptr()), "tail_bwd")
+    torch.cuda.synchronize()
+    tol = lambda ref: 3e-5 * ref.abs().max().item() + 1e-9
+    np.testing.assert_allclose(d_kp.cpu().numpy(), kp.grad.reshape(R * k, -1).numpy(), rtol=0, atol=tol(kp.grad))
+    np.testing.assert_allclose(d_qp.cpu().numpy(), qp.grad.reshape(R, -1).numpy(), rtol=0, atol=tol(qp.grad))
+    np.testing.assert_allclose(d_v.cpu()[:, :Cc].numpy(), v.grad.reshape(R * k, -1).numpy(), rtol=0, atol=tol(v.grad))
+    assert torch.all(d_v.cpu()[:, Cc:] == 0)
+    np.testing.assert_allclose(d_inf.cpu().numpy(), influ.grad.numpy(), rtol=0, atol=tol(influ.grad))
