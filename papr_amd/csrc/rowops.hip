@@ -83,7 +83,11 @@ __global__ __launch_bounds__(256) void rownorm_bwd_kernel(const float* dy, const
 // reduced with wave shuffles; the C-wide weighted sum puts one output channel on each lane.
 // Reference: models/attn.py:217-225 (+:54) and models/model.py:519-534.
 
-__device__ __forceinline__ float bcast(float v, int src) { return __shfl(v, src, 64); }
+// value of lane `src` (wave-uniform index) in every lane.  v_readlane ignores EXEC, so this is safe
+// inside divergent code where a ds_bpermute shuffle would return 0 for masked-off source lanes.
+__device__ __forceinline__ float bcast(float v, int src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
+}
 
 __global__ __launch_bounds__(256) void tail_fwd_kernel(papr_tail_desc d, const float* __restrict__ kp,
                                                        const float* __restrict__ qp, const float* __restrict__ v,

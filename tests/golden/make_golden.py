@@ -211,6 +211,18 @@ def g8_manifest(model):
     print("wrote g8_manifest.json", n_attn, n_rend)
 
 
+def g8_init(cfg, name):
+    """Statistics of the reference's freshly initialised parameters under setup_seed(1)."""
+    setup_seed(1)
+    model = get_model(DictAsMember(copy.deepcopy(cfg)), "cpu")
+    sd = model.state_dict()
+    names = [n for n in sd if sd[n].is_floating_point()]
+    save(name, names=np.array(names), stats=np.stack([stats(sd[n]) for n in names]),
+         points=npf(sd["points"]), pc_feats_head=npf(sd["pc_feats"][:8]),
+         wk_head=npf(sd["proximity_attn.attention_layer.w_k.weight"][:4]),
+         inc_bias=npf(sd["renderer.inc.double_conv.0.bias"]))
+
+
 def g9_dp(cfg):
     """2-image batch == mean of the two single-image gradients (the 2-rank DP oracle)."""
     model = build(cfg)
@@ -244,6 +256,10 @@ def g9_dp(cfg):
 if __name__ == "__main__":
     small = {"geoms": {"points": {"init_num": 1000}}}
     cfg1 = load_cfg("nerfsyn/chair.yml", **small)
+    if "--init-only" in sys.argv:
+        g8_init(cfg1, "g8_init_chair1k.npz")
+        g8_init(load_cfg("nerfsyn/lego.yml", **small), "g8_init_lego1k.npz")
+        sys.exit(0)
     g1_g2()
     m = model_case("chair1k", cfg1)
     g3_g4(m)
@@ -258,3 +274,5 @@ if __name__ == "__main__":
     model_case("tiny_norender", load_cfg("nerfsyn/chair.yml", **tiny), n_img=2, hw=8, ray_seed=4)
     g7_trajectory(cfg1)
     g9_dp(cfg1)
+    g8_init(cfg1, "g8_init_chair1k.npz")
+    g8_init(load_cfg("nerfsyn/lego.yml", **small), "g8_init_lego1k.npz")

@@ -30,7 +30,8 @@ def test_library_loads_on_device():
 def _knn(points, ro, rd, k, eps=1e-6):
     from papr_amd import ops
     N, H, W, _ = rd.shape
-    idx, dist = ops.ray_knn(points.to(dev()), ro.to(dev()), rd.reshape(-1, 3).contiguous().to(dev()), H * W, k, eps, want_dist=True)
+    p_d, ro_d, rd_d = points.to(dev()), ro.to(dev()), rd.reshape(-1, 3).contiguous().to(dev())
+    idx, dist = ops.ray_knn(p_d, ro_d, rd_d, H * W, k, eps, want_dist=True)
     torch.cuda.synchronize()
     return idx.cpu(), dist.cpu()
 
@@ -131,9 +132,11 @@ def test_features_forward_match_oracle(tag):
     qry = torch.empty((R, plan.qry.ld_in), device=d)
     val = torch.empty((R * k, plan.val.ld_in), device=d)
     sel = torch.empty((R * k, 3), device=d)
-    hip.check(hip.lib().papr_build_features_fwd(C.byref(fd), hip.ptr(st["points"].to(d)), hip.ptr(st["pc_feats"].to(d)),
-                                                hip.ptr(ro.to(d)), hip.ptr(rd.reshape(-1, 3).contiguous().to(d)), R, rd.shape[1] * rd.shape[2],
-                                                hip.ptr(idx.reshape(R, k).int().to(d)), hip.ptr(key), hip.ptr(qry), hip.ptr(val),
+    # keep every device tensor alive in a local: a temporary would be freed (and reused) before the launch
+    pts_d, f_d, ro_d, rd_d = st["points"].to(d), st["pc_feats"].to(d), ro.to(d), rd.reshape(-1, 3).contiguous().to(d)
+    idx_d = idx.reshape(R, k).int().to(d)
+    hip.check(hip.lib().papr_build_features_fwd(C.byref(fd), hip.ptr(pts_d), hip.ptr(f_d), hip.ptr(ro_d), hip.ptr(rd_d), R,
+                                                rd.shape[1] * rd.shape[2], hip.ptr(idx_d), hip.ptr(key), hip.ptr(qry), hip.ptr(val),
                                                 hip.ptr(sel), hip.stream_ptr()), "features_fwd")
     torch.cuda.synchronize()
     kw, qw, vw = plan.key_w, plan.qry_w, plan.val_w
@@ -171,14 +174,16 @@ def test_features_backward_matches_autograd():
     gv_p = torch.zeros((R * k, plan.val.ld_in)); gv_p[:, :plan.val_w] = gv.reshape(R * k, -1)
     d_pts = torch.zeros((P, 3), device=d)
     d_f = torch.zeros((P, 64), device=d)
-    hip.check(hip.lib().papr_build_features_bwd(C.byref(fd), hip.ptr(st["points"].detach().to(d)), hip.ptr(ro.to(d)),
-                                                hip.ptr(rd.reshape(-1, 3).contiguous().to(d)), R, rd.shape[1] * rd.shape[2],
-                                                hip.ptr(idx.reshape(R, k).int().to(d)), hip.ptr(gk_p.to(d)), hip.ptr(gv_p.to(d)),
-                                                hip.ptr(d_pts), hip.ptr(d_f), hip.stream_ptr()), "features_bwd")
+    pts_d, ro_d, rd_d = st["points"].detach().to(d), ro.to(d), rd.reshape(-1, 3).contiguous().to(d)
+    idx_d, gk_d, gv_d = idx.reshape(R, k).int().to(d), gk_p.to(d), gv_p.to(d)
+    hip.check(hip.lib().papr_build_features_bwd(C.byref(fd), hip.ptr(pts_d), hip.ptr(ro_d), hip.ptr(rd_d), R, rd.shape[1] * rd.shape[2],
+                                                hip.ptr(idx_d), hip.ptr(gk_d), hip.ptr(gv_d), hip.ptr(d_pts), hip.ptr(d_f),
+                                                hip.stream_ptr()), "features_bwd")
     torch.cuda.synchronize()
     ref = st["points"].grad
     np.testing.assert_allclose(d_pts.cpu().numpy(), ref.numpy(), rtol=0, atol=2e-4 * ref.abs().max().item())
-    np.testing.assert_allclose(d_f.cpu().numpy(), st["pc_feats"].grad.numpy(), rtol=0, atol=1e-5)
+    fref = st["pc_feats"].grad          # sums of up to a few hundred N(0,1) terms, atomics add in any order
+    np.testing.assert_allclose(d_f.cpu().numpy(), fref.numpy(), rtol=0, atol=3e-6 * fref.abs().max().item())
 
 
 # ------------------------------------------------------------------------------------- row norm
@@ -254,7 +259,8 @@ def test_mlp_forward_backward_vs_torch(M, d_in, width, d_out, n, act, skips):
     gp = torch.zeros(M, spec.ld_out[-1]); gp[:, :d_out] = gy
     wmax = max(width, spec.ld_in, spec.ld_out[-1])
     scratch = [torch.empty((M, wmax), device=d) for _ in range(2)]
-    d_ws, d_bs, d_x = ops.mlp_backward(spec, [w.detach() for w in ew], [b.detach() for b in eb], xd, M, outs, gp.to(d), scratch, True)
+    gp_d = gp.to(d)
+    d_ws, d_bs, d_x = ops.mlp_backward(spec, [w.detach() for w in ew], [b.detach() for b in eb], xd, M, outs, gp_d, scratch, True)
     torch.cuda.synchronize()
     # chain the gradients of the effective weights back to the reference-shaped parameters
     torch.autograd.backward(ew + eb, d_ws + d_bs)
@@ -305,8 +311,9 @@ def test_attention_tail_forward_backward(R, k, d_model, Cc, act, normalize):
     np.testing.assert_allclose(fused.cpu().numpy(), fused_ref.detach().numpy(), rtol=0, atol=1e-5)
     d_kp = torch.empty_like(kpd); d_qp = torch.empty_like(qpd); d_v = torch.empty_like(vd)
     d_inf = torch.zeros((P, 1), device=d)
+    gf_d, ga_d = gf.to(d), ga.to(d)
     hip.check(hip.lib().papr_attn_tail_bwd(C.byref(td), hip.ptr(kpd), hip.ptr(qpd), hip.ptr(vd), hip.ptr(infd), hip.ptr(idxd), R,
-                                           hip.ptr(scores), hip.ptr(attn), hip.ptr(gf.to(d)), hip.ptr(ga.to(d)), hip.ptr(d_kp),
+                                           hip.ptr(scores), hip.ptr(attn), hip.ptr(gf_d), hip.ptr(ga_d), hip.ptr(d_kp),
                                            hip.ptr(d_qp), hip.ptr(d_v), hip.ptr(d_inf), hip.stream_ptr()), "tail_bwd")
     torch.cuda.synchronize()
     tol = lambda ref: 3e-5 * ref.abs().max().item() + 1e-9

@@ -1,0 +1,210 @@
+"""Host-side behaviour of papr_amd.PAPR that needs no GPU: construction, state-dict surface,
+initialisation stream, optimizers/schedules, prune/add, checkpoints, config merge, C-ABI exports."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, ROOT, case_cfg, golden
+
+
+def seed_all(s):
+    import random
+    torch.manual_seed(s)
+    np.random.seed(s)
+    random.seed(s)
+
+
+def build(tag="chair1k", seed=1):
+    from papr_amd import get_model
+    seed_all(seed)
+    return get_model(case_cfg(tag), device="cpu")
+
+
+def stats(t):
+    t = t.detach().double()
+    return np.array([t.sum().item(), t.abs().sum().item(), t.norm().item(), t.abs().max().item()])
+
+
+def test_state_dict_matches_reference_manifest():
+    from papr_amd import get_model, load_config
+    man = json.load(open(os.path.join(GOLDEN, "g8_manifest.json")))
+    seed_all(1)
+    m = get_model(load_config("nerfsyn/chair.yml", overrides={"training": {"losses": {"lpips": 0.0}}}), device="cpu")
+    sd = m.state_dict()
+    ref = {k: v for k, v in man.items() if not k.startswith("__")}
+    assert list(sd.keys()) == list(dict(sorted(ref.items())).keys()) or set(sd.keys()) == set(ref.keys())
+    for k, (shape, dtype) in ref.items():
+        assert list(sd[k].shape) == shape, k
+        assert str(sd[k].dtype).replace("torch.", "") == dtype, k
+    assert sorted(m.optimizers.keys()) == man["__optimizers__"]
+    assert sum(p.numel() for p in m.proximity_attn.parameters()) == man["__counts__"]["attn"]
+    assert sum(p.numel() for p in m.renderer.parameters()) == man["__counts__"]["renderer"]
+
+
+@pytest.mark.parametrize("tag", ["chair1k", "lego1k"])
+def test_initialisation_reproduces_reference_rng_stream(tag):
+    """Same seed -> the same initial parameters as the reference (same construction order)."""
+    g = golden("g8_init_%s.npz" % tag)
+    m = build(tag)
+    sd = m.state_dict()
+    np.testing.assert_array_equal(sd["points"].numpy(), g["points"])
+    np.testing.assert_array_equal(sd["pc_feats"][:8].numpy(), g["pc_feats_head"])
+    np.testing.assert_array_equal(sd["proximity_attn.attention_layer.w_k.weight"][:4].numpy(), g["wk_head"])
+    np.testing.assert_array_equal(sd["renderer.inc.double_conv.0.bias"].numpy(), g["inc_bias"])
+    for name, ref in zip(g["names"], g["stats"]):
+        np.testing.assert_allclose(stats(sd[str(name)]), ref, rtol=1e-12, atol=0, err_msg=str(name))
+
+
+def test_forward_without_device_fails_loudly():
+    from formula import synth_rays
+    m = build()
+    ro, rd, c2w = synth_rays(1, 4, 4)
+    with pytest.raises(RuntimeError, match="no CPU"):
+        m(ro, rd, c2w)
+    with pytest.raises(RuntimeError, match="no CPU"):
+        m.evaluate(ro, rd, c2w)
+
+
+def test_schedules_follow_reference_trajectory():
+    """lr sequence of torch's SequentialLR objects == closed form == reference golden lrs."""
+    from papr_amd.schedule import lr_at
+    g = golden("g7_trajectory.npz")
+    m = build()
+    cfg = case_cfg("chair1k")
+    lr = cfg["training"]["lr"]
+    key = {"points": "points", "attn": "attn", "points_influ_scores": "points_influ_scores", "pc_feats": "feats",
+           "renderer": "generator"}
+    for step in range(4):
+        for name, opt in m.optimizers.items():
+            want = lr_at(lr[key[name]], cfg["training"]["steps"], step)
+            assert opt.param_groups[0]["lr"] == pytest.approx(want, rel=1e-9, abs=1e-30), (name, step)
+        for p in m.parameters():
+            if p.requires_grad:
+                p.grad = torch.zeros_like(p)
+        m.step(step)
+    assert m.attn_lr == pytest.approx(lr_at(lr["attn"], cfg["training"]["steps"], 4), rel=1e-9)
+    # after the reference's 3 steps its recorded lrs are those of scheduler epoch 3
+    m2 = build()
+    for step in range(3):
+        for p in m2.parameters():
+            if p.requires_grad:
+                p.grad = torch.zeros_like(p)
+        m2.step(step)
+    assert m2.attn_lr == pytest.approx(float(g["attn_lr"]), rel=1e-9)
+    assert m2.pts_lr == pytest.approx(float(g["pts_lr"]), rel=1e-9)
+
+
+def test_init_optimizers_fast_forward_equals_stepping():
+    m = build()
+    for step in range(25):
+        for s in m.schedulers.values():
+            s.step()
+    lrs = {n: o.param_groups[0]["lr"] for n, o in m.optimizers.items()}
+    m.clear_optimizer(); m.clear_scheduler()
+    m.init_optimizers(25)
+    for n, o in m.optimizers.items():
+        assert o.param_groups[0]["lr"] == pytest.approx(lrs[n], rel=1e-12)
+
+
+def test_prune_keeps_strictly_greater_and_drops_untouched_points():
+    m = build()
+    with torch.no_grad():
+        m.points_influ_scores[:10] = 0.5
+        m.points_influ_scores[10:20] = -0.1
+    old_pts = m.points.data.clone()
+    n = m.prune_points(0.0)           # influence init is exactly 0.0: `0 > 0` is false -> pruned
+    assert int(n) == 990 and m.points.shape == (10, 3) and m.pc_feats.shape == (10, 64)
+    assert torch.equal(m.points.data, old_pts[:10])
+    assert isinstance(m.points, torch.nn.Parameter) and m.points.requires_grad
+
+
+def test_add_points_matches_reference_algorithm():
+    """Same numpy seed -> same new points as the reference's add_points_knn (restated in the test)."""
+    from scipy.spatial import KDTree
+    m = build()
+    P0 = m.points.shape[0]
+    pts = m.points.detach().clone().numpy()
+    np.random.seed(7)
+    n = m.add_points(50)
+    assert n == 50 and m.points.shape[0] == P0 + 50 and m.points_influ_scores.shape == (P0 + 50, 1)
+    # restate: sparsest sites by std of 10-NN distances, random convex combination of 3 neighbours
+    np.random.seed(7)
+    tree = KDTree(pts)
+    d, _ = tree.query(pts, k=10)
+    sites = np.argsort(d.std(axis=-1))[-50:]
+    _, nn = tree.query(pts[sites], k=4)
+    nn = nn[:, 1:]
+    w = np.random.uniform(0, 1, (50, 3)).astype(np.float32)
+    w /= w.sum(-1, keepdims=True)
+    want = (pts[nn] * w[..., None]).sum(-2)
+    np.testing.assert_allclose(m.points.detach().numpy()[P0:], want, rtol=0, atol=1e-6)
+    assert torch.equal(m.points.detach()[:P0], torch.from_numpy(pts))
+
+
+def test_save_load_roundtrip_with_changed_point_count(tmp_path):
+    m = build()
+    with torch.no_grad():
+        m.points_influ_scores[:300] = 1.0
+    m.prune_points(0.0)
+    m.save(1234, str(tmp_path))
+    for f in ("model.pth", "optimizers.pth", "schedulers.pth", "scaler.pth"):
+        assert (tmp_path / f).exists()
+    ck = torch.load(tmp_path / "model.pth")
+    assert list(ck.keys()) == ["1234"]
+    m2 = build(seed=5)
+    assert m2.points.shape[0] == 1000
+    step = m2.load(str(tmp_path))
+    assert step == 1234 and m2.points.shape[0] == 300
+    for (k1, v1), (k2, v2) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2), k1
+
+
+def test_config_merge_semantics():
+    from papr_amd.config import load_config, deep_merge, eval_config, ConfigNode
+    cfg = load_config("nerfsyn/lego.yml")
+    assert cfg["geoms"]["background"]["constant"] == 3.0
+    assert cfg["models"]["attn"]["embed"]["value"]["skip_layers"] == [5]
+    assert cfg["models"]["attn"]["embed"]["key"]["ff_act"] == "leakyrelu"
+    assert cfg["test"]["datasets"][0]["path"].endswith("lego/") and cfg["test"]["datasets"][0]["mode"] == "test"
+    base = {"test": {"datasets": [{"name": "testset", "a": 1, "b": 2}]}}
+    deep_merge(base, {"test": {"datasets": [{"name": "testset", "b": 3}, {"name": "extra", "a": 9}]}})
+    assert base["test"]["datasets"] == [{"name": "testset", "a": 1, "b": 3}, {"name": "extra", "a": 9, "b": 3}]
+    ev = eval_config(load_config("nerfsyn/chair.yml"))
+    assert ev["dataset"]["mode"] == "test" and ev["dataset"]["extract_patch"] is False
+    node = ConfigNode(cfg)
+    assert node.geoms.points.select_k == 20 and "max_points" not in node
+
+
+def test_unsupported_options_fail_at_construction():
+    from papr_amd import get_model
+    from papr_amd.config import deep_merge
+    for over in ({"models": {"attn": {"embed": {"key": {"ff_act": "gelu"}}}}},
+                 {"models": {"attn": {"embed": {"value": {"use_wn": True}}}}},
+                 {"exposure_control": {"use": True}},
+                 {"models": {"renderer": {"generator": {"type": "mlp"}}}}):
+        cfg = deep_merge(case_cfg("chair1k"), over)
+        with pytest.raises(NotImplementedError):
+            get_model(cfg, device="cpu")
+    with pytest.raises(NotImplementedError):
+        from papr_amd import get_loss
+        get_loss({"mse": 1.0, "lpips": 0.01})
+
+
+def test_c_abi_library_exports_every_declared_symbol():
+    from papr_amd import hip
+    header = open(os.path.join(ROOT, "include", "papr_hip.h")).read()
+    declared = set(re.findall(r"\b(papr_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(hip.EXPORTS), declared ^ set(hip.EXPORTS)
+    assert os.path.exists(hip.LIB_PATH), "run __graft_entry__.build() first"
+    lib = ctypes.CDLL(hip.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    lib.papr_abi_version.restype = ctypes.c_int
+    assert lib.papr_abi_version() == 1
+    lib.papr_mlp_bwd_workspace_bytes.restype = ctypes.c_size_t
+    assert lib.papr_mlp_bwd_workspace_bytes() == 256 * (256 * 256 + 256) * 4
