@@ -152,6 +152,24 @@ int papr_attn_tail_bwd(const papr_tail_desc* d, const float* kp, const float* qp
                        const float* attn, const float* d_fused, const float* d_attn, float* d_kp,
                        float* d_qp, float* d_v, float* d_influ, papr_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Optional timing of the GEMM / kNN launches with HIP events recorded on the launch stream
+ * (used by bench.py for the live roofline figure; off by default, process-wide switch).
+ * kernel ids: 0 gemm_nt<128x256>  1 gemm_nt<128x128>  2 gemm_nt<256x64>  3 gemm_nt<256x32>
+ *             4 gemm_tn (split-M weight gradient)      5 ray_knn
+ */
+typedef struct {
+    int32_t kernel;
+    int32_t N, K;
+    int64_t M;      /* rows (rays for kernel 5, with N = points, K = k) */
+    float ms;       /* hipEventElapsedTime between the events bracketing the launch */
+} papr_profile_record;
+
+int papr_profile_enable(int on);
+/* Waits for the recorded events, writes up to `cap` records (oldest first), clears the log and
+ * returns the number of records that were pending. */
+int papr_profile_collect(papr_profile_record* out, int cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,5 +1,7 @@
 #include "papr_common.h"
 #include <stdarg.h>
+#include <mutex>
+#include <vector>
 
 static thread_local char g_err[512] = "";
 
@@ -12,3 +14,50 @@ void papr_set_error(const char* fmt, ...) {
 
 extern "C" const char* papr_last_error(void) { return g_err; }
 extern "C" int papr_abi_version(void) { return 1; }
+
+// ---- optional launch timing (diagnostics only; see papr_profile_enable in papr_hip.h) ----------
+namespace {
+struct Pending { papr_profile_record rec; hipEvent_t a, b; };
+std::mutex g_mu;
+std::vector<Pending> g_log;
+bool g_on = false;
+}  // namespace
+
+bool papr_prof_on() { return g_on; }
+
+void papr_prof_begin(int kernel, long M, int N, int K, hipStream_t s) {
+    Pending p;
+    p.rec.kernel = kernel; p.rec.M = M; p.rec.N = N; p.rec.K = K; p.rec.ms = 0.f;
+    (void)hipEventCreate(&p.a);
+    (void)hipEventCreate(&p.b);
+    (void)hipEventRecord(p.a, s);
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_log.push_back(p);
+}
+
+void papr_prof_end(hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_log.empty()) (void)hipEventRecord(g_log.back().b, s);
+}
+
+extern "C" int papr_profile_enable(int on) {
+    g_on = on != 0;
+    return 0;
+}
+
+extern "C" int papr_profile_collect(papr_profile_record* out, int cap) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int n = (int)g_log.size();
+    for (int i = 0; i < n; ++i) {
+        Pending& p = g_log[i];
+        (void)hipEventSynchronize(p.b);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, p.a, p.b);
+        p.rec.ms = ms;
+        if (out && i < cap) out[i] = p.rec;
+        (void)hipEventDestroy(p.a);
+        (void)hipEventDestroy(p.b);
+    }
+    g_log.clear();
+    return n;
+}

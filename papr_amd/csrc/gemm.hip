@@ -170,7 +170,10 @@ template <int BM, int BN, int TM, int TN>
 int launch_nt(const NTArgs& a, hipStream_t s) {
     dim3 grid((unsigned)((a.M + BM - 1) / BM), (unsigned)((a.N + BN - 1) / BN));
     size_t lds = (size_t)(BM + BN) * PITCH * sizeof(float);
+    const bool prof = papr_prof_on();
+    if (prof) papr_prof_begin(BN == 256 ? 0 : BN == 128 ? 1 : BN == 64 ? 2 : 3, a.M, a.N, a.K1 + (a.A2 ? a.K2 : 0), s);
     gemm_nt_kernel<BM, BN, TM, TN><<<grid, dim3(256), lds, s>>>(a);
+    if (prof) papr_prof_end(s);
     PAPR_CHECK_LAUNCH("gemm_nt");
     return 0;
 }
@@ -337,7 +340,10 @@ int gemm_tn(const float* G, long ldg, int N, const float* X, long ldx, int K, lo
     a.G = G; a.ldg = ldg; a.N = N; a.X = X; a.ldx = ldx; a.K = K; a.M = M; a.rows_per_slice = rows_per_slice;
     a.slab = static_cast<float*>(workspace);
     a.bias_slab = a.slab + (size_t)MAX_SLICES * SLAB * SLAB;
+    const bool prof = papr_prof_on();
+    if (prof) papr_prof_begin(4, M, N, K, s);
     gemm_tn_kernel<<<dim3(S), dim3(512), 2 * TN_ROWS * SLAB * sizeof(float), s>>>(a);
+    if (prof) papr_prof_end(s);
     PAPR_CHECK_LAUNCH("gemm_tn");
     slab_reduce_kernel<<<dim3(SLAB * SLAB / 4 / 256), dim3(256), 0, s>>>(a.slab, a.bias_slab, S, N, K, dW, ldw, db);
     PAPR_CHECK_LAUNCH("slab_reduce");

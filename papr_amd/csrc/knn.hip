@@ -144,7 +144,10 @@ extern "C" int papr_ray_knn(const float* points, int64_t P, const float* rays_o,
     PAPR_CHECK_LAUNCH("pack_rays");
     constexpr int T = 8, PPL = 4;
     long tiles = (R + T - 1) / T;
+    const bool prof = papr_prof_on();
+    if (prof) papr_prof_begin(5, R, (int)P, k, s);
     ray_knn_kernel<T, PPL><<<dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, s>>>(points, (int)P, rec, R, k, out_idx, out_dist);
+    if (prof) papr_prof_end(s);
     PAPR_CHECK_LAUNCH("ray_knn");
     return 0;
 }

@@ -18,7 +18,7 @@ EXPORTS = [
     "papr_abi_version", "papr_last_error", "papr_ray_knn_workspace_bytes", "papr_ray_knn",
     "papr_feature_widths", "papr_build_features_fwd", "papr_build_features_bwd",
     "papr_rownorm_fwd", "papr_rownorm_bwd", "papr_mlp_bwd_workspace_bytes", "papr_mlp_fwd", "papr_mlp_bwd",
-    "papr_attn_tail_fwd", "papr_attn_tail_bwd",
+    "papr_attn_tail_fwd", "papr_attn_tail_bwd", "papr_profile_enable", "papr_profile_collect",
 ]
 
 
@@ -33,6 +33,10 @@ class Layer(C.Structure):
     _fields_ = [("weight", C.c_void_p), ("weight_t", C.c_void_p), ("bias", C.c_void_p),
                 ("n_in", C.c_int32), ("n_out", C.c_int32), ("ldw", C.c_int32), ("ldwt", C.c_int32),
                 ("n_skip", C.c_int32), ("skip_col", C.c_int32), ("act", C.c_int32)]
+
+
+class ProfileRecord(C.Structure):
+    _fields_ = [("kernel", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("M", C.c_int64), ("ms", C.c_float)]
 
 
 class TailDesc(C.Structure):
@@ -74,6 +78,8 @@ def lib():
                                i32, C.POINTER(vp), C.POINTER(vp), vp, vp, vp]
     L.papr_attn_tail_fwd.argtypes = [C.POINTER(TailDesc), vp, vp, vp, vp, vp, i64, vp, vp, vp, vp]
     L.papr_attn_tail_bwd.argtypes = [C.POINTER(TailDesc), vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.papr_profile_enable.argtypes = [i32]
+    L.papr_profile_collect.argtypes = [C.POINTER(ProfileRecord), i32]
     for name in EXPORTS:
         getattr(L, name)  # every declared entry point must resolve
     _check_single_hip_runtime()
@@ -92,6 +98,17 @@ def _check_single_hip_runtime():
         return
     if len(seen) > 1:
         raise RuntimeError("papr_amd: two HIP runtimes are mapped (%s); device pointers would not be shared" % sorted(seen))
+
+
+def profile_enable(on):
+    lib().papr_profile_enable(1 if on else 0)
+
+
+def profile_collect(cap=65536):
+    """[(kernel, M, N, K, ms), ...] of the launches timed since the last call."""
+    buf = (ProfileRecord * cap)()
+    n = lib().papr_profile_collect(buf, cap)
+    return [(r.kernel, r.M, r.N, r.K, r.ms) for r in buf[:min(n, cap)]]
 
 
 def check(code, what):
