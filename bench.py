@@ -11,7 +11,7 @@ see papr_amd/data.py).  With N > 1 every rank renders its own patch (weak scalin
 averaged with one RCCL all-reduce inside PAPR.step().
 
 The JSON line also carries
-  roofline      the dominant kernel (gemm_nt<128x256>: embedding-MLP forward layers and data
+  roofline      the dominant kernel (gemm_nt<128x256 tile>: embedding-MLP forward layers and data
                 gradients), timed live with HIP events on the launch stream during the timed steps
   roofline_knn  the ray -> k-nearest-points kernel against its logical HBM byte count (north_star)
   cpu_baseline  the CPU oracle's train step (torch fp32, same math) on this host's cores, on a
@@ -70,7 +70,7 @@ def cpu_baseline(cfg, state, edge, steps):
     import copy
     cfg = copy.deepcopy(cfg)
     cfg["dataset"]["patches"] = {"height": edge, "width": edge, "max_patches": 1}
-    torch.set_num_threads(os.cpu_count())
+    torch.set_num_threads(min(os.cpu_count(), 16))   # 16 threads is the fastest setting on the 256-thread EPYC host (scripts/cpu_threads_sweep.py)
     data = SyntheticRayData(cfg["dataset"], n_views=8, seed=3, device="cpu")
     st = O.trainable_state({k: v.detach().cpu() for k, v in state.items()}, cfg)
     opts = O.make_optimizers(st, cfg)
@@ -171,8 +171,8 @@ def main():
         "config": {"workload": "configs/nerfsyn/chair.yml: P=%d points, one %dx%d patch (R=%d rays) per rank per step, k=%d, "
                                "U-Net head, MSE loss (LPIPS weight 0: VGG weights unavailable offline), use_amp=false"
                                % (P, H, W, R, k),
-                   "global_batch_rays": world * R, "parallelism": "dp%d" % world, "final_loss": float(loss)},
-        "roofline": {"kernel": "gemm_nt_kernel<128,256,4,2> (embedding-MLP forward + data-gradient GEMMs)",
+                   "global_batch_rays": world * R, "parallelism": "dp%d" % world, "final_loss": float(loss.detach())},
+        "roofline": {"kernel": "gemm_nt_kernel<128,256,2,2> (embedding-MLP forward + data-gradient GEMMs)",
                      "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                      "frac": achieved / FP32_MFMA_PEAK_TF, "traffic": traffic,
                      "launches": len(nt), "avg_launch_ms": ms / max(len(nt), 1),

@@ -12,7 +12,7 @@
 // fp32 parity mode: v_mfma_f32_32x32x2_f32 (exact fp32 products and accumulation, 256 FLOP/clk/CU,
 // 157 TFLOP/s peak).  An MFMA of this type occupies the matrix pipe for 64 cycles and needs only one
 // VGPR per operand, so LDS bandwidth is irrelevant; what matters is that every SIMD always has an
-// MFMA to issue.  gemm_nt therefore runs two 4-wave workgroups per CU (<=256 VGPRs, 55 KB LDS each):
+// MFMA to issue.  gemm_nt therefore runs two 8-wave workgroups per CU (128 VGPRs, 55 KB LDS each):
 // while one is in its global->LDS hand-over or its epilogue, the other keeps the matrix pipe busy.
 //
 // LDS layout for gemm_nt: row-major [rows][32 + 4] fp32 (144-byte rows).  A lane reads 4 consecutive
@@ -20,6 +20,7 @@
 // take k+4..k+7, so one 16-byte read per operand feeds 256 cycles of matrix work, and the 36-float
 // pitch maps the 16 lanes of a read group onto 16 distinct 4-bank slots (conflict-free).
 #include "papr_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -42,12 +43,14 @@ struct NTArgs {
 };
 
 template <int BM, int BN, int TM, int TN>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NTArgs p) {
+__global__ __launch_bounds__(64 * (BM / (32 * TM)) * (BN / (32 * TN)), (BM / (32 * TM)) * (BN / (32 * TN)) / 2)
+void gemm_nt_kernel(NTArgs p) {
     constexpr int WN = BN / (32 * TN);          // waves along n
     constexpr int WM = BM / (32 * TM);          // waves along m
-    static_assert(WM * WN == 4, "four waves per workgroup");
-    constexpr int A_LD = BM / 32;               // float4 loads per thread for the A slab
-    constexpr int W_LD = BN / 32;
+    constexpr int NTHR = 64 * WM * WN;          // 4 or 8 waves; two workgroups per CU either way
+    static_assert(WM * WN == 4 || WM * WN == 8, "four or eight waves per workgroup");
+    constexpr int A_LD = BM * 8 / NTHR;         // float4 loads per thread for the A slab
+    constexpr int W_LD = BN * 8 / NTHR;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                  // [BM][PITCH]
@@ -72,7 +75,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NTArgs p) {
         else { src = p.A2; ld = p.lda2; klim = p.K2; k0 = (kt - nt1) * BK; wcol = p.wcol2 + k0; }
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) {
-            int f = tid + 256 * i;
+            int f = tid + NTHR * i;
             int row = f >> 3, kq = (f & 7) * 4;
             long m = m0 + row;
             ra[i] = (m < p.M && k0 + kq < klim) ? *reinterpret_cast<const float4*>(src + m * ld + k0 + kq)
@@ -80,7 +83,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NTArgs p) {
         }
 #pragma unroll
         for (int i = 0; i < W_LD; ++i) {
-            int f = tid + 256 * i;
+            int f = tid + NTHR * i;
             int row = f >> 3, kq = (f & 7) * 4;
             int n = n0 + row;
             rw[i] = (n < p.N && k0 + kq < klim) ? *reinterpret_cast<const float4*>(p.W + (long)n * p.ldw + wcol + kq)
@@ -90,12 +93,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NTArgs p) {
     auto store_slab = [&]() {
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) {
-            int f = tid + 256 * i;
+            int f = tid + NTHR * i;
             *reinterpret_cast<float4*>(As + (f >> 3) * PITCH + (f & 7) * 4) = ra[i];
         }
 #pragma unroll
         for (int i = 0; i < W_LD; ++i) {
-            int f = tid + 256 * i;
+            int f = tid + NTHR * i;
             *reinterpret_cast<float4*>(Ws + (f >> 3) * PITCH + (f & 7) * 4) = rw[i];
         }
     };
@@ -140,27 +143,60 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NTArgs p) {
         }
     }
 
-    // epilogue: D[row = (e&3) + 8*(e>>2) + 4*(lane>>5)][col = lane&31]
+    // Epilogue.  The accumulator layout is D[row = (e&3) + 8*(e>>2) + 4*(lane>>5)][col = lane&31]: a
+    // lane owns one column, so direct stores would be 4-byte.  Each 32x32 tile is instead bounced
+    // through a per-wave LDS patch (free after the last barrier of the k loop) and leaves as 16-byte
+    // row segments: 4 store instructions per tile instead of 16, and the activation-derivative mask
+    // of the data-gradient / the old C of an accumulating call come in as 16-byte loads too.
+    constexpr int EP = 36;
+    float* patch = smem + wave * (32 * EP);
+    const float slope = p.act == PAPR_ACT_RELU ? 0.f : (p.act == PAPR_ACT_LEAKY_RELU ? 0.2f : 1.f);
+    const int pr = lane >> 3, pc = (lane & 7) * 4;     // this lane's (row, first column) inside a tile, +8 rows per step
+    const int wr_off = (4 * (lane >> 5)) * EP + (lane & 31);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
-        if (col >= p.N) continue;
-        const float b = (!p.dgrad && p.bias) ? p.bias[col] : 0.f;
+        const int col = n0 + (wn * TN + j) * 32 + pc;
+        const bool col_ok = col < p.N;
+        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!p.dgrad && p.bias && col_ok) b4 = *reinterpret_cast<const float4*>(p.bias + col);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                long row = m0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                if (row >= p.M) continue;
-                float v = acc[i][j][e];
-                if (p.dgrad) {
-                    if (p.mask_src) v *= papr_act_grad(p.mask_src[row * p.ld_mask + col], p.act);
-                } else {
-                    v = papr_act(v + b, p.act);
+            for (int e = 0; e < 16; ++e) patch[wr_off + ((e & 3) + 8 * (e >> 2)) * EP] = acc[i][j][e];
+            const long row0 = m0 + (wm * TM + i) * 32 + pr;
+            float4 v[4], aux[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v[t] = *reinterpret_cast<const float4*>(patch + (pr + 8 * t) * EP + pc);
+            const bool need_aux = p.dgrad ? (p.mask_src != nullptr) : false;
+            if (need_aux || p.accumulate) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const long row = row0 + 8 * t;
+                    const bool ok = col_ok && row < p.M;
+                    if (need_aux) {
+                        aux[t] = ok ? *reinterpret_cast<const float4*>(p.mask_src + row * p.ld_mask + col) : make_float4(1.f, 1.f, 1.f, 1.f);
+                    }
                 }
-                float* dst = p.C + row * p.ldc + col;
-                if (p.accumulate) v += *dst;
-                *dst = v;
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const long row = row0 + 8 * t;
+                if (!(col_ok && row < p.M)) continue;
+                float4 r = v[t];
+                if (p.dgrad) {
+                    if (need_aux) {
+                        r.x *= aux[t].x > 0.f ? 1.f : slope; r.y *= aux[t].y > 0.f ? 1.f : slope;
+                        r.z *= aux[t].z > 0.f ? 1.f : slope; r.w *= aux[t].w > 0.f ? 1.f : slope;
+                    }
+                } else {
+                    r.x += b4.x; r.y += b4.y; r.z += b4.z; r.w += b4.w;
+                    // (+0.f turns the -0 of a negative input times slope 0 into the +0 torch's relu returns)
+                    r.x = r.x > 0.f ? r.x : r.x * slope + 0.f; r.y = r.y > 0.f ? r.y : r.y * slope + 0.f;
+                    r.z = r.z > 0.f ? r.z : r.z * slope + 0.f; r.w = r.w > 0.f ? r.w : r.w * slope + 0.f;
+                }
+                float4* dst = reinterpret_cast<float4*>(p.C + row * p.ldc + col);
+                if (p.accumulate) { float4 o = *dst; r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w; }
+                *dst = r;
             }
         }
     }
@@ -172,17 +208,22 @@ int launch_nt(const NTArgs& a, hipStream_t s) {
     size_t lds = (size_t)(BM + BN) * PITCH * sizeof(float);
     const bool prof = papr_prof_on();
     if (prof) papr_prof_begin(BN == 256 ? 0 : BN == 128 ? 1 : BN == 64 ? 2 : 3, a.M, a.N, a.K1 + (a.A2 ? a.K2 : 0), s);
-    gemm_nt_kernel<BM, BN, TM, TN><<<grid, dim3(256), lds, s>>>(a);
+    gemm_nt_kernel<BM, BN, TM, TN><<<grid, dim3(64 * (BM / (32 * TM)) * (BN / (32 * TN))), lds, s>>>(a);
     if (prof) papr_prof_end(s);
     PAPR_CHECK_LAUNCH("gemm_nt");
     return 0;
 }
 
+// 8 waves x (64x64) beats 4 waves x (128x64) on the 128x256 tile: 586 vs 628 us per 512000x256x256
+// layer (4 waves per SIMD hide the slab hand-over and the epilogue better).  PAPR_NT_WAVES4 keeps the
+// old shape reachable for A/B runs.
+static const bool NT_WAVES4 = getenv("PAPR_NT_WAVES4") != nullptr;
+
 int gemm_nt(const NTArgs& a, hipStream_t s) {
     PAPR_REQUIRE(a.K1 % 4 == 0 && a.lda % 4 == 0 && a.ldw % 4 == 0, "gemm_nt: K1/lda/ldw must be multiples of 4 (%d,%ld,%d)", a.K1, a.lda, a.ldw);
     PAPR_REQUIRE(!a.A2 || (a.K2 % 4 == 0 && a.lda2 % 4 == 0 && a.wcol2 % 4 == 0), "gemm_nt: segment-2 sizes must be multiples of 4");
     if (a.M <= 0 || a.N <= 0) return 0;
-    if (a.N > 128) return launch_nt<128, 256, 4, 2>(a, s);
+    if (a.N > 128) return NT_WAVES4 ? launch_nt<128, 256, 4, 2>(a, s) : launch_nt<128, 256, 2, 2>(a, s);
     if (a.N > 64) return launch_nt<128, 128, 2, 2>(a, s);
     if (a.N > 32) return launch_nt<256, 64, 2, 2>(a, s);
     return launch_nt<256, 32, 2, 1>(a, s);
@@ -298,29 +339,45 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(TNArgs p) {
 }
 
 // dW[n][k] (ld) = sum_s slab[s][n][k] ;  db[n] = sum_s bias_slab[s][n]
+// One workgroup = 16 float4 elements x 16 slab groups: every thread sums S/16 slabs with independent
+// loads, then the 16 partial sums of an element meet in LDS.  (A thread-per-element loop over all S
+// slabs is a 256-deep dependent load chain on 64 workgroups: 113 us instead of ~10.)
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bias_slab,
                                                           int S, int N, int K, float* __restrict__ dW, int ldw,
                                                           float* __restrict__ db) {
-    int e = blockIdx.x * blockDim.x + threadIdx.x;   // one float4 of the 256x256 tile
-    if (e < SLAB * SLAB / 4) {
-        int n = e >> 6, k = (e & 63) * 4;
-        if (n < N && k < K) {
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int s = 0; s < S; ++s) {
-                float4 v = *reinterpret_cast<const float4*>(slab + (long)s * SLAB * SLAB + n * SLAB + k);
-                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-            }
-            float* dst = dW + (long)n * ldw + k;
-            dst[0] = acc.x;
-            if (k + 1 < K) dst[1] = acc.y;
-            if (k + 2 < K) dst[2] = acc.z;
-            if (k + 3 < K) dst[3] = acc.w;
+    __shared__ float4 part[16][17];
+    const int el = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int e = blockIdx.x * 16 + el;              // float4 index inside the 256x256 tile
+    const int n = e >> 6, k = (e & 63) * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n < N && k < K) {
+        for (int s = grp; s < S; s += 16) {
+            float4 v = *reinterpret_cast<const float4*>(slab + (long)s * SLAB * SLAB + n * SLAB + k);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
     }
-    if (db && e < N) {
-        float acc = 0.f;
-        for (int s = 0; s < S; ++s) acc += bias_slab[(long)s * SLAB + e];
-        db[e] = acc;
+    part[grp][el] = acc;
+    __syncthreads();
+    if (grp == 0 && n < N && k < K) {
+#pragma unroll
+        for (int g = 1; g < 16; ++g) { float4 v = part[g][el]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+        float* dst = dW + (long)n * ldw + k;
+        dst[0] = acc.x;
+        if (k + 1 < K) dst[1] = acc.y;
+        if (k + 2 < K) dst[2] = acc.z;
+        if (k + 3 < K) dst[3] = acc.w;
+    }
+    if (db && blockIdx.x < 16) {                      // bias: 256 columns, 16 per workgroup
+        const int c = blockIdx.x * 16 + el;
+        float b = 0.f;
+        if (c < N) for (int s = grp; s < S; s += 16) b += bias_slab[(long)s * SLAB + c];
+        __syncthreads();
+        part[grp][el].x = b;
+        __syncthreads();
+        if (grp == 0 && c < N) {
+            for (int g = 1; g < 16; ++g) b += part[g][el].x;
+            db[c] = b;
+        }
     }
 }
 
@@ -345,7 +402,7 @@ int gemm_tn(const float* G, long ldg, int N, const float* X, long ldx, int K, lo
     gemm_tn_kernel<<<dim3(S), dim3(512), 2 * TN_ROWS * SLAB * sizeof(float), s>>>(a);
     if (prof) papr_prof_end(s);
     PAPR_CHECK_LAUNCH("gemm_tn");
-    slab_reduce_kernel<<<dim3(SLAB * SLAB / 4 / 256), dim3(256), 0, s>>>(a.slab, a.bias_slab, S, N, K, dW, ldw, db);
+    slab_reduce_kernel<<<dim3(SLAB * SLAB / 4 / 16), dim3(256), 0, s>>>(a.slab, a.bias_slab, S, N, K, dW, ldw, db);
     PAPR_CHECK_LAUNCH("slab_reduce");
     return 0;
 }
