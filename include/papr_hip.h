@@ -36,11 +36,12 @@ const char* papr_last_error(void);
  *                                        (models/model.py:258-283): R x P distance tensors + topk.
  * points (P,3); rays_o (N,3); rays_d (R,3) with R = N * rays_per_image; ray r belongs to image
  * r / rays_per_image.  Distance = | v - d (v.d)/(d.d+eps) |, v = p - o, d used as given.
- * out_idx (R,k) int32, ascending distance, ties broken towards the smaller point index;
- * out_dist (R,k) or NULL.  Requires 1 <= k <= 64 and k <= P.
- * workspace: papr_ray_knn_workspace_bytes(R) bytes.
+ * out_idx (R,k) int32, ascending in (distance, point index); out_dist (R,k) or NULL.  When several
+ * points tie exactly at the k-th distance, which of them enters the set is unspecified but
+ * reproducible (the reference's topk(sorted=False) is unordered there too).
+ * Requires 1 <= k <= 64 and k <= P.  workspace: papr_ray_knn_workspace_bytes(R, P) bytes.
  */
-size_t papr_ray_knn_workspace_bytes(int64_t R);
+size_t papr_ray_knn_workspace_bytes(int64_t R, int64_t P);
 int papr_ray_knn(const float* points, int64_t P, const float* rays_o, const float* rays_d, int64_t R,
                  int64_t rays_per_image, int k, float eps, int32_t* out_idx, float* out_dist,
                  void* workspace, papr_stream_t stream);

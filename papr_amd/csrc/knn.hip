@@ -4,19 +4,30 @@
 // five R x P fp32 tensors and runs torch.topk over them.  Here nothing of size R x P ever exists.
 //
 // Work decomposition (wave64, one wave = one tile of T rays against ALL points):
-//   * the 64 lanes of a wave each hold PPL points of the current batch in VGPRs (coalesced loads
-//     of the xyz stream, 12 B/point); the batch is reused for all T rays of the tile, so the
-//     point stream is read once per T rays;
+//   * the 64 lanes of a wave each hold PPL points of the current batch in VGPRs (coalesced 16-byte
+//     loads of a {x,y,z,index} stream); the batch is reused for all T rays of the tile, so the point
+//     stream is read once per T rays;
 //   * the ray constants (origin, direction, d.d+eps and its reciprocal) are wave-uniform and come
 //     in through scalar loads (s_load -> SGPRs), so every VALU op has one VGPR and one SGPR operand;
-//   * each ray's running top list lives ACROSS the lanes of one VGPR (lane j = j-th nearest so
-//     far, +inf padded): a candidate test is one v_cmp + ballot against the k-th distance kept in
-//     an SGPR, and an insertion is ballot/popcount + a one-lane shift.  There is no per-lane
-//     divergence and no scratch: the list never leaves registers.
+//   * each ray's running k-set lives ACROSS the lanes of one VGPR pair (lanes 0..k-1, unordered);
+//     its largest member (the k-th distance so far) and the lane holding it sit in SGPRs.  A
+//     candidate test is one v_cmp + ballot against that SGPR; an insertion overwrites the max lane
+//     and re-derives the max with a 6-step DPP reduction -- pure VALU, no LDS, no divergence.  The
+//     set is ranked once at the end so the output is ascending in (distance, index);
+//   * the rays of a tile are neighbouring pixels, so only the first one pays for a cold start: the
+//     others start from its neighbour set (see ray_knn_kernel).
+//
+// The stream is a scattered copy of the cloud (position i holds point (i*A) mod P, A coprime to P,
+// written by a tiny pre-pass): an index-ordered walk over a lattice-initialised (or otherwise
+// spatially sorted) cloud approaches every ray monotonically and turns most points into
+// insertions; a scattered walk tightens the k-th distance after a few hundred points, leaving about
+// k (1 + ln(P/k)) insertions per ray.
 //
 // Arithmetic follows the reference formulation operation by operation (no FMA contraction, IEEE
-// division) so that near-tie neighbours resolve the same way: v = p - o; t = (v.d)/(d.d+eps);
-// D = v - d t; select on |D|^2 (sqrt is monotone; exact ties are unordered in the reference too).
+// division, torch.norm's fma chain) so that near-tie neighbours resolve the same way:
+// v = p - o; t = (v.d)/(d.d+eps); D = v - d t; select on |D|^2 (sqrt is monotone).  Exact ties at
+// the k-th distance are unordered in the reference (topk sorted=False); here the first one met in
+// the (fixed) stream order is kept, so results are reproducible run to run.
 #include "papr_common.h"
 
 namespace {
@@ -39,17 +50,97 @@ __global__ __launch_bounds__(256) void pack_rays_kernel(const float* __restrict_
     reinterpret_cast<float4*>(rec)[r * 2 + 1] = b;
 }
 
-__device__ __forceinline__ float lane_shift_up(float v) { return __shfl_up(v, 1, 64); }
-__device__ __forceinline__ int lane_shift_up(int v) { return __shfl_up(v, 1, 64); }
+// stream[i] = {xyz of point (i*mul) mod P, bit pattern of that index}
+__global__ __launch_bounds__(256) void scatter_points_kernel(const float* __restrict__ points, int P, int mul,
+                                                             float4* __restrict__ stream) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    int src = (int)(((long)i * mul) % P);
+    stream[i] = make_float4(points[src * 3 + 0], points[src * 3 + 1], points[src * 3 + 2], __int_as_float(src));
+}
 
 __device__ __forceinline__ float read_lane(float v, int lane) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
 
+// Squared distances are >= 0, so their bit patterns order like unsigned integers: the k-set is kept as
+// raw bits and reduced with v_max_u32, which takes a DPP operand directly (a float max would drag in
+// canonicalisation moves).  Identity 0 + bound_ctrl lets the compiler fold each step into one VALU op.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_umax(unsigned v) {
+    unsigned moved = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, true);
+    return v > moved ? v : moved;
+}
+
+// maximum over the 64 lanes, returned wave-uniform (gfx9 DPP: quad_perm, row_half_mirror, row_mirror,
+// row_bcast:15, row_bcast:31; the total lands in lane 63)
+__device__ __forceinline__ unsigned wave_umax(unsigned v) {
+    v = dpp_umax<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
+    v = dpp_umax<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
+    v = dpp_umax<0x141, 0xf>(v);   // row_half_mirror
+    v = dpp_umax<0x140, 0xf>(v);   // row_mirror
+    v = dpp_umax<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+    v = dpp_umax<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+struct RayK {   // wave-uniform ray constants (SGPRs)
+    float ox, oy, oz, dx, dy, dz, den, rcp;
+};
+
+// |D|^2 of point p for ray c, in the reference's operation order
+__device__ __forceinline__ float ray_dist2(const RayK& c, float px, float py, float pz) {
+    float vx = px - c.ox, vy = py - c.oy, vz = pz - c.oz;
+    float vd = (vx * c.dx + vy * c.dy) + vz * c.dz;
+    // correctly rounded vd / den from the exact reciprocal (one Newton step on the quotient)
+    float q0 = vd * c.rcp;
+    float rem = __builtin_fmaf(-q0, c.den, vd);
+    float tt = __builtin_fmaf(rem, c.rcp, q0);
+    float ex = vx - c.dx * tt, ey = vy - c.dy * tt, ez = vz - c.dz * tt;
+    // torch.norm accumulates its squares with an fma chain: fma(z,z, fma(y,y, x*x))
+    return __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
+}
+
+constexpr unsigned INF_BITS = 0x7f800000u;
+
+// One ray's k-set: lanes < k hold (distance bits, point index), unordered; lanes >= k hold 0 bits.
+struct KSet {
+    unsigned bits;   // per lane
+    int idx;         // per lane
+    unsigned thr;    // uniform: largest member = current k-th smallest
+    int tl;          // uniform: a lane holding it
+    __device__ __forceinline__ void refresh() {
+        thr = wave_umax(bits);
+        tl = __builtin_ctzll(__ballot(bits == thr));
+    }
+    // offer the candidates flagged in d2 < thr; DEDUP skips points that are already members (seeded sets)
+    template <bool DEDUP>
+    __device__ __forceinline__ void offer(float d2, int pidx, int lane) {
+        unsigned long long m = __ballot(__float_as_uint(d2) < thr);
+        while (m) {
+            int src = __builtin_ctzll(m);
+            m &= m - 1;
+            unsigned cb = (unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(d2), src);
+            if (cb < thr) {
+                int ci = __builtin_amdgcn_readlane(pidx, src);
+                if (DEDUP && __ballot(idx == ci) != 0) continue;
+                bool here = lane == tl;
+                bits = here ? cb : bits;
+                idx = here ? ci : idx;
+                refresh();
+            }
+        }
+    }
+};
+
+// Phase A finds ray 0's neighbours by streaming the whole cloud.  The other T-1 rays of the tile are
+// adjacent pixels: their k-sets are SEEDED with ray 0's neighbours (exact distances recomputed per
+// ray), which puts their thresholds within a few percent of final before the stream starts, so phase
+// B performs a handful of insertions per ray instead of ~k(1 + ln(P/k)).  Exactness does not depend
+// on the seed: any closer point met in the stream still replaces the current maximum.
 template <int T, int PPL>
-__global__ __launch_bounds__(256) void ray_knn_kernel(const float* __restrict__ points, int P,
-                                                      const float* rec, long R, int k,
-                                                      int* __restrict__ out_idx,
+__global__ __launch_bounds__(256) void ray_knn_kernel(const float4* __restrict__ stream, const float* __restrict__ points,
+                                                      int P, const float* rec, long R, int k, int* __restrict__ out_idx,
                                                       float* __restrict__ out_dist) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -58,77 +149,91 @@ __global__ __launch_bounds__(256) void ray_knn_kernel(const float* __restrict__ 
     if (r0 >= R) return;
 
     cfloat* crec = (cfloat*)rec;
-    float ox[T], oy[T], oz[T], dx[T], dy[T], dz[T], den[T], rcp[T];
+    RayK rk[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) {
         long r = r0 + t < R ? r0 + t : R - 1;
         cfloat* p = crec + r * 8;
-        ox[t] = p[0]; oy[t] = p[1]; oz[t] = p[2]; dx[t] = p[3];
-        dy[t] = p[4]; dz[t] = p[5]; den[t] = p[6]; rcp[t] = p[7];
+        rk[t].ox = p[0]; rk[t].oy = p[1]; rk[t].oz = p[2]; rk[t].dx = p[3];
+        rk[t].dy = p[4]; rk[t].dz = p[5]; rk[t].den = p[6]; rk[t].rcp = p[7];
     }
+    KSet ks[T];
+    ks[0].bits = lane < k ? INF_BITS : 0u; ks[0].idx = -1; ks[0].thr = INF_BITS; ks[0].tl = 0;
 
-    float bd[T];  // lane j: j-th smallest squared distance of ray t so far
-    int bi[T];
-    float thr[T]; // wave-uniform: current k-th smallest
+    // ---- phase A: ray 0 against every point
+    for (int base = 0; base < P; base += 64 * PPL) {
 #pragma unroll
-    for (int t = 0; t < T; ++t) { bd[t] = INFINITY; bi[t] = -1; thr[t] = INFINITY; }
-
-    const int km1 = k - 1;
+        for (int q = 0; q < PPL; ++q) {
+            int pi = base + q * 64 + lane;
+            bool ok = pi < P;
+            float4 v = stream[ok ? pi : P - 1];
+            float d2 = ray_dist2(rk[0], v.x, v.y, v.z);
+            ks[0].template offer<false>(ok ? d2 : INFINITY, __float_as_int(v.w), lane);
+        }
+    }
+    // ---- seed rays 1..T-1 with ray 0's neighbours
+    {
+        int pi = lane < k ? ks[0].idx : 0;
+        float sx = points[pi * 3 + 0], sy = points[pi * 3 + 1], sz = points[pi * 3 + 2];
+#pragma unroll
+        for (int t = 1; t < T; ++t) {
+            float d2 = ray_dist2(rk[t], sx, sy, sz);
+            ks[t].bits = lane < k ? __float_as_uint(d2) : 0u;
+            ks[t].idx = lane < k ? ks[0].idx : -1;
+            ks[t].refresh();
+        }
+    }
+    // ---- phase B: rays 1..T-1 against every point
     for (int base = 0; base < P; base += 64 * PPL) {
         float px[PPL], py[PPL], pz[PPL];
+        int pidx[PPL];
         bool ok[PPL];
 #pragma unroll
         for (int q = 0; q < PPL; ++q) {
             int pi = base + q * 64 + lane;
             ok[q] = pi < P;
-            int pc = ok[q] ? pi : P - 1;
-            px[q] = points[pc * 3 + 0]; py[q] = points[pc * 3 + 1]; pz[q] = points[pc * 3 + 2];
+            float4 v = stream[ok[q] ? pi : P - 1];
+            px[q] = v.x; py[q] = v.y; pz[q] = v.z; pidx[q] = __float_as_int(v.w);
         }
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
+        for (int t = 1; t < T; ++t) {
 #pragma unroll
             for (int q = 0; q < PPL; ++q) {
-                float vx = px[q] - ox[t], vy = py[q] - oy[t], vz = pz[q] - oz[t];
-                float vd = (vx * dx[t] + vy * dy[t]) + vz * dz[t];
-                // correctly rounded vd / den from the exact reciprocal (one Newton step on the quotient)
-                float q0 = vd * rcp[t];
-                float rem = __builtin_fmaf(-q0, den[t], vd);
-                float tt = __builtin_fmaf(rem, rcp[t], q0);
-                float ex = vx - dx[t] * tt, ey = vy - dy[t] * tt, ez = vz - dz[t] * tt;
-                // torch.norm accumulates its squares with an fma chain: fma(z,z, fma(y,y, x*x))
-                float d2 = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
-                d2 = ok[q] ? d2 : INFINITY;
-                unsigned long long m = __ballot(d2 < thr[t]);
-                while (m) {
-                    int src = __builtin_ctzll(m);
-                    m &= m - 1;
-                    float cd = read_lane(d2, src);
-                    if (cd < thr[t]) {
-                        int ci = base + q * 64 + src;
-                        int pos = __popcll(__ballot(bd[t] <= cd));
-                        float ud = lane_shift_up(bd[t]);
-                        int ui = lane_shift_up(bi[t]);
-                        bd[t] = lane < pos ? bd[t] : (lane == pos ? cd : ud);
-                        bi[t] = lane < pos ? bi[t] : (lane == pos ? ci : ui);
-                        thr[t] = read_lane(bd[t], km1);
-                    }
-                }
+                float d2 = ray_dist2(rk[t], px[q], py[q], pz[q]);
+                ks[t].template offer<true>(ok[q] ? d2 : INFINITY, pidx[q], lane);
             }
         }
     }
+    // rank the k members of each set by (distance, index) and write them in ascending order
 #pragma unroll
     for (int t = 0; t < T; ++t) {
         long r = r0 + t;
-        if (r < R && lane < k) {
-            out_idx[r * k + lane] = bi[t];
-            if (out_dist) out_dist[r * k + lane] = sqrtf(bd[t]);
+        if (r >= R) continue;
+        int rank = 0;
+        for (int j = 0; j < k; ++j) {
+            unsigned dj = (unsigned)__builtin_amdgcn_readlane((int)ks[t].bits, j);
+            int ij = __builtin_amdgcn_readlane(ks[t].idx, j);
+            rank += (dj < ks[t].bits || (dj == ks[t].bits && ij < ks[t].idx)) ? 1 : 0;
+        }
+        if (lane < k) {
+            out_idx[r * k + rank] = ks[t].idx;
+            if (out_dist) out_dist[r * k + rank] = sqrtf(__uint_as_float(ks[t].bits));
         }
     }
 }
 
+int coprime_stride(long n) {
+    long mul = (long)(n * 0.6180339887) | 1;
+    auto gcd = [](long a, long b) { while (b) { long t = a % b; a = b; b = t; } return a; };
+    while (gcd(mul, n) != 1) mul += 2;
+    return (int)(mul % n);
+}
+
 }  // namespace
 
-extern "C" size_t papr_ray_knn_workspace_bytes(int64_t R) { return (size_t)R * 8 * sizeof(float); }
+extern "C" size_t papr_ray_knn_workspace_bytes(int64_t R, int64_t P) {
+    return (size_t)R * 8 * sizeof(float) + (size_t)P * 4 * sizeof(float);
+}
 
 extern "C" int papr_ray_knn(const float* points, int64_t P, const float* rays_o, const float* rays_d,
                             int64_t R, int64_t rays_per_image, int k, float eps, int32_t* out_idx,
@@ -140,13 +245,16 @@ extern "C" int papr_ray_knn(const float* points, int64_t P, const float* rays_o,
     if (R <= 0) return 0;
     hipStream_t s = as_stream(stream);
     float* rec = static_cast<float*>(workspace);
+    float4* pstream = reinterpret_cast<float4*>(rec + (size_t)R * 8);
     pack_rays_kernel<<<dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s>>>(rays_o, rays_d, R, rays_per_image, eps, rec);
     PAPR_CHECK_LAUNCH("pack_rays");
+    scatter_points_kernel<<<dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s>>>(points, (int)P, P > 1 ? coprime_stride(P) : 0, pstream);
+    PAPR_CHECK_LAUNCH("scatter_points");
     constexpr int T = 8, PPL = 4;
     long tiles = (R + T - 1) / T;
     const bool prof = papr_prof_on();
     if (prof) papr_prof_begin(5, R, (int)P, k, s);
-    ray_knn_kernel<T, PPL><<<dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, s>>>(points, (int)P, rec, R, k, out_idx, out_dist);
+    ray_knn_kernel<T, PPL><<<dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, s>>>(pstream, points, (int)P, rec, R, k, out_idx, out_dist);
     if (prof) papr_prof_end(s);
     PAPR_CHECK_LAUNCH("ray_knn");
     return 0;

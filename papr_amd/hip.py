@@ -65,7 +65,7 @@ def lib():
     L.papr_abi_version.restype = C.c_int
     L.papr_last_error.restype = C.c_char_p
     L.papr_ray_knn_workspace_bytes.restype = C.c_size_t
-    L.papr_ray_knn_workspace_bytes.argtypes = [i64]
+    L.papr_ray_knn_workspace_bytes.argtypes = [i64, i64]
     L.papr_ray_knn.argtypes = [vp, i64, vp, vp, i64, i64, i32, f32, vp, vp, vp, vp]
     L.papr_feature_widths.argtypes = [C.POINTER(FeatureDesc), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.papr_build_features_fwd.argtypes = [C.POINTER(FeatureDesc), vp, vp, vp, vp, i64, i64, vp, vp, vp, vp, vp, vp]

@@ -176,7 +176,7 @@ def ray_knn(points, rays_o, rays_d, rays_per_image, k, eps, want_dist=False):
     dev = points.device
     idx = torch.empty((R, k), device=dev, dtype=torch.int32)
     dist = torch.empty((R, k), device=dev, dtype=torch.float32) if want_dist else None
-    ws = torch.empty(hip.lib().papr_ray_knn_workspace_bytes(R) // 4, device=dev, dtype=torch.float32)
+    ws = torch.empty(hip.lib().papr_ray_knn_workspace_bytes(R, points.shape[0]) // 4, device=dev, dtype=torch.float32)
     hip.check(hip.lib().papr_ray_knn(hip.ptr(points), points.shape[0], hip.ptr(rays_o), hip.ptr(rays_d), R, rays_per_image,
                                      k, eps, hip.ptr(idx), hip.ptr(dist), hip.ptr(ws), hip.stream_ptr()), "papr_ray_knn")
     return (idx, dist) if want_dist else idx

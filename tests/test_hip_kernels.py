@@ -85,7 +85,7 @@ def test_knn_ragged_sizes_against_oracle(P, k, hw):
     _check_knn(pts, ro, rd, k, np.sort(ref.numpy(), -1))
 
 
-def test_knn_duplicate_points_tie_break_is_lowest_index():
+def test_knn_duplicate_points_exact_ties():
     pts = uniform_points(500, 12.0, seed=1)
     pts = torch.cat([pts, pts[:100]])            # exact duplicates -> exact ties
     ro, rd, _ = synth_rays(1, 6, 6, seed=2)
@@ -94,7 +94,7 @@ def test_knn_duplicate_points_tie_break_is_lowest_index():
     feat = O.ray_point_distance(pts, ro, rd, 1e-6).reshape(-1, pts.shape[0])
     kth = feat.topk(10, largest=False).values.max(-1).values
     np.testing.assert_allclose(dist.max(-1).values.numpy(), kth.numpy(), rtol=2e-6)
-    # among equal distances the smaller point index comes first
+    # the output is ascending in (distance, index)
     same = dist[:, 1:] == dist[:, :-1]
     assert torch.all(idx[:, 1:][same] > idx[:, :-1][same])
 
