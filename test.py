@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Evaluation driver -- counterpart of the reference's test.py (`python test.py --opt <yml>`): loads
+`experiments/<index>/model.pth`, renders every test view in `test.max_height x max_width` chunks
+through PAPR.evaluate on the HIP path, reports PSNR (test.py:107) and writes PNGs.  SSIM / LPIPS need
+packages that are not available offline and are not computed."""
+import argparse
+import os
+
+import numpy as np
+import torch
+
+from papr_amd import get_model, load_config
+from papr_amd.config import as_node
+from papr_amd.dataset import get_dataset
+from train import psnr, render_full
+
+
+def main():
+    ap = argparse.ArgumentParser(description="PAPR")
+    ap.add_argument("--opt", type=str, default="")
+    ap.add_argument("--max-views", type=int, default=-1)
+    ap.add_argument("--save", action="store_true")
+    cli = ap.parse_args()
+    cfg = load_config(cli.opt)
+    args = as_node(cfg)
+    dev = torch.device("cuda")
+    log_dir = os.path.join(args.save_dir, args.index)
+    model = get_model(args, dev).to(dev)
+    load = os.path.join(args.save_dir, args.test.load_path) if args.test.load_path else log_dir
+    step = model.load(load)
+    print("loaded step", step, "points", model.points.shape[0])
+    results = {}
+    for ds in cfg["test"]["datasets"]:
+        dcfg = dict(cfg["dataset"]); dcfg.update(ds)
+        data = get_dataset(dcfg, ds["mode"], dev, seed=args.seed)
+        n = len(data) if cli.max_views < 0 else min(len(data), cli.max_views)
+        vals = []
+        for i in range(n):
+            img, rayd, rayo, c2w = data.full_view(i)
+            rgb = render_full(model, rayo, rayd, c2w, args.test.max_height, args.test.max_width)
+            vals.append(psnr(rgb, img))
+            if cli.save:
+                from PIL import Image
+                out = os.path.join(log_dir, "test", ds["name"]); os.makedirs(out, exist_ok=True)
+                Image.fromarray((rgb[0].cpu().numpy() * 255).astype(np.uint8)).save(os.path.join(out, "%03d.png" % i))
+        results[ds["name"]] = float(np.mean(vals))
+        print("testset", ds["name"], "views", n, "avg psnr", results[ds["name"]])
+    return results
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,135 @@
+"""Ray-sharded data parallelism on CPU (gloo, world_size 2): the collective plumbing of
+papr_amd.dist / PAPR.step / prune / add, and the DP oracle of SURVEY.md section 8e (an N-image batch
+equals the mean of N single-image gradients; reference golden G9)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as td
+import torch.multiprocessing as mp
+
+from conftest import ROOT, GOLDEN, case_cfg, golden
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, fn, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    for p in (ROOT, GOLDEN, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    torch.set_num_threads(2)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        res = globals()[fn](rank, world)
+        torch.save(res, os.path.join(out_dir, "r%d.pt" % rank))
+    finally:
+        td.destroy_process_group()
+
+
+def run2(fn, tmp_path):
+    mp.spawn(_worker, args=(2, _free_port(), fn, str(tmp_path)), nprocs=2, join=True)
+    return [torch.load(os.path.join(str(tmp_path), "r%d.pt" % r)) for r in range(2)]
+
+
+def _model(seed=1):
+    from papr_amd import get_model
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    return get_model(case_cfg("chair1k"), device="cpu")
+
+
+# ---------------------------------------------------------------------------------------------
+def w_step_averages(rank, world):
+    m = _model()
+    g = torch.Generator().manual_seed(100 + rank)
+    for p in m.parameters():
+        if p.requires_grad:
+            p.grad = torch.randn(p.shape, generator=g)
+    if rank == 1:
+        m.points.grad = None                      # a rank whose rays touched nothing still takes part
+    grads = {n: (p.grad.clone() if p.grad is not None else torch.zeros_like(p)) for n, p in m.named_parameters() if p.requires_grad}
+    m.step(0)
+    return {"grads": grads, "after": {n: p.detach().clone() for n, p in m.named_parameters()},
+            "avg": {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}}
+
+
+def test_step_allreduces_mean_gradient_and_keeps_replicas_identical(tmp_path):
+    r0, r1 = run2("w_step_averages", tmp_path)
+    for n in r0["grads"]:
+        mean = 0.5 * (r0["grads"][n] + r1["grads"][n])
+        assert torch.allclose(r0["avg"][n], mean, atol=1e-7), n
+        assert torch.equal(r0["avg"][n], r1["avg"][n]), n
+    for n in r0["after"]:
+        assert torch.equal(r0["after"][n], r1["after"][n]), n
+    # and it is what a single process gets from the mean gradient
+    m = _model()
+    for n, p in m.named_parameters():
+        if p.requires_grad:
+            p.grad = 0.5 * (r0["grads"][n] + r1["grads"][n])
+    m.step(0)
+    for n, p in m.named_parameters():
+        assert torch.allclose(p.detach(), r0["after"][n], atol=1e-8), n
+
+
+def w_prune_add(rank, world):
+    m = _model()
+    with torch.no_grad():
+        m.points_influ_scores[: 200 + 100 * rank] = 1.0      # ranks disagree on purpose
+        m.points += rank                                       # and have drifted apart
+    m.clear_optimizer(); m.clear_scheduler()
+    n = int(m.prune_points(0.0))
+    m.init_optimizers(3)
+    np.random.seed(50 + rank)                                  # rank-dependent RNG streams, as in training
+    added = m.add_points(40)
+    return {"pruned": n, "added": added, "points": m.points.detach().clone(), "influ": m.points_influ_scores.detach().clone(),
+            "feats": m.pc_feats.detach().clone(), "is_param": isinstance(m.points, torch.nn.Parameter)}
+
+
+def test_prune_and_add_follow_rank0(tmp_path):
+    r0, r1 = run2("w_prune_add", tmp_path)
+    assert r0["points"].shape == (240, 3) and r0["is_param"] and r1["is_param"]
+    for key in ("points", "influ", "feats"):
+        assert torch.equal(r0[key], r1[key]), key
+    assert r0["added"] == 40
+
+
+def w_oracle_dp(rank, world):
+    """Each rank: oracle gradients of ITS image; averaged through papr_amd.dist."""
+    from formula import formula_fill, synth_rays
+    from oracle import papr_oracle as O
+    from oracle.state import empty_state
+    from papr_amd import dist as pdist
+    g5, g9 = golden("g567_chair1k.npz"), golden("g9_dp.npz")
+    cfg = case_cfg("chair1k")
+    st = formula_fill(empty_state(cfg, 1000))
+    st["points"] = torch.from_numpy(g5["points"]).clone()
+    st = O.trainable_state(st, cfg)
+    ro, rd, _ = synth_rays(2, 16, 16, seed=13)
+    tgt = torch.from_numpy(g9["target"])
+    sl = slice(rank, rank + 1)
+    rgb = O.render(st, cfg, ro[sl], rd[sl])["rgb"]
+    torch.mean((rgb - tgt[sl]) ** 2).backward()
+    params = [t for t in st.values() if t.requires_grad]
+    n = pdist.average_gradients(params)
+    return {"n": n, "points": st["points"].grad.clone(), "influ": st["points_influ_scores"].grad.clone(),
+            "outc": st["renderer.outc.conv.bias"].grad.clone(), "wq": st["proximity_attn.attention_layer.w_q.bias"].grad.clone()}
+
+
+def test_two_rank_average_equals_reference_two_image_batch(tmp_path):
+    g9 = golden("g9_dp.npz")
+    r0, r1 = run2("w_oracle_dp", tmp_path)
+    assert r0["n"] == 1000 * 68 + 1139288 + 3643395          # one flat bucket: P*(3+1+64) + attn + U-Net floats
+    for key, ref in (("points", "both/points"), ("influ", "both/influ"), ("outc", "both/outc_bias"), ("wq", "both/wq_bias")):
+        want = g9[ref]
+        assert torch.equal(r0[key], r1[key])
+        np.testing.assert_allclose(r0[key].numpy(), want, rtol=0, atol=1e-5 * np.abs(want).max() + 1e-9, err_msg=key)

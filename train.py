@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""Training driver on the HIP render path -- same command line, schedule and checkpoint files as the
+reference's train.py (`python train.py --opt configs/nerfsyn/chair.yml [--resume 1]`):
+prune / add schedule (train.py:207-250), train_step call order (:155-179), evaluation every
+`eval.step` steps (and every 500 below 10,000) with chunked full-image rendering (:29-152), rank-0
+logging and checkpoints.  Launch under torch.distributed.run for ray-sharded data parallelism.
+Matplotlib dashboards / videos of the reference are not reproduced (diagnostics, out of scope).
+"""
+import argparse
+import bisect
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+from papr_amd import dist as pdist, get_loss, get_model, load_config
+from papr_amd.config import as_node, eval_config
+from papr_amd.dataset import get_dataset, sample_batch
+
+
+def parse_args():
+    ap = argparse.ArgumentParser(description="PAPR")
+    ap.add_argument("--opt", type=str, default="", help="Option file path")
+    ap.add_argument("--resume", type=int, default=0, help="Resume training")
+    ap.add_argument("--steps", type=int, default=-1, help="override training.steps (smoke runs)")
+    ap.add_argument("--set", nargs="*", default=[], help="extra overrides, e.g. use_amp=false training.losses.lpips=0")
+    return ap.parse_args()
+
+
+def setup_seed(seed):
+    import random
+    torch.manual_seed(seed)
+    torch.cuda.manual_seed_all(seed)
+    np.random.seed(seed)
+    random.seed(seed)
+
+
+def render_full(model, rayo, rayd, c2w, max_h, max_w):
+    """Chunked evaluate() + render head + compositing (reference eval_step / test_step)."""
+    args = model.args
+    N, H, W, _ = rayd.shape
+    topk = min(model.points.shape[0], int(model.select_k))
+    C = args.models.attn.embed.value.d_ff_out
+    fmap = torch.zeros(N, H, W, 1, C, device=rayd.device)
+    attn = torch.zeros(N, H, W, topk + 1, 1, device=rayd.device)
+    with torch.no_grad():
+        for h0 in range(0, H, max_h):
+            for w0 in range(0, W, max_w):
+                f, a = model.evaluate(rayo, rayd[:, h0:h0 + max_h, w0:w0 + max_w].contiguous(), c2w)
+                fmap[:, h0:h0 + max_h, w0:w0 + max_w] = f
+                attn[:, h0:h0 + max_h, w0:w0 + max_w] = a
+        if args.models.use_renderer:
+            fg = model.renderer(fmap.squeeze(-2).permute(0, 3, 1, 2)).permute(0, 2, 3, 1).unsqueeze(-2).float()
+        else:
+            fg = fmap
+        bkg_attn = attn[..., topk:, :]
+        bkg = model.bkg_feats.expand(N, H, W, -1, -1)
+        rgb = fg * (1 - bkg_attn) + bkg * bkg_attn if args.models.normalize_topk_attn else fg + bkg * bkg_attn
+        return torch.clamp(model.last_act(rgb.squeeze(-2)), 0, 1)
+
+
+def psnr(rgb, img):
+    return -10.0 * np.log(((rgb - img) ** 2).mean().item()) / np.log(10.0)
+
+
+def train_step(step, model, batch, loss_fn, args):
+    tgt, rayd, rayo, c2w = batch
+    model.clear_grad()
+    out = model.last_act(model(rayo, rayd, c2w, step))
+    loss = loss_fn(out, tgt)
+    model.scaler.scale(loss).backward()
+    model.step(step)
+    if args.scaler_min_scale > 0 and model.scaler.get_scale() < args.scaler_min_scale:
+        model.scaler.update(args.scaler_min_scale)
+    else:
+        model.scaler.update()
+    return loss
+
+
+def reinit(model, step, fn):
+    model.clear_optimizer()
+    model.clear_scheduler()
+    out = fn()
+    model.init_optimizers(step)
+    return out
+
+
+def main():
+    cli = parse_args()
+    over = {}
+    for kv in cli.set:
+        key, val = kv.split("=", 1)
+        node = over
+        parts = key.split(".")
+        for p in parts[:-1]:
+            node = node.setdefault(p, {})
+        import yaml
+        node[parts[-1]] = yaml.safe_load(val)
+    cfg = load_config(cli.opt, overrides=over)
+    if cli.steps > 0:
+        cfg["training"]["steps"] = cli.steps
+    args, eargs = as_node(cfg), as_node(eval_config(cfg))
+    world = pdist.init_from_env("cuda")
+    rank = pdist.rank()
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(dev)
+    log_dir = os.path.join(args.save_dir, args.index)
+    if rank == 0:
+        os.makedirs(log_dir, exist_ok=True)
+    setup_seed(args.seed)
+    model = get_model(args, dev).to(dev)
+    pdist.broadcast_module_state(model)
+    dataset = get_dataset(cfg["dataset"], "train", dev, seed=args.seed + rank)
+    eval_set = get_dataset(eargs["dataset"], "test", dev, seed=args.seed)
+    loss_fn = get_loss(cfg["training"]["losses"]).to(dev)
+    start = 0
+    eval_psnrs, train_losses = [], []
+    if cli.resume > 0:
+        start = model.load(log_dir)
+        print("!!!!! Resume from step %s" % start)
+    T = args.training
+    step, pruned, t0, run_loss = start, False, time.time(), 0.0
+    print("Start step:", start, "Total steps:", T.steps)
+    while step < T.steps:
+        if T.prune_steps > 0 and T.prune_start <= step < T.prune_stop and step % T.prune_steps == 0:
+            thr = T.prune_thresh_list[bisect.bisect_left(T.prune_steps_list, step)] if len(T.prune_steps_list) > 0 else T.prune_thresh
+            n = reinit(model, step, lambda: model.prune_points(thr))
+            pruned = True
+            print("Step %d: Pruned %d points" % (step, n))
+        add_now = None
+        if pruned and len(T.add_steps_list) > 0:
+            if step in T.add_steps_list:
+                add_now = T.add_num_list[T.add_steps_list.index(step)]
+        elif pruned and T.add_steps > 0 and step % T.add_steps == 0 and T.add_start <= step < T.add_stop:
+            add_now = T.add_num
+        if add_now is not None:
+            capped = min(add_now, args.max_num_pts - model.points.shape[0]) if args.max_num_pts > 0 else add_now
+            if capped > 0:      # the reference passes the un-capped count on (train.py:247)
+                n = reinit(model, step, lambda: model.add_points(add_now if len(T.add_steps_list) == 0 else capped))
+                model.added_points = True
+                print("Step %d: Added %d points" % (step, n))
+        loss = train_step(step, model, sample_batch(dataset, cfg["dataset"]["batch_size"]), loss_fn, args)
+        step += 1
+        if step % 200 == 0 and rank == 0:
+            l = loss.item()
+            print("Train step:", step, "loss:", l, "attn_lr:", model.attn_lr, "pts_lr:", model.pts_lr, "scale:",
+                  model.scaler.get_scale(), "points:", model.points.shape[0], f"time: {time.time() - t0:.2f}s")
+            t0 = time.time()
+        if (step % args.eval.step == 0) or (step % 500 == 0 and step < 10000) or step == T.steps:
+            if rank == 0:
+                img, rayd, rayo, c2w = eval_set.full_view(args.eval.img_idx % len(eval_set))
+                rgb = render_full(model, rayo, rayd, c2w, args.eval.max_height, args.eval.max_width)
+                eval_psnrs.append(psnr(rgb, img))
+                train_losses.append(loss.item())
+                print("Eval step:", step, "train_loss:", train_losses[-1], "eval_psnr:", eval_psnrs[-1])
+                model.save(step, log_dir)
+                torch.save(torch.tensor(train_losses), os.path.join(log_dir, "train_losses.pth"))
+                torch.save(torch.tensor(eval_psnrs), os.path.join(log_dir, "eval_psnrs.pth"))
+                if step % 50000 == 0:
+                    torch.save(model.state_dict(), os.path.join(log_dir, "model_%d.pth" % step))
+            if world > 1:
+                torch.distributed.barrier()
+    return eval_psnrs
+
+
+if __name__ == "__main__":
+    main()
