@@ -130,9 +130,14 @@ int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float* x, int ldx
 /* ------------------------------------------------------------------------------------
  * K4  attention tail        replaces attention("scaled-dot") + score_act (models/attn.py:217-225)
  *                           and the softmax / renormalise / weighted sum of models/model.py:519-534.
- * kp (R*k, ld_kp): W_k K + b_k rows;  qp (R, ld_qp): W_q Q + b_q rows;  v (R*k, ld_v), C columns.
- * scores (R,k) = act(qp.kp_j / sqrt(d_model));  z = [scores * influ[idx], bkg_score];
- * attn (R,k+1) = softmax(z);  fused (R,C) = sum_j attn_j / (sum_{j<k} attn_j if normalize) * v_j.
+ * kp (R*k, ld_kp), qp (R, ld_qp): the two operands of the per-ray dot products, d_model wide;
+ * score_bias (R) or NULL: added to every dot product of ray r before scaling.
+ *   scores (R,k) = act((qp . kp_j + score_bias) / sqrt(scale_dim));  z = [scores * influ[idx], bkg_score];
+ *   attn (R,k+1) = softmax(z);  fused (R,C) = sum_j attn_j / (sum_{j<k} attn_j if normalize) * v_j.
+ * The literal reference form is kp = W_k K + b_k, qp = W_q Q + b_q, score_bias = NULL.  The host
+ * (papr_amd/ops.py) instead passes kp = K (the key embedding itself), qp = W_k^T (W_q Q + b_q) and
+ * score_bias = b_k . (W_q Q + b_q): the same bilinear form with the R*k-row W_k product replaced by
+ * an R-row one.
  */
 typedef struct {
     int32_t k, d_model, C;
@@ -140,18 +145,19 @@ typedef struct {
     int32_t score_act;
     int32_t normalize;
     float bkg_score;
+    int32_t scale_dim;      /* scores are divided by sqrt(scale_dim) (the reference's d_model); 0 -> d_model */
 } papr_tail_desc;
 
-int papr_attn_tail_fwd(const papr_tail_desc* d, const float* kp, const float* qp, const float* v,
-                       const float* influ, const int32_t* idx, int64_t R, float* scores, float* attn,
-                       float* fused, papr_stream_t stream);
+int papr_attn_tail_fwd(const papr_tail_desc* d, const float* kp, const float* qp, const float* score_bias,
+                       const float* v, const float* influ, const int32_t* idx, int64_t R, float* scores,
+                       float* attn, float* fused, papr_stream_t stream);
 
-/* d_v rows are overwritten; d_kp rows are overwritten; d_qp (R, ld_qp) overwritten;
- * d_influ (P) accumulated with atomic adds (caller zeroes). */
+/* d_v rows are overwritten; d_kp rows are overwritten; d_qp (R, ld_qp) overwritten; d_score_bias (R) or
+ * NULL overwritten; d_influ (P) accumulated with atomic adds (caller zeroes). */
 int papr_attn_tail_bwd(const papr_tail_desc* d, const float* kp, const float* qp, const float* v,
                        const float* influ, const int32_t* idx, int64_t R, const float* scores,
                        const float* attn, const float* d_fused, const float* d_attn, float* d_kp,
-                       float* d_qp, float* d_v, float* d_influ, papr_stream_t stream);
+                       float* d_qp, float* d_v, float* d_influ, float* d_score_bias, papr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Optional timing of the GEMM / kNN launches with HIP events recorded on the launch stream

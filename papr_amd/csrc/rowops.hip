@@ -91,6 +91,7 @@ __device__ __forceinline__ float bcast(float v, int src) {
 
 __global__ __launch_bounds__(256) void tail_fwd_kernel(papr_tail_desc d, const float* __restrict__ kp,
                                                        const float* __restrict__ qp, const float* __restrict__ v,
+                                                       const float* __restrict__ score_bias,
                                                        const float* __restrict__ influ, const int* __restrict__ idx,
                                                        long R, float* __restrict__ scores, float* __restrict__ attn,
                                                        float* __restrict__ fused) {
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(256) void tail_fwd_kernel(papr_tail_desc d, const f
     long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= R) return;
     const int k = d.k;
-    const float inv_sqrt_d = 1.0f / sqrtf((float)d.d_model);
+    const float inv_sqrt_d = 1.0f / sqrtf((float)(d.scale_dim > 0 ? d.scale_dim : d.d_model));
     const float* q = qp + r * d.ld_qp;
     float my_score = 0.f;
     for (int j = 0; j < k; ++j) {
@@ -112,6 +113,7 @@ __global__ __launch_bounds__(256) void tail_fwd_kernel(papr_tail_desc d, const f
         float dot = wave_sum(part);
         if (lane == j) my_score = dot;
     }
+    if (score_bias) my_score += score_bias[r];
     float z = -INFINITY;
     if (lane < k) {
         float sc = papr_act(my_score * inv_sqrt_d, d.score_act);
@@ -141,12 +143,12 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(papr_tail_desc d, const f
                                                        const float* __restrict__ attn, const float* __restrict__ d_fused,
                                                        const float* __restrict__ d_attn, float* __restrict__ d_kp,
                                                        float* __restrict__ d_qp, float* __restrict__ d_v,
-                                                       float* __restrict__ d_influ) {
+                                                       float* __restrict__ d_influ, float* __restrict__ d_score_bias) {
     const int lane = threadIdx.x & 63;
     long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= R) return;
     const int k = d.k;
-    const float inv_sqrt_d = 1.0f / sqrtf((float)d.d_model);
+    const float inv_sqrt_d = 1.0f / sqrtf((float)(d.scale_dim > 0 ? d.scale_dim : d.d_model));
     float a = lane <= k ? attn[r * (k + 1) + lane] : 0.f;
     float top = lane < k ? a : 0.f;
     float tsum = 1.f;
@@ -180,6 +182,10 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(papr_tail_desc d, const f
     if (lane < k) {
         unsafeAtomicAdd(d_influ + pi, dz * sc);
         ddot = dz * w * papr_act_grad(sc, d.score_act) * inv_sqrt_d;
+    }
+    if (d_score_bias) {
+        float sb = wave_sum(ddot);
+        if (lane == 0) d_score_bias[r] = sb;
     }
     // d_qp = sum_j ddot_j kp_j ;  d_kp_j = ddot_j qp
     const float* q = qp + r * d.ld_qp;
@@ -231,13 +237,13 @@ static int check_tail(const papr_tail_desc* d, const char* who) {
     return 0;
 }
 
-extern "C" int papr_attn_tail_fwd(const papr_tail_desc* d, const float* kp, const float* qp, const float* v,
-                                  const float* influ, const int32_t* idx, int64_t R, float* scores, float* attn,
+extern "C" int papr_attn_tail_fwd(const papr_tail_desc* d, const float* kp, const float* qp, const float* score_bias,
+                                  const float* v, const float* influ, const int32_t* idx, int64_t R, float* scores, float* attn,
                                   float* fused, papr_stream_t stream) {
     if (int e = check_tail(d, "papr_attn_tail_fwd")) return e;
     PAPR_REQUIRE(kp && qp && v && influ && idx && scores && attn && fused, "papr_attn_tail_fwd: null pointer");
     if (R <= 0) return 0;
-    tail_fwd_kernel<<<dim3((unsigned)((R + 3) / 4)), dim3(256), 0, as_stream(stream)>>>(*d, kp, qp, v, influ, idx, R, scores, attn, fused);
+    tail_fwd_kernel<<<dim3((unsigned)((R + 3) / 4)), dim3(256), 0, as_stream(stream)>>>(*d, kp, qp, v, score_bias, influ, idx, R, scores, attn, fused);
     PAPR_CHECK_LAUNCH("tail_fwd");
     return 0;
 }
@@ -245,13 +251,13 @@ extern "C" int papr_attn_tail_fwd(const papr_tail_desc* d, const float* kp, cons
 extern "C" int papr_attn_tail_bwd(const papr_tail_desc* d, const float* kp, const float* qp, const float* v,
                                   const float* influ, const int32_t* idx, int64_t R, const float* scores,
                                   const float* attn, const float* d_fused, const float* d_attn, float* d_kp,
-                                  float* d_qp, float* d_v, float* d_influ, papr_stream_t stream) {
+                                  float* d_qp, float* d_v, float* d_influ, float* d_score_bias, papr_stream_t stream) {
     if (int e = check_tail(d, "papr_attn_tail_bwd")) return e;
     PAPR_REQUIRE(kp && qp && v && influ && idx && scores && attn && d_fused && d_kp && d_qp && d_v && d_influ,
                  "papr_attn_tail_bwd: null pointer");
     if (R <= 0) return 0;
     tail_bwd_kernel<<<dim3((unsigned)((R + 3) / 4)), dim3(256), 0, as_stream(stream)>>>(
-        *d, kp, qp, v, influ, idx, R, scores, attn, d_fused, d_attn, d_kp, d_qp, d_v, d_influ);
+        *d, kp, qp, v, influ, idx, R, scores, attn, d_fused, d_attn, d_kp, d_qp, d_v, d_influ, d_score_bias);
     PAPR_CHECK_LAUNCH("tail_bwd");
     return 0;
 }

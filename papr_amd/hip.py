@@ -42,7 +42,7 @@ class ProfileRecord(C.Structure):
 class TailDesc(C.Structure):
     _fields_ = [("k", C.c_int32), ("d_model", C.c_int32), ("C", C.c_int32), ("ld_kp", C.c_int32),
                 ("ld_qp", C.c_int32), ("ld_v", C.c_int32), ("score_act", C.c_int32), ("normalize", C.c_int32),
-                ("bkg_score", C.c_float)]
+                ("bkg_score", C.c_float), ("scale_dim", C.c_int32)]
 
 
 _lib = None
@@ -76,8 +76,8 @@ def lib():
     L.papr_mlp_fwd.argtypes = [C.POINTER(Layer), i32, vp, i32, i64, C.POINTER(vp), C.POINTER(C.c_int32), vp]
     L.papr_mlp_bwd.argtypes = [C.POINTER(Layer), i32, vp, i32, i64, C.POINTER(vp), C.POINTER(C.c_int32), vp, vp, vp,
                                i32, C.POINTER(vp), C.POINTER(vp), vp, vp, vp]
-    L.papr_attn_tail_fwd.argtypes = [C.POINTER(TailDesc), vp, vp, vp, vp, vp, i64, vp, vp, vp, vp]
-    L.papr_attn_tail_bwd.argtypes = [C.POINTER(TailDesc), vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.papr_attn_tail_fwd.argtypes = [C.POINTER(TailDesc), vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp]
+    L.papr_attn_tail_bwd.argtypes = [C.POINTER(TailDesc), vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.papr_profile_enable.argtypes = [i32]
     L.papr_profile_collect.argtypes = [C.POINTER(ProfileRecord), i32]
     for name in EXPORTS:

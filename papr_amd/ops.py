@@ -155,6 +155,21 @@ def mlp_backward(spec, ws, bs, x, M, outs, d_out, scratch, need_dx):
     return d_ws, d_bs, d_x
 
 
+def linear_rows(x, w):
+    """out = x @ w.T on the MFMA GEMM (no bias, no activation).  x (M, ldx), w (n_out, ldx) with n_out % 4 == 0.
+    Row results do not depend on M (unlike a library GEMM, whose tiling follows the problem size), which keeps
+    chunked evaluation bit-identical to whole-image evaluation."""
+    M, n_out = x.shape[0], w.shape[0]
+    out = torch.empty((M, n_out), device=x.device, dtype=torch.float32)
+    tab = (hip.Layer * 1)()
+    t = tab[0]
+    t.weight, t.weight_t, t.bias = w.data_ptr(), None, None
+    t.n_in, t.n_out, t.ldw, t.ldwt, t.n_skip, t.skip_col, t.act = x.shape[1], n_out, w.shape[1], 0, 0, 0, 0
+    hip.check(hip.lib().papr_mlp_fwd(tab, 1, hip.ptr(x), x.shape[1], M, hip.ptr_array([out]), hip.i32_array([n_out]),
+                                     hip.stream_ptr()), "papr_mlp_fwd")
+    return out
+
+
 def rownorm_(x, width, eps):
     """In-place row standardisation; returns stats (rows,2)."""
     stats = torch.empty((x.shape[0], 2), device=x.device, dtype=torch.float32)
@@ -251,8 +266,10 @@ class RenderPath:
 
     def tail_desc(self, k):
         t = hip.TailDesc()
-        t.k, t.d_model, t.C = k, self.d_model, self.C
-        t.ld_kp, t.ld_qp, t.ld_v = self.wk.ld_out[0], self.wq.ld_out[0], self.val.ld_out[-1]
+        # kp operand = the key embedding rows themselves, qp operand = W_k^T (W_q Q + b_q): see render path below
+        t.k, t.d_model, t.C = k, self.key.d_out, self.C
+        t.scale_dim = self.d_model
+        t.ld_kp, t.ld_qp, t.ld_v = self.key.ld_out[-1], self.key.d_out + 4, self.val.ld_out[-1]
         t.score_act = hip.ACT[self.score_act]
         t.normalize = int(self.normalize)
         t.bkg_score = self.bkg_score
@@ -312,22 +329,26 @@ class _RenderFn(torch.autograd.Function):
         if plan.kq_norm:
             kst2 = rownorm_(K, plan.key.d_out, eps)
             qst2 = rownorm_(Q, plan.qry.d_out, eps)
-        kp = mlp_forward(plan.wk, wkw, wkb, K, M, True)[0]
+        # score_j = (W_q Q + b_q).(W_k K_j + b_k) = K_j.(W_k^T q') + b_k.q'  with q' = W_q Q + b_q: the R*k-row w_k
+        # product of the reference (models/attn.py:217) becomes two R-row products (plain library GEMMs)
         qp = mlp_forward(plan.wq, wqw, wqb, Q, R, True)[0]
+        w_aug = torch.cat([wkw[0].t(), wkb[0][None, :], wkb[0].new_zeros((3, wkb[0].shape[0]))], 0).contiguous()
+        g = linear_rows(qp, w_aug)                           # (R, key.d_out + 4): [W_k^T q' | b_k.q' | 0 0 0]
+        c0 = g[:, plan.key.d_out].contiguous()               # (R,)
         v_outs = mlp_forward(plan.val, vw, vb, val_in, M, keep)
         V = v_outs[-1]
         td = plan.tail_desc(k)
         scores = torch.empty((R, k), device=dev, dtype=torch.float32)
         attn = torch.empty((R, k + 1), device=dev, dtype=torch.float32)
         fused = torch.empty((R, plan.C), device=dev, dtype=torch.float32)
-        hip.check(lib.papr_attn_tail_fwd(C.byref(td), hip.ptr(kp), hip.ptr(qp), hip.ptr(V), hip.ptr(influ), hip.ptr(idx), R,
+        hip.check(lib.papr_attn_tail_fwd(C.byref(td), hip.ptr(K), hip.ptr(g), hip.ptr(c0), hip.ptr(V), hip.ptr(influ), hip.ptr(idx), R,
                                          hip.ptr(scores), hip.ptr(attn), hip.ptr(fused), hip.stream_ptr()), "papr_attn_tail_fwd")
         ctx.plan, ctx.rpi, ctx.n = plan, rays_per_image, (n_k, n_q, n_v)
         ctx.mark_non_differentiable(sel)
         if keep:
             ctx.saved = dict(rays_o=rays_o, rays_d=rays_d, idx=idx, points=points, influ=influ, key_in=key_in, qry_in=qry_in,
                              val_in=val_in, kst=kst, qst=qst, kst2=kst2, qst2=qst2, k_outs=k_outs, q_outs=q_outs,
-                             v_outs=v_outs, kp=kp, qp=qp, scores=scores, attn=attn, wb=wb, P=points.shape[0],
+                             v_outs=v_outs, g=g, qp=qp, scores=scores, attn=attn, wb=wb, P=points.shape[0],
                              feat_shape=None if pc_feats is None else pc_feats.shape)
         return fused, attn, sel
 
@@ -351,19 +372,25 @@ class _RenderFn(torch.autograd.Function):
         K, Q, V = s["k_outs"][-1], s["q_outs"][-1], s["v_outs"][-1]
 
         td = plan.tail_desc(k)
-        d_kp = torch.empty_like(s["kp"])
-        d_qp = torch.empty_like(s["qp"])
+        d_K = torch.empty_like(K) if K.shape[1] == plan.key.d_out else torch.zeros_like(K)
+        d_g = torch.empty_like(s["g"])
+        d_c0 = torch.empty((R,), device=dev, dtype=torch.float32)
         d_V = torch.empty_like(V)
         d_influ = torch.zeros((s["P"], 1), device=dev, dtype=torch.float32)
         d_fused = d_fused.contiguous()
         d_attn = d_attn.contiguous() if d_attn is not None else None
-        hip.check(lib.papr_attn_tail_bwd(C.byref(td), hip.ptr(s["kp"]), hip.ptr(s["qp"]), hip.ptr(V), hip.ptr(s["influ"]), hip.ptr(idx),
-                                         R, hip.ptr(s["scores"]), hip.ptr(s["attn"]), hip.ptr(d_fused), hip.ptr(d_attn), hip.ptr(d_kp),
-                                         hip.ptr(d_qp), hip.ptr(d_V), hip.ptr(d_influ), hip.stream_ptr()), "papr_attn_tail_bwd")
+        hip.check(lib.papr_attn_tail_bwd(C.byref(td), hip.ptr(K), hip.ptr(s["g"]), hip.ptr(V), hip.ptr(s["influ"]), hip.ptr(idx),
+                                         R, hip.ptr(s["scores"]), hip.ptr(s["attn"]), hip.ptr(d_fused), hip.ptr(d_attn), hip.ptr(d_K),
+                                         hip.ptr(d_g), hip.ptr(d_V), hip.ptr(d_influ), hip.ptr(d_c0), hip.stream_ptr()), "papr_attn_tail_bwd")
+        # backward of g = q' W_k, c0 = q'.b_k (R-row library GEMMs)
+        qp = s["qp"]
+        d_g = d_g[:, :plan.key.d_out]                        # the tail kernel fills d_model = key.d_out columns
+        d_qp = torch.addmm(torch.outer(d_c0, wkb[0]), d_g, wkw[0].t())
+        d_wk = [torch.matmul(qp.t(), d_g)]
+        d_wkb = [torch.mv(qp.t(), d_c0)]
         wmax = max(plan.key.width, plan.qry.width, plan.val.width, plan.key.ld_in, plan.val.ld_in, plan.d_model)
         scratch = [torch.empty((M, wmax), device=dev, dtype=torch.float32) for _ in range(2)]
         # key branch
-        d_wk, d_wkb, d_K = mlp_backward(plan.wk, wkw, wkb, K, M, [s["kp"]], d_kp, scratch, True)
         if plan.kq_norm:
             rownorm_bwd_(d_K, K, s["kst2"], plan.key.d_out, eps)
         need_pts = ctx.needs_input_grad[5]
@@ -372,7 +399,7 @@ class _RenderFn(torch.autograd.Function):
             rownorm_bwd_(d_key, s["key_in"], s["kst"], plan.key_w, eps)
         # query branch (the ray directions need no gradient)
         qscratch = [t[:R] for t in scratch]
-        d_wq, d_wqb, d_Q = mlp_backward(plan.wq, wqw, wqb, Q, R, [s["qp"]], d_qp, qscratch, True)
+        d_wq, d_wqb, d_Q = mlp_backward(plan.wq, wqw, wqb, Q, R, [qp], d_qp.contiguous(), qscratch, True)
         if plan.kq_norm:
             rownorm_bwd_(d_Q, Q, s["qst2"], plan.qry.d_out, eps)
         d_qw, d_qb, _ = mlp_backward(plan.qry, qw, qb, s["qry_in"], R, s["q_outs"], d_Q, qscratch, False)

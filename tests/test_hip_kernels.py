@@ -287,7 +287,9 @@ def test_attention_tail_forward_backward(R, k, d_model, Cc, act, normalize):
     influ = (torch.rand(P, 1, generator=gen) * 1.2 - 0.2).requires_grad_(True)
     idx = torch.randint(0, P, (R, k), generator=gen)
     bkg = 3.0
-    sc = torch.matmul(qp, kp.transpose(-2, -1)).squeeze(1) / d_model ** 0.5
+    sb = torch.randn(R, generator=gen).requires_grad_(True)          # per-ray additive term of the dot products
+    scale_dim = 2 * d_model if R == 65 else d_model                  # the divisor need not be the dot width
+    sc = (torch.matmul(qp, kp.transpose(-2, -1)).squeeze(1) + sb[:, None]) / scale_dim ** 0.5
     sc = O._act(sc, act)
     fused_ref, attn_ref = O.attention_tail(sc, influ[idx].squeeze(-1), v, bkg, normalize)
     gf = torch.randn(R, Cc, generator=gen)
@@ -297,24 +299,26 @@ def test_attention_tail_forward_backward(R, k, d_model, Cc, act, normalize):
     d = dev()
     td = hip.TailDesc()
     td.k, td.d_model, td.C, td.ld_kp, td.ld_qp, td.ld_v = k, d_model, Cc, d_model, d_model, ldv
-    td.score_act, td.normalize, td.bkg_score = hip.ACT[act], int(normalize), bkg
+    td.score_act, td.normalize, td.bkg_score, td.scale_dim = hip.ACT[act], int(normalize), bkg, scale_dim
+    sbd = sb.detach().to(d)
     kpd = kp.detach().reshape(R * k, d_model).to(d)
     qpd = qp.detach().reshape(R, d_model).to(d)
     vp = torch.zeros(R * k, ldv); vp[:, :Cc] = v.detach().reshape(R * k, Cc)
     vd = vp.to(d)
     infd, idxd = influ.detach().to(d), idx.int().to(d)
     scores = torch.empty((R, k), device=d); attn = torch.empty((R, k + 1), device=d); fused = torch.empty((R, Cc), device=d)
-    hip.check(hip.lib().papr_attn_tail_fwd(C.byref(td), hip.ptr(kpd), hip.ptr(qpd), hip.ptr(vd), hip.ptr(infd), hip.ptr(idxd), R,
+    hip.check(hip.lib().papr_attn_tail_fwd(C.byref(td), hip.ptr(kpd), hip.ptr(qpd), hip.ptr(sbd), hip.ptr(vd), hip.ptr(infd), hip.ptr(idxd), R,
                                            hip.ptr(scores), hip.ptr(attn), hip.ptr(fused), hip.stream_ptr()), "tail_fwd")
     np.testing.assert_allclose(scores.cpu().numpy(), sc.detach().numpy(), rtol=0, atol=5e-6)
     np.testing.assert_allclose(attn.cpu().numpy(), attn_ref.detach().numpy(), rtol=0, atol=2e-6)
     np.testing.assert_allclose(fused.cpu().numpy(), fused_ref.detach().numpy(), rtol=0, atol=1e-5)
     d_kp = torch.empty_like(kpd); d_qp = torch.empty_like(qpd); d_v = torch.empty_like(vd)
     d_inf = torch.zeros((P, 1), device=d)
+    d_sb = torch.empty((R,), device=d)
     gf_d, ga_d = gf.to(d), ga.to(d)
     hip.check(hip.lib().papr_attn_tail_bwd(C.byref(td), hip.ptr(kpd), hip.ptr(qpd), hip.ptr(vd), hip.ptr(infd), hip.ptr(idxd), R,
                                            hip.ptr(scores), hip.ptr(attn), hip.ptr(gf_d), hip.ptr(ga_d), hip.ptr(d_kp),
-                                           hip.ptr(d_qp), hip.ptr(d_v), hip.ptr(d_inf), hip.stream_ptr()), "tail_bwd")
+                                           hip.ptr(d_qp), hip.ptr(d_v), hip.ptr(d_inf), hip.ptr(d_sb), hip.stream_ptr()), "tail_bwd")
     torch.cuda.synchronize()
     tol = lambda ref: 3e-5 * ref.abs().max().item() + 1e-9
     np.testing.assert_allclose(d_kp.cpu().numpy(), kp.grad.reshape(R * k, -1).numpy(), rtol=0, atol=tol(kp.grad))
@@ -322,3 +326,4 @@ def test_attention_tail_forward_backward(R, k, d_model, Cc, act, normalize):
     np.testing.assert_allclose(d_v.cpu()[:, :Cc].numpy(), v.grad.reshape(R * k, -1).numpy(), rtol=0, atol=tol(v.grad))
     assert torch.all(d_v.cpu()[:, Cc:] == 0)
     np.testing.assert_allclose(d_inf.cpu().numpy(), influ.grad.numpy(), rtol=0, atol=tol(influ.grad))
+    np.testing.assert_allclose(d_sb.cpu().numpy(), sb.grad.numpy(), rtol=0, atol=tol(sb.grad))
