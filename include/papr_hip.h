@@ -86,6 +86,23 @@ int papr_build_features_bwd(const papr_feature_desc* d, const float* points, con
                             const float* d_key, const float* d_val, float* d_points, float* d_pc_feats,
                             papr_stream_t stream);
 
+/* Same backward, but instead of atomics it writes one gradient row {dx,dy,dz,0} per pair into
+ * d_pair_points (R*k,4); the per-point feature columns stay in d_val / d_key.  Feed both to
+ * papr_segment_reduce for a balanced, nearly atomic-free scatter (replaces the
+ * index_put_(accumulate=True) backward of the three gathers, models/model.py:330,435,509). */
+int papr_build_features_bwd_pairs(const papr_feature_desc* d, const float* points, const float* rays_o,
+                                  const float* rays_d, int64_t R, int64_t rays_per_image, const int32_t* idx,
+                                  const float* d_key, const float* d_val, float* d_pair_points, papr_stream_t stream);
+
+/* order (M = R*k) int64: pair ids grouped by selected point (a stable sort of idx); sorted_pts (M) int32:
+ * the point of each entry; seg (P+1) int64: group bounds.  d_points[p] += sum of pair_points rows,
+ * d_influ[p] += sum of pair_influ, d_feats[p][c] += sum of rows[pair][col0 + c] (c < ncols <= 128) over
+ * point p's group.  Any of the three inputs may be NULL.  Outputs must be zeroed by the caller: groups
+ * that straddle the kernel's fixed-size chunks are completed with atomic adds. */
+int papr_segment_reduce(const int64_t* order, const int32_t* sorted_pts, const int64_t* seg, int64_t M, int64_t P,
+                        const float* pair_points, const float* pair_influ, const float* rows, int ld, int col0,
+                        int ncols, float* d_points, float* d_influ, float* d_feats, papr_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * Row standardisation  y = (x - mean) / (std_unbiased + eps)      (the non-affine core of the
  * reference LayerNorm, models/attn.py:39-42; the a_2/b_2 affine is folded into the next Linear by
@@ -153,11 +170,14 @@ int papr_attn_tail_fwd(const papr_tail_desc* d, const float* kp, const float* qp
                        float* attn, float* fused, papr_stream_t stream);
 
 /* d_v rows are overwritten; d_kp rows are overwritten; d_qp (R, ld_qp) overwritten; d_score_bias (R) or
- * NULL overwritten; d_influ (P) accumulated with atomic adds (caller zeroes). */
+ * NULL overwritten.  Influence gradient: either d_pair_influ (R*k) receives one term per pair (to be
+ * summed per point by papr_segment_reduce; d_influ may be NULL), or, when d_pair_influ is NULL, the terms
+ * are accumulated into d_influ (P) with atomic adds (caller zeroes). */
 int papr_attn_tail_bwd(const papr_tail_desc* d, const float* kp, const float* qp, const float* v,
                        const float* influ, const int32_t* idx, int64_t R, const float* scores,
                        const float* attn, const float* d_fused, const float* d_attn, float* d_kp,
-                       float* d_qp, float* d_v, float* d_influ, float* d_score_bias, papr_stream_t stream);
+                       float* d_qp, float* d_v, float* d_influ, float* d_score_bias, float* d_pair_influ,
+                       papr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Optional timing of the GEMM / kNN launches with HIP events recorded on the launch stream

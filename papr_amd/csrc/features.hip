@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void features_bwd_kernel(FeatParams fp, const 
                                                            long rays_per_image, const int* __restrict__ idx,
                                                            const float* __restrict__ d_key,
                                                            const float* __restrict__ d_val,
-                                                           float* __restrict__ d_points) {
+                                                           float* __restrict__ d_points, float4* __restrict__ d_pair) {
     const papr_feature_desc& d = fp.d;
     long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
     long M = R * d.k;
@@ -166,9 +166,13 @@ __global__ __launch_bounds__(256) void features_bwd_kernel(FeatParams fp, const 
     }
     // s = r t, u = v - r t, t = (v.r)/(r.r+eps)  =>  dL/dv = gu + r * (r.(gs - gu)) / (r.r+eps)
     float w = (g.rx * (gs[0] - gu[0]) + g.ry * (gs[1] - gu[1]) + g.rz * (gs[2] - gu[2])) / g.rr;
-    unsafeAtomicAdd(d_points + pi * 3 + 0, gu[0] + g.rx * w);
-    unsafeAtomicAdd(d_points + pi * 3 + 1, gu[1] + g.ry * w);
-    unsafeAtomicAdd(d_points + pi * 3 + 2, gu[2] + g.rz * w);
+    if (d_pair) {           // per-pair rows for the deterministic segmented reduction (papr_segment_reduce)
+        d_pair[m] = make_float4(gu[0] + g.rx * w, gu[1] + g.ry * w, gu[2] + g.rz * w, 0.f);
+    } else {
+        unsafeAtomicAdd(d_points + pi * 3 + 0, gu[0] + g.rx * w);
+        unsafeAtomicAdd(d_points + pi * 3 + 1, gu[1] + g.ry * w);
+        unsafeAtomicAdd(d_points + pi * 3 + 2, gu[2] + g.rz * w);
+    }
 }
 
 // scatter-add of the un-encoded per-point feature block: 4 columns per thread
@@ -184,6 +188,73 @@ __global__ __launch_bounds__(256) void feats_scatter_kernel(const float* __restr
     float* dst = d_pc_feats + (long)idx[m] * feat_dim + c;
 #pragma unroll
     for (int j = 0; j < 4; ++j) unsafeAtomicAdd(dst + j, src[j]);
+}
+
+// Gradient of per-point parameters as a segmented sum over the pairs that selected each point.
+// `order` lists pair ids grouped by point (stable sort of idx), `sorted_pts` the point of each entry,
+// seg[p]..seg[p+1] point p's group.  Work is cut into fixed chunks of SEG_CH sorted entries, one wave
+// per chunk (a wave-per-point split is hopelessly unbalanced: a few points are selected by thousands
+// of rays).  Lanes span the feature columns, lanes 0-2 also carry xyz and lane 3 the influence term.
+// A group that lies inside one chunk is stored directly; a group that straddles chunks is finished
+// with atomic adds (a few per chunk instead of 67 per pair).  Outputs must be zeroed by the caller.
+constexpr int SEG_CH = 128;
+
+__global__ __launch_bounds__(256) void segment_reduce_kernel(const long* __restrict__ order, const int* __restrict__ sorted_pts,
+                                                             const long* __restrict__ seg, long M,
+                                                             const float* __restrict__ pair_points, const float* __restrict__ pair_influ,
+                                                             const float* __restrict__ rows, int ld, int col0, int ncols,
+                                                             float* __restrict__ d_points, float* __restrict__ d_influ,
+                                                             float* __restrict__ d_feats) {
+    const int lane = threadIdx.x & 63;
+    const long e0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * SEG_CH;
+    if (e0 >= M) return;
+    const int n = (int)(M - e0 < SEG_CH ? M - e0 : SEG_CH);
+    // this chunk's entries: lane holds entries lane and lane+64
+    int ma = e0 + lane < M ? (int)order[e0 + lane] : 0, mb = e0 + 64 + lane < M ? (int)order[e0 + 64 + lane] : 0;
+    int pa = e0 + lane < M ? sorted_pts[e0 + lane] : 0, pb = e0 + 64 + lane < M ? sorted_pts[e0 + 64 + lane] : 0;
+    const bool has_small = (pair_points && lane < 3) || (pair_influ && lane == 3);
+    const bool c0_ok = rows && lane < ncols, c1_ok = rows && lane + 64 < ncols;
+    float small = 0.f, acc0 = 0.f, acc1 = 0.f;
+    int cur = __builtin_amdgcn_readlane(pa, 0);
+
+    auto flush = [&](int p) {
+        const bool interior = seg[p] >= e0 && seg[p + 1] <= e0 + n;
+        if (interior) {
+            if (pair_points && lane < 3) d_points[p * 3 + lane] = small;
+            if (pair_influ && lane == 3) d_influ[p] = small;
+            if (c0_ok) d_feats[(long)p * ncols + lane] = acc0;
+            if (c1_ok) d_feats[(long)p * ncols + lane + 64] = acc1;
+        } else {
+            if (pair_points && lane < 3) unsafeAtomicAdd(d_points + p * 3 + lane, small);
+            if (pair_influ && lane == 3) unsafeAtomicAdd(d_influ + p, small);
+            if (c0_ok) unsafeAtomicAdd(d_feats + (long)p * ncols + lane, acc0);
+            if (c1_ok) unsafeAtomicAdd(d_feats + (long)p * ncols + lane + 64, acc1);
+        }
+        small = acc0 = acc1 = 0.f;
+    };
+    auto entry = [&](int j, int& m, int& pt) {       // wave-uniform (pair id, point) of entry j
+        m = j < 64 ? __builtin_amdgcn_readlane(ma, j) : __builtin_amdgcn_readlane(mb, j - 64);
+        pt = j < 64 ? __builtin_amdgcn_readlane(pa, j) : __builtin_amdgcn_readlane(pb, j - 64);
+    };
+    for (int j0 = 0; j0 < n; j0 += 4) {
+        int m[4], pt[4];
+        float vs[4], v0[4], v1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                // issue the loads of four entries before using any
+            entry(j0 + u < n ? j0 + u : n - 1, m[u], pt[u]);
+            vs[u] = v0[u] = v1[u] = 0.f;
+            if (has_small) vs[u] = lane < 3 ? pair_points[(long)m[u] * 4 + lane] : pair_influ[m[u]];
+            if (c0_ok) v0[u] = rows[(long)m[u] * ld + col0 + lane];
+            if (c1_ok) v1[u] = rows[(long)m[u] * ld + col0 + lane + 64];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (j0 + u >= n) break;
+            if (pt[u] != cur) { flush(cur); cur = pt[u]; }
+            small += vs[u]; acc0 += v0[u]; acc1 += v1[u];
+        }
+    }
+    flush(cur);
 }
 
 int fill_params(const papr_feature_desc* d, FeatParams* fp) {
@@ -252,7 +323,7 @@ extern "C" int papr_build_features_bwd(const papr_feature_desc* d, const float* 
     hipStream_t s = as_stream(stream);
     long M = R * d->k;
     features_bwd_kernel<<<dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s>>>(fp, points, rays_o, rays_d, R,
-                                                                             rays_per_image, idx, d_key, d_val, d_points);
+                                                                             rays_per_image, idx, d_key, d_val, d_points, nullptr);
     PAPR_CHECK_LAUNCH("features_bwd");
     if (d_pc_feats) {
         long n = M * (d->feat_dim / 4);
@@ -267,5 +338,38 @@ extern "C" int papr_build_features_bwd(const papr_feature_desc* d, const float* 
             PAPR_CHECK_LAUNCH("feats_scatter(key)");
         }
     }
+    return 0;
+}
+
+extern "C" int papr_build_features_bwd_pairs(const papr_feature_desc* d, const float* points, const float* rays_o,
+                                             const float* rays_d, int64_t R, int64_t rays_per_image, const int32_t* idx,
+                                             const float* d_key, const float* d_val, float* d_pair_points,
+                                             papr_stream_t stream) {
+    PAPR_REQUIRE(d && points && rays_o && rays_d && idx && d_pair_points, "papr_build_features_bwd_pairs: null pointer");
+    FeatParams fp;
+    fill_params(d, &fp);
+    if (int e = check_desc(d, fp, "papr_build_features_bwd_pairs")) return e;
+    if (R <= 0) return 0;
+    long M = R * d->k;
+    features_bwd_kernel<<<dim3((unsigned)((M + 255) / 256)), dim3(256), 0, as_stream(stream)>>>(
+        fp, points, rays_o, rays_d, R, rays_per_image, idx, d_key, d_val, nullptr, reinterpret_cast<float4*>(d_pair_points));
+    PAPR_CHECK_LAUNCH("features_bwd(pairs)");
+    return 0;
+}
+
+extern "C" int papr_segment_reduce(const int64_t* order, const int32_t* sorted_pts, const int64_t* seg, int64_t M, int64_t P,
+                                   const float* pair_points, const float* pair_influ, const float* rows, int ld, int col0,
+                                   int ncols, float* d_points, float* d_influ, float* d_feats, papr_stream_t stream) {
+    PAPR_REQUIRE(order && sorted_pts && seg, "papr_segment_reduce: null index arrays");
+    PAPR_REQUIRE(M < ((int64_t)1 << 31), "papr_segment_reduce: more than 2^31 pairs");
+    PAPR_REQUIRE(!rows || (d_feats && ncols >= 1 && ncols <= 128), "papr_segment_reduce: 1 <= ncols <= 128 and d_feats required");
+    PAPR_REQUIRE(!pair_points || d_points, "papr_segment_reduce: d_points required");
+    PAPR_REQUIRE(!pair_influ || d_influ, "papr_segment_reduce: d_influ required");
+    if (P <= 0 || M <= 0) return 0;
+    const long chunks = (M + SEG_CH - 1) / SEG_CH;
+    segment_reduce_kernel<<<dim3((unsigned)((chunks + 3) / 4)), dim3(256), 0, as_stream(stream)>>>(
+        reinterpret_cast<const long*>(order), sorted_pts, reinterpret_cast<const long*>(seg), M, pair_points, pair_influ, rows, ld,
+        col0, ncols, d_points, d_influ, d_feats);
+    PAPR_CHECK_LAUNCH("segment_reduce");
     return 0;
 }

@@ -143,7 +143,8 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(papr_tail_desc d, const f
                                                        const float* __restrict__ attn, const float* __restrict__ d_fused,
                                                        const float* __restrict__ d_attn, float* __restrict__ d_kp,
                                                        float* __restrict__ d_qp, float* __restrict__ d_v,
-                                                       float* __restrict__ d_influ, float* __restrict__ d_score_bias) {
+                                                       float* __restrict__ d_influ, float* __restrict__ d_score_bias,
+                                                       float* __restrict__ d_pair_influ) {
     const int lane = threadIdx.x & 63;
     long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= R) return;
@@ -180,7 +181,8 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(papr_tail_desc d, const f
     float w = lane < k ? influ[pi] : 0.f;
     float ddot = 0.f;
     if (lane < k) {
-        unsafeAtomicAdd(d_influ + pi, dz * sc);
+        if (d_pair_influ) d_pair_influ[r * k + lane] = dz * sc;   // summed per point by papr_segment_reduce
+        else unsafeAtomicAdd(d_influ + pi, dz * sc);
         ddot = dz * w * papr_act_grad(sc, d.score_act) * inv_sqrt_d;
     }
     if (d_score_bias) {
@@ -251,13 +253,14 @@ extern "C" int papr_attn_tail_fwd(const papr_tail_desc* d, const float* kp, cons
 extern "C" int papr_attn_tail_bwd(const papr_tail_desc* d, const float* kp, const float* qp, const float* v,
                                   const float* influ, const int32_t* idx, int64_t R, const float* scores,
                                   const float* attn, const float* d_fused, const float* d_attn, float* d_kp,
-                                  float* d_qp, float* d_v, float* d_influ, float* d_score_bias, papr_stream_t stream) {
+                                  float* d_qp, float* d_v, float* d_influ, float* d_score_bias, float* d_pair_influ,
+                                  papr_stream_t stream) {
     if (int e = check_tail(d, "papr_attn_tail_bwd")) return e;
-    PAPR_REQUIRE(kp && qp && v && influ && idx && scores && attn && d_fused && d_kp && d_qp && d_v && d_influ,
+    PAPR_REQUIRE(kp && qp && v && influ && idx && scores && attn && d_fused && d_kp && d_qp && d_v && (d_influ || d_pair_influ),
                  "papr_attn_tail_bwd: null pointer");
     if (R <= 0) return 0;
     tail_bwd_kernel<<<dim3((unsigned)((R + 3) / 4)), dim3(256), 0, as_stream(stream)>>>(
-        *d, kp, qp, v, influ, idx, R, scores, attn, d_fused, d_attn, d_kp, d_qp, d_v, d_influ, d_score_bias);
+        *d, kp, qp, v, influ, idx, R, scores, attn, d_fused, d_attn, d_kp, d_qp, d_v, d_influ, d_score_bias, d_pair_influ);
     PAPR_CHECK_LAUNCH("tail_bwd");
     return 0;
 }

@@ -16,7 +16,8 @@ ACT = {"none": 0, "relu": 1, "leakyrelu": 2}
 
 EXPORTS = [
     "papr_abi_version", "papr_last_error", "papr_ray_knn_workspace_bytes", "papr_ray_knn",
-    "papr_feature_widths", "papr_build_features_fwd", "papr_build_features_bwd",
+    "papr_feature_widths", "papr_build_features_fwd", "papr_build_features_bwd", "papr_build_features_bwd_pairs",
+    "papr_segment_reduce",
     "papr_rownorm_fwd", "papr_rownorm_bwd", "papr_mlp_bwd_workspace_bytes", "papr_mlp_fwd", "papr_mlp_bwd",
     "papr_attn_tail_fwd", "papr_attn_tail_bwd", "papr_profile_enable", "papr_profile_collect",
 ]
@@ -70,6 +71,8 @@ def lib():
     L.papr_feature_widths.argtypes = [C.POINTER(FeatureDesc), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.papr_build_features_fwd.argtypes = [C.POINTER(FeatureDesc), vp, vp, vp, vp, i64, i64, vp, vp, vp, vp, vp, vp]
     L.papr_build_features_bwd.argtypes = [C.POINTER(FeatureDesc), vp, vp, vp, i64, i64, vp, vp, vp, vp, vp, vp]
+    L.papr_build_features_bwd_pairs.argtypes = [C.POINTER(FeatureDesc), vp, vp, vp, i64, i64, vp, vp, vp, vp, vp]
+    L.papr_segment_reduce.argtypes = [vp, vp, vp, i64, i64, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]
     L.papr_rownorm_fwd.argtypes = [vp, i64, i32, i32, f32, vp, vp, vp]
     L.papr_rownorm_bwd.argtypes = [vp, vp, vp, i64, i32, i32, f32, vp, vp]
     L.papr_mlp_bwd_workspace_bytes.restype = C.c_size_t
@@ -77,7 +80,7 @@ def lib():
     L.papr_mlp_bwd.argtypes = [C.POINTER(Layer), i32, vp, i32, i64, C.POINTER(vp), C.POINTER(C.c_int32), vp, vp, vp,
                                i32, C.POINTER(vp), C.POINTER(vp), vp, vp, vp]
     L.papr_attn_tail_fwd.argtypes = [C.POINTER(TailDesc), vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp]
-    L.papr_attn_tail_bwd.argtypes = [C.POINTER(TailDesc), vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.papr_attn_tail_bwd.argtypes = [C.POINTER(TailDesc), vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.papr_profile_enable.argtypes = [i32]
     L.papr_profile_collect.argtypes = [C.POINTER(ProfileRecord), i32]
     for name in EXPORTS:

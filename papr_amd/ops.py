@@ -346,9 +346,14 @@ class _RenderFn(torch.autograd.Function):
         ctx.plan, ctx.rpi, ctx.n = plan, rays_per_image, (n_k, n_q, n_v)
         ctx.mark_non_differentiable(sel)
         if keep:
+            # pairs grouped by selected point, for the atomic-free scatter of the per-point gradients
+            flat = idx.view(-1)
+            sorted_pts, order = torch.sort(flat, stable=True)
+            seg = torch.zeros(points.shape[0] + 1, device=dev, dtype=torch.int64)
+            torch.cumsum(torch.bincount(flat, minlength=points.shape[0]), 0, out=seg[1:])
             ctx.saved = dict(rays_o=rays_o, rays_d=rays_d, idx=idx, points=points, influ=influ, key_in=key_in, qry_in=qry_in,
                              val_in=val_in, kst=kst, qst=qst, kst2=kst2, qst2=qst2, k_outs=k_outs, q_outs=q_outs,
-                             v_outs=v_outs, g=g, qp=qp, scores=scores, attn=attn, wb=wb, P=points.shape[0],
+                             v_outs=v_outs, g=g, qp=qp, order=order, sorted_pts=sorted_pts, seg=seg, scores=scores, attn=attn, wb=wb, P=points.shape[0],
                              feat_shape=None if pc_feats is None else pc_feats.shape)
         return fused, attn, sel
 
@@ -377,11 +382,12 @@ class _RenderFn(torch.autograd.Function):
         d_c0 = torch.empty((R,), device=dev, dtype=torch.float32)
         d_V = torch.empty_like(V)
         d_influ = torch.zeros((s["P"], 1), device=dev, dtype=torch.float32)
+        pair_influ = torch.empty((M,), device=dev, dtype=torch.float32)
         d_fused = d_fused.contiguous()
         d_attn = d_attn.contiguous() if d_attn is not None else None
         hip.check(lib.papr_attn_tail_bwd(C.byref(td), hip.ptr(K), hip.ptr(s["g"]), hip.ptr(V), hip.ptr(s["influ"]), hip.ptr(idx),
                                          R, hip.ptr(s["scores"]), hip.ptr(s["attn"]), hip.ptr(d_fused), hip.ptr(d_attn), hip.ptr(d_K),
-                                         hip.ptr(d_g), hip.ptr(d_V), hip.ptr(d_influ), hip.ptr(d_c0), hip.stream_ptr()), "papr_attn_tail_bwd")
+                                         hip.ptr(d_g), hip.ptr(d_V), None, hip.ptr(d_c0), hip.ptr(pair_influ), hip.stream_ptr()), "papr_attn_tail_bwd")
         # backward of g = q' W_k, c0 = q'.b_k (R-row library GEMMs)
         qp = s["qp"]
         d_g = d_g[:, :plan.key.d_out]                        # the tail kernel fills d_model = key.d_out columns
@@ -406,15 +412,31 @@ class _RenderFn(torch.autograd.Function):
         # value branch
         need_val_dx = need_pts or ctx.needs_input_grad[6]
         d_vw, d_vb, d_val = mlp_backward(plan.val, vw, vb, s["val_in"], M, s["v_outs"], d_V, scratch, need_val_dx)
-        # gather / geometry / encoding backward
-        d_points = d_feats = None
-        if need_pts or ctx.needs_input_grad[6]:
-            d_points = torch.zeros((s["P"], 3), device=dev, dtype=torch.float32)
-            d_feats = torch.zeros(s["feat_shape"], device=dev, dtype=torch.float32) if plan.use_feats else None
+        # gather / geometry / encoding backward: per-pair gradient rows, then one segmented sum per point
+        d_points = d_feats = pair_pts = None
+        need_geo = need_pts or ctx.needs_input_grad[6]
+        if need_geo:
+            pair_pts = torch.empty((M, 4), device=dev, dtype=torch.float32)
             fd = plan.feature_desc(k)
-            hip.check(lib.papr_build_features_bwd(C.byref(fd), hip.ptr(s["points"]), hip.ptr(s["rays_o"]), hip.ptr(s["rays_d"]), R,
-                                                  ctx.rpi, hip.ptr(idx), hip.ptr(d_key), hip.ptr(d_val), hip.ptr(d_points),
-                                                  hip.ptr(d_feats), hip.stream_ptr()), "papr_build_features_bwd")
+            hip.check(lib.papr_build_features_bwd_pairs(C.byref(fd), hip.ptr(s["points"]), hip.ptr(s["rays_o"]), hip.ptr(s["rays_d"]), R,
+                                                        ctx.rpi, hip.ptr(idx), hip.ptr(d_key), hip.ptr(d_val), hip.ptr(pair_pts),
+                                                        hip.stream_ptr()), "papr_build_features_bwd_pairs")
+            d_points = torch.zeros((s["P"], 3), device=dev, dtype=torch.float32)
+        fdim = plan.feat_dim
+        rows, ld, col0 = None, 0, 0
+        if need_geo and plan.use_feats:
+            d_feats = torch.zeros(s["feat_shape"], device=dev, dtype=torch.float32)
+            if plan.fdesc.val_has_feats:
+                rows, ld, col0 = d_val, d_val.shape[1], plan.val_w - fdim
+            else:
+                rows, ld, col0 = d_key, d_key.shape[1], plan.key_w - fdim
+        hip.check(lib.papr_segment_reduce(hip.ptr(s["order"]), hip.ptr(s["sorted_pts"]), hip.ptr(s["seg"]), M, s["P"], hip.ptr(pair_pts), hip.ptr(pair_influ),
+                                          hip.ptr(rows), ld, col0, fdim if rows is not None else 0, hip.ptr(d_points), hip.ptr(d_influ),
+                                          hip.ptr(d_feats), hip.stream_ptr()), "papr_segment_reduce")
+        if need_geo and plan.fdesc.val_has_feats and plan.fdesc.key_has_feats:      # features feed both branches
+            hip.check(lib.papr_segment_reduce(hip.ptr(s["order"]), hip.ptr(s["sorted_pts"]), hip.ptr(s["seg"]), M, s["P"], None, None,
+                                              hip.ptr(d_key), d_key.shape[1], plan.key_w - fdim, fdim, None, None, hip.ptr(d_feats),
+                                              hip.stream_ptr()), "papr_segment_reduce")
         ctx.saved = None
         grads_wb = d_kw + d_kb + d_wk + d_wkb + d_qw + d_qb + d_wq + d_wqb + d_vw + d_vb
         return (None, None, None, None, None, d_points, d_feats, d_influ, None, None, None) + tuple(grads_wb)

@@ -318,7 +318,7 @@ def test_attention_tail_forward_backward(R, k, d_model, Cc, act, normalize):
     gf_d, ga_d = gf.to(d), ga.to(d)
     hip.check(hip.lib().papr_attn_tail_bwd(C.byref(td), hip.ptr(kpd), hip.ptr(qpd), hip.ptr(vd), hip.ptr(infd), hip.ptr(idxd), R,
                                            hip.ptr(scores), hip.ptr(attn), hip.ptr(gf_d), hip.ptr(ga_d), hip.ptr(d_kp),
-                                           hip.ptr(d_qp), hip.ptr(d_v), hip.ptr(d_inf), hip.ptr(d_sb), hip.stream_ptr()), "tail_bwd")
+                                           hip.ptr(d_qp), hip.ptr(d_v), hip.ptr(d_inf), hip.ptr(d_sb), None, hip.stream_ptr()), "tail_bwd")
     torch.cuda.synchronize()
     tol = lambda ref: 3e-5 * ref.abs().max().item() + 1e-9
     np.testing.assert_allclose(d_kp.cpu().numpy(), kp.grad.reshape(R * k, -1).numpy(), rtol=0, atol=tol(kp.grad))
