@@ -26,8 +26,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 32;        // k-slab per stage
-constexpr int PITCH = BK + 4; // LDS row pitch (floats)
+constexpr int BK = 32;        // default k-slab per stage (single-buffered variant)
 
 struct NTArgs {
     const float* A;  long lda;  int K1;
@@ -42,15 +41,20 @@ struct NTArgs {
     long M; int N;
 };
 
-template <int BM, int BN, int TM, int TN>
+// BKT: k-slab per stage (32 or 16).  DB: two LDS buffers and ONE barrier per stage (compute slab t,
+// write slab t+1 into the other buffer, barrier) instead of barrier / write / barrier.
+template <int BM, int BN, int TM, int TN, int BKT = BK, bool DB = false>
 __global__ __launch_bounds__(64 * (BM / (32 * TM)) * (BN / (32 * TN)), (BM / (32 * TM)) * (BN / (32 * TN)) / 2)
 void gemm_nt_kernel(NTArgs p) {
+    constexpr int PITCH = BKT + 4;              // LDS row pitch (floats): 16-lane read groups hit 16 distinct 4-bank slots
+    constexpr int KQ = BKT / 4;                 // float4 per slab row
     constexpr int WN = BN / (32 * TN);          // waves along n
     constexpr int WM = BM / (32 * TM);          // waves along m
     constexpr int NTHR = 64 * WM * WN;          // 4 or 8 waves; two workgroups per CU either way
     static_assert(WM * WN == 4 || WM * WN == 8, "four or eight waves per workgroup");
-    constexpr int A_LD = BM * 8 / NTHR;         // float4 loads per thread for the A slab
-    constexpr int W_LD = BN * 8 / NTHR;
+    constexpr int A_LD = BM * KQ / NTHR;        // float4 loads per thread for the A slab
+    constexpr int W_LD = BN * KQ / NTHR;
+    constexpr int BUF = (BM + BN) * PITCH;      // floats per LDS buffer
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                  // [BM][PITCH]
@@ -63,20 +67,20 @@ void gemm_nt_kernel(NTArgs p) {
     const long m0 = (long)blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
 
-    const int nt1 = (p.K1 + BK - 1) / BK;
-    const int nt2 = p.A2 ? (p.K2 + BK - 1) / BK : 0;
+    const int nt1 = (p.K1 + BKT - 1) / BKT;
+    const int nt2 = p.A2 ? (p.K2 + BKT - 1) / BKT : 0;
     const int nt = nt1 + nt2;
 
     float4 ra[A_LD], rw[W_LD];
 
     auto load_slab = [&](int kt) {
         const float* src; long ld; int klim, k0, wcol;
-        if (kt < nt1) { src = p.A; ld = p.lda; klim = p.K1; k0 = kt * BK; wcol = k0; }
-        else { src = p.A2; ld = p.lda2; klim = p.K2; k0 = (kt - nt1) * BK; wcol = p.wcol2 + k0; }
+        if (kt < nt1) { src = p.A; ld = p.lda; klim = p.K1; k0 = kt * BKT; wcol = k0; }
+        else { src = p.A2; ld = p.lda2; klim = p.K2; k0 = (kt - nt1) * BKT; wcol = p.wcol2 + k0; }
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) {
             int f = tid + NTHR * i;
-            int row = f >> 3, kq = (f & 7) * 4;
+            int row = f / KQ, kq = (f % KQ) * 4;
             long m = m0 + row;
             ra[i] = (m < p.M && k0 + kq < klim) ? *reinterpret_cast<const float4*>(src + m * ld + k0 + kq)
                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -84,22 +88,22 @@ void gemm_nt_kernel(NTArgs p) {
 #pragma unroll
         for (int i = 0; i < W_LD; ++i) {
             int f = tid + NTHR * i;
-            int row = f >> 3, kq = (f & 7) * 4;
+            int row = f / KQ, kq = (f % KQ) * 4;
             int n = n0 + row;
             rw[i] = (n < p.N && k0 + kq < klim) ? *reinterpret_cast<const float4*>(p.W + (long)n * p.ldw + wcol + kq)
                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    auto store_slab = [&]() {
+    auto store_slab = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) {
             int f = tid + NTHR * i;
-            *reinterpret_cast<float4*>(As + (f >> 3) * PITCH + (f & 7) * 4) = ra[i];
+            *reinterpret_cast<float4*>(As + buf * BUF + (f / KQ) * PITCH + (f % KQ) * 4) = ra[i];
         }
 #pragma unroll
         for (int i = 0; i < W_LD; ++i) {
             int f = tid + NTHR * i;
-            *reinterpret_cast<float4*>(Ws + (f >> 3) * PITCH + (f & 7) * 4) = rw[i];
+            *reinterpret_cast<float4*>(Ws + buf * BUF + (f / KQ) * PITCH + (f % KQ) * 4) = rw[i];
         }
     };
 
@@ -115,17 +119,18 @@ void gemm_nt_kernel(NTArgs p) {
     const float* w_base = Ws + (wn * TN * 32 + (lane & 31)) * PITCH + 4 * (lane >> 5);
 
     load_slab(0);
-    store_slab();
+    store_slab(0);
     __syncthreads();
     for (int kt = 0; kt < nt; ++kt) {
         if (kt + 1 < nt) load_slab(kt + 1);
+        const int cur = DB ? (kt & 1) * BUF : 0;
 #pragma unroll
-        for (int kb = 0; kb < BK; kb += 8) {
+        for (int kb = 0; kb < BKT; kb += 8) {
             float4 af[TM], wf[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(a_base + i * 32 * PITCH + kb);
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(a_base + cur + i * 32 * PITCH + kb);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const float4*>(w_base + j * 32 * PITCH + kb);
+            for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const float4*>(w_base + cur + j * 32 * PITCH + kb);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -136,10 +141,15 @@ void gemm_nt_kernel(NTArgs p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, wf[j].w, acc[i][j], 0, 0, 0);
                 }
         }
-        __syncthreads();
-        if (kt + 1 < nt) {
-            store_slab();
+        if (DB) {
+            if (kt + 1 < nt) store_slab((kt + 1) & 1);      // the other buffer: its last readers passed the previous barrier
             __syncthreads();
+        } else {
+            __syncthreads();
+            if (kt + 1 < nt) {
+                store_slab(0);
+                __syncthreads();
+            }
         }
     }
 
@@ -202,13 +212,13 @@ void gemm_nt_kernel(NTArgs p) {
     }
 }
 
-template <int BM, int BN, int TM, int TN>
+template <int BM, int BN, int TM, int TN, int BKT = BK, bool DB = false>
 int launch_nt(const NTArgs& a, hipStream_t s) {
     dim3 grid((unsigned)((a.M + BM - 1) / BM), (unsigned)((a.N + BN - 1) / BN));
-    size_t lds = (size_t)(BM + BN) * PITCH * sizeof(float);
+    size_t lds = (size_t)(DB ? 2 : 1) * (BM + BN) * (BKT + 4) * sizeof(float);
     const bool prof = papr_prof_on();
     if (prof) papr_prof_begin(BN == 256 ? 0 : BN == 128 ? 1 : BN == 64 ? 2 : 3, a.M, a.N, a.K1 + (a.A2 ? a.K2 : 0), s);
-    gemm_nt_kernel<BM, BN, TM, TN><<<grid, dim3(64 * (BM / (32 * TM)) * (BN / (32 * TN))), lds, s>>>(a);
+    gemm_nt_kernel<BM, BN, TM, TN, BKT, DB><<<grid, dim3(64 * (BM / (32 * TM)) * (BN / (32 * TN))), lds, s>>>(a);
     if (prof) papr_prof_end(s);
     PAPR_CHECK_LAUNCH("gemm_nt");
     return 0;
@@ -218,12 +228,18 @@ int launch_nt(const NTArgs& a, hipStream_t s) {
 // layer (4 waves per SIMD hide the slab hand-over and the epilogue better).  PAPR_NT_WAVES4 keeps the
 // old shape reachable for A/B runs.
 static const bool NT_WAVES4 = getenv("PAPR_NT_WAVES4") != nullptr;
+static const int NT_VARIANT = getenv("PAPR_NT_VARIANT") ? atoi(getenv("PAPR_NT_VARIANT")) : 0;   // A/B switch
 
 int gemm_nt(const NTArgs& a, hipStream_t s) {
     PAPR_REQUIRE(a.K1 % 4 == 0 && a.lda % 4 == 0 && a.ldw % 4 == 0, "gemm_nt: K1/lda/ldw must be multiples of 4 (%d,%ld,%d)", a.K1, a.lda, a.ldw);
     PAPR_REQUIRE(!a.A2 || (a.K2 % 4 == 0 && a.lda2 % 4 == 0 && a.wcol2 % 4 == 0), "gemm_nt: segment-2 sizes must be multiples of 4");
     if (a.M <= 0 || a.N <= 0) return 0;
-    if (a.N > 128) return NT_WAVES4 ? launch_nt<128, 256, 4, 2>(a, s) : launch_nt<128, 256, 2, 2>(a, s);
+    if (a.N > 128) {
+        if (NT_WAVES4) return launch_nt<128, 256, 4, 2>(a, s);
+        if (NT_VARIANT == 1) return launch_nt<128, 256, 2, 2, 16, true>(a, s);
+        if (NT_VARIANT == 2) return launch_nt<128, 256, 2, 2, 32, true>(a, s);
+        return launch_nt<128, 256, 2, 2>(a, s);
+    }
     if (a.N > 64) return launch_nt<128, 128, 2, 2>(a, s);
     if (a.N > 32) return launch_nt<256, 64, 2, 2>(a, s);
     return launch_nt<256, 32, 2, 1>(a, s);

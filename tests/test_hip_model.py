@@ -186,3 +186,40 @@ def test_select_all_points_when_k_exceeds_cloud():
         ref = O.render(st, cfg, ro, rd)
     assert m.selected_points.shape == (1, 5, 5, 27, 3)
     np.testing.assert_allclose(rgb.cpu().numpy(), ref["rgb"].numpy(), rtol=0, atol=RGB_TOL)
+
+
+@pytest.mark.parametrize("scene,P,patch", [("nerfsyn/lego.yml", 30000, 40), ("t2/Barn.yml", 5000, 36)])
+def test_full_scene_configs_match_oracle(scene, P, patch):
+    """BASELINE configs 3 and 4 at their own hyper-parameters (lego: 30k points, skip layer, LeakyReLU,
+    bkg 3.0; Barn: coord_scale 30, init_scale 1.8): a crop of a full view against the oracle, plus one
+    training step whose gradients must agree."""
+    from papr_amd import get_model, load_config
+    from papr_amd.config import deep_merge
+    from papr_amd.data import get_rays, make_cameras
+    from conftest import PARITY
+    cfg = deep_merge(load_config(scene), PARITY)
+    cfg = deep_merge(cfg, {"geoms": {"points": {"init_num": P}}})
+    torch.manual_seed(3); np.random.seed(3)
+    m = get_model(cfg, device="cpu")
+    formula_fill(m.state_dict())
+    st = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m = m.to("cuda")
+    c2w = make_cameras(1, seed=4, coord_scale=cfg["dataset"]["coord_scale"])
+    ro, rd = get_rays(800, 800, 1111.0, 1111.0, c2w, 380, 390, patch, patch)
+    with torch.no_grad():
+        fused, attn = m.evaluate(*cuda(ro, rd, c2w))
+        ref = O.render(st, cfg, ro, rd, want_rgb=False)
+    assert np.array_equal(np.sort(m.select_k_ind.cpu().numpy(), -1), np.sort(ref["idx"].numpy(), -1))
+    np.testing.assert_allclose(fused.squeeze(-2).cpu().numpy(), ref["fused"].numpy(), rtol=0, atol=RGB_TOL)
+    # one backward
+    rgb = m(*cuda(ro, rd, c2w))
+    torch.mean((rgb - 0.3) ** 2).backward()
+    so = O.trainable_state(st, cfg)
+    r2 = O.render(so, cfg, ro, rd)
+    torch.mean((r2["rgb"] - 0.3) ** 2).backward()
+    np.testing.assert_allclose(rgb.detach().cpu().numpy(), r2["rgb"].detach().numpy(), rtol=0, atol=RGB_TOL)
+    for name in ("points", "pc_feats", "points_influ_scores", "proximity_attn.embed.embed_v.mlp.model.11.weight",
+                 "proximity_attn.attention_layer.w_k.weight", "proximity_attn.embed.embed_k.innorm.a_2"):
+        ref_g = so[name].grad
+        got = dict(m.named_parameters())[name].grad.cpu()
+        assert (got - ref_g).abs().max().item() <= 2e-3 * ref_g.abs().max().item() + 1e-12, name
