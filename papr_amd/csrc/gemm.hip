@@ -21,6 +21,7 @@
 // pitch maps the 16 lanes of a read group onto 16 distinct 4-bank slots (conflict-free).
 #include "papr_common.h"
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -39,6 +40,8 @@ struct NTArgs {
     int accumulate;   // C += ...
     float* C; long ldc;
     long M; int N;
+    const unsigned* amax_in;   // split-f16 mode: bit pattern of max|A| (device scalar), 0/NULL -> 1.0
+    unsigned* amax_out;        // split-f16 mode: atomicMax'ed with the bit pattern of max|C| (or NULL)
 };
 
 // BKT: k-slab per stage (32 or 16).  DB: two LDS buffers and ONE barrier per stage (compute slab t,
@@ -212,6 +215,233 @@ void gemm_nt_kernel(NTArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// gemm_nt_h3: the same product at fp32-grade accuracy on the f16 matrix pipe (16x the fp32 MFMA rate).
+// Every fp32 operand x is split on the fly into two halves, hi = f16(x s), lo = f16(x s - hi), with a
+// power-of-two scale s that puts the tensor's max|x| just under 2^14 (exact, undone in the epilogue).
+// hi + lo carries 22 mantissa bits; a.b ~ hi_a hi_b + hi_a lo_b + lo_a hi_b is three
+// v_mfma_f32_32x32x16_f16 with fp32 accumulation (each product is exact in fp32), the dropped lo.lo
+// term is 2^-22 relative.  Three matrix instructions instead of sixteen: the layer turns HBM-bound.
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a full workgroup fence, and
+// on gfx950 loads and stores share vmcnt: the fence therefore drains every global load in flight, i.e.
+// the slab prefetch, at each barrier.  Harmless when a slab's matrix work outlasts an HBM round trip
+// (fp32 MFMA), fatal when it does not (split-f16: ~1.5k cycles of MFMA per slab).
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float pow2_from_biased(int e) {       // 2^(e-127), e clamped to the normal range
+    e = e < 1 ? 1 : (e > 254 ? 254 : e);
+    return __uint_as_float((unsigned)e << 23);
+}
+
+__device__ __forceinline__ void split4(const float4& v, float s, half4& hi, half4& lo) {
+    float x0 = v.x * s, x1 = v.y * s, x2 = v.z * s, x3 = v.w * s;
+    hi = half4{(_Float16)x0, (_Float16)x1, (_Float16)x2, (_Float16)x3};
+    lo = half4{(_Float16)(x0 - (float)hi[0]), (_Float16)(x1 - (float)hi[1]), (_Float16)(x2 - (float)hi[2]), (_Float16)(x3 - (float)hi[3])};
+}
+
+template <int BM, int BN, int TM, int TN, int D>
+__global__ __launch_bounds__(512, 2) void gemm_nt_h3_kernel(NTArgs p) {
+    constexpr int WN = BN / (32 * TN), WM = BM / (32 * TM);
+    static_assert(WM * WN == 8, "eight waves per workgroup");
+    constexpr int NTHR = 512, BKT = 32, KQ = BKT / 4;
+    constexpr int HP = BKT + 8;                 // LDS row pitch in halfs (80 B): conflict-free ds_read_b128
+    constexpr int A_LD = BM * KQ / NTHR, W_LD = BN * KQ / NTHR;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    _Float16* Ah = reinterpret_cast<_Float16*>(smem);          // [BM][HP]  hi plane
+    _Float16* Al = Ah + BM * HP;                               // lo plane
+    _Float16* Wh = Al + BM * HP;                               // [BN][HP]
+    _Float16* Wl = Wh + BN * HP;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const long m0 = (long)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int nt1 = (p.K1 + BKT - 1) / BKT;
+    const int nt2 = p.A2 ? (p.K2 + BKT - 1) / BKT : 0;
+    const int nt = nt1 + nt2;
+
+    // scale: max|A| -> [2^13, 2^14)
+    const unsigned amax = p.amax_in ? *p.amax_in : 0u;
+    const int ea = amax ? (int)((amax >> 23) & 0xff) : 127 + 13;
+    const float a_scale = pow2_from_biased(127 + 13 - (ea - 127));
+    const float inv_scale = pow2_from_biased(127 - 13 + (ea - 127));
+
+    // The matrix work of a slab is ~1.5k cycles, far less than an HBM round trip, so the k loop is a
+    // streaming loop: slab t lives in register set t % D and D-1 slabs are always in flight.
+    float4 ra[D][A_LD], rw[D][W_LD];
+    auto load_slab = [&](int kt, float4 (&qa)[A_LD], float4 (&qw)[W_LD]) {
+        const float* src; long ld; int klim, k0, wcol;
+        if (kt < nt1) { src = p.A; ld = p.lda; klim = p.K1; k0 = kt * BKT; wcol = k0; }
+        else { src = p.A2; ld = p.lda2; klim = p.K2; k0 = (kt - nt1) * BKT; wcol = p.wcol2 + k0; }
+        // Unconditional loads from clamped addresses (out-of-range lanes are zeroed when the slab is split):
+        // a load under an exec-masked branch makes hipcc wait vmcnt(0) at the first use, which would drain
+        // the whole prefetch ring instead of just the oldest slab.
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            int f = tid + NTHR * i, row = f / KQ, kq = (f % KQ) * 4;
+            long m = m0 + row;
+            m = m < p.M ? m : p.M - 1;
+            int kk = k0 + kq < klim ? k0 + kq : 0;
+            qa[i] = *reinterpret_cast<const float4*>(src + m * ld + kk);
+        }
+#pragma unroll
+        for (int i = 0; i < W_LD; ++i) {
+            int f = tid + NTHR * i, row = f / KQ, kq = (f % KQ) * 4;
+            int n = n0 + row;
+            n = n < p.N ? n : p.N - 1;
+            int kk = k0 + kq < klim ? wcol + kq : 0;
+            qw[i] = *reinterpret_cast<const float4*>(p.W + (long)n * p.ldw + kk);
+        }
+    };
+    auto store_slab = [&](int kt, const float4 (&qa)[A_LD], const float4 (&qw)[W_LD]) {
+        const int klim = kt < nt1 ? p.K1 : p.K2, k0 = (kt < nt1 ? kt : kt - nt1) * BKT;
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            int f = tid + NTHR * i, off = (f / KQ) * HP + (f % KQ) * 4;
+            const bool ok = m0 + f / KQ < p.M && k0 + (f % KQ) * 4 < klim;
+            half4 hi, lo;
+            split4(qa[i], ok ? a_scale : 0.f, hi, lo);
+            *reinterpret_cast<half4*>(Ah + off) = hi;
+            *reinterpret_cast<half4*>(Al + off) = lo;
+        }
+#pragma unroll
+        for (int i = 0; i < W_LD; ++i) {
+            int f = tid + NTHR * i, off = (f / KQ) * HP + (f % KQ) * 4;
+            const bool ok = n0 + f / KQ < p.N && k0 + (f % KQ) * 4 < klim;
+            half4 hi, lo;
+            split4(qw[i], ok ? 1.0f : 0.f, hi, lo);
+            *reinterpret_cast<half4*>(Wh + off) = hi;
+            *reinterpret_cast<half4*>(Wl + off) = lo;
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // lane (i = lane&31, h = lane>>5) feeds row i, k = 8h..8h+7 of each 16-wide k step (A and W alike)
+    const int frag = (lane & 31) * HP + 8 * (lane >> 5);
+#pragma unroll
+    for (int u = 0; u < D; ++u)
+        if (u < nt) load_slab(u, ra[u], rw[u]);
+    store_slab(0, ra[0], rw[0]);
+    lds_barrier();
+    for (int kt0 = 0; kt0 < nt; kt0 += D) {
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+            const int kt = kt0 + u;
+            if (kt >= nt) break;
+#pragma unroll
+            for (int ks = 0; ks < BKT; ks += 16) {
+                half8 ah[TM], al[TM];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    int o = (wm * TM + i) * 32 * HP + frag + ks;
+                    ah[i] = *reinterpret_cast<const half8*>(Ah + o);
+                    al[i] = *reinterpret_cast<const half8*>(Al + o);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    int o = (wn * TN + j) * 32 * HP + frag + ks;
+                    half8 wh = *reinterpret_cast<const half8*>(Wh + o);
+                    half8 wl = *reinterpret_cast<const half8*>(Wl + o);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], wh, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wl, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wh, acc[i][j], 0, 0, 0);
+                    }
+                }
+            }
+            lds_barrier();
+            if (kt + 1 < nt) {
+                store_slab(kt + 1, ra[(u + 1) % D], rw[(u + 1) % D]);       // slab kt+1, requested D-1 iterations ago
+                if (kt + D < nt) load_slab(kt + D, ra[u], rw[u]);   // set u was drained into LDS one iteration ago
+                lds_barrier();
+            }
+        }
+    }
+
+    // epilogue: as gemm_nt_kernel, plus the un-scaling and the max|C| needed by the next layer's scale
+    constexpr int EP = 36;
+    float* patch = smem + wave * (32 * EP);
+    const float slope = p.act == PAPR_ACT_RELU ? 0.f : (p.act == PAPR_ACT_LEAKY_RELU ? 0.2f : 1.f);
+    const int pr = lane >> 3, pc = (lane & 7) * 4;
+    const int wr_off = (4 * (lane >> 5)) * EP + (lane & 31);
+    const bool need_aux = p.dgrad && p.mask_src != nullptr;
+    float cmax = 0.f;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + (wn * TN + j) * 32 + pc;
+        const bool col_ok = col < p.N;
+        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!p.dgrad && p.bias && col_ok) b4 = *reinterpret_cast<const float4*>(p.bias + col);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) patch[wr_off + ((e & 3) + 8 * (e >> 2)) * EP] = acc[i][j][e] * inv_scale;
+            const long row0 = m0 + (wm * TM + i) * 32 + pr;
+            float4 v[4], aux[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v[t] = *reinterpret_cast<const float4*>(patch + (pr + 8 * t) * EP + pc);
+            if (need_aux) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const long row = row0 + 8 * t;
+                    aux[t] = (col_ok && row < p.M) ? *reinterpret_cast<const float4*>(p.mask_src + row * p.ld_mask + col) : make_float4(1.f, 1.f, 1.f, 1.f);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const long row = row0 + 8 * t;
+                if (!(col_ok && row < p.M)) continue;
+                float4 r = v[t];
+                if (p.dgrad) {
+                    if (need_aux) {
+                        r.x *= aux[t].x > 0.f ? 1.f : slope; r.y *= aux[t].y > 0.f ? 1.f : slope;
+                        r.z *= aux[t].z > 0.f ? 1.f : slope; r.w *= aux[t].w > 0.f ? 1.f : slope;
+                    }
+                } else {
+                    r.x += b4.x; r.y += b4.y; r.z += b4.z; r.w += b4.w;
+                    r.x = r.x > 0.f ? r.x : r.x * slope + 0.f; r.y = r.y > 0.f ? r.y : r.y * slope + 0.f;
+                    r.z = r.z > 0.f ? r.z : r.z * slope + 0.f; r.w = r.w > 0.f ? r.w : r.w * slope + 0.f;
+                }
+                float4* dst = reinterpret_cast<float4*>(p.C + row * p.ldc + col);
+                if (p.accumulate) { float4 o = *dst; r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w; }
+                *dst = r;
+                cmax = fmaxf(cmax, fmaxf(fmaxf(fabsf(r.x), fabsf(r.y)), fmaxf(fabsf(r.z), fabsf(r.w))));
+            }
+        }
+    }
+    if (p.amax_out) {
+        cmax = wave_max(cmax);
+        if (lane == 0) atomicMax(p.amax_out, __float_as_uint(cmax));
+    }
+}
+
+// max |x| of an (M, width) block of rows -> atomicMax on the bit pattern
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long M, int width, long ld, unsigned* out) {
+    const long total = M * (width / 4);
+    float mx = 0.f;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        long m = e / (width / 4);
+        int c = (int)(e - m * (width / 4)) * 4;
+        float4 v = *reinterpret_cast<const float4*>(x + m * ld + c);
+        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(mx));
+}
+
 template <int BM, int BN, int TM, int TN, int BKT = BK, bool DB = false>
 int launch_nt(const NTArgs& a, hipStream_t s) {
     dim3 grid((unsigned)((a.M + BM - 1) / BM), (unsigned)((a.N + BN - 1) / BN));
@@ -230,11 +460,52 @@ int launch_nt(const NTArgs& a, hipStream_t s) {
 static const bool NT_WAVES4 = getenv("PAPR_NT_WAVES4") != nullptr;
 static const int NT_VARIANT = getenv("PAPR_NT_VARIANT") ? atoi(getenv("PAPR_NT_VARIANT")) : 0;   // A/B switch
 
+// Opt-in (PAPR_GEMM_MODE=h3): run the wide forward / data-gradient GEMMs on the split-f16 kernel.  It passes
+// the same parity tests as the fp32-MFMA kernel and is ~20 % faster per layer (447 vs 586 us), but it is
+// still latency-bound (2.3 TB/s of HBM, matrix pipe < 20 % busy), so the fp32-MFMA kernel stays the default
+// until the streaming structure is rebuilt.
+static const bool GEMM_H3 = getenv("PAPR_GEMM_MODE") && !strcmp(getenv("PAPR_GEMM_MODE"), "h3");
+
+// scratch for the split-f16 mode: one max|.| word per tensor of a chain (experiment: process-wide buffer)
+struct AmaxRing {
+    unsigned* buf = nullptr;
+    int next = 0;
+    unsigned* begin(hipStream_t s) {
+        if (!buf) { if (hipMalloc(&buf, 256 * sizeof(unsigned)) != hipSuccess) return nullptr; }
+        (void)hipMemsetAsync(buf, 0, 256 * sizeof(unsigned), s);
+        next = 0;
+        return buf;
+    }
+    unsigned* slot() { return buf + (next++ & 255); }
+};
+static AmaxRing g_amax;
+
+int launch_absmax(const float* x, long M, int width, long ld, unsigned* out, hipStream_t s) {
+    long total = M * (width / 4);
+    int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    absmax_kernel<<<dim3(blocks), dim3(256), 0, s>>>(x, M, width, ld, out);
+    PAPR_CHECK_LAUNCH("absmax");
+    return 0;
+}
+
+int launch_nt_h3(const NTArgs& a, hipStream_t s) {
+    constexpr int BM = 128, BN = 256;
+    dim3 grid((unsigned)((a.M + BM - 1) / BM), (unsigned)((a.N + BN - 1) / BN));
+    size_t lds = (size_t)(BM + BN) * 40 * 2 * sizeof(_Float16);
+    const bool prof = papr_prof_on();
+    if (prof) papr_prof_begin(0, a.M, a.N, a.K1 + (a.A2 ? a.K2 : 0), s);
+    gemm_nt_h3_kernel<BM, BN, 2, 2, 2><<<grid, dim3(512), lds, s>>>(a);
+    if (prof) papr_prof_end(s);
+    PAPR_CHECK_LAUNCH("gemm_nt_h3");
+    return 0;
+}
+
 int gemm_nt(const NTArgs& a, hipStream_t s) {
     PAPR_REQUIRE(a.K1 % 4 == 0 && a.lda % 4 == 0 && a.ldw % 4 == 0, "gemm_nt: K1/lda/ldw must be multiples of 4 (%d,%ld,%d)", a.K1, a.lda, a.ldw);
     PAPR_REQUIRE(!a.A2 || (a.K2 % 4 == 0 && a.lda2 % 4 == 0 && a.wcol2 % 4 == 0), "gemm_nt: segment-2 sizes must be multiples of 4");
     if (a.M <= 0 || a.N <= 0) return 0;
     if (a.N > 128) {
+        if (a.amax_in) return launch_nt_h3(a, s);
         if (NT_WAVES4) return launch_nt<128, 256, 4, 2>(a, s);
         if (NT_VARIANT == 1) return launch_nt<128, 256, 2, 2, 16, true>(a, s);
         if (NT_VARIANT == 2) return launch_nt<128, 256, 2, 2, 32, true>(a, s);
@@ -443,6 +714,8 @@ extern "C" int papr_mlp_fwd(const papr_layer* layers, int n_layers, const float*
                             float* const* outs, const int32_t* ld_out, papr_stream_t stream) {
     PAPR_REQUIRE(layers && x && outs && ld_out && n_layers >= 1, "papr_mlp_fwd: bad arguments");
     hipStream_t s = as_stream(stream);
+    unsigned* have_amax = nullptr;          // split-f16 mode: max|input of the current layer|, when known
+    if (GEMM_H3) PAPR_REQUIRE(g_amax.begin(s), "papr_mlp_fwd: amax scratch allocation failed");
     for (int i = 0; i < n_layers; ++i) {
         const papr_layer& L = layers[i];
         PAPR_REQUIRE(L.weight && outs[i], "papr_mlp_fwd: layer %d has null weight/output", i);
@@ -454,6 +727,17 @@ extern "C" int papr_mlp_fwd(const papr_layer* layers, int n_layers, const float*
         if (L.n_skip > 0) { a.A2 = x; a.lda2 = ldx; a.K2 = L.n_skip; a.wcol2 = L.skip_col; }
         a.W = L.weight; a.ldw = L.ldw; a.bias = L.bias; a.act = L.act;
         a.C = outs[i]; a.ldc = ld_out[i]; a.M = M; a.N = L.n_out;
+        if (GEMM_H3 && L.n_out > 128 && L.n_skip == 0) {
+            if (!have_amax) {
+                have_amax = g_amax.slot();
+                if (int e = launch_absmax(a.A, M, L.n_in, a.lda, have_amax, s)) return e;
+            }
+            a.amax_in = have_amax;
+            a.amax_out = g_amax.slot();
+            have_amax = a.amax_out;
+        } else {
+            have_amax = nullptr;
+        }
         if (int e = gemm_nt(a, s)) return e;
     }
     return 0;
@@ -473,6 +757,19 @@ extern "C" int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float*
         hipError_t e = hipMemsetAsync(d_x, 0, (size_t)M * ldx * sizeof(float), s);
         PAPR_REQUIRE(e == hipSuccess, "papr_mlp_bwd: memset failed");
     }
+    unsigned* have_amax = nullptr;          // split-f16 mode: max|g|, when known
+    if (GEMM_H3) PAPR_REQUIRE(g_amax.begin(s), "papr_mlp_bwd: amax scratch allocation failed");
+    auto h3_setup = [&](NTArgs& a) -> int {    // choose the split-f16 kernel for a wide data-gradient
+        if (!(GEMM_H3 && a.N > 128)) { have_amax = nullptr; return 0; }
+        if (!have_amax) {
+            have_amax = g_amax.slot();
+            if (int e = launch_absmax(a.A, a.M, a.K1, a.lda, have_amax, s)) return e;
+        }
+        a.amax_in = have_amax;
+        a.amax_out = g_amax.slot();
+        have_amax = a.amax_out;
+        return 0;
+    };
     // gradient w.r.t. the last layer's pre-activation
     float* g = d_out;
     long ldg = ld_out[n_layers - 1];
@@ -512,6 +809,7 @@ extern "C" int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float*
             a.dgrad = 1; a.act = layers[i - 1].act; a.mask_src = outs[i - 1]; a.ld_mask = ld_out[i - 1];
             a.C = gnext; a.ldc = ld_scratch; a.M = M; a.N = L.n_in;
             PAPR_REQUIRE(ld_scratch >= L.n_in, "papr_mlp_bwd: scratch stride %d < %d", ld_scratch, L.n_in);
+            if (int e = h3_setup(a)) return e;
             if (int e = gemm_nt(a, s)) return e;
             g = gnext;
             ldg = ld_scratch;
