@@ -244,26 +244,44 @@ __device__ __forceinline__ void split4(const float4& v, float s, half4& hi, half
     lo = half4{(_Float16)(x0 - (float)hi[0]), (_Float16)(x1 - (float)hi[1]), (_Float16)(x2 - (float)hi[2]), (_Float16)(x3 - (float)hi[3])};
 }
 
+// Persistent streaming structure.  A slab's matrix work (~1.2k cycles) is far shorter than a loaded HBM
+// round trip (8-11k cycles measured), and the first-touch latency plus the store tail of a one-tile
+// workgroup cost more than its eight slabs.  So: one workgroup per CU walks many row tiles; the slabs of
+// all its tiles form ONE stream; slab g+D is requested while slab g is multiplied (register ring, D = 4,
+// unconditional loads so that hipcc counts vmcnt instead of draining it); LDS is double-buffered, so a
+// slab costs one LDS-only barrier and the hi/lo split of the next slab overlaps the other waves' MFMAs;
+// a tile's epilogue runs while the next tile's slabs are already in flight.
+#ifdef PAPR_H3_TRACE
+__device__ long long g_h3_trace[256];
+#define H3_STAMP(slot) do { if (blockIdx.x == 100 && threadIdx.x == 0 && (slot) < 256) g_h3_trace[slot] = __builtin_readcyclecounter(); } while (0)
+extern "C" int papr_h3_trace_read(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_h3_trace), sizeof(long long) * 256) == hipSuccess ? 0 : 1; }
+#else
+#define H3_STAMP(slot) do {} while (0)
+#endif
+
 template <int BM, int BN, int TM, int TN, int D>
-__global__ __launch_bounds__(512, 2) void gemm_nt_h3_kernel(NTArgs p) {
+__global__ __launch_bounds__(512, 2) void gemm_nt_h3_kernel(NTArgs p, int tiles_m, const _Float16* __restrict__ w_hi, const _Float16* __restrict__ w_lo, int w_pitch) {
+    H3_STAMP(0);
     constexpr int WN = BN / (32 * TN), WM = BM / (32 * TM);
     static_assert(WM * WN == 8, "eight waves per workgroup");
     constexpr int NTHR = 512, BKT = 32, KQ = BKT / 4;
     constexpr int HP = BKT + 8;                 // LDS row pitch in halfs (80 B): conflict-free ds_read_b128
-    constexpr int A_LD = BM * KQ / NTHR, W_LD = BN * KQ / NTHR;
+    constexpr int A_LD = BM * KQ / NTHR;
+    constexpr int W_LD = BN * (BKT / 8) / NTHR;   // 16-byte chunks (8 halfs) per thread and plane
+    constexpr int PLANE_A = BM * HP, PLANE_W = BN * HP, BUF = 2 * (PLANE_A + PLANE_W);   // halfs per LDS buffer
+    constexpr int EP = 36;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    _Float16* Ah = reinterpret_cast<_Float16*>(smem);          // [BM][HP]  hi plane
-    _Float16* Al = Ah + BM * HP;                               // lo plane
-    _Float16* Wh = Al + BM * HP;                               // [BN][HP]
-    _Float16* Wl = Wh + BN * HP;
+    _Float16* lds = reinterpret_cast<_Float16*>(smem);         // two slab buffers: [Ah | Al | Wh | Wl] each
+    float* patch_base = smem + BUF;                            // (2 * BUF halfs = BUF floats) epilogue patches behind them
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const long m0 = (long)blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
     const int nt1 = (p.K1 + BKT - 1) / BKT;
     const int nt2 = p.A2 ? (p.K2 + BKT - 1) / BKT : 0;
     const int nt = nt1 + nt2;
+    const int my_tiles = (tiles_m - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int total = my_tiles * nt;
 
     // scale: max|A| -> [2^13, 2^14)
     const unsigned amax = p.amax_in ? *p.amax_in : 0u;
@@ -271,39 +289,56 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_h3_kernel(NTArgs p) {
     const float a_scale = pow2_from_biased(127 + 13 - (ea - 127));
     const float inv_scale = pow2_from_biased(127 - 13 + (ea - 127));
 
-    // The matrix work of a slab is ~1.5k cycles, far less than an HBM round trip, so the k loop is a
-    // streaming loop: slab t lives in register set t % D and D-1 slabs are always in flight.
-    float4 ra[D][A_LD], rw[D][W_LD];
-    auto load_slab = [&](int kt, float4 (&qa)[A_LD], float4 (&qw)[W_LD]) {
+    float4 ra[D][A_LD];
+    half8 rwh[D][W_LD], rwl[D][W_LD];             // the weight arrives pre-split (w_hi / w_lo planes)
+    // (tile, k-slab) of stream position g; nt is small, so the division is a handful of scalar ops
+    auto slab_coords = [&](int g, long& m0, int& kt) {
+        int ti = __builtin_amdgcn_readfirstlane(g / nt);
+        kt = g - ti * nt;
+        m0 = ((long)blockIdx.x + (long)ti * gridDim.x) * BM;
+    };
+    // per-thread constants of the slab copy: row inside the tile and k offset inside the slab
+    int a_row[A_LD], a_kq[A_LD];
+    int w_off[W_LD], w_lds[W_LD];               // element offset into the planes (row n0+r, chunk c) / into the LDS plane
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) { int f = tid + NTHR * i; a_row[i] = f / KQ; a_kq[i] = (f % KQ) * 4; }
+#pragma unroll
+    for (int i = 0; i < W_LD; ++i) {
+        int f = tid + NTHR * i, r = f / (BKT / 8), c = (f % (BKT / 8)) * 8;
+        w_off[i] = (n0 + r) * w_pitch + c;      // planes are zero-padded to whole tiles: no guards
+        w_lds[i] = r * HP + c;
+    }
+    auto load_slab = [&](int g, float4 (&qa)[A_LD], half8 (&qh)[W_LD], half8 (&ql)[W_LD]) {
+        long m0; int kt;
+        slab_coords(g, m0, kt);
         const float* src; long ld; int klim, k0, wcol;
         if (kt < nt1) { src = p.A; ld = p.lda; klim = p.K1; k0 = kt * BKT; wcol = k0; }
         else { src = p.A2; ld = p.lda2; klim = p.K2; k0 = (kt - nt1) * BKT; wcol = p.wcol2 + k0; }
-        // Unconditional loads from clamped addresses (out-of-range lanes are zeroed when the slab is split):
-        // a load under an exec-masked branch makes hipcc wait vmcnt(0) at the first use, which would drain
-        // the whole prefetch ring instead of just the oldest slab.
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) {
-            int f = tid + NTHR * i, row = f / KQ, kq = (f % KQ) * 4;
-            long m = m0 + row;
+            long m = m0 + a_row[i];
             m = m < p.M ? m : p.M - 1;
-            int kk = k0 + kq < klim ? k0 + kq : 0;
+            int kk = k0 + a_kq[i] < klim ? k0 + a_kq[i] : 0;
             qa[i] = *reinterpret_cast<const float4*>(src + m * ld + kk);
         }
 #pragma unroll
         for (int i = 0; i < W_LD; ++i) {
-            int f = tid + NTHR * i, row = f / KQ, kq = (f % KQ) * 4;
-            int n = n0 + row;
-            n = n < p.N ? n : p.N - 1;
-            int kk = k0 + kq < klim ? wcol + kq : 0;
-            qw[i] = *reinterpret_cast<const float4*>(p.W + (long)n * p.ldw + kk);
+            qh[i] = *reinterpret_cast<const half8*>(w_hi + w_off[i] + wcol);
+            ql[i] = *reinterpret_cast<const half8*>(w_lo + w_off[i] + wcol);
         }
     };
-    auto store_slab = [&](int kt, const float4 (&qa)[A_LD], const float4 (&qw)[W_LD]) {
+    auto store_slab = [&](int g, const float4 (&qa)[A_LD], const half8 (&qh)[W_LD], const half8 (&ql)[W_LD]) {
+        long m0; int kt;
+        slab_coords(g, m0, kt);
         const int klim = kt < nt1 ? p.K1 : p.K2, k0 = (kt < nt1 ? kt : kt - nt1) * BKT;
+        _Float16* Ah = lds + (g & 1) * BUF;
+        _Float16* Al = Ah + PLANE_A;
+        _Float16* Wh = Al + PLANE_A;
+        _Float16* Wl = Wh + PLANE_W;
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) {
-            int f = tid + NTHR * i, off = (f / KQ) * HP + (f % KQ) * 4;
-            const bool ok = m0 + f / KQ < p.M && k0 + (f % KQ) * 4 < klim;
+            int off = a_row[i] * HP + a_kq[i];
+            const bool ok = m0 + a_row[i] < p.M && k0 + a_kq[i] < klim;
             half4 hi, lo;
             split4(qa[i], ok ? a_scale : 0.f, hi, lo);
             *reinterpret_cast<half4*>(Ah + off) = hi;
@@ -311,35 +346,97 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_h3_kernel(NTArgs p) {
         }
 #pragma unroll
         for (int i = 0; i < W_LD; ++i) {
-            int f = tid + NTHR * i, off = (f / KQ) * HP + (f % KQ) * 4;
-            const bool ok = n0 + f / KQ < p.N && k0 + (f % KQ) * 4 < klim;
-            half4 hi, lo;
-            split4(qw[i], ok ? 1.0f : 0.f, hi, lo);
-            *reinterpret_cast<half4*>(Wh + off) = hi;
-            *reinterpret_cast<half4*>(Wl + off) = lo;
+            *reinterpret_cast<half8*>(Wh + w_lds[i]) = qh[i];
+            *reinterpret_cast<half8*>(Wl + w_lds[i]) = ql[i];
         }
     };
 
     f32x16 acc[TM][TN];
+    auto clear_acc = [&]() {
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    };
+    clear_acc();
+
+    // epilogue of one finished tile: un-scale, bias / activation or derivative mask, 16-byte row stores
+    // (per-wave LDS patch turns the column-per-lane accumulators into rows), max|C| for the next layer
+    float* patch = patch_base + wave * (32 * EP);
+    const float slope = p.act == PAPR_ACT_RELU ? 0.f : (p.act == PAPR_ACT_LEAKY_RELU ? 0.2f : 1.f);
+    const int pr = lane >> 3, pc = (lane & 7) * 4;
+    const int wr_off = (4 * (lane >> 5)) * EP + (lane & 31);
+    const bool need_aux = p.dgrad && p.mask_src != nullptr;
+    float cmax = 0.f;
+    float4 bias4[TN];                           // loaded once: inside the tile loop it would be a dependent L2 trip per tile
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + (wn * TN + j) * 32 + pc;
+        bias4[j] = (!p.dgrad && p.bias && col < p.N) ? *reinterpret_cast<const float4*>(p.bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    auto epilogue = [&](long m0) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + (wn * TN + j) * 32 + pc;
+            const bool col_ok = col < p.N;
+            const float4 b4 = bias4[j];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) patch[wr_off + ((e & 3) + 8 * (e >> 2)) * EP] = acc[i][j][e] * inv_scale;
+                const long row0 = m0 + (wm * TM + i) * 32 + pr;
+                float4 v[4], aux[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[t] = *reinterpret_cast<const float4*>(patch + (pr + 8 * t) * EP + pc);
+                if (need_aux) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const long row = row0 + 8 * t;
+                        aux[t] = (col_ok && row < p.M) ? *reinterpret_cast<const float4*>(p.mask_src + row * p.ld_mask + col) : make_float4(1.f, 1.f, 1.f, 1.f);
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const long row = row0 + 8 * t;
+                    if (!(col_ok && row < p.M)) continue;
+                    float4 r = v[t];
+                    if (p.dgrad) {
+                        if (need_aux) {
+                            r.x *= aux[t].x > 0.f ? 1.f : slope; r.y *= aux[t].y > 0.f ? 1.f : slope;
+                            r.z *= aux[t].z > 0.f ? 1.f : slope; r.w *= aux[t].w > 0.f ? 1.f : slope;
+                        }
+                    } else {
+                        r.x += b4.x; r.y += b4.y; r.z += b4.z; r.w += b4.w;
+                        r.x = r.x > 0.f ? r.x : r.x * slope + 0.f; r.y = r.y > 0.f ? r.y : r.y * slope + 0.f;
+                        r.z = r.z > 0.f ? r.z : r.z * slope + 0.f; r.w = r.w > 0.f ? r.w : r.w * slope + 0.f;
+                    }
+                    float4* dst = reinterpret_cast<float4*>(p.C + row * p.ldc + col);
+                    if (p.accumulate) { float4 o = *dst; r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w; }
+                    *dst = r;
+                    cmax = fmaxf(cmax, fmaxf(fmaxf(fabsf(r.x), fabsf(r.y)), fmaxf(fabsf(r.z), fabsf(r.w))));
+                }
+            }
+        }
+    };
 
     // lane (i = lane&31, h = lane>>5) feeds row i, k = 8h..8h+7 of each 16-wide k step (A and W alike)
     const int frag = (lane & 31) * HP + 8 * (lane >> 5);
 #pragma unroll
     for (int u = 0; u < D; ++u)
-        if (u < nt) load_slab(u, ra[u], rw[u]);
-    store_slab(0, ra[0], rw[0]);
+        if (u < total) load_slab(u, ra[u], rwh[u], rwl[u]);
+    if (total > 0) store_slab(0, ra[0], rwh[0], rwl[0]);
     lds_barrier();
-    for (int kt0 = 0; kt0 < nt; kt0 += D) {
+    for (int g0 = 0; g0 < total; g0 += D) {
 #pragma unroll
         for (int u = 0; u < D; ++u) {
-            const int kt = kt0 + u;
-            if (kt >= nt) break;
+            const int g = g0 + u;
+            if (g >= total) break;
+            const _Float16* Ah = lds + (g & 1) * BUF;
+            const _Float16* Al = Ah + PLANE_A;
+            const _Float16* Wh = Al + PLANE_A;
+            const _Float16* Wl = Wh + PLANE_W;
 #pragma unroll
             for (int ks = 0; ks < BKT; ks += 16) {
                 half8 ah[TM], al[TM];
@@ -362,64 +459,22 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_h3_kernel(NTArgs p) {
                     }
                 }
             }
+            // slab g+1 (requested D-1 iterations ago) goes into the other LDS buffer, whose last readers
+            // passed the previous barrier; ring set u is then free for slab g+D
+            H3_STAMP(1 + g * 5);
+            if (g + 1 < total) store_slab(g + 1, ra[(u + 1) % D], rwh[(u + 1) % D], rwl[(u + 1) % D]);
+            H3_STAMP(2 + g * 5);
+            if (g + D < total) load_slab(g + D, ra[u], rwh[u], rwl[u]);
+            H3_STAMP(3 + g * 5);
+            long m0; int kt;
+            slab_coords(g, m0, kt);
+            if (kt == nt - 1) {
+                epilogue(m0);
+                clear_acc();
+            }
+            H3_STAMP(4 + g * 5);
             lds_barrier();
-            if (kt + 1 < nt) {
-                store_slab(kt + 1, ra[(u + 1) % D], rw[(u + 1) % D]);       // slab kt+1, requested D-1 iterations ago
-                if (kt + D < nt) load_slab(kt + D, ra[u], rw[u]);   // set u was drained into LDS one iteration ago
-                lds_barrier();
-            }
-        }
-    }
-
-    // epilogue: as gemm_nt_kernel, plus the un-scaling and the max|C| needed by the next layer's scale
-    constexpr int EP = 36;
-    float* patch = smem + wave * (32 * EP);
-    const float slope = p.act == PAPR_ACT_RELU ? 0.f : (p.act == PAPR_ACT_LEAKY_RELU ? 0.2f : 1.f);
-    const int pr = lane >> 3, pc = (lane & 7) * 4;
-    const int wr_off = (4 * (lane >> 5)) * EP + (lane & 31);
-    const bool need_aux = p.dgrad && p.mask_src != nullptr;
-    float cmax = 0.f;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = n0 + (wn * TN + j) * 32 + pc;
-        const bool col_ok = col < p.N;
-        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (!p.dgrad && p.bias && col_ok) b4 = *reinterpret_cast<const float4*>(p.bias + col);
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) patch[wr_off + ((e & 3) + 8 * (e >> 2)) * EP] = acc[i][j][e] * inv_scale;
-            const long row0 = m0 + (wm * TM + i) * 32 + pr;
-            float4 v[4], aux[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) v[t] = *reinterpret_cast<const float4*>(patch + (pr + 8 * t) * EP + pc);
-            if (need_aux) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const long row = row0 + 8 * t;
-                    aux[t] = (col_ok && row < p.M) ? *reinterpret_cast<const float4*>(p.mask_src + row * p.ld_mask + col) : make_float4(1.f, 1.f, 1.f, 1.f);
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const long row = row0 + 8 * t;
-                if (!(col_ok && row < p.M)) continue;
-                float4 r = v[t];
-                if (p.dgrad) {
-                    if (need_aux) {
-                        r.x *= aux[t].x > 0.f ? 1.f : slope; r.y *= aux[t].y > 0.f ? 1.f : slope;
-                        r.z *= aux[t].z > 0.f ? 1.f : slope; r.w *= aux[t].w > 0.f ? 1.f : slope;
-                    }
-                } else {
-                    r.x += b4.x; r.y += b4.y; r.z += b4.z; r.w += b4.w;
-                    r.x = r.x > 0.f ? r.x : r.x * slope + 0.f; r.y = r.y > 0.f ? r.y : r.y * slope + 0.f;
-                    r.z = r.z > 0.f ? r.z : r.z * slope + 0.f; r.w = r.w > 0.f ? r.w : r.w * slope + 0.f;
-                }
-                float4* dst = reinterpret_cast<float4*>(p.C + row * p.ldc + col);
-                if (p.accumulate) { float4 o = *dst; r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w; }
-                *dst = r;
-                cmax = fmaxf(cmax, fmaxf(fmaxf(fabsf(r.x), fabsf(r.y)), fmaxf(fabsf(r.z), fabsf(r.w))));
-            }
+            H3_STAMP(5 + g * 5);
         }
     }
     if (p.amax_out) {
@@ -488,13 +543,54 @@ int launch_absmax(const float* x, long M, int width, long ld, unsigned* out, hip
     return 0;
 }
 
+// W (N, ldw) fp32 -> hi/lo f16 planes (rows padded to a multiple of 256, pitch to a multiple of 32, zeros)
+__global__ __launch_bounds__(256) void split_weight_kernel(const float* __restrict__ W, int N, int ncols, int ldw, int rows_pad, int pitch,
+                                                           _Float16* __restrict__ hi, _Float16* __restrict__ lo) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= rows_pad * pitch) return;
+    int n = e / pitch, c = e - n * pitch;
+    float x = (n < N && c < ncols) ? W[(long)n * ldw + c] : 0.f;
+    _Float16 h = (_Float16)x;
+    hi[e] = h;
+    lo[e] = (_Float16)(x - (float)h);
+}
+
+struct WeightPlanes {           // experiment: process-wide scratch for the pre-split weight of the launch in flight
+    _Float16* buf = nullptr;
+    static constexpr size_t HALFS = 2 * 512 * 704;
+    _Float16* get() {
+        if (!buf && hipMalloc(&buf, HALFS * sizeof(_Float16)) != hipSuccess) buf = nullptr;
+        return buf;
+    }
+};
+static WeightPlanes g_wplanes;
+
 int launch_nt_h3(const NTArgs& a, hipStream_t s) {
     constexpr int BM = 128, BN = 256;
-    dim3 grid((unsigned)((a.M + BM - 1) / BM), (unsigned)((a.N + BN - 1) / BN));
-    size_t lds = (size_t)(BM + BN) * 40 * 2 * sizeof(_Float16);
+    const int tiles_m = (int)((a.M + BM - 1) / BM);
+    static int n_cu = 0;
+    if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu <= 0) n_cu = 256; }
+    dim3 grid((unsigned)(tiles_m < n_cu ? tiles_m : n_cu), (unsigned)((a.N + BN - 1) / BN));   // one persistent workgroup per CU
+    size_t lds = (size_t)2 * 2 * (BM + BN) * 40 * sizeof(_Float16) + (size_t)8 * 32 * 36 * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_h3_kernel<BM, BN, 2, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
     const bool prof = papr_prof_on();
     if (prof) papr_prof_begin(0, a.M, a.N, a.K1 + (a.A2 ? a.K2 : 0), s);
-    gemm_nt_h3_kernel<BM, BN, 2, 2, 2><<<grid, dim3(512), lds, s>>>(a);
+    // pre-split the weight once per launch (64k-180k elements): the hot loop then copies f16 planes verbatim
+    const int ncols = a.A2 ? a.wcol2 + a.K2 : a.K1;
+    const int pitch = (ncols + 31) / 32 * 32, rows_pad = (a.N + BN - 1) / BN * BN;
+    PAPR_REQUIRE((size_t)2 * rows_pad * pitch <= WeightPlanes::HALFS, "gemm_nt_h3: weight %d x %d too large for the split scratch", a.N, ncols);
+    PAPR_REQUIRE(!a.A2 || a.K1 % 32 == 0, "gemm_nt_h3: first K segment must be a multiple of 32 when a second one follows");
+    _Float16* planes = g_wplanes.get();
+    PAPR_REQUIRE(planes, "gemm_nt_h3: scratch allocation failed");
+    _Float16* w_hi = planes;
+    _Float16* w_lo = planes + (size_t)rows_pad * pitch;
+    split_weight_kernel<<<dim3((rows_pad * pitch + 255) / 256), dim3(256), 0, s>>>(a.W, a.N, ncols, a.ldw, rows_pad, pitch, w_hi, w_lo);
+    PAPR_CHECK_LAUNCH("split_weight");
+    gemm_nt_h3_kernel<BM, BN, 2, 2, 4><<<grid, dim3(512), lds, s>>>(a, tiles_m, w_hi, w_lo, pitch);
     if (prof) papr_prof_end(s);
     PAPR_CHECK_LAUNCH("gemm_nt_h3");
     return 0;
