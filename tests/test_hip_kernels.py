@@ -329,11 +329,13 @@ def test_attention_tail_forward_backward(R, k, d_model, Cc, act, normalize):
     np.testing.assert_allclose(d_sb.cpu().numpy(), sb.grad.numpy(), rtol=0, atol=tol(sb.grad))
 
 
-def test_split_f16_gemm_mode_meets_the_same_mlp_parity():
-    """PAPR_GEMM_MODE=h3 routes the wide GEMMs through the split-f16 (hi/lo, 3 MFMA) kernel; it must pass the
-    fp32 parity tests unchanged.  The switch is read when the library loads, hence the child process."""
+@pytest.mark.parametrize("mode", ["h3", "fwd"])
+def test_other_gemm_modes_meet_the_same_mlp_parity(mode):
+    """PAPR_GEMM_MODE selects which wide GEMMs use the split-f16 (hi/lo, 3 MFMA) kernel (default: none);
+    `fwd` (forward layers) and `h3` (data-gradients too) must pass the same MLP parity tests.  The switch is read when the
+    library loads, hence the child process."""
     import os, subprocess, sys
-    env = dict(os.environ, PAPR_GEMM_MODE="h3")
+    env = dict(os.environ, PAPR_GEMM_MODE=mode)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-k", "mlp_forward_backward"],
                        env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-2000:]
