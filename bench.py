@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--points", type=int, default=10000, help="point-cloud size (chair.yml: 10000 at init, <=30000 late)")
     ap.add_argument("--scene", default="nerfsyn/chair.yml")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gemm-mode", default="f32", choices=["f32", "fwd", "h3"],
+                    help="f32: every GEMM on fp32 MFMA (parity mode, default); fwd/h3: split-f16 kernel for forward / all wide GEMMs")
     ap.add_argument("--cpu-rays", type=int, default=32, help="edge of the CPU-baseline patch (32 -> 1,024 rays)")
     ap.add_argument("--cpu-steps", type=int, default=8)
     return ap.parse_args()
@@ -89,6 +91,7 @@ def cpu_baseline(cfg, state, edge, steps):
 
 def main():
     args = parse()
+    os.environ["PAPR_GEMM_MODE"] = args.gemm_mode       # read by libpapr_hip.so when it loads
     from papr_amd import dist as pdist, get_model, get_loss, hip
     from papr_amd.data import SyntheticRayData
     world = pdist.init_from_env("cuda")
@@ -164,14 +167,15 @@ def main():
         traffic = json.load(open(tpath)).get("gemm_nt_128x256_bytes_per_launch")
     achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     out = {
-        "metric": "train rays/sec, nerf_synthetic/chair (PAPR), fp32 parity mode",
+        "metric": "train rays/sec, nerf_synthetic/chair (PAPR), " + ("fp32 parity mode" if args.gemm_mode == "f32" else
+                                                                        "split-f16 GEMM mode '%s'" % args.gemm_mode),
         "value": world * R * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32" if args.gemm_mode == "f32" else "f32 via split-f16 MFMA (hi/lo halves, fp32 accumulate)", "data": "synthetic",
         "config": {"workload": "configs/nerfsyn/chair.yml: P=%d points, one %dx%d patch (R=%d rays) per rank per step, k=%d, "
                                "U-Net head, MSE loss (LPIPS weight 0: VGG weights unavailable offline), use_amp=false"
                                % (P, H, W, R, k),
-                   "global_batch_rays": world * R, "parallelism": "dp%d" % world, "final_loss": float(loss.detach())},
+                   "global_batch_rays": world * R, "parallelism": "dp%d" % world, "gemm_mode": args.gemm_mode, "final_loss": float(loss.detach())},
         "roofline": {"kernel": "gemm_nt_kernel<128,256,2,2> (embedding-MLP forward + data-gradient GEMMs)",
                      "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                      "frac": achieved / FP32_MFMA_PEAK_TF, "traffic": traffic,
