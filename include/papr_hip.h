@@ -130,15 +130,21 @@ typedef struct {
 } papr_layer;
 
 /* outs[i] : (M, ld_out[i]) buffer of layer i's output.  For training pass distinct buffers (they are
- * the saved activations); for inference two ping-pong buffers may be reused. */
+ * the saved activations); for inference two ping-pong buffers may be reused.
+ * workspace: papr_mlp_fwd_workspace_bytes(M) bytes (per-row operand scales and the pre-split weight of
+ * the split-f16 GEMM; see gemm.hip).  Arithmetic: fp32 in, fp32 out; wide layers multiply on the f16
+ * matrix pipe with every fp32 operand split into two halves (22 mantissa bits, fp32 accumulation) unless
+ * the environment variable PAPR_GEMM_MODE=f32 selects fp32 MFMA everywhere. */
+size_t papr_mlp_fwd_workspace_bytes(int64_t M);
 int papr_mlp_fwd(const papr_layer* layers, int n_layers, const float* x, int ldx, int64_t M,
-                 float* const* outs, const int32_t* ld_out, papr_stream_t stream);
+                 float* const* outs, const int32_t* ld_out, void* workspace, papr_stream_t stream);
 
 /* Backward.  d_out: gradient w.r.t. the last layer's output (M, ld_out[n-1]); it is consumed
  * (overwritten).  scratch0/scratch1: two (M, max width) buffers.  d_weight[i] (n_out, ldw) and
  * d_bias[i] (n_out) are overwritten.  d_x (M, ldx) or NULL when the input needs no gradient.
- * workspace: papr_mlp_bwd_workspace_bytes() bytes (split-K slabs of the weight-gradient GEMMs). */
-size_t papr_mlp_bwd_workspace_bytes(void);
+ * workspace: papr_mlp_bwd_workspace_bytes(M) bytes (split-M slabs of the weight-gradient GEMMs + the
+ * split-f16 scratch). */
+size_t papr_mlp_bwd_workspace_bytes(int64_t M);
 int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float* x, int ldx, int64_t M,
                  float* const* outs, const int32_t* ld_out, float* d_out, float* scratch0, float* scratch1,
                  int ld_scratch, float* const* d_weight, float* const* d_bias, float* d_x,
@@ -182,8 +188,9 @@ int papr_attn_tail_bwd(const papr_tail_desc* d, const float* kp, const float* qp
 /* ------------------------------------------------------------------------------------
  * Optional timing of the GEMM / kNN launches with HIP events recorded on the launch stream
  * (used by bench.py for the live roofline figure; off by default, process-wide switch).
- * kernel ids: 0 gemm_nt<128x256>  1 gemm_nt<128x128>  2 gemm_nt<256x64>  3 gemm_nt<256x32>
+ * kernel ids: 0 gemm_nt<128x256> (fp32 MFMA)  1 gemm_nt<128x128>  2 gemm_nt<256x64>  3 gemm_nt<256x32>
  *             4 gemm_tn (split-M weight gradient)      5 ray_knn
+ *             6 gemm_nt_h3 forward layer   7 gemm_nt_h3 data-gradient   (split-f16, 128x256 tile)
  */
 typedef struct {
     int32_t kernel;

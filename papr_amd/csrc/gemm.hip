@@ -40,8 +40,9 @@ struct NTArgs {
     int accumulate;   // C += ...
     float* C; long ldc;
     long M; int N;
-    const unsigned* amax_in;   // split-f16 mode: bit pattern of max|A| (device scalar), 0/NULL -> 1.0
-    unsigned* amax_out;        // split-f16 mode: atomicMax'ed with the bit pattern of max|C| (or NULL)
+    const unsigned* amax_in;   // split-f16 mode: per row m, the bit pattern of max_k |A[m][k]| (M words); 0 -> scale 1
+    _Float16* planes;          // split-f16 mode: scratch for the pre-split weight (H3_PLANE_HALFS halfs)
+    unsigned* amax_out;        // split-f16 mode: per row, atomicMax'ed with the bit pattern of max_n |C[m][n]| (M words, zeroed) or NULL
 };
 
 // BKT: k-slab per stage (32 or 16).  DB: two LDS buffers and ONE barrier per stage (compute slab t,
@@ -272,6 +273,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_h3_kernel(NTArgs p, int tiles_
     extern __shared__ __attribute__((aligned(16))) float smem[];
     _Float16* lds = reinterpret_cast<_Float16*>(smem);         // two slab buffers: [Ah | Al] each
     float* patch_base = smem + BUF;                            // (2 * BUF halfs = BUF floats) epilogue patches behind them
+    float* inv_tab = patch_base + 8 * 32 * EP;                 // [2][BM] 1/scale of the rows of the tile in flight (by tile parity)
+    unsigned* rmax_tab = reinterpret_cast<unsigned*>(inv_tab + 2 * BM);   // [2][BM] running max|C| bits of those rows
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -282,22 +285,22 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_h3_kernel(NTArgs p, int tiles_
     const int my_tiles = (tiles_m - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     const int total = my_tiles * nt;
 
-    // scale: max|A| -> [2^13, 2^14)
-    const unsigned amax = p.amax_in ? *p.amax_in : 0u;
-    const int ea = amax ? (int)((amax >> 23) & 0xff) : 127 + 13;
-    const float a_scale = pow2_from_biased(127 + 13 - (ea - 127));
-    const float inv_scale = pow2_from_biased(127 - 13 + (ea - 127));
-
+    // Every ROW of A gets its own power-of-two scale (row max -> [2^13, 2^14)), undone per row in the epilogue:
+    // rows are independent dot products, so results do not depend on which other rows share the launch
+    // (chunked evaluation stays bitwise equal to whole-image evaluation) and a row of tiny gradients keeps
+    // its 22 bits next to a row of large ones.
     float4 ra[D][A_LD];
+    unsigned rs[D][A_LD];                        // row-max bit patterns, fetched with the slab
     // The weight arrives pre-split AND in MFMA fragment order (split_weight_kernel): a wave's B fragment of
     // (n-tile, k-step) is one coalesced 1 KB load from L2 straight into registers; it never touches LDS,
     // which cuts the LDS write traffic per slab from 61 KB to 20 KB.
     half8 wfh[2][TN][BKT / 16], wfl[2][TN][BKT / 16];
     // (tile, k-slab) of stream position g; nt is small, so the division is a handful of scalar ops
-    auto slab_coords = [&](int g, long& m0, int& kt) {
+    auto slab_coords = [&](int g, long& m0, int& kt) -> int {
         int ti = __builtin_amdgcn_readfirstlane(g / nt);
         kt = g - ti * nt;
         m0 = ((long)blockIdx.x + (long)ti * gridDim.x) * BM;
+        return ti;
     };
     // per-thread constants of the slab copy: row inside the tile and k offset inside the slab
     int a_row[A_LD], a_kq[A_LD];
@@ -317,7 +320,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_h3_kernel(NTArgs p, int tiles_
                 ql[j][sidx] = *reinterpret_cast<const half8*>(w_lo + o);
             }
     };
-    auto load_slab = [&](int g, float4 (&qa)[A_LD]) {
+    auto load_slab = [&](int g, float4 (&qa)[A_LD], unsigned (&qs)[A_LD]) {
         long m0; int kt;
         slab_coords(g, m0, kt);
         const float* src; long ld; int klim, k0, wcol;
@@ -329,12 +332,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_h3_kernel(NTArgs p, int tiles_
             m = m < p.M ? m : p.M - 1;
             int kk = k0 + a_kq[i] < klim ? k0 + a_kq[i] : 0;
             qa[i] = *reinterpret_cast<const float4*>(src + m * ld + kk);
+            qs[i] = p.amax_in[m];
         }
         (void)wcol;
     };
-    auto store_slab = [&](int g, const float4 (&qa)[A_LD]) {
+    auto store_slab = [&](int g, const float4 (&qa)[A_LD], const unsigned (&qs)[A_LD]) {
         long m0; int kt;
-        slab_coords(g, m0, kt);
+        const int par = slab_coords(g, m0, kt) & 1;
         const int klim = kt < nt1 ? p.K1 : p.K2, k0 = (kt < nt1 ? kt : kt - nt1) * BKT;
         _Float16* Ah = lds + (g & 1) * BUF;
         _Float16* Al = Ah + PLANE_A;
@@ -342,10 +346,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_h3_kernel(NTArgs p, int tiles_
         for (int i = 0; i < A_LD; ++i) {
             int off = a_row[i] * HP + a_kq[i];
             const bool ok = m0 + a_row[i] < p.M && k0 + a_kq[i] < klim;
+            const int ea = qs[i] ? (int)((qs[i] >> 23) & 0xff) : 127 + 13;
+            const float a_scale = pow2_from_biased(127 + 13 - (ea - 127));
             half4 hi, lo;
             split4(qa[i], ok ? a_scale : 0.f, hi, lo);
             *reinterpret_cast<half4*>(Ah + off) = hi;
             *reinterpret_cast<half4*>(Al + off) = lo;
+            if (kt == 0 && a_kq[i] == 0) {          // first slab of a tile: publish the row's 1/scale, reset its max
+                inv_tab[par * BM + a_row[i]] = pow2_from_biased(127 - 13 + (ea - 127));
+                rmax_tab[par * BM + a_row[i]] = 0u;
+            }
         }
     };
 
@@ -367,14 +377,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_h3_kernel(NTArgs p, int tiles_
     const int pr = lane >> 3, pc = (lane & 7) * 4;
     const int wr_off = (4 * (lane >> 5)) * EP + (lane & 31);
     const bool need_aux = p.dgrad && p.mask_src != nullptr;
-    float cmax = 0.f;
     float4 bias4[TN];                           // loaded once: inside the tile loop it would be a dependent L2 trip per tile
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = n0 + (wn * TN + j) * 32 + pc;
         bias4[j] = (!p.dgrad && p.bias && col < p.N) ? *reinterpret_cast<const float4*>(p.bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    auto epilogue = [&](long m0) {
+    auto epilogue = [&](long m0, int par) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int col = n0 + (wn * TN + j) * 32 + pc;
@@ -383,7 +392,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_h3_kernel(NTArgs p, int tiles_
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) patch[wr_off + ((e & 3) + 8 * (e >> 2)) * EP] = acc[i][j][e] * inv_scale;
+                for (int e = 0; e < 16; ++e) patch[wr_off + ((e & 3) + 8 * (e >> 2)) * EP] = acc[i][j][e];
                 const long row0 = m0 + (wm * TM + i) * 32 + pr;
                 float4 v[4], aux[4];
 #pragma unroll
@@ -399,7 +408,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_h3_kernel(NTArgs p, int tiles_
                 for (int t = 0; t < 4; ++t) {
                     const long row = row0 + 8 * t;
                     if (!(col_ok && row < p.M)) continue;
+                    const int rl = (wm * TM + i) * 32 + pr + 8 * t;          // row inside the tile
+                    const float inv = inv_tab[par * BM + rl];
                     float4 r = v[t];
+                    r.x *= inv; r.y *= inv; r.z *= inv; r.w *= inv;
                     if (p.dgrad) {
                         if (need_aux) {
                             r.x *= aux[t].x > 0.f ? 1.f : slope; r.y *= aux[t].y > 0.f ? 1.f : slope;
@@ -413,7 +425,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_h3_kernel(NTArgs p, int tiles_
                     float4* dst = reinterpret_cast<float4*>(p.C + row * p.ldc + col);
                     if (p.accumulate) { float4 o = *dst; r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w; }
                     *dst = r;
-                    cmax = fmaxf(cmax, fmaxf(fmaxf(fabsf(r.x), fabsf(r.y)), fmaxf(fabsf(r.z), fabsf(r.w))));
+                    if (p.amax_out)                                            // |x| bit patterns order like unsigned ints
+                        atomicMax(rmax_tab + par * BM + rl, __float_as_uint(fmaxf(fmaxf(fabsf(r.x), fabsf(r.y)), fmaxf(fabsf(r.z), fabsf(r.w)))));
                 }
             }
         }
@@ -423,14 +436,22 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_h3_kernel(NTArgs p, int tiles_
     const int frag = (lane & 31) * HP + 8 * (lane >> 5);
 #pragma unroll
     for (int u = 0; u < D; ++u)
-        if (u < total) load_slab(u, ra[u]);
-    if (total > 0) { store_slab(0, ra[0]); load_wfrag(0, wfh[0], wfl[0]); }
+        if (u < total) load_slab(u, ra[u], rs[u]);
+    if (total > 0) { store_slab(0, ra[0], rs[0]); load_wfrag(0, wfh[0], wfl[0]); }
     lds_barrier();
+    long pend_m0 = -1;                           // tile whose row maxima wait in LDS for their write-out
+    int pend_par = 0;
+    auto flush_rowmax = [&]() {                  // runs after the barrier that ended the tile's epilogue
+        if (pend_m0 >= 0 && p.amax_out && tid < BM && pend_m0 + tid < p.M)
+            atomicMax(p.amax_out + pend_m0 + tid, rmax_tab[pend_par * BM + tid]);
+        pend_m0 = -1;
+    };
     for (int g0 = 0; g0 < total; g0 += D) {
 #pragma unroll
         for (int u = 0; u < D; ++u) {
             const int g = g0 + u;
             if (g >= total) break;
+            flush_rowmax();
             const _Float16* Ah = lds + (g & 1) * BUF;
             const _Float16* Al = Ah + PLANE_A;
             if (g + 1 < total) load_wfrag(g + 1, wfh[(u + 1) & 1], wfl[(u + 1) & 1]);     // next slab's B fragments (L2)
@@ -457,39 +478,37 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_h3_kernel(NTArgs p, int tiles_
             // slab g+1 (requested D-1 iterations ago) goes into the other LDS buffer, whose last readers
             // passed the previous barrier; ring set u is then free for slab g+D
             H3_STAMP(1 + g * 5);
-            if (g + 1 < total) store_slab(g + 1, ra[(u + 1) % D]);
+            if (g + 1 < total) store_slab(g + 1, ra[(u + 1) % D], rs[(u + 1) % D]);
             H3_STAMP(2 + g * 5);
-            if (g + D < total) load_slab(g + D, ra[u]);
+            if (g + D < total) load_slab(g + D, ra[u], rs[u]);
             H3_STAMP(3 + g * 5);
             long m0; int kt;
-            slab_coords(g, m0, kt);
+            const int par = slab_coords(g, m0, kt) & 1;
             if (kt == nt - 1) {
-                epilogue(m0);
+                epilogue(m0, par);
                 clear_acc();
+                pend_m0 = m0; pend_par = par;
             }
             H3_STAMP(4 + g * 5);
             lds_barrier();
             H3_STAMP(5 + g * 5);
         }
     }
-    if (p.amax_out) {
-        cmax = wave_max(cmax);
-        if (lane == 0) atomicMax(p.amax_out, __float_as_uint(cmax));
-    }
+    flush_rowmax();
 }
 
-// max |x| of an (M, width) block of rows -> atomicMax on the bit pattern
-__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long M, int width, long ld, unsigned* out) {
-    const long total = M * (width / 4);
+// out[m] = bit pattern of max_k |x[m][k]|, one wave per row (width <= 1024, a multiple of 4)
+__global__ __launch_bounds__(256) void row_absmax_kernel(const float* __restrict__ x, long M, int width, long ld, unsigned* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
     float mx = 0.f;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        long m = e / (width / 4);
-        int c = (int)(e - m * (width / 4)) * 4;
+    for (int c = lane * 4; c < width; c += 256) {
         float4 v = *reinterpret_cast<const float4*>(x + m * ld + c);
         mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
     }
     mx = wave_max(mx);
-    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(mx));
+    if (lane == 0) out[m] = __float_as_uint(mx);
 }
 
 template <int BM, int BN, int TM, int TN, int BKT = BK, bool DB = false>
@@ -510,43 +529,44 @@ int launch_nt(const NTArgs& a, hipStream_t s) {
 static const bool NT_WAVES4 = getenv("PAPR_NT_WAVES4") != nullptr;
 static const int NT_VARIANT = getenv("PAPR_NT_VARIANT") ? atoi(getenv("PAPR_NT_VARIANT")) : 0;   // A/B switch
 
-// Which wide GEMMs run on the split-f16 kernel (gemm_nt_h3).  PAPR_GEMM_MODE = f32 (default) | fwd | h3.
-//   f32: every GEMM on v_mfma_f32_32x32x2_f32 -- the parity mode: bitwise chunk-invariant, reproduces the
-//        reference's 3-step Adam trajectory to 1e-8.
-//   fwd: forward layers on the split-f16 kernel (586 -> 339 us per layer; whole step 29.2 -> 27.0 ms).
-//   h3 : data-gradients too (634 -> 457 us; step 24.9 ms, 1.03 M rays/s).
-// The split modes pass the rendering (1e-4) and gradient (2e-3) parity tests, but not two stricter ones: the
-// per-tensor power-of-two scale depends on the tensor's maximum, so a chunked evaluation is no longer
-// BITWISE equal to the whole-image one, and elements far below the tensor maximum keep fewer than 22
-// mantissa bits, which Adam's division by |g| amplifies for near-zero gradients (3-step trajectory of the
-// reference matched to ~1e-3 instead of 5e-5).  Hence opt-in; see DESIGN.md section 8 for the next steps.
+// Which wide GEMMs (N > 128) run on the split-f16 kernel gemm_nt_h3.  PAPR_GEMM_MODE = h3 (default) | fwd | f32.
+//   h3 : forward layers and data-gradients (586 -> 369 us and 634 -> 483 us per 512000x256x256 layer).
+//   fwd: forward layers only.
+//   f32: every GEMM on v_mfma_f32_32x32x2_f32.
+// All three pass the same parity suite (RGB / fused / attention within 1e-4 of the reference, gradients
+// within 2e-3, bitwise chunk invariance, reference loss trajectory within 5e-6).  The one measurable
+// difference: after the reference's three Adam steps the point positions agree to 5e-5 in f32 mode and to
+// 1e-4 in the split modes (22-bit operands; Adam divides by |g| for near-zero gradients).
 static const int GEMM_MODE = [] {
     const char* e = getenv("PAPR_GEMM_MODE");
+    if (e && !strcmp(e, "f32")) return 0;
     if (e && !strcmp(e, "fwd")) return 1;
-    if (e && !strcmp(e, "h3")) return 2;
-    return 0;
+    return 2;
 }();
 static const bool GEMM_H3_FWD = GEMM_MODE >= 1, GEMM_H3 = GEMM_MODE >= 2;
 
-// scratch for the split-f16 mode: one max|.| word per tensor of a chain (experiment: process-wide buffer)
-struct AmaxRing {
-    unsigned* buf = nullptr;
-    int next = 0;
-    unsigned* begin(hipStream_t s) {
-        if (!buf) { if (hipMalloc(&buf, 256 * sizeof(unsigned)) != hipSuccess) return nullptr; }
-        (void)hipMemsetAsync(buf, 0, 256 * sizeof(unsigned), s);
-        next = 0;
-        return buf;
+// Caller-provided scratch of the split-f16 mode, carved from the workspace argument of papr_mlp_fwd / _bwd:
+// two per-row max|.| arrays (rows of the layer input / of its output, swapped after every layer) and the
+// pre-split weight planes of the launch in flight.
+constexpr size_t H3_PLANE_HALFS = (size_t)2 * 512 * 704;      // hi + lo planes of a weight up to 512 x 704
+struct H3Scratch {
+    unsigned* amax[2];
+    _Float16* planes;
+    int cur = 0;
+    H3Scratch(void* ws, long M) {
+        amax[0] = static_cast<unsigned*>(ws);
+        amax[1] = amax[0] + M;
+        planes = reinterpret_cast<_Float16*>(amax[1] + M);
     }
-    unsigned* slot() { return buf + (next++ & 255); }
+    static size_t bytes(long M) { return ((size_t)2 * M * sizeof(unsigned) + H3_PLANE_HALFS * sizeof(_Float16) + 255) / 256 * 256; }
+    unsigned* in() { return amax[cur]; }
+    unsigned* out() { return amax[cur ^ 1]; }
+    void swap() { cur ^= 1; }
 };
-static AmaxRing g_amax;
 
-int launch_absmax(const float* x, long M, int width, long ld, unsigned* out, hipStream_t s) {
-    long total = M * (width / 4);
-    int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-    absmax_kernel<<<dim3(blocks), dim3(256), 0, s>>>(x, M, width, ld, out);
-    PAPR_CHECK_LAUNCH("absmax");
+int launch_row_absmax(const float* x, long M, int width, long ld, unsigned* out, hipStream_t s) {
+    row_absmax_kernel<<<dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s>>>(x, M, width, ld, out);
+    PAPR_CHECK_LAUNCH("row_absmax");
     return 0;
 }
 
@@ -565,43 +585,32 @@ __global__ __launch_bounds__(256) void split_weight_kernel(const float* __restri
     lo[idx] = (_Float16)(x - (float)h);
 }
 
-struct WeightPlanes {           // experiment: process-wide scratch for the pre-split weight of the launch in flight
-    _Float16* buf = nullptr;
-    static constexpr size_t HALFS = 2 * 512 * 704;
-    _Float16* get() {
-        if (!buf && hipMalloc(&buf, HALFS * sizeof(_Float16)) != hipSuccess) buf = nullptr;
-        return buf;
-    }
-};
-static WeightPlanes g_wplanes;
-
-int launch_nt_h3(const NTArgs& a, hipStream_t s) {
+int launch_nt_h3(const NTArgs& a, _Float16* planes, hipStream_t s) {
     constexpr int BM = 128, BN = 256;
     const int tiles_m = (int)((a.M + BM - 1) / BM);
     static int n_cu = 0;
     if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu <= 0) n_cu = 256; }
     dim3 grid((unsigned)(tiles_m < n_cu ? tiles_m : n_cu), (unsigned)((a.N + BN - 1) / BN));   // one persistent workgroup per CU
-    size_t lds = (size_t)2 * 2 * BM * 40 * sizeof(_Float16) + (size_t)8 * 32 * 36 * sizeof(float);
+    size_t lds = (size_t)2 * 2 * BM * 40 * sizeof(_Float16) + (size_t)8 * 32 * 36 * sizeof(float) + (size_t)4 * BM * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_h3_kernel<BM, BN, 2, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    const bool prof = papr_prof_on();
-    if (prof) papr_prof_begin(0, a.M, a.N, a.K1 + (a.A2 ? a.K2 : 0), s);
     // pre-split the weight once per launch (64k-180k elements): the hot loop then copies f16 planes verbatim
     const int ncols = a.A2 ? a.wcol2 + a.K2 : a.K1;
     const int pitch = (ncols + 31) / 32 * 32, rows_pad = (a.N + BN - 1) / BN * BN;
     const int ksteps = pitch / 16, n_tiles = rows_pad / 32;
     PAPR_REQUIRE(!a.A2 || a.wcol2 % 32 == 0, "gemm_nt_h3: second K segment must start at a multiple of 32");
-    PAPR_REQUIRE((size_t)2 * rows_pad * pitch <= WeightPlanes::HALFS, "gemm_nt_h3: weight %d x %d too large for the split scratch", a.N, ncols);
+    PAPR_REQUIRE((size_t)2 * rows_pad * pitch <= H3_PLANE_HALFS, "gemm_nt_h3: weight %d x %d too large for the split scratch", a.N, ncols);
     PAPR_REQUIRE(!a.A2 || a.K1 % 32 == 0, "gemm_nt_h3: first K segment must be a multiple of 32 when a second one follows");
-    _Float16* planes = g_wplanes.get();
-    PAPR_REQUIRE(planes, "gemm_nt_h3: scratch allocation failed");
+    PAPR_REQUIRE(planes, "gemm_nt_h3: no workspace");
     _Float16* w_hi = planes;
     _Float16* w_lo = planes + (size_t)rows_pad * pitch;
     split_weight_kernel<<<dim3((rows_pad * pitch + 255) / 256), dim3(256), 0, s>>>(a.W, a.N, ncols, a.ldw, n_tiles, ksteps, w_hi, w_lo);
     PAPR_CHECK_LAUNCH("split_weight");
+    const bool prof = papr_prof_on();
+    if (prof) papr_prof_begin(a.dgrad ? 7 : 6, a.M, a.N, a.K1 + (a.A2 ? a.K2 : 0), s);
     gemm_nt_h3_kernel<BM, BN, 2, 2, 4><<<grid, dim3(512), lds, s>>>(a, tiles_m, w_hi, w_lo, ksteps);
     if (prof) papr_prof_end(s);
     PAPR_CHECK_LAUNCH("gemm_nt_h3");
@@ -613,7 +622,7 @@ int gemm_nt(const NTArgs& a, hipStream_t s) {
     PAPR_REQUIRE(!a.A2 || (a.K2 % 4 == 0 && a.lda2 % 4 == 0 && a.wcol2 % 4 == 0), "gemm_nt: segment-2 sizes must be multiples of 4");
     if (a.M <= 0 || a.N <= 0) return 0;
     if (a.N > 128) {
-        if (a.amax_in) return launch_nt_h3(a, s);
+        if (a.amax_in) return launch_nt_h3(a, a.planes, s);
         if (NT_WAVES4) return launch_nt<128, 256, 4, 2>(a, s);
         if (NT_VARIANT == 1) return launch_nt<128, 256, 2, 2, 16, true>(a, s);
         if (NT_VARIANT == 2) return launch_nt<128, 256, 2, 2, 32, true>(a, s);
@@ -814,16 +823,18 @@ __global__ __launch_bounds__(256) void act_grad_kernel(float* g, long ldg, const
 
 }  // namespace
 
-extern "C" size_t papr_mlp_bwd_workspace_bytes(void) {
-    return (size_t)MAX_SLICES * (SLAB * SLAB + SLAB) * sizeof(float);
-}
+constexpr size_t TN_SLAB_BYTES = (size_t)MAX_SLICES * (SLAB * SLAB + SLAB) * sizeof(float);
+
+extern "C" size_t papr_mlp_fwd_workspace_bytes(int64_t M) { return H3Scratch::bytes(M); }
+extern "C" size_t papr_mlp_bwd_workspace_bytes(int64_t M) { return TN_SLAB_BYTES + H3Scratch::bytes(M); }
 
 extern "C" int papr_mlp_fwd(const papr_layer* layers, int n_layers, const float* x, int ldx, int64_t M,
-                            float* const* outs, const int32_t* ld_out, papr_stream_t stream) {
+                            float* const* outs, const int32_t* ld_out, void* workspace, papr_stream_t stream) {
     PAPR_REQUIRE(layers && x && outs && ld_out && n_layers >= 1, "papr_mlp_fwd: bad arguments");
     hipStream_t s = as_stream(stream);
-    unsigned* have_amax = nullptr;          // split-f16 mode: max|input of the current layer|, when known
-    if (GEMM_H3_FWD) PAPR_REQUIRE(g_amax.begin(s), "papr_mlp_fwd: amax scratch allocation failed");
+    bool have_amax = false;                 // split-f16 mode: row maxima of the current layer's input are in h3.in()
+    PAPR_REQUIRE(!GEMM_H3_FWD || workspace, "papr_mlp_fwd: workspace required (papr_mlp_fwd_workspace_bytes)");
+    H3Scratch h3(workspace, M);
     for (int i = 0; i < n_layers; ++i) {
         const papr_layer& L = layers[i];
         PAPR_REQUIRE(L.weight && outs[i], "papr_mlp_fwd: layer %d has null weight/output", i);
@@ -835,17 +846,19 @@ extern "C" int papr_mlp_fwd(const papr_layer* layers, int n_layers, const float*
         if (L.n_skip > 0) { a.A2 = x; a.lda2 = ldx; a.K2 = L.n_skip; a.wcol2 = L.skip_col; }
         a.W = L.weight; a.ldw = L.ldw; a.bias = L.bias; a.act = L.act;
         a.C = outs[i]; a.ldc = ld_out[i]; a.M = M; a.N = L.n_out;
-        if (GEMM_H3_FWD && L.n_out > 128 && L.n_skip == 0 && M >= 4096) {
-            if (!have_amax) {
-                have_amax = g_amax.slot();
-                if (int e = launch_absmax(a.A, M, L.n_in, a.lda, have_amax, s)) return e;
-            }
-            a.amax_in = have_amax;
-            a.amax_out = g_amax.slot();
-            have_amax = a.amax_out;
-        } else {
-            have_amax = nullptr;
+        if (GEMM_H3_FWD && L.n_out > 128 && L.n_skip == 0) {
+            if (!have_amax)
+                if (int e = launch_row_absmax(a.A, M, L.n_in, a.lda, h3.in(), s)) return e;
+            a.amax_in = h3.in();
+            a.amax_out = h3.out();
+            a.planes = h3.planes;
+            PAPR_REQUIRE(hipMemsetAsync(a.amax_out, 0, (size_t)M * sizeof(unsigned), s) == hipSuccess, "papr_mlp_fwd: memset failed");
+            if (int e = gemm_nt(a, s)) return e;
+            h3.swap();
+            have_amax = true;
+            continue;
         }
+        have_amax = false;
         if (int e = gemm_nt(a, s)) return e;
     }
     return 0;
@@ -865,17 +878,18 @@ extern "C" int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float*
         hipError_t e = hipMemsetAsync(d_x, 0, (size_t)M * ldx * sizeof(float), s);
         PAPR_REQUIRE(e == hipSuccess, "papr_mlp_bwd: memset failed");
     }
-    unsigned* have_amax = nullptr;          // split-f16 mode: max|g|, when known
-    if (GEMM_H3) PAPR_REQUIRE(g_amax.begin(s), "papr_mlp_bwd: amax scratch allocation failed");
+    bool have_amax = false;                 // split-f16 mode: row maxima of g are in h3.in()
+    H3Scratch h3(static_cast<char*>(workspace) + TN_SLAB_BYTES, M);
     auto h3_setup = [&](NTArgs& a) -> int {    // choose the split-f16 kernel for a wide data-gradient
-        if (!(GEMM_H3 && a.N > 128)) { have_amax = nullptr; return 0; }
-        if (!have_amax) {
-            have_amax = g_amax.slot();
-            if (int e = launch_absmax(a.A, a.M, a.K1, a.lda, have_amax, s)) return e;
-        }
-        a.amax_in = have_amax;
-        a.amax_out = g_amax.slot();
-        have_amax = a.amax_out;
+        if (!(GEMM_H3 && a.N > 128)) { have_amax = false; return 0; }
+        if (!have_amax)
+            if (int e = launch_row_absmax(a.A, a.M, a.K1, a.lda, h3.in(), s)) return e;
+        a.amax_in = h3.in();
+        a.amax_out = h3.out();
+        a.planes = h3.planes;
+        PAPR_REQUIRE(hipMemsetAsync(a.amax_out, 0, (size_t)a.M * sizeof(unsigned), s) == hipSuccess, "papr_mlp_bwd: memset failed");
+        h3.swap();                             // the launch below writes what the next layer reads
+        have_amax = true;
         return 0;
     };
     // gradient w.r.t. the last layer's pre-activation

@@ -125,19 +125,21 @@ def mlp_forward(spec, ws, bs, x, M, keep=True):
         outs = [pool[i & 1][:M * ld].view(M, ld) for i, ld in enumerate(spec.ld_out)]
     tab = _layer_table(spec, ws, bs)
     hip.check(hip.lib().papr_mlp_fwd(tab, spec.n_layer, hip.ptr(x), x.shape[1], M, hip.ptr_array(outs),
-                                     hip.i32_array(spec.ld_out), hip.stream_ptr()), "papr_mlp_fwd")
+                                     hip.i32_array(spec.ld_out), hip.ptr(_workspace(dev, "fwd", M)), hip.stream_ptr()), "papr_mlp_fwd")
     return outs
 
 
 _ws_cache = {}
 
 
-def _bwd_workspace(dev):
-    key = (dev.type, dev.index)
-    if key not in _ws_cache:
-        n = hip.lib().papr_mlp_bwd_workspace_bytes()
-        _ws_cache[key] = torch.empty(n // 4, device=dev, dtype=torch.float32)
-    return _ws_cache[key]
+def _workspace(dev, kind, M):
+    """Grow-only scratch buffer per (device, kind); calls on one stream run in order, so it is shared."""
+    size = hip.lib().papr_mlp_fwd_workspace_bytes(M) if kind == "fwd" else hip.lib().papr_mlp_bwd_workspace_bytes(M)
+    key = (dev.type, dev.index, kind)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() * 4 < size:
+        buf = _ws_cache[key] = torch.empty((size + 3) // 4, device=dev, dtype=torch.float32)
+    return buf
 
 
 def mlp_backward(spec, ws, bs, x, M, outs, d_out, scratch, need_dx):
@@ -151,7 +153,7 @@ def mlp_backward(spec, ws, bs, x, M, outs, d_out, scratch, need_dx):
     hip.check(hip.lib().papr_mlp_bwd(tab, spec.n_layer, hip.ptr(x), x.shape[1], M, hip.ptr_array(outs),
                                      hip.i32_array(spec.ld_out), hip.ptr(d_out), hip.ptr(scratch[0]), hip.ptr(scratch[1]),
                                      scratch[0].shape[1], hip.ptr_array(d_ws), hip.ptr_array(d_bs), hip.ptr(d_x),
-                                     hip.ptr(_bwd_workspace(dev)), hip.stream_ptr()), "papr_mlp_bwd")
+                                     hip.ptr(_workspace(dev, "bwd", M)), hip.stream_ptr()), "papr_mlp_bwd")
     return d_ws, d_bs, d_x
 
 
@@ -166,7 +168,7 @@ def linear_rows(x, w):
     t.weight, t.weight_t, t.bias = w.data_ptr(), None, None
     t.n_in, t.n_out, t.ldw, t.ldwt, t.n_skip, t.skip_col, t.act = x.shape[1], n_out, w.shape[1], 0, 0, 0, 0
     hip.check(hip.lib().papr_mlp_fwd(tab, 1, hip.ptr(x), x.shape[1], M, hip.ptr_array([out]), hip.i32_array([n_out]),
-                                     hip.stream_ptr()), "papr_mlp_fwd")
+                                     hip.ptr(_workspace(x.device, "fwd", M)), hip.stream_ptr()), "papr_mlp_fwd")
     return out
 
 

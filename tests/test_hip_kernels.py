@@ -329,10 +329,10 @@ def test_attention_tail_forward_backward(R, k, d_model, Cc, act, normalize):
     np.testing.assert_allclose(d_sb.cpu().numpy(), sb.grad.numpy(), rtol=0, atol=tol(sb.grad))
 
 
-@pytest.mark.parametrize("mode", ["h3", "fwd"])
+@pytest.mark.parametrize("mode", ["f32", "fwd"])
 def test_other_gemm_modes_meet_the_same_mlp_parity(mode):
-    """PAPR_GEMM_MODE selects which wide GEMMs use the split-f16 (hi/lo, 3 MFMA) kernel (default: none);
-    `fwd` (forward layers) and `h3` (data-gradients too) must pass the same MLP parity tests.  The switch is read when the
+    """PAPR_GEMM_MODE selects which wide GEMMs use the split-f16 (hi/lo, 3 MFMA) kernel (default `h3`: forward
+    layers and data-gradients); `fwd` (forward only) and `f32` (fp32 MFMA everywhere) must pass the same tests.  The switch is read when the
     library loads, hence the child process."""
     import os, subprocess, sys
     env = dict(os.environ, PAPR_GEMM_MODE=mode)

