@@ -40,8 +40,9 @@ def parse():
     ap.add_argument("--points", type=int, default=10000, help="point-cloud size (chair.yml: 10000 at init, <=30000 late)")
     ap.add_argument("--scene", default="nerfsyn/chair.yml")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gemm-mode", default="h3", choices=["f32", "fwd", "h3"],
-                    help="h3 (default): wide forward + data-gradient GEMMs on the split-f16 kernel; fwd: forward only; f32: fp32 MFMA everywhere")
+    ap.add_argument("--gemm-mode", default="h3", choices=["f32", "fwd", "dgrad", "h3"],
+                    help="h3 (default): wide forward, data-gradient and weight-gradient GEMMs on the split-f16 kernels; "
+                         "dgrad: forward + data-gradient; fwd: forward only; f32: fp32 MFMA everywhere")
     ap.add_argument("--cpu-rays", type=int, default=32, help="edge of the CPU-baseline patch (32 -> 1,024 rays)")
     ap.add_argument("--cpu-steps", type=int, default=8)
     return ap.parse_args()
@@ -182,11 +183,26 @@ def main():
                     "avg_launch_ms": ms / max(len(rs), 1), "algorithmic_bytes_per_launch": by / max(len(rs), 1),
                     "fp32_equivalent_tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0, "share_of_step_time": ms / (dt * 1e3)}
 
+    def wgrad_h3_line():
+        # split-f16 weight gradient: G (M x N) and X (M x K) are read once, the 256 per-CU partial tiles are
+        # written once and read once by the reduction
+        rs = [r for r in recs if r[0] == 8]
+        ms = sum(r[4] for r in rs)
+        by = sum(4.0 * M * (Nn + true_k.get(K, K)) for _, M, Nn, K, _ in rs)
+        fl = sum(2.0 * M * Nn * true_k.get(K, K) for _, M, Nn, K, _ in rs)
+        ach = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        return ms, {"kernel": "gemm_tn_h3_kernel (weight gradients, one slice of the rows per CU, split-f16 MFMA)",
+                    "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                    "traffic": traffic_db.get("gemm_tn_h3_bytes_per_launch"), "launches": len(rs),
+                    "avg_launch_ms": ms / max(len(rs), 1), "algorithmic_bytes_per_launch": by / max(len(rs), 1),
+                    "fp32_equivalent_tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0, "share_of_step_time": ms / (dt * 1e3)}
+
     nt_ms, nt_line = mfma_line("gemm_nt_kernel<128,256,2,2> (embedding-MLP forward + data-gradient GEMMs, fp32 MFMA)", (0,),
                                "gemm_nt_128x256_bytes_per_launch")
     tn_ms, tn_line = mfma_line("gemm_tn_kernel (weight gradients, split over M, fp32 MFMA)", (4,), "gemm_tn_bytes_per_launch")
     h3_ms, h3 = h3_line()
-    dominant = max(((nt_ms, nt_line), (tn_ms, tn_line), (h3_ms, h3)), key=lambda t: t[0])[1]
+    wg_ms, wg = wgrad_h3_line()
+    dominant = max(((nt_ms, nt_line), (tn_ms, tn_line), (h3_ms, h3), (wg_ms, wg)), key=lambda t: t[0])[1]
     knn = [r for r in recs if r[0] == 5]
     knn_ms = sum(r[4] for r in knn) / max(len(knn), 1)
     knn_bytes = R * (12.0 * P + 12 + 4 * k)
@@ -202,7 +218,8 @@ def main():
         "roofline": dominant,
         "roofline_gemm_nt_fp32": nt_line if nt_ms > 0 and dominant is not nt_line else None,
         "roofline_gemm_nt_h3": h3 if h3_ms > 0 and dominant is not h3 else None,
-        "roofline_wgrad": tn_line if dominant is not tn_line else None,
+        "roofline_wgrad": tn_line if tn_ms > 0 and dominant is not tn_line else None,
+        "roofline_wgrad_h3": wg if wg_ms > 0 and dominant is not wg else None,
         "roofline_knn": {"kernel": "ray_knn_kernel<8,4>", "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
                          "achieved": knn_bytes / (knn_ms * 1e-3) / 1e9 if knn_ms > 0 else 0.0,
                          "frac": knn_bytes / (knn_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if knn_ms > 0 else 0.0,

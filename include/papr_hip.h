@@ -134,10 +134,15 @@ typedef struct {
  * workspace: papr_mlp_fwd_workspace_bytes(M) bytes (per-row operand scales and the pre-split weight of
  * the split-f16 GEMM; see gemm.hip).  Arithmetic: fp32 in, fp32 out; wide layers multiply on the f16
  * matrix pipe with every fp32 operand split into two halves (22 mantissa bits, fp32 accumulation) unless
- * the environment variable PAPR_GEMM_MODE=f32 selects fp32 MFMA everywhere. */
+ * the environment variable PAPR_GEMM_MODE=f32 selects fp32 MFMA everywhere.
+ * row_absmax: NULL, or (n_layers, M) floats that receive max_k |input row m of layer i| at [i*M + m] for
+ * every layer that ran on the split-f16 kernel (other entries undefined).  Pass the same buffer to
+ * papr_mlp_bwd: the weight-gradient GEMM of such a layer then also runs with split-f16 operands, scaled
+ * by these maxima (without it, weight-gradients use fp32 MFMA). */
 size_t papr_mlp_fwd_workspace_bytes(int64_t M);
 int papr_mlp_fwd(const papr_layer* layers, int n_layers, const float* x, int ldx, int64_t M,
-                 float* const* outs, const int32_t* ld_out, void* workspace, papr_stream_t stream);
+                 float* const* outs, const int32_t* ld_out, float* row_absmax, void* workspace,
+                 papr_stream_t stream);
 
 /* Backward.  d_out: gradient w.r.t. the last layer's output (M, ld_out[n-1]); it is consumed
  * (overwritten).  scratch0/scratch1: two (M, max width) buffers.  d_weight[i] (n_out, ldw) and
@@ -146,9 +151,9 @@ int papr_mlp_fwd(const papr_layer* layers, int n_layers, const float* x, int ldx
  * split-f16 scratch). */
 size_t papr_mlp_bwd_workspace_bytes(int64_t M);
 int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float* x, int ldx, int64_t M,
-                 float* const* outs, const int32_t* ld_out, float* d_out, float* scratch0, float* scratch1,
-                 int ld_scratch, float* const* d_weight, float* const* d_bias, float* d_x,
-                 void* workspace, papr_stream_t stream);
+                 float* const* outs, const int32_t* ld_out, const float* row_absmax, float* d_out,
+                 float* scratch0, float* scratch1, int ld_scratch, float* const* d_weight,
+                 float* const* d_bias, float* d_x, void* workspace, papr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * K4  attention tail        replaces attention("scaled-dot") + score_act (models/attn.py:217-225)
@@ -191,6 +196,7 @@ int papr_attn_tail_bwd(const papr_tail_desc* d, const float* kp, const float* qp
  * kernel ids: 0 gemm_nt<128x256> (fp32 MFMA)  1 gemm_nt<128x128>  2 gemm_nt<256x64>  3 gemm_nt<256x32>
  *             4 gemm_tn (split-M weight gradient)      5 ray_knn
  *             6 gemm_nt_h3 forward layer   7 gemm_nt_h3 data-gradient   (split-f16, 128x256 tile)
+ *             8 gemm_tn_h3 (split-f16 weight gradient)
  */
 typedef struct {
     int32_t kernel;

@@ -529,10 +529,12 @@ int launch_nt(const NTArgs& a, hipStream_t s) {
 static const bool NT_WAVES4 = getenv("PAPR_NT_WAVES4") != nullptr;
 static const int NT_VARIANT = getenv("PAPR_NT_VARIANT") ? atoi(getenv("PAPR_NT_VARIANT")) : 0;   // A/B switch
 
-// Which wide GEMMs (N > 128) run on the split-f16 kernel gemm_nt_h3.  PAPR_GEMM_MODE = h3 (default) | fwd | f32.
-//   h3 : forward layers and data-gradients (586 -> 369 us and 634 -> 483 us per 512000x256x256 layer).
-//   fwd: forward layers only.
-//   f32: every GEMM on v_mfma_f32_32x32x2_f32.
+// Which wide GEMMs run on the split-f16 kernels.  PAPR_GEMM_MODE = h3 (default) | dgrad | fwd | f32.
+//   h3   : forward layers, data-gradients (586 -> 369 us and 634 -> 483 us per 512000x256x256 layer) and
+//          weight-gradients (gemm_tn_h3).
+//   dgrad: forward layers and data-gradients.
+//   fwd  : forward layers only.
+//   f32  : every GEMM on v_mfma_f32_32x32x2_f32.
 // All three pass the same parity suite (RGB / fused / attention within 1e-4 of the reference, gradients
 // within 2e-3, bitwise chunk invariance, reference loss trajectory within 5e-6).  The one measurable
 // difference: after the reference's three Adam steps the point positions agree to 5e-5 in f32 mode and to
@@ -541,9 +543,10 @@ static const int GEMM_MODE = [] {
     const char* e = getenv("PAPR_GEMM_MODE");
     if (e && !strcmp(e, "f32")) return 0;
     if (e && !strcmp(e, "fwd")) return 1;
-    return 2;
+    if (e && !strcmp(e, "dgrad")) return 2;
+    return 3;
 }();
-static const bool GEMM_H3_FWD = GEMM_MODE >= 1, GEMM_H3 = GEMM_MODE >= 2;
+static const bool GEMM_H3_FWD = GEMM_MODE >= 1, GEMM_H3 = GEMM_MODE >= 2, GEMM_H3_WGRAD = GEMM_MODE >= 3;
 
 // Caller-provided scratch of the split-f16 mode, carved from the workspace argument of papr_mlp_fwd / _bwd:
 // two per-row max|.| arrays (rows of the layer input / of its output, swapped after every layer) and the
@@ -746,17 +749,22 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(TNArgs p) {
 // One workgroup = 16 float4 elements x 16 slab groups: every thread sums S/16 slabs with independent
 // loads, then the 16 partial sums of an element meet in LDS.  (A thread-per-element loop over all S
 // slabs is a 256-deep dependent load chain on 64 workgroups: 113 us instead of ~10.)
+// PERM: the slabs come from gemm_tn_h3 with both axes in LDS-row order (row r holds column 4 (r & 63) + (r >> 6)).
+template <bool PERM>
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bias_slab,
                                                           int S, int N, int K, float* __restrict__ dW, int ldw,
                                                           float* __restrict__ db) {
     __shared__ float4 part[16][17];
     const int el = threadIdx.x & 15, grp = threadIdx.x >> 4;
     const int e = blockIdx.x * 16 + el;              // float4 index inside the 256x256 tile
-    const int n = e >> 6, k = (e & 63) * 4;
+    const int rn = e >> 6, rk = (e & 63) * 4;        // position inside the slab
+    const int n = PERM ? 4 * (rn & 63) + (rn >> 6) : rn;
+    const int k = PERM ? 4 * (rk & 63) + (rk >> 6) : rk;          // column of the first element
+    constexpr int KS = PERM ? 4 : 1;                              // column step between the four elements
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (n < N && k < K) {
         for (int s = grp; s < S; s += 16) {
-            float4 v = *reinterpret_cast<const float4*>(slab + (long)s * SLAB * SLAB + n * SLAB + k);
+            float4 v = *reinterpret_cast<const float4*>(slab + (long)s * SLAB * SLAB + rn * SLAB + rk);
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
     }
@@ -767,9 +775,9 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
         for (int g = 1; g < 16; ++g) { float4 v = part[g][el]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
         float* dst = dW + (long)n * ldw + k;
         dst[0] = acc.x;
-        if (k + 1 < K) dst[1] = acc.y;
-        if (k + 2 < K) dst[2] = acc.z;
-        if (k + 3 < K) dst[3] = acc.w;
+        if (k + KS < K) dst[KS] = acc.y;
+        if (k + 2 * KS < K) dst[2 * KS] = acc.z;
+        if (k + 3 * KS < K) dst[3 * KS] = acc.w;
     }
     if (db && blockIdx.x < 16) {                      // bias: 256 columns, 16 per workgroup
         const int c = blockIdx.x * 16 + el;
@@ -806,7 +814,230 @@ int gemm_tn(const float* G, long ldg, int N, const float* X, long ldx, int K, lo
     gemm_tn_kernel<<<dim3(S), dim3(512), 2 * TN_ROWS * SLAB * sizeof(float), s>>>(a);
     if (prof) papr_prof_end(s);
     PAPR_CHECK_LAUNCH("gemm_tn");
-    slab_reduce_kernel<<<dim3(SLAB * SLAB / 4 / 16), dim3(256), 0, s>>>(a.slab, a.bias_slab, S, N, K, dW, ldw, db);
+    slab_reduce_kernel<false><<<dim3(SLAB * SLAB / 4 / 16), dim3(256), 0, s>>>(a.slab, a.bias_slab, S, N, K, dW, ldw, db);
+    PAPR_CHECK_LAUNCH("slab_reduce");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// gemm_tn_h3: the weight-gradient on the f16 matrix pipe with split operands (see gemm_nt_h3 for the
+// arithmetic).  The reduction runs over the rows m, so an MFMA operand is 8 CONSECUTIVE ROWS of one
+// column: the LDS image is the transpose of the global one.  A thread loads a 4 x 4 block (4 rows, one
+// float4 each); read column-wise its registers are already the transposed 4-row runs, so each column
+// goes out as one 8-byte LDS write per plane -- no shuffles.  Column c = 4 l + j of lane l is stored at
+// LDS row rho(c) = l + 64 j: the 16 lanes of a ds_write_b64 group then hit consecutive LDS rows, which
+// the 72-byte row pitch (36 halfs) spreads over all 32 banks, and the 32 lanes of a fragment read
+// (consecutive LDS rows again) over all 64.  The output tile therefore comes out with both axes
+// permuted by rho; slab_reduce_kernel<true> undoes that when it writes dW.
+//
+// Scales: a per-row factor cannot leave a sum over rows, so G and X get ONE power-of-two scale per
+// workgroup slice (max over the slice's per-row maxima, which the forward pass / the previous
+// data-gradient already produced).  Rows far below the slice maximum lose relative precision, but the
+// error they contribute is 2^-25 of the LARGEST term of the sum, below the fp32 rounding of the sum itself.
+struct TNH3Args {
+    const float* G; long ldg; int N;
+    const float* X; long ldx; int K;
+    long M; long rows_per_slice;
+    const float* gmax; const float* xmax;      // per-row max |.| of G and of X
+    float* slab; float* bias_slab;
+};
+
+constexpr int T3_HP = 36;                         // LDS row pitch in halfs
+constexpr int T3_PLANE = SLAB * T3_HP;            // halfs per plane (256 LDS rows x 32 m)
+constexpr size_t T3_LDS_BYTES = (size_t)2 * 4 * T3_PLANE * sizeof(_Float16);    // two buffers of [Gh Gl Xh Xl]
+
+__device__ __forceinline__ half8 lds_read8(const _Float16* q) {
+    half4 a = *reinterpret_cast<const half4*>(q), b = *reinterpret_cast<const half4*>(q + 4);
+    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// FULL: every 32-column tile holds real columns (N, K > 131): the hot loop has no tile tests
+template <bool FULL>
+__global__ __launch_bounds__(512, 2) void gemm_tn_h3_kernel(TNH3Args p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    _Float16* lds = reinterpret_cast<_Float16*>(smem);
+    __shared__ float red[2][8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: row tests and tile skips become SALU
+    const int wn = wave >> 2, wk = wave & 3;     // wave's corner in LDS-row space: n-tiles 4 wn .. +3, k-tiles 2 wk, 2 wk + 1
+    const long mbeg = (long)blockIdx.x * p.rows_per_slice;
+    long mend = mbeg + p.rows_per_slice;
+    if (mend > p.M) mend = p.M;
+    if (mbeg >= mend) return;                    // (the launch never creates such a slice)
+
+    // slice scales
+    float gm = 0.f, xm = 0.f;
+    for (long m = mbeg + tid; m < mend; m += 512) { gm = fmaxf(gm, p.gmax[m]); xm = fmaxf(xm, p.xmax[m]); }
+    gm = wave_max(gm); xm = wave_max(xm);
+    if (lane == 0) { red[0][wave] = gm; red[1][wave] = xm; }
+    __syncthreads();
+    gm = red[0][0]; xm = red[1][0];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) { gm = fmaxf(gm, red[0][w]); xm = fmaxf(xm, red[1][w]); }
+    const int eg = gm > 0.f ? (int)((__float_as_uint(gm) >> 23) & 0xff) : 127 + 13;
+    const int ex = xm > 0.f ? (int)((__float_as_uint(xm) >> 23) & 0xff) : 127 + 13;
+    const float g_scale = 4 * lane < p.N ? pow2_from_biased(127 + 13 - (eg - 127)) : 0.f;     // columns beyond the matrix become zeros
+    const float x_scale = 4 * lane < p.K ? pow2_from_biased(127 + 13 - (ex - 127)) : 0.f;
+    const float g_inv = pow2_from_biased(127 - 13 + (eg - 127)), x_inv = pow2_from_biased(127 - 13 + (ex - 127));
+
+    // which 32-row tiles of the LDS image hold real columns: tile t covers columns 4 (32 (t & 1) + i) + (t >> 1)
+    bool live_n[4], live_k[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) live_n[i] = FULL || 128 * ((wn * 4 + i) & 1) + ((wn * 4 + i) >> 1) < p.N;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) live_k[j] = FULL || 128 * ((wk * 2 + j) & 1) + ((wk * 2 + j) >> 1) < p.K;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    float colsum[4] = {0.f, 0.f, 0.f, 0.f};
+
+    // stage = 32 rows; wave w carries rows 4 w .. 4 w + 3 of it, lane l the columns 4 l .. 4 l + 3 (one full row per load)
+    const int cg = 4 * lane < p.N ? 4 * lane : 0, cx = 4 * lane < p.K ? 4 * lane : 0;
+    float4 rg[4], rx[4];
+    auto load_stage = [&](long st, float4 (&qg)[4], float4 (&qx)[4]) {      // unconditional, from clamped rows
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            long m = mbeg + st * TN_ROWS + 4 * wave + r;
+            m = m < mend ? m : mend - 1;
+            qg[r] = *reinterpret_cast<const float4*>(p.G + m * p.ldg + cg);
+            qx[r] = *reinterpret_cast<const float4*>(p.X + m * p.ldx + cx);
+        }
+    };
+    auto put_block = [&](const float4 (&q)[4], const float (&sc)[4], _Float16* hi_plane, _Float16* lo_plane) {
+        const float y[4][4] = {{q[0].x * sc[0], q[0].y * sc[0], q[0].z * sc[0], q[0].w * sc[0]},
+                               {q[1].x * sc[1], q[1].y * sc[1], q[1].z * sc[1], q[1].w * sc[1]},
+                               {q[2].x * sc[2], q[2].y * sc[2], q[2].z * sc[2], q[2].w * sc[2]},
+                               {q[3].x * sc[3], q[3].y * sc[3], q[3].z * sc[3], q[3].w * sc[3]}};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            half4 hi = half4{(_Float16)y[0][j], (_Float16)y[1][j], (_Float16)y[2][j], (_Float16)y[3][j]};
+            half4 lo = half4{(_Float16)(y[0][j] - (float)hi[0]), (_Float16)(y[1][j] - (float)hi[1]),
+                             (_Float16)(y[2][j] - (float)hi[2]), (_Float16)(y[3][j] - (float)hi[3])};
+            const int off = (lane + 64 * j) * T3_HP + 4 * wave;
+            *reinterpret_cast<half4*>(hi_plane + off) = hi;
+            *reinterpret_cast<half4*>(lo_plane + off) = lo;
+        }
+    };
+    auto store_stage = [&](long st, const float4 (&qg)[4], const float4 (&qx)[4]) {
+        _Float16* base = lds + (st & 1) * (4 * T3_PLANE);
+        float sg[4], sx[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool ok = mbeg + st * TN_ROWS + 4 * wave + r < mend;
+            sg[r] = ok ? g_scale : 0.f;
+            sx[r] = ok ? x_scale : 0.f;
+            if (ok) { colsum[0] += qg[r].x; colsum[1] += qg[r].y; colsum[2] += qg[r].z; colsum[3] += qg[r].w; }
+        }
+        put_block(qg, sg, base, base + T3_PLANE);
+        put_block(qx, sx, base + 2 * T3_PLANE, base + 3 * T3_PLANE);
+    };
+    const int frag = (lane & 31) * T3_HP + 8 * (lane >> 5);
+    auto multiply = [&](long st) {
+        const _Float16* Gh = lds + (st & 1) * (4 * T3_PLANE);
+        const _Float16* Gl = Gh + T3_PLANE;
+        const _Float16* Xh = Gh + 2 * T3_PLANE;
+        const _Float16* Xl = Gh + 3 * T3_PLANE;
+#pragma unroll
+        for (int ks = 0; ks < TN_ROWS; ks += 16) {
+            half8 xh[2], xl[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int o = (wk * 2 + j) * 32 * T3_HP + frag + ks;
+                xh[j] = lds_read8(Xh + o);
+                xl[j] = lds_read8(Xl + o);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (!live_n[i]) continue;
+                const int o = (wn * 4 + i) * 32 * T3_HP + frag + ks;
+                const half8 gh = lds_read8(Gh + o), gl = lds_read8(Gl + o);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (!live_k[j]) continue;
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gl, xh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, xl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, xh[j], acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    // One register set: stage st+2 is requested as soon as stage st+1 has left the registers for LDS, and
+    // has the whole matrix phase of stage st+1 to arrive (a second set does not fit beside the 128
+    // accumulator registers: the compiler spilled 158 dwords with it).
+    const long nst = (mend - mbeg + TN_ROWS - 1) / TN_ROWS;
+    load_stage(0, rg, rx);
+    store_stage(0, rg, rx);
+    load_stage(1, rg, rx);
+    lds_barrier();
+    for (long st = 0; st < nst; ++st) {
+        multiply(st);
+        if (st + 1 < nst) store_stage(st + 1, rg, rx);
+        load_stage(st + 2, rg, rx);
+        lds_barrier();
+    }
+
+    // slab in LDS-row order on both axes (un-permuted by the reduction), un-scaled
+    float* out = p.slab + (long)blockIdx.x * SLAB * SLAB;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (!(live_n[i] && live_k[j])) continue;
+            const int kk = (wk * 2 + j) * 32 + (lane & 31);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int nn = (wn * 4 + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                out[nn * SLAB + kk] = acc[i][j][e] * g_inv * x_inv;
+            }
+        }
+    // column sums of G: the 8 waves hold partial sums of the same columns
+    float* cs = smem;                               // the stage buffers are idle now (last barrier passed)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cs[wave * SLAB + 4 * lane + j] = colsum[j];
+    __syncthreads();
+    if (tid < SLAB) {
+        float b = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) b += cs[w * SLAB + tid];
+        p.bias_slab[(long)blockIdx.x * SLAB + tid] = b;
+    }
+}
+
+// dW = G^T X on the split-f16 kernel; gmax / xmax: per-row max |.| of G and X (M floats each)
+int gemm_tn_h3(const float* G, long ldg, int N, const float* X, long ldx, int K, long M, const float* gmax, const float* xmax,
+               float* dW, int ldw, float* db, void* workspace, hipStream_t s) {
+    PAPR_REQUIRE(N <= SLAB && K <= SLAB, "gemm_tn_h3: N=%d, K=%d exceed %d", N, K, SLAB);
+    PAPR_REQUIRE(N % 4 == 0 && K % 4 == 0 && ldg % 4 == 0 && ldx % 4 == 0, "gemm_tn_h3: sizes must be multiples of 4");
+    if (M <= 0) return 0;
+    static int n_cu = 0;
+    if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu <= 0 || n_cu > MAX_SLICES) n_cu = MAX_SLICES; }
+    long stages = (M + TN_ROWS - 1) / TN_ROWS;
+    int S = (int)(stages < n_cu ? stages : n_cu);                   // one workgroup per CU streams one slice
+    long rows_per_slice = ((stages + S - 1) / S) * TN_ROWS;
+    S = (int)((M + rows_per_slice - 1) / rows_per_slice);
+    TNH3Args a;
+    a.G = G; a.ldg = ldg; a.N = N; a.X = X; a.ldx = ldx; a.K = K; a.M = M; a.rows_per_slice = rows_per_slice;
+    a.gmax = gmax; a.xmax = xmax;
+    a.slab = static_cast<float*>(workspace);
+    a.bias_slab = a.slab + (size_t)MAX_SLICES * SLAB * SLAB;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_h3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T3_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_h3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T3_LDS_BYTES);
+        attr_set = true;
+    }
+    const bool prof = papr_prof_on();
+    if (prof) papr_prof_begin(8, M, N, K, s);
+    if (N > 131 && K > 131) gemm_tn_h3_kernel<true><<<dim3(S), dim3(512), T3_LDS_BYTES, s>>>(a);      // 128 + 3 < N: all eight tiles live
+    else gemm_tn_h3_kernel<false><<<dim3(S), dim3(512), T3_LDS_BYTES, s>>>(a);
+    if (prof) papr_prof_end(s);
+    PAPR_CHECK_LAUNCH("gemm_tn_h3");
+    slab_reduce_kernel<true><<<dim3(SLAB * SLAB / 4 / 16), dim3(256), 0, s>>>(a.slab, a.bias_slab, S, N, K, dW, ldw, db);
     PAPR_CHECK_LAUNCH("slab_reduce");
     return 0;
 }
@@ -828,8 +1059,12 @@ constexpr size_t TN_SLAB_BYTES = (size_t)MAX_SLICES * (SLAB * SLAB + SLAB) * siz
 extern "C" size_t papr_mlp_fwd_workspace_bytes(int64_t M) { return H3Scratch::bytes(M); }
 extern "C" size_t papr_mlp_bwd_workspace_bytes(int64_t M) { return TN_SLAB_BYTES + H3Scratch::bytes(M); }
 
+// layer i runs on the split-f16 forward kernel (and so leaves the row maxima of its input behind)
+static bool layer_on_h3(const papr_layer& L) { return GEMM_H3_FWD && L.n_out > 128 && L.n_skip == 0; }
+
 extern "C" int papr_mlp_fwd(const papr_layer* layers, int n_layers, const float* x, int ldx, int64_t M,
-                            float* const* outs, const int32_t* ld_out, void* workspace, papr_stream_t stream) {
+                            float* const* outs, const int32_t* ld_out, float* row_absmax, void* workspace,
+                            papr_stream_t stream) {
     PAPR_REQUIRE(layers && x && outs && ld_out && n_layers >= 1, "papr_mlp_fwd: bad arguments");
     hipStream_t s = as_stream(stream);
     bool have_amax = false;                 // split-f16 mode: row maxima of the current layer's input are in h3.in()
@@ -846,11 +1081,14 @@ extern "C" int papr_mlp_fwd(const papr_layer* layers, int n_layers, const float*
         if (L.n_skip > 0) { a.A2 = x; a.lda2 = ldx; a.K2 = L.n_skip; a.wcol2 = L.skip_col; }
         a.W = L.weight; a.ldw = L.ldw; a.bias = L.bias; a.act = L.act;
         a.C = outs[i]; a.ldc = ld_out[i]; a.M = M; a.N = L.n_out;
-        if (GEMM_H3_FWD && L.n_out > 128 && L.n_skip == 0) {
+        if (layer_on_h3(L)) {
+            // with row_absmax the maxima of layer i's input rows stay in row_absmax[i*M ..) for papr_mlp_bwd
+            unsigned* saved = reinterpret_cast<unsigned*>(row_absmax);
+            unsigned* in = saved ? saved + (size_t)i * M : h3.in();
             if (!have_amax)
-                if (int e = launch_row_absmax(a.A, M, L.n_in, a.lda, h3.in(), s)) return e;
-            a.amax_in = h3.in();
-            a.amax_out = h3.out();
+                if (int e = launch_row_absmax(a.A, M, L.n_in, a.lda, in, s)) return e;
+            a.amax_in = in;
+            a.amax_out = saved && i + 1 < n_layers ? saved + (size_t)(i + 1) * M : h3.out();
             a.planes = h3.planes;
             PAPR_REQUIRE(hipMemsetAsync(a.amax_out, 0, (size_t)M * sizeof(unsigned), s) == hipSuccess, "papr_mlp_fwd: memset failed");
             if (int e = gemm_nt(a, s)) return e;
@@ -865,9 +1103,9 @@ extern "C" int papr_mlp_fwd(const papr_layer* layers, int n_layers, const float*
 }
 
 extern "C" int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float* x, int ldx, int64_t M,
-                            float* const* outs, const int32_t* ld_out, float* d_out, float* scratch0, float* scratch1,
-                            int ld_scratch, float* const* d_weight, float* const* d_bias, float* d_x, void* workspace,
-                            papr_stream_t stream) {
+                            float* const* outs, const int32_t* ld_out, const float* row_absmax, float* d_out,
+                            float* scratch0, float* scratch1, int ld_scratch, float* const* d_weight,
+                            float* const* d_bias, float* d_x, void* workspace, papr_stream_t stream) {
     PAPR_REQUIRE(layers && x && outs && ld_out && d_out && d_weight && d_bias && workspace && n_layers >= 1,
                  "papr_mlp_bwd: bad arguments");
     PAPR_REQUIRE(n_layers == 1 || (scratch0 && scratch1), "papr_mlp_bwd: scratch buffers required");
@@ -908,8 +1146,16 @@ extern "C" int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float*
         const float* in = i == 0 ? x : outs[i - 1];
         long ld_in = i == 0 ? ldx : ld_out[i - 1];
         PAPR_REQUIRE(d_weight[i], "papr_mlp_bwd: layer %d has null d_weight", i);
-        // weight / bias gradients
-        if (int e = gemm_tn(g, ldg, L.n_out, in, ld_in, L.n_in, M, d_weight[i], L.ldw, d_bias[i], workspace, s)) return e;
+        // weight / bias gradients: split-f16 when the forward pass left the row maxima of this layer's input
+        const bool wgrad_h3 = GEMM_H3_WGRAD && row_absmax && layer_on_h3(L) && L.n_out <= SLAB && L.n_in <= SLAB;
+        if (wgrad_h3) {
+            if (!have_amax) {
+                if (int e = launch_row_absmax(g, M, L.n_out, ldg, h3.in(), s)) return e;
+                have_amax = true;
+            }
+            if (int e = gemm_tn_h3(g, ldg, L.n_out, in, ld_in, L.n_in, M, reinterpret_cast<const float*>(h3.in()),
+                                   row_absmax + (size_t)i * M, d_weight[i], L.ldw, d_bias[i], workspace, s)) return e;
+        } else if (int e = gemm_tn(g, ldg, L.n_out, in, ld_in, L.n_in, M, d_weight[i], L.ldw, d_bias[i], workspace, s)) return e;
         if (L.n_skip > 0)
             if (int e = gemm_tn(g, ldg, L.n_out, x, ldx, L.n_skip, M, d_weight[i] + L.skip_col, L.ldw, nullptr, workspace, s)) return e;
         // data gradients

@@ -80,8 +80,8 @@ def lib():
     L.papr_mlp_fwd_workspace_bytes.argtypes = [i64]
     L.papr_mlp_bwd_workspace_bytes.restype = C.c_size_t
     L.papr_mlp_bwd_workspace_bytes.argtypes = [i64]
-    L.papr_mlp_fwd.argtypes = [C.POINTER(Layer), i32, vp, i32, i64, C.POINTER(vp), C.POINTER(C.c_int32), vp, vp]
-    L.papr_mlp_bwd.argtypes = [C.POINTER(Layer), i32, vp, i32, i64, C.POINTER(vp), C.POINTER(C.c_int32), vp, vp, vp,
+    L.papr_mlp_fwd.argtypes = [C.POINTER(Layer), i32, vp, i32, i64, C.POINTER(vp), C.POINTER(C.c_int32), vp, vp, vp]
+    L.papr_mlp_bwd.argtypes = [C.POINTER(Layer), i32, vp, i32, i64, C.POINTER(vp), C.POINTER(C.c_int32), vp, vp, vp, vp,
                                i32, C.POINTER(vp), C.POINTER(vp), vp, vp, vp]
     L.papr_attn_tail_fwd.argtypes = [C.POINTER(TailDesc), vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp]
     L.papr_attn_tail_bwd.argtypes = [C.POINTER(TailDesc), vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]

@@ -115,17 +115,25 @@ def _layer_table(spec, ws, bs, wts=None):
     return tab
 
 
+class LayerOutputs(list):
+    """The saved activations of one chain plus the per-row input maxima papr_mlp_fwd leaves for papr_mlp_bwd."""
+    row_absmax = None
+
+
 def mlp_forward(spec, ws, bs, x, M, keep=True):
     """Run the chain; returns the list of layer outputs (all kept, or two ping-pong buffers)."""
     dev = x.device
+    outs = LayerOutputs()
     if keep:
-        outs = [torch.empty((M, ld), device=dev, dtype=torch.float32) for ld in spec.ld_out]
+        outs.extend(torch.empty((M, ld), device=dev, dtype=torch.float32) for ld in spec.ld_out)
+        outs.row_absmax = torch.empty((spec.n_layer, M), device=dev, dtype=torch.float32)
     else:
         pool = [torch.empty(M * max(spec.ld_out), device=dev, dtype=torch.float32) for _ in range(2)]
-        outs = [pool[i & 1][:M * ld].view(M, ld) for i, ld in enumerate(spec.ld_out)]
+        outs.extend(pool[i & 1][:M * ld].view(M, ld) for i, ld in enumerate(spec.ld_out))
     tab = _layer_table(spec, ws, bs)
     hip.check(hip.lib().papr_mlp_fwd(tab, spec.n_layer, hip.ptr(x), x.shape[1], M, hip.ptr_array(outs),
-                                     hip.i32_array(spec.ld_out), hip.ptr(_workspace(dev, "fwd", M)), hip.stream_ptr()), "papr_mlp_fwd")
+                                     hip.i32_array(spec.ld_out), hip.ptr(outs.row_absmax),
+                                     hip.ptr(_workspace(dev, "fwd", M)), hip.stream_ptr()), "papr_mlp_fwd")
     return outs
 
 
@@ -151,7 +159,8 @@ def mlp_backward(spec, ws, bs, x, M, outs, d_out, scratch, need_dx):
     d_bs = [torch.empty_like(b) for b in bs]
     d_x = torch.empty_like(x) if need_dx else None
     hip.check(hip.lib().papr_mlp_bwd(tab, spec.n_layer, hip.ptr(x), x.shape[1], M, hip.ptr_array(outs),
-                                     hip.i32_array(spec.ld_out), hip.ptr(d_out), hip.ptr(scratch[0]), hip.ptr(scratch[1]),
+                                     hip.i32_array(spec.ld_out), hip.ptr(getattr(outs, "row_absmax", None)),
+                                     hip.ptr(d_out), hip.ptr(scratch[0]), hip.ptr(scratch[1]),
                                      scratch[0].shape[1], hip.ptr_array(d_ws), hip.ptr_array(d_bs), hip.ptr(d_x),
                                      hip.ptr(_workspace(dev, "bwd", M)), hip.stream_ptr()), "papr_mlp_bwd")
     return d_ws, d_bs, d_x
@@ -168,7 +177,7 @@ def linear_rows(x, w):
     t.weight, t.weight_t, t.bias = w.data_ptr(), None, None
     t.n_in, t.n_out, t.ldw, t.ldwt, t.n_skip, t.skip_col, t.act = x.shape[1], n_out, w.shape[1], 0, 0, 0, 0
     hip.check(hip.lib().papr_mlp_fwd(tab, 1, hip.ptr(x), x.shape[1], M, hip.ptr_array([out]), hip.i32_array([n_out]),
-                                     hip.ptr(_workspace(x.device, "fwd", M)), hip.stream_ptr()), "papr_mlp_fwd")
+                                     None, hip.ptr(_workspace(x.device, "fwd", M)), hip.stream_ptr()), "papr_mlp_fwd")
     return out
 
 

@@ -40,3 +40,6 @@ def rep(tag, recs, kid):
 rep("fwd  gemm_nt", fwd, 0)
 rep("dgrad gemm_nt", bwd, 0)
 rep("wgrad gemm_tn", bwd, 4)
+rep("fwd  gemm_nt_h3", fwd, 6)
+rep("dgrad gemm_nt_h3", bwd, 7)
+rep("wgrad gemm_tn_h3", bwd, 8)

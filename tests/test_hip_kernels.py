@@ -23,7 +23,7 @@ def dev():
 
 def test_library_loads_on_device():
     from papr_amd import hip
-    assert hip.lib().papr_abi_version() == 1
+    assert hip.lib().papr_abi_version() == 2
 
 
 # ------------------------------------------------------------------------------------------- K1
@@ -227,6 +227,10 @@ def _ref_mlp(x, ws, bs, acts, skips, d_in):
     (129, 39, 64, 3, 4, "relu", []),
     (4100, 142, 128, 64, 3, "relu", [1]),
     (33, 27, 256, 256, 2, "none", []),
+    # 244 row slices of nine stages each in the weight-gradient kernel.  No activation: with 18 M ReLU inputs a few
+    # lie within rounding of zero and the masks of two correct fp32 implementations differ (torch fp32 itself is
+    # 6e-2 from torch fp64 on d_x there; scripts/probes/mlp_err.py)
+    (70001, 64, 256, 160, 3, "none", []),
 ])
 def test_mlp_forward_backward_vs_torch(M, d_in, width, d_out, n, act, skips):
     from papr_amd import ops
@@ -329,11 +333,12 @@ def test_attention_tail_forward_backward(R, k, d_model, Cc, act, normalize):
     np.testing.assert_allclose(d_sb.cpu().numpy(), sb.grad.numpy(), rtol=0, atol=tol(sb.grad))
 
 
-@pytest.mark.parametrize("mode", ["f32", "fwd"])
+@pytest.mark.parametrize("mode", ["f32", "fwd", "dgrad"])
 def test_other_gemm_modes_meet_the_same_mlp_parity(mode):
-    """PAPR_GEMM_MODE selects which wide GEMMs use the split-f16 (hi/lo, 3 MFMA) kernel (default `h3`: forward
-    layers and data-gradients); `fwd` (forward only) and `f32` (fp32 MFMA everywhere) must pass the same tests.  The switch is read when the
-    library loads, hence the child process."""
+    """PAPR_GEMM_MODE selects which wide GEMMs use the split-f16 (hi/lo, 3 MFMA) kernels (default `h3`: forward
+    layers, data-gradients and weight-gradients); `dgrad` (no weight-gradients), `fwd` (forward only) and `f32`
+    (fp32 MFMA everywhere) must pass the same tests.  The switch is read when the library loads, hence the
+    child process."""
     import os, subprocess, sys
     env = dict(os.environ, PAPR_GEMM_MODE=mode)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-k", "mlp_forward_backward"],
