@@ -3,14 +3,18 @@
 
 rocprofv3 7.2 writes `*_results.db` by default; this turns its `kernels` view into the same table
 `--stats` prints, so the summary can be committed under profiles/ as plain text.
-usage: python scripts/rocpd_summary.py gpurun_out/prof1/r01_results.db [min_start_fraction]
+usage: python scripts/rocpd_summary.py gpurun_out/prof1/r01_results.db [min_start_fraction | last:N[:marker]]
+
+`last:N` keeps the dispatches from the N-th last launch of the marker kernel (default ray_knn_kernel, the first
+kernel of every step) onwards, i.e. the last N steps: warm-up steps (MIOpen's solver search runs seconds of
+naive convolutions there) stay out of the table.
 """
 import re
 import sqlite3
 import sys
 
 
-def main(path, skip_frac=0.0):
+def main(path, skip="0"):
     db = sqlite3.connect(path)
     cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
     name_col = "name" if "name" in cols else "kernel_name"
@@ -19,7 +23,14 @@ def main(path, skip_frac=0.0):
         print("no kernel dispatches recorded")
         return
     t0, t1 = rows[0][1], rows[-1][2]
-    cut = t0 + (t1 - t0) * skip_frac
+    if skip.startswith("last:"):
+        parts = skip.split(":")
+        n, marker = int(parts[1]), (parts[2] if len(parts) > 2 else "ray_knn_kernel")
+        marks = [s for name, s, e in rows if marker in name]
+        cut = marks[-n] if len(marks) >= n else t0
+        print("# last %d steps (from the %d-th last %s launch): %.3f ms of wall time" % (n, n, marker, (t1 - cut) / 1e6))
+    else:
+        cut = t0 + (t1 - t0) * float(skip)
     agg = {}
     for name, s, e in rows:
         if s < cut:
@@ -37,4 +48,4 @@ def main(path, skip_frac=0.0):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], float(sys.argv[2]) if len(sys.argv) > 2 else 0.0)
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "0")
