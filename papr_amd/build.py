@@ -10,7 +10,7 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libpapr_hip.so")
-SOURCES = ["error.hip", "knn.hip", "features.hip", "rowops.hip", "gemm.hip"]
+SOURCES = ["error.hip", "knn.hip", "features.hip", "rowops.hip", "gemm.hip", "chain.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics",
          "-Wall", "-Wno-unused-function"]
 
@@ -24,7 +24,7 @@ def _stale(target, deps):
 
 def build_library(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    headers = [os.path.join(CSRC, "papr_common.h"), os.path.join(os.path.dirname(PKG), "include", "papr_hip.h")]
+    headers = [os.path.join(CSRC, h) for h in ("papr_common.h", "h3_common.h", "chain.h")] + [os.path.join(os.path.dirname(PKG), "include", "papr_hip.h")]
     objdir = os.path.join(PKG, "build")
     os.makedirs(objdir, exist_ok=True)
     objs, procs = [], []

@@ -1,0 +1,32 @@
+// Host-side interface of the fused layer-run kernel (chain.hip), used by the drivers in gemm.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+constexpr int CHAIN_MAX_LAYERS = 8;
+
+struct ChainLayer {
+    const _Float16* w_hi;      // weight planes in MFMA fragment order (split_weight_kernel): n_tiles x ksteps fragments
+    const _Float16* w_lo;
+    const float* bias;         // forward: (N) or null
+    const float* mask;         // data-gradient: activation outputs whose derivative multiplies this layer's result, or null
+    long ld_mask;
+    float* C;                  // (M, ldc) result rows, or null when nobody needs them in memory
+    long ldc;
+    float* rowmax;             // (M) max |.| of every result row, or null
+    int N;                     // result width (<= 256; a multiple of 32 unless this is the last layer of the run)
+    int ksteps;                // input width / 16, planes padded to a multiple of 32 columns (even)
+    int act;                   // forward: activation; data-gradient: activation whose derivative is applied
+};
+
+struct ChainArgs {
+    const float* A0; long lda0; int K0;   // input rows (M, lda0), K0 <= 256 real columns
+    float* rowmax0;                       // (M) receives max |.| of every input row, or null
+    long M;
+    int n_layers;
+    ChainLayer L[CHAIN_MAX_LAYERS];
+};
+
+size_t papr_chain_lds_bytes();
+// prof_cols: sum of the widths of the stored results (+ masks read), for the profiling record
+int papr_launch_chain(const ChainArgs& a, bool dgrad, long prof_cols, hipStream_t s);

@@ -1,0 +1,313 @@
+// K3b: a whole run of embedding-MLP layers in ONE kernel (split-f16 MFMA, see gemm.hip for the arithmetic).
+//
+// Replaces the same reference lines as gemm_nt (MLP.forward, models/mlp.py:47-59, and its autograd
+// data-gradient) for runs of consecutive layers without skip input and at most 256 wide.
+//
+// Why: layer by layer, the split-f16 GEMM is HBM-bound -- it reads the (M x 256) input and writes the
+// (M x 256) output of every layer.  But a workgroup's 128 x 256 output tile holds COMPLETE rows, and
+// those rows are exactly the A operand of the next layer for the same 128 rows.  So a workgroup carries
+// its 128 rows through all layers of the run: the activations stay in LDS as split f16 planes, HBM sees
+// the input once and each saved activation once (training), or only the last one (inference).
+//
+// Per layer and tile:   k-loop   16 k-steps x 12 MFMA per wave, A fragments from LDS (resident, no
+//                                staging barriers), W fragments straight from L2 in fragment order
+//                       phase 1  accumulators -> per-wave LDS patch -> rows: un-scale, bias/activation
+//                                (or derivative mask), 16-byte global stores, row maxima (LDS atomics)
+//                       phase 2  rows -> per-row power-of-two scale from the row maxima -> hi/lo split
+//                                -> the A planes of the next layer
+// with one LDS-only barrier between the stages (the patch aliases the then-idle A planes).
+#include "papr_common.h"
+#include "h3_common.h"
+#include "chain.h"
+
+namespace {
+
+constexpr int CH_BM = 64;                   // rows per tile
+constexpr int CH_THREADS = 256;             // four waves, one per SIMD, each a 64 x 64 corner of the 64 x 256 tile
+constexpr int CH_AP = 264;                  // A-plane row pitch in halfs (528 B: conflict-free ds_read_b128)
+constexpr int CH_PLANE = CH_BM * CH_AP;     // halfs per plane
+constexpr size_t CH_LDS_BYTES = (size_t)2 * CH_PLANE * sizeof(_Float16) + CH_BM * sizeof(float) + 2 * CH_BM * sizeof(unsigned) + CHAIN_MAX_LAYERS * 256 * sizeof(float);
+
+// max over the 8 lanes that share a row segment (lanes 8q .. 8q+7), on the DPP network
+__device__ __forceinline__ float seg8_max(float v) {
+    int x = __float_as_int(v);
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0xB1, 0xf, 0xf, false)));    // quad_perm [1,0,3,2]
+    x = __float_as_int(v);
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x4E, 0xf, 0xf, false)));    // quad_perm [2,3,0,1]
+    x = __float_as_int(v);
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x141, 0xf, 0xf, false)));   // row_half_mirror
+    return v;
+}
+__device__ __forceinline__ float wave64_max(float v) {
+    v = seg8_max(v);
+    int x = __float_as_int(v);
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x140, 0xf, 0xf, false)));   // row_mirror: 16 lanes
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    v = fmaxf(v, __shfl_xor(v, 32, 64));
+    return v;
+}
+
+__device__ __forceinline__ float scale_from_max(unsigned bits, float& inv) {      // row max -> [2^13, 2^14)
+    const int ea = bits ? (int)((bits >> 23) & 0xff) : 127 + 13;
+    inv = pow2_from_biased(127 - 13 + (ea - 127));
+    return pow2_from_biased(127 + 13 - (ea - 127));
+}
+
+#ifdef PAPR_H3_TRACE
+__device__ long long g_chain_trace[256];
+#define CH_STAMP() do { if (blockIdx.x == 100 && threadIdx.x == 0 && trace_slot < 256) g_chain_trace[trace_slot++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define CH_STAMP() do {} while (0)
+#endif
+
+template <bool DGRAD>
+__global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(ChainArgs p, int tiles_m) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    _Float16* Ah = reinterpret_cast<_Float16*>(smem);
+    _Float16* Al = Ah + CH_PLANE;
+    float* inv_tab = reinterpret_cast<float*>(Al + CH_PLANE);            // [64] 1/scale of the rows of the A planes
+    unsigned* rmax_tab = reinterpret_cast<unsigned*>(inv_tab + CH_BM);   // [2][64] max|C| bit patterns, by layer parity
+    float* bias_tab = reinterpret_cast<float*>(rmax_tab + 2 * CH_BM);    // [layers][256]: a global load in phase 1 would wait for the stores before it (loads and stores share vmcnt)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int wm = 0;                        // (one wave row: the tile is 64 rows)
+    const int wn = wave;                         // wave tile: all 64 rows, columns 64 wn .. +63
+    const int frag = (lane & 31) * CH_AP + 8 * (lane >> 5);
+
+#ifdef PAPR_H3_TRACE
+    int trace_slot = 0;
+#endif
+    for (int l = 0; l < p.n_layers; ++l)
+        if (tid < 256) bias_tab[l * 256 + tid] = (!DGRAD && p.L[l].bias && tid < p.L[l].N) ? p.L[l].bias[tid] : 0.f;
+
+    // W fragments: fragment (n-tile t, k-step s) of a layer's planes starts at ((t * ksteps + s) * 64 + lane) * 8 halfs.
+    // They come straight from L2 (~1k cycles under load, a k-step is 384): a ring of four k-steps, three in
+    // flight, and the first three of the NEXT layer are requested before this layer's row phases.
+    half8 wfh[4][2], wfl[4][2];
+    auto load_w = [&](int l, int ks, half8 (&qh)[2], half8 (&ql)[2]) {
+        const ChainLayer& L = p.L[l];
+        ks = ks < L.ksteps ? ks : L.ksteps - 1;
+#ifdef CH_EXP_NO_W
+        if (ks > 2) return;                  // experiment: only the first fragments are ever loaded
+#endif
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int t = 32 * (wn * 2 + j) < L.N ? wn * 2 + j : 0;
+            const long o = ((long)(t * L.ksteps + ks) * 64 + lane) * 8;
+            qh[j] = *reinterpret_cast<const half8*>(L.w_hi + o);
+            ql[j] = *reinterpret_cast<const half8*>(L.w_lo + o);
+        }
+    };
+    load_w(0, 0, wfh[0], wfl[0]);
+    load_w(0, 1, wfh[1], wfl[1]);
+    load_w(0, 2, wfh[2], wfl[2]);
+    for (int tile = blockIdx.x; tile < tiles_m; tile += gridDim.x) {
+        const long m0 = (long)tile * CH_BM;
+        CH_STAMP();
+        // ---- stage the tile's input rows: one row per wave and pass, row maximum on the way ----
+        {
+            const int kpad = p.L[0].ksteps * 16;
+            const int c = 4 * lane;
+#pragma unroll 1
+            for (int r0 = wave; r0 < CH_BM; r0 += 32) {
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    long m = m0 + r0 + 4 * u;
+                    m = m < p.M ? m : p.M - 1;
+                    v[u] = c < p.K0 ? *reinterpret_cast<const float4*>(p.A0 + m * p.lda0 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int r = r0 + 4 * u;
+                    float mx = fmaxf(fmaxf(fabsf(v[u].x), fabsf(v[u].y)), fmaxf(fabsf(v[u].z), fabsf(v[u].w)));
+                    mx = wave64_max(mx);
+                    float inv;
+                    const float sc = scale_from_max(__float_as_uint(mx), inv);
+                    if (c < kpad) {
+                        half4 hi, lo;
+                        split4(v[u], sc, hi, lo);
+                        *reinterpret_cast<half4*>(Ah + r * CH_AP + c) = hi;
+                        *reinterpret_cast<half4*>(Al + r * CH_AP + c) = lo;
+                    }
+                    if (lane == 0) {
+                        inv_tab[r] = inv;
+                        if (p.rowmax0 && m0 + r < p.M) p.rowmax0[m0 + r] = mx;
+                    }
+                }
+            }
+            if (tid < CH_BM) rmax_tab[tid] = 0u;
+        }
+        lds_barrier();
+        CH_STAMP();
+
+#pragma unroll 1
+        for (int l = 0; l < p.n_layers; ++l) {
+            const ChainLayer& L = p.L[l];
+            const int par = l & 1;
+            const int N = L.N, ksteps = L.ksteps;
+            bool live[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) live[j] = 32 * (wn * 2 + j) < N;
+            f32x16 acc[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+            // ---- k-loop
+            auto k_step = [&](int ks, const half8 (&qh)[2], const half8 (&ql)[2]) {
+                half8 ah[2], al[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+#ifdef CH_EXP_NO_A
+                    const int o = (wm * 2 + i) * 32 * CH_AP + frag;      // experiment: always the same fragment (one LDS read hoisted out)
+#else
+                    const int o = (wm * 2 + i) * 32 * CH_AP + frag + ks * 16;
+#endif
+                    ah[i] = *reinterpret_cast<const half8*>(Ah + o);
+                    al[i] = *reinterpret_cast<const half8*>(Al + o);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (!live[j]) continue;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        // W fragment as the row operand: the accumulators hold C^T (lane = row m, registers = columns n)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh[j], al[i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ql[j], ah[i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh[j], ah[i], acc[i][j], 0, 0, 0);
+                    }
+                }
+            };
+#pragma unroll 1
+            for (int ks = 0; ks < ksteps; ks += 4) {           // ksteps is even (planes are padded to 32 columns)
+                load_w(l, ks + 3, wfh[3], wfl[3]);
+                k_step(ks, wfh[0], wfl[0]);
+                load_w(l, ks + 4, wfh[0], wfl[0]);
+                k_step(ks + 1, wfh[1], wfl[1]);
+                load_w(l, ks + 5, wfh[1], wfl[1]);
+                if (ks + 2 < ksteps) {
+                    k_step(ks + 2, wfh[2], wfl[2]);
+                    load_w(l, ks + 6, wfh[2], wfl[2]);
+                    k_step(ks + 3, wfh[3], wfl[3]);
+                }
+            }
+            {   // first fragments of what comes next: the next layer, or layer 0 of the next tile
+                const int ln = l + 1 < p.n_layers ? l + 1 : 0;
+                load_w(ln, 0, wfh[0], wfl[0]);
+                load_w(ln, 1, wfh[1], wfl[1]);
+                load_w(ln, 2, wfh[2], wfl[2]);
+            }
+            CH_STAMP();
+            lds_barrier();                                      // every wave is done reading the A planes
+            CH_STAMP();
+
+            // ---- phase 1 (accumulators hold C^T: lane = row, registers = columns): un-scale, bias / activation or
+            // derivative mask, 16-byte stores, row maxima
+            const float slope = L.act == PAPR_ACT_RELU ? 0.f : (L.act == PAPR_ACT_LEAKY_RELU ? 0.2f : 1.f);
+            const bool more = l + 1 < p.n_layers;
+            const int hh = lane >> 5;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int rl = i * 32 + (lane & 31);
+                const long row = m0 + rl;
+                const long rowc = row < p.M ? row : p.M - 1;
+                const float inv = inv_tab[rl];
+                float mx = 0.f;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (!live[j]) continue;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int col = (wn * 2 + j) * 32 + 8 * g + 4 * hh;
+                        const bool col_ok = col < N;
+                        float4 r = make_float4(acc[i][j][4 * g] * inv, acc[i][j][4 * g + 1] * inv, acc[i][j][4 * g + 2] * inv, acc[i][j][4 * g + 3] * inv);
+                        if (DGRAD) {
+                            if (L.mask) {
+                                const float4 a4 = col_ok ? *reinterpret_cast<const float4*>(L.mask + rowc * L.ld_mask + col) : make_float4(1.f, 1.f, 1.f, 1.f);
+                                r.x *= a4.x > 0.f ? 1.f : slope; r.y *= a4.y > 0.f ? 1.f : slope;
+                                r.z *= a4.z > 0.f ? 1.f : slope; r.w *= a4.w > 0.f ? 1.f : slope;
+                            }
+                        } else {
+                            const float4 b4 = *reinterpret_cast<const float4*>(bias_tab + l * 256 + col);
+                            r.x += b4.x; r.y += b4.y; r.z += b4.z; r.w += b4.w;
+                            // (+0.f turns the -0 of a negative input times slope 0 into the +0 torch's relu returns)
+                            r.x = r.x > 0.f ? r.x : r.x * slope + 0.f; r.y = r.y > 0.f ? r.y : r.y * slope + 0.f;
+                            r.z = r.z > 0.f ? r.z : r.z * slope + 0.f; r.w = r.w > 0.f ? r.w : r.w * slope + 0.f;
+                        }
+                        if (!col_ok) r = make_float4(0.f, 0.f, 0.f, 0.f);
+                        acc[i][j][4 * g] = r.x; acc[i][j][4 * g + 1] = r.y; acc[i][j][4 * g + 2] = r.z; acc[i][j][4 * g + 3] = r.w;
+                        if (L.C && col_ok && row < p.M) *reinterpret_cast<float4*>(L.C + row * L.ldc + col) = r;
+                        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(r.x), fabsf(r.y)), fmaxf(fabsf(r.z), fabsf(r.w))));
+                    }
+                }
+                if (live[0]) atomicMax(rmax_tab + par * CH_BM + rl, __float_as_uint(mx));
+            }
+            CH_STAMP();
+            lds_barrier();                                      // row maxima complete
+            CH_STAMP();
+
+            // ---- phase 2: the rows become the A planes of the next layer
+            if (tid < CH_BM) {
+                if (L.rowmax && m0 + tid < p.M) L.rowmax[m0 + tid] = __uint_as_float(rmax_tab[par * CH_BM + tid]);
+                rmax_tab[(par ^ 1) * CH_BM + tid] = 0u;
+            }
+            if (more) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int rl = i * 32 + (lane & 31);
+                    float inv;
+                    const float sc = scale_from_max(rmax_tab[par * CH_BM + rl], inv);
+                    if (wn == 0 && hh == 0) inv_tab[rl] = inv;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        if (!live[j]) continue;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int col = (wn * 2 + j) * 32 + 8 * g + 4 * hh;
+                            half4 hi, lo;
+                            split4(make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]), sc, hi, lo);
+                            *reinterpret_cast<half4*>(Ah + rl * CH_AP + col) = hi;
+                            *reinterpret_cast<half4*>(Al + rl * CH_AP + col) = lo;
+                        }
+                    }
+                }
+            }
+            lds_barrier();
+            CH_STAMP();
+        }
+    }
+}
+
+}  // namespace
+
+#ifdef PAPR_H3_TRACE
+extern "C" int papr_chain_trace_read(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chain_trace), sizeof(long long) * 256) == hipSuccess ? 0 : 1; }
+#endif
+
+size_t papr_chain_lds_bytes() { return CH_LDS_BYTES; }
+
+int papr_launch_chain(const ChainArgs& a, bool dgrad, long prof_cols, hipStream_t s) {
+    PAPR_REQUIRE(a.n_layers >= 1 && a.n_layers <= CHAIN_MAX_LAYERS, "mlp_chain: %d layers", a.n_layers);
+    PAPR_REQUIRE(a.K0 % 4 == 0 && a.lda0 % 4 == 0 && a.K0 <= 256, "mlp_chain: input width %d", a.K0);
+    if (a.M <= 0) return 0;
+    const int tiles_m = (int)((a.M + CH_BM - 1) / CH_BM);
+    static int n_cu = 0;
+    if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu <= 0) n_cu = 256; }
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_chain_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CH_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_chain_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CH_LDS_BYTES);
+        attr_set = true;
+    }
+    dim3 grid((unsigned)(tiles_m < 2 * n_cu ? tiles_m : 2 * n_cu));     // two workgroups per CU: one multiplies while the other is in its row phases
+    const bool prof = papr_prof_on();
+    if (prof) papr_prof_begin(dgrad ? 10 : 9, a.M, (int)prof_cols, a.K0, s);
+    if (dgrad) mlp_chain_kernel<true><<<grid, dim3(CH_THREADS), CH_LDS_BYTES, s>>>(a, tiles_m);
+    else mlp_chain_kernel<false><<<grid, dim3(CH_THREADS), CH_LDS_BYTES, s>>>(a, tiles_m);
+    if (prof) papr_prof_end(s);
+    PAPR_CHECK_LAUNCH("mlp_chain");
+    return 0;
+}

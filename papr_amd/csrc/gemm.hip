@@ -20,12 +20,12 @@
 // take k+4..k+7, so one 16-byte read per operand feeds 256 cycles of matrix work, and the 36-float
 // pitch maps the 16 lanes of a read group onto 16 distinct 4-bank slots (conflict-free).
 #include "papr_common.h"
+#include "h3_common.h"
+#include "chain.h"
 #include <stdlib.h>
 #include <string.h>
 
 namespace {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BK = 32;        // default k-slab per stage (single-buffered variant)
 
@@ -223,28 +223,6 @@ void gemm_nt_kernel(NTArgs p) {
 // hi + lo carries 22 mantissa bits; a.b ~ hi_a hi_b + hi_a lo_b + lo_a hi_b is three
 // v_mfma_f32_32x32x16_f16 with fp32 accumulation (each product is exact in fp32), the dropped lo.lo
 // term is 2^-22 relative.  Three matrix instructions instead of sixteen: the layer turns HBM-bound.
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a full workgroup fence, and
-// on gfx950 loads and stores share vmcnt: the fence therefore drains every global load in flight, i.e.
-// the slab prefetch, at each barrier.  Harmless when a slab's matrix work outlasts an HBM round trip
-// (fp32 MFMA), fatal when it does not (split-f16: ~1.5k cycles of MFMA per slab).
-__device__ __forceinline__ void lds_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ float pow2_from_biased(int e) {       // 2^(e-127), e clamped to the normal range
-    e = e < 1 ? 1 : (e > 254 ? 254 : e);
-    return __uint_as_float((unsigned)e << 23);
-}
-
-__device__ __forceinline__ void split4(const float4& v, float s, half4& hi, half4& lo) {
-    float x0 = v.x * s, x1 = v.y * s, x2 = v.z * s, x3 = v.w * s;
-    hi = half4{(_Float16)x0, (_Float16)x1, (_Float16)x2, (_Float16)x3};
-    lo = half4{(_Float16)(x0 - (float)hi[0]), (_Float16)(x1 - (float)hi[1]), (_Float16)(x2 - (float)hi[2]), (_Float16)(x3 - (float)hi[3])};
-}
-
 // Persistent streaming structure.  A slab's matrix work (~1.2k cycles) is far shorter than a loaded HBM
 // round trip (8-11k cycles measured), and the first-touch latency plus the store tail of a one-tile
 // workgroup cost more than its eight slabs.  So: one workgroup per CU walks many row tiles; the slabs of
@@ -529,9 +507,10 @@ int launch_nt(const NTArgs& a, hipStream_t s) {
 static const bool NT_WAVES4 = getenv("PAPR_NT_WAVES4") != nullptr;
 static const int NT_VARIANT = getenv("PAPR_NT_VARIANT") ? atoi(getenv("PAPR_NT_VARIANT")) : 0;   // A/B switch
 
-// Which wide GEMMs run on the split-f16 kernels.  PAPR_GEMM_MODE = h3 (default) | dgrad | fwd | f32.
-//   h3   : forward layers, data-gradients (586 -> 369 us and 634 -> 483 us per 512000x256x256 layer) and
-//          weight-gradients (gemm_tn_h3).
+// Which wide GEMMs run on the split-f16 kernels.  PAPR_GEMM_MODE = h3 (default) | layers | dgrad | fwd | f32.
+//   h3   : everything below, and runs of consecutive layers fused into one kernel (chain.hip).
+//   layers: forward layers, data-gradients (586 -> 369 us and 634 -> 483 us per 512000x256x256 layer) and
+//          weight-gradients (gemm_tn_h3), one launch per layer.
 //   dgrad: forward layers and data-gradients.
 //   fwd  : forward layers only.
 //   f32  : every GEMM on v_mfma_f32_32x32x2_f32.
@@ -544,14 +523,15 @@ static const int GEMM_MODE = [] {
     if (e && !strcmp(e, "f32")) return 0;
     if (e && !strcmp(e, "fwd")) return 1;
     if (e && !strcmp(e, "dgrad")) return 2;
-    return 3;
+    if (e && !strcmp(e, "layers")) return 3;
+    return 4;
 }();
-static const bool GEMM_H3_FWD = GEMM_MODE >= 1, GEMM_H3 = GEMM_MODE >= 2, GEMM_H3_WGRAD = GEMM_MODE >= 3;
+static const bool GEMM_H3_FWD = GEMM_MODE >= 1, GEMM_H3 = GEMM_MODE >= 2, GEMM_H3_WGRAD = GEMM_MODE >= 3, GEMM_CHAIN = GEMM_MODE >= 4;
 
 // Caller-provided scratch of the split-f16 mode, carved from the workspace argument of papr_mlp_fwd / _bwd:
 // two per-row max|.| arrays (rows of the layer input / of its output, swapped after every layer) and the
 // pre-split weight planes of the launch in flight.
-constexpr size_t H3_PLANE_HALFS = (size_t)2 * 512 * 704;      // hi + lo planes of a weight up to 512 x 704
+constexpr size_t H3_PLANE_HALFS = (size_t)CHAIN_MAX_LAYERS * 2 * 256 * 256;      // hi + lo planes of a weight up to 512 x 704, or of a fused run of up to 8 layers of 256 x 256
 struct H3Scratch {
     unsigned* amax[2];
     _Float16* planes;
@@ -1062,6 +1042,41 @@ extern "C" size_t papr_mlp_bwd_workspace_bytes(int64_t M) { return TN_SLAB_BYTES
 // layer i runs on the split-f16 forward kernel (and so leaves the row maxima of its input behind)
 static bool layer_on_h3(const papr_layer& L) { return GEMM_H3_FWD && L.n_out > 128 && L.n_skip == 0; }
 
+// Layers [b, e) that one fused launch (chain.hip) can carry: no skip inputs, at most 256 wide, the widths between
+// two fused layers multiples of 32.  Returns e (e - b < 2: no fusion).
+static int chain_run_end(const papr_layer* layers, int n_layers, int b) {
+    if (!GEMM_CHAIN) return b;
+    int e = b;
+    while (e < n_layers && e - b < CHAIN_MAX_LAYERS) {
+        const papr_layer& L = layers[e];
+        if (L.n_skip > 0 || L.n_in > 256 || L.n_out > 256 || L.n_in % 4 || L.n_out % 4) break;
+        if (e > b && (layers[e - 1].n_out % 32 || layers[e - 1].n_out != L.n_in)) break;
+        ++e;
+    }
+    return e;
+}
+
+// the forward pass left max |input row| of layer i in row_absmax: split-f16 layers and members of fused runs
+static bool layer_rowmax_saved(const papr_layer* layers, int n_layers, int i) {
+    for (int b = 0; b < n_layers;) {
+        const int e = chain_run_end(layers, n_layers, b);
+        if (e - b >= 2) {
+            if (i >= b && i < e) return true;
+            b = e;
+        } else ++b;
+    }
+    return layer_on_h3(layers[i]);
+}
+
+// pre-split W (N x K, leading dimension ldw) into fragment-order planes at `planes`; returns the halfs used
+static size_t chain_split_weight(const float* W, int N, int K, int ldw, _Float16* planes, ChainLayer& L, hipStream_t s) {
+    const int pitch = (K + 31) / 32 * 32, n_tiles = (N + 31) / 32;
+    const size_t plane = (size_t)n_tiles * 32 * pitch;
+    split_weight_kernel<<<dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, s>>>(W, N, K, ldw, n_tiles, pitch / 16, planes, planes + plane);
+    L.w_hi = planes; L.w_lo = planes + plane; L.ksteps = pitch / 16; L.N = N;
+    return 2 * plane;
+}
+
 extern "C" int papr_mlp_fwd(const papr_layer* layers, int n_layers, const float* x, int ldx, int64_t M,
                             float* const* outs, const int32_t* ld_out, float* row_absmax, void* workspace,
                             papr_stream_t stream) {
@@ -1074,6 +1089,32 @@ extern "C" int papr_mlp_fwd(const papr_layer* layers, int n_layers, const float*
         const papr_layer& L = layers[i];
         PAPR_REQUIRE(L.weight && outs[i], "papr_mlp_fwd: layer %d has null weight/output", i);
         PAPR_REQUIRE(ld_out[i] >= L.n_out, "papr_mlp_fwd: layer %d output stride %d < %d", i, ld_out[i], L.n_out);
+        if (const int e = chain_run_end(layers, n_layers, i); e - i >= 2) {
+            // layers [i, e) in one launch; without row_absmax (inference) only the run's last result reaches memory
+            float* saved = row_absmax;
+            ChainArgs c = {};
+            c.A0 = i == 0 ? x : outs[i - 1]; c.lda0 = i == 0 ? ldx : ld_out[i - 1]; c.K0 = L.n_in;
+            c.rowmax0 = saved ? saved + (size_t)i * M : nullptr;
+            c.M = M; c.n_layers = e - i;
+            size_t used = 0;
+            long cols = 0;
+            for (int l = i; l < e; ++l) {
+                ChainLayer& cl = c.L[l - i];
+                PAPR_REQUIRE(layers[l].weight && outs[l] && ld_out[l] >= layers[l].n_out, "papr_mlp_fwd: layer %d has null weight/output", l);
+                used += chain_split_weight(layers[l].weight, layers[l].n_out, layers[l].n_in, layers[l].ldw, h3.planes + used, cl, s);
+                PAPR_CHECK_LAUNCH("split_weight");
+                cl.bias = layers[l].bias; cl.act = layers[l].act;
+                cl.C = (saved || l == e - 1) ? outs[l] : nullptr; cl.ldc = ld_out[l];
+                if (cl.C) cols += layers[l].n_out;
+                cl.rowmax = l + 1 < n_layers ? (saved ? saved + (size_t)(l + 1) * M : (l == e - 1 ? reinterpret_cast<float*>(h3.out()) : nullptr)) : nullptr;
+            }
+            PAPR_REQUIRE(used <= H3_PLANE_HALFS, "papr_mlp_fwd: fused run needs %zu plane halfs", used);
+            if (int err = papr_launch_chain(c, false, cols, s)) return err;
+            if (!saved) h3.swap();
+            have_amax = true;
+            i = e - 1;
+            continue;
+        }
         NTArgs a = {};
         a.A = i == 0 ? x : outs[i - 1];
         a.lda = i == 0 ? ldx : ld_out[i - 1];
@@ -1147,7 +1188,7 @@ extern "C" int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float*
         long ld_in = i == 0 ? ldx : ld_out[i - 1];
         PAPR_REQUIRE(d_weight[i], "papr_mlp_bwd: layer %d has null d_weight", i);
         // weight / bias gradients: split-f16 when the forward pass left the row maxima of this layer's input
-        const bool wgrad_h3 = GEMM_H3_WGRAD && row_absmax && layer_on_h3(L) && L.n_out <= SLAB && L.n_in <= SLAB;
+        const bool wgrad_h3 = GEMM_H3_WGRAD && row_absmax && layer_rowmax_saved(layers, n_layers, i) && L.n_out <= SLAB && L.n_in <= SLAB;
         if (wgrad_h3) {
             if (!have_amax) {
                 if (int e = launch_row_absmax(g, M, L.n_out, ldg, h3.in(), s)) return e;

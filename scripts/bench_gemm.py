@@ -43,3 +43,15 @@ rep("wgrad gemm_tn", bwd, 4)
 rep("fwd  gemm_nt_h3", fwd, 6)
 rep("dgrad gemm_nt_h3", bwd, 7)
 rep("wgrad gemm_tn_h3", bwd, 8)
+def rep_chain(tag, recs, kid):
+    r = [x for x in recs if x[0] == kid]
+    if not r: return
+    ms = sum(x[4] for x in r) / len(r)
+    print("%-28s n=%3d avg %.1f us per launch (%d stored/masked columns, %.0f GB/s algorithmic)" % (tag, len(r), ms * 1e3, r[0][2], 4.0 * r[0][1] * (r[0][2] + r[0][3]) / ms / 1e6))
+rep_chain("fwd  mlp_chain", fwd, 9)
+rep_chain("dgrad mlp_chain", bwd, 10)
+hip.profile_enable(True)
+for rep_ in range(5):
+    ops.mlp_forward(spec, ws, bs, x, M, keep=False)
+hip.profile_enable(False)
+rep_chain("inference mlp_chain", hip.profile_collect(), 9)

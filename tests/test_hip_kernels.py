@@ -333,7 +333,7 @@ def test_attention_tail_forward_backward(R, k, d_model, Cc, act, normalize):
     np.testing.assert_allclose(d_sb.cpu().numpy(), sb.grad.numpy(), rtol=0, atol=tol(sb.grad))
 
 
-@pytest.mark.parametrize("mode", ["f32", "fwd", "dgrad"])
+@pytest.mark.parametrize("mode", ["f32", "fwd", "dgrad", "layers"])
 def test_other_gemm_modes_meet_the_same_mlp_parity(mode):
     """PAPR_GEMM_MODE selects which wide GEMMs use the split-f16 (hi/lo, 3 MFMA) kernels (default `h3`: forward
     layers, data-gradients and weight-gradients); `dgrad` (no weight-gradients), `fwd` (forward only) and `f32`
