@@ -156,6 +156,26 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(ChainArgs p, i
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+            // data-gradient: the activation rows whose derivative masks the result are requested before the k-loop
+            // (a load issued among the stores of phase 1 would wait for them: loads and stores share vmcnt)
+            const int hh = lane >> 5;
+            float4 aux[2][2][4];
+            if (DGRAD && L.mask) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    long row = m0 + i * 32 + (lane & 31);
+                    row = row < p.M ? row : p.M - 1;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            int col = (wn * 2 + j) * 32 + 8 * g + 4 * hh;
+                            col = col < N ? col : 0;
+                            aux[i][j][g] = *reinterpret_cast<const float4*>(L.mask + row * L.ld_mask + col);
+                        }
+                }
+            }
+
             // ---- k-loop
             auto k_step = [&](int ks, const half8 (&qh)[2], const half8 (&ql)[2]) {
                 half8 ah[2], al[2];
@@ -208,12 +228,10 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(ChainArgs p, i
             // derivative mask, 16-byte stores, row maxima
             const float slope = L.act == PAPR_ACT_RELU ? 0.f : (L.act == PAPR_ACT_LEAKY_RELU ? 0.2f : 1.f);
             const bool more = l + 1 < p.n_layers;
-            const int hh = lane >> 5;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int rl = i * 32 + (lane & 31);
                 const long row = m0 + rl;
-                const long rowc = row < p.M ? row : p.M - 1;
                 const float inv = inv_tab[rl];
                 float mx = 0.f;
 #pragma unroll
@@ -226,7 +244,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(ChainArgs p, i
                         float4 r = make_float4(acc[i][j][4 * g] * inv, acc[i][j][4 * g + 1] * inv, acc[i][j][4 * g + 2] * inv, acc[i][j][4 * g + 3] * inv);
                         if (DGRAD) {
                             if (L.mask) {
-                                const float4 a4 = col_ok ? *reinterpret_cast<const float4*>(L.mask + rowc * L.ld_mask + col) : make_float4(1.f, 1.f, 1.f, 1.f);
+                                const float4 a4 = aux[i][j][g];
                                 r.x *= a4.x > 0.f ? 1.f : slope; r.y *= a4.y > 0.f ? 1.f : slope;
                                 r.z *= a4.z > 0.f ? 1.f : slope; r.w *= a4.w > 0.f ? 1.f : slope;
                             }

@@ -1037,7 +1037,6 @@ __global__ __launch_bounds__(256) void act_grad_kernel(float* g, long ldg, const
 constexpr size_t TN_SLAB_BYTES = (size_t)MAX_SLICES * (SLAB * SLAB + SLAB) * sizeof(float);
 
 extern "C" size_t papr_mlp_fwd_workspace_bytes(int64_t M) { return H3Scratch::bytes(M); }
-extern "C" size_t papr_mlp_bwd_workspace_bytes(int64_t M) { return TN_SLAB_BYTES + H3Scratch::bytes(M); }
 
 // layer i runs on the split-f16 forward kernel (and so leaves the row maxima of its input behind)
 static bool layer_on_h3(const papr_layer& L) { return GEMM_H3_FWD && L.n_out > 128 && L.n_skip == 0; }
@@ -1143,6 +1142,23 @@ extern "C" int papr_mlp_fwd(const papr_layer* layers, int n_layers, const float*
     return 0;
 }
 
+// Scratch of the backward pass behind the slabs and the split-f16 scratch: the gradient rows of every layer of
+// a fused run (the weight-gradients run after the run's data-gradient launch and need all of them) and their
+// per-row maxima.
+constexpr int G_LD = 256;
+struct BwdRunScratch {
+    float* g[CHAIN_MAX_LAYERS];
+    float* gmax[CHAIN_MAX_LAYERS + 1];
+    BwdRunScratch(void* base, long M) {
+        float* q = static_cast<float*>(base);
+        for (int i = 0; i < CHAIN_MAX_LAYERS; ++i) { g[i] = q; q += (size_t)M * G_LD; }
+        for (int i = 0; i <= CHAIN_MAX_LAYERS; ++i) { gmax[i] = q; q += M; }
+    }
+    static size_t bytes(long M) { return GEMM_CHAIN ? ((size_t)CHAIN_MAX_LAYERS * M * G_LD + (size_t)(CHAIN_MAX_LAYERS + 1) * M) * sizeof(float) : 0; }
+};
+
+extern "C" size_t papr_mlp_bwd_workspace_bytes(int64_t M) { return TN_SLAB_BYTES + H3Scratch::bytes(M) + BwdRunScratch::bytes(M); }
+
 extern "C" int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float* x, int ldx, int64_t M,
                             float* const* outs, const int32_t* ld_out, const float* row_absmax, float* d_out,
                             float* scratch0, float* scratch1, int ld_scratch, float* const* d_weight,
@@ -1157,20 +1173,23 @@ extern "C" int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float*
         hipError_t e = hipMemsetAsync(d_x, 0, (size_t)M * ldx * sizeof(float), s);
         PAPR_REQUIRE(e == hipSuccess, "papr_mlp_bwd: memset failed");
     }
-    bool have_amax = false;                 // split-f16 mode: row maxima of g are in h3.in()
     H3Scratch h3(static_cast<char*>(workspace) + TN_SLAB_BYTES, M);
-    auto h3_setup = [&](NTArgs& a) -> int {    // choose the split-f16 kernel for a wide data-gradient
-        if (!(GEMM_H3 && a.N > 128)) { have_amax = false; return 0; }
-        if (!have_amax)
-            if (int e = launch_row_absmax(a.A, a.M, a.K1, a.lda, h3.in(), s)) return e;
-        a.amax_in = h3.in();
-        a.amax_out = h3.out();
-        a.planes = h3.planes;
-        PAPR_REQUIRE(hipMemsetAsync(a.amax_out, 0, (size_t)a.M * sizeof(unsigned), s) == hipSuccess, "papr_mlp_bwd: memset failed");
-        h3.swap();                             // the launch below writes what the next layer reads
-        have_amax = true;
+    BwdRunScratch runs(static_cast<char*>(workspace) + TN_SLAB_BYTES + H3Scratch::bytes(M), M);
+    const unsigned* gmax = nullptr;          // per-row max |g| of the current gradient rows, when known
+    auto need_gmax = [&](const float* g, long ldg, int width) -> int {
+        if (gmax) return 0;
+        if (int e = launch_row_absmax(g, M, width, ldg, h3.in(), s)) return e;
+        gmax = h3.in();
         return 0;
     };
+    // run boundaries as the forward pass saw them
+    int run_begin[64];
+    PAPR_REQUIRE(n_layers <= 64, "papr_mlp_bwd: %d layers", n_layers);
+    for (int b = 0; b < n_layers;) {
+        const int e = chain_run_end(layers, n_layers, b);
+        if (e - b >= 2) { for (int l = b; l < e; ++l) run_begin[l] = b; b = e; }
+        else { run_begin[b] = -1; ++b; }
+    }
     // gradient w.r.t. the last layer's pre-activation
     float* g = d_out;
     long ldg = ld_out[n_layers - 1];
@@ -1182,23 +1201,79 @@ extern "C" int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float*
             PAPR_CHECK_LAUNCH("act_grad");
         }
     }
-    for (int i = n_layers - 1; i >= 0; --i) {
+    auto wgrad = [&](int i, const float* gi, long ldgi, const float* gmax_i) -> int {
         const papr_layer& L = layers[i];
         const float* in = i == 0 ? x : outs[i - 1];
-        long ld_in = i == 0 ? ldx : ld_out[i - 1];
+        const long ld_in = i == 0 ? ldx : ld_out[i - 1];
         PAPR_REQUIRE(d_weight[i], "papr_mlp_bwd: layer %d has null d_weight", i);
-        // weight / bias gradients: split-f16 when the forward pass left the row maxima of this layer's input
-        const bool wgrad_h3 = GEMM_H3_WGRAD && row_absmax && layer_rowmax_saved(layers, n_layers, i) && L.n_out <= SLAB && L.n_in <= SLAB;
-        if (wgrad_h3) {
-            if (!have_amax) {
-                if (int e = launch_row_absmax(g, M, L.n_out, ldg, h3.in(), s)) return e;
-                have_amax = true;
-            }
-            if (int e = gemm_tn_h3(g, ldg, L.n_out, in, ld_in, L.n_in, M, reinterpret_cast<const float*>(h3.in()),
-                                   row_absmax + (size_t)i * M, d_weight[i], L.ldw, d_bias[i], workspace, s)) return e;
-        } else if (int e = gemm_tn(g, ldg, L.n_out, in, ld_in, L.n_in, M, d_weight[i], L.ldw, d_bias[i], workspace, s)) return e;
+        // split-f16 when the forward pass left the row maxima of this layer's input
+        const bool h3w = GEMM_H3_WGRAD && row_absmax && gmax_i && layer_rowmax_saved(layers, n_layers, i) && L.n_out <= SLAB && L.n_in <= SLAB;
+        if (h3w) {
+            if (int e = gemm_tn_h3(gi, ldgi, L.n_out, in, ld_in, L.n_in, M, gmax_i, row_absmax + (size_t)i * M, d_weight[i], L.ldw, d_bias[i], workspace, s)) return e;
+        } else if (int e = gemm_tn(gi, ldgi, L.n_out, in, ld_in, L.n_in, M, d_weight[i], L.ldw, d_bias[i], workspace, s)) return e;
         if (L.n_skip > 0)
-            if (int e = gemm_tn(g, ldg, L.n_out, x, ldx, L.n_skip, M, d_weight[i] + L.skip_col, L.ldw, nullptr, workspace, s)) return e;
+            if (int e = gemm_tn(gi, ldgi, L.n_out, x, ldx, L.n_skip, M, d_weight[i] + L.skip_col, L.ldw, nullptr, workspace, s)) return e;
+        return 0;
+    };
+    for (int i = n_layers - 1; i >= 0; --i) {
+        const papr_layer& L = layers[i];
+        if (const int b = run_begin[i]; b >= 0) {
+            // ---- fused run [b, i]: one data-gradient launch down to the gradient of the run's input, then the
+            // weight-gradients of its layers
+            const bool to_dx = b == 0 && d_x && !any_skip;       // layer 0's data-gradient joins the run unless d_x accumulates
+            const int last = b == 0 ? (to_dx ? 0 : 1) : b;       // lowest layer whose data-gradient the launch computes
+            ChainArgs c = {};
+            c.A0 = g; c.lda0 = ldg; c.K0 = L.n_out; c.rowmax0 = runs.gmax[CHAIN_MAX_LAYERS];
+            c.M = M;
+            size_t used = 0;
+            long cols = 0;
+            for (int l = i; l >= last; --l) {
+                const papr_layer& Ll = layers[l];
+                PAPR_REQUIRE(Ll.weight_t, "papr_mlp_bwd: layer %d needs weight_t", l);
+                ChainLayer& cl = c.L[c.n_layers++];
+                used += chain_split_weight(Ll.weight_t, Ll.n_in, Ll.n_out, Ll.ldwt, h3.planes + used, cl, s);
+                PAPR_CHECK_LAUNCH("split_weight");
+                if (l > 0) {
+                    cl.mask = outs[l - 1]; cl.ld_mask = ld_out[l - 1]; cl.act = layers[l - 1].act;
+                    cl.C = runs.g[l - 1 - (b > 0 ? b - 1 : 0)]; cl.ldc = G_LD;
+                    cl.rowmax = runs.gmax[l - 1 - (b > 0 ? b - 1 : 0)];
+                    cols += 2 * Ll.n_in;
+                } else {
+                    cl.C = d_x; cl.ldc = ldx; cl.act = PAPR_ACT_NONE;
+                    cols += Ll.n_in;
+                }
+            }
+            PAPR_REQUIRE(used <= H3_PLANE_HALFS, "papr_mlp_bwd: fused run needs %zu plane halfs", used);
+            if (c.n_layers > 0)
+                if (int err = papr_launch_chain(c, true, cols, s)) return err;
+            auto slot = [&](int l) { return l - (b > 0 ? b - 1 : 0); };
+            // (the launch above leaves max |g| of the run's top rows in the last gmax slot, computed while staging them)
+            if (c.n_layers == 0)
+                if (int err = launch_row_absmax(g, M, L.n_out, ldg, reinterpret_cast<unsigned*>(runs.gmax[CHAIN_MAX_LAYERS]), s)) return err;
+            for (int l = i; l >= b; --l) {
+                const float* gl = l == i ? g : runs.g[slot(l)];
+                const long ldl = l == i ? ldg : G_LD;
+                const float* gm = l == i ? runs.gmax[CHAIN_MAX_LAYERS] : runs.gmax[slot(l)];
+                if (int err = wgrad(l, gl, ldl, gm)) return err;
+            }
+            if (b == 0 && d_x && !to_dx) {                       // d_x accumulates (a skip layer wrote into it): separate launch
+                PAPR_REQUIRE(layers[0].weight_t, "papr_mlp_bwd: layer 0 needs weight_t");
+                NTArgs a = {};
+                a.A = runs.g[slot(0)]; a.lda = G_LD; a.K1 = layers[0].n_out;
+                a.W = layers[0].weight_t; a.ldw = layers[0].ldwt;
+                a.dgrad = 1; a.accumulate = 1;
+                a.C = d_x; a.ldc = ldx; a.M = M; a.N = layers[0].n_in;
+                if (int err = gemm_nt(a, s)) return err;
+            }
+            if (b > 0) { g = runs.g[slot(b - 1)]; ldg = G_LD; gmax = reinterpret_cast<const unsigned*>(runs.gmax[slot(b - 1)]); }
+            i = b;                                               // (the loop's --i moves below the run)
+            continue;
+        }
+        // ---- single layer
+        const bool h3w = GEMM_H3_WGRAD && row_absmax && layer_rowmax_saved(layers, n_layers, i) && L.n_out <= SLAB && L.n_in <= SLAB;
+        if (h3w)
+            if (int e = need_gmax(g, ldg, L.n_out)) return e;
+        if (int e = wgrad(i, g, ldg, h3w ? reinterpret_cast<const float*>(gmax) : nullptr)) return e;
         // data gradients
         if (L.n_skip > 0 && d_x) {
             PAPR_REQUIRE(L.weight_t, "papr_mlp_bwd: layer %d needs weight_t", i);
@@ -1218,8 +1293,19 @@ extern "C" int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float*
             a.dgrad = 1; a.act = layers[i - 1].act; a.mask_src = outs[i - 1]; a.ld_mask = ld_out[i - 1];
             a.C = gnext; a.ldc = ld_scratch; a.M = M; a.N = L.n_in;
             PAPR_REQUIRE(ld_scratch >= L.n_in, "papr_mlp_bwd: scratch stride %d < %d", ld_scratch, L.n_in);
-            if (int e = h3_setup(a)) return e;
-            if (int e = gemm_nt(a, s)) return e;
+            if (GEMM_H3 && a.N > 128) {                          // split-f16 data-gradient: row maxima in, row maxima out
+                if (int e = need_gmax(g, ldg, L.n_out)) return e;
+                a.amax_in = gmax;
+                a.amax_out = gmax == h3.in() ? h3.out() : h3.in();
+                a.planes = h3.planes;
+                PAPR_REQUIRE(hipMemsetAsync(a.amax_out, 0, (size_t)M * sizeof(unsigned), s) == hipSuccess, "papr_mlp_bwd: memset failed");
+                if (int e = gemm_nt(a, s)) return e;
+                if (a.amax_out == h3.out()) h3.swap();
+                gmax = a.amax_out;
+            } else {
+                if (int e = gemm_nt(a, s)) return e;
+                gmax = nullptr;
+            }
             g = gnext;
             ldg = ld_scratch;
         } else if (d_x) {

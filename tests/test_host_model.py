@@ -210,5 +210,5 @@ def test_c_abi_library_exports_every_declared_symbol():
     lib.papr_mlp_bwd_workspace_bytes.argtypes = [ctypes.c_int64]
     lib.papr_mlp_fwd_workspace_bytes.restype = ctypes.c_size_t
     lib.papr_mlp_fwd_workspace_bytes.argtypes = [ctypes.c_int64]
-    assert lib.papr_mlp_bwd_workspace_bytes(1000) == 256 * (256 * 256 + 256) * 4 + lib.papr_mlp_fwd_workspace_bytes(1000)
+    assert lib.papr_mlp_bwd_workspace_bytes(1000) >= 256 * (256 * 256 + 256) * 4 + lib.papr_mlp_fwd_workspace_bytes(1000)
     assert lib.papr_mlp_fwd_workspace_bytes(1000) >= 2 * 1000 * 4 + 2 * 512 * 704 * 2
