@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TF = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 FLOP/clk/CU x 256 CU x 2.4 GHz
 HBM_PEAK_GBS = 8000.0         # spec; 6.29 TB/s measured copy ceiling
+F16_MFMA_PEAK_TF = 2500.0     # MI355X_MICROARCH.md: dense f16/bf16 MFMA (v_mfma_f32_32x32x16_f16, 32 cycles per SIMD)
 
 
 def parse():
@@ -40,9 +41,9 @@ def parse():
     ap.add_argument("--points", type=int, default=10000, help="point-cloud size (chair.yml: 10000 at init, <=30000 late)")
     ap.add_argument("--scene", default="nerfsyn/chair.yml")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gemm-mode", default="h3", choices=["f32", "fwd", "dgrad", "h3"],
-                    help="h3 (default): wide forward, data-gradient and weight-gradient GEMMs on the split-f16 kernels; "
-                         "dgrad: forward + data-gradient; fwd: forward only; f32: fp32 MFMA everywhere")
+    ap.add_argument("--gemm-mode", default="h3", choices=["f32", "fwd", "dgrad", "layers", "h3"],
+                    help="h3 (default): split-f16 MFMA everywhere, consecutive layers fused into one launch; layers: the same "
+                         "arithmetic, one launch per layer; dgrad: forward + data-gradient only; fwd: forward only; f32: fp32 MFMA everywhere")
     ap.add_argument("--cpu-rays", type=int, default=32, help="edge of the CPU-baseline patch (32 -> 1,024 rays)")
     ap.add_argument("--cpu-steps", type=int, default=8)
     return ap.parse_args()
@@ -161,7 +162,7 @@ def main():
     def mfma_line(kernel, ids, key):
         rs = [r for r in recs if r[0] in ids]
         ms = sum(r[4] for r in rs)
-        fl = sum(2.0 * M * min(Nn, 256) * true_k.get(K, K) for _, M, Nn, K, _ in rs)
+        fl = sum(2.0 * M * min(Nn, 256) * true_k.get(K, K) for _, M, Nn, K, *_ in rs)
         ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         return ms, {"kernel": kernel, "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                     "frac": ach / FP32_MFMA_PEAK_TF, "traffic": traffic_db.get(key), "launches": len(rs),
@@ -174,8 +175,8 @@ def main():
         # mask of a data-gradient launch.
         rs = [r for r in recs if r[0] in (6, 7)]
         ms = sum(r[4] for r in rs)
-        by = sum(4.0 * (M * (true_k.get(K, K) + Nn + (Nn if kid == 7 else 0)) + Nn * K) for kid, M, Nn, K, _ in rs)
-        fl = sum(2.0 * M * Nn * true_k.get(K, K) for _, M, Nn, K, _ in rs)
+        by = sum(4.0 * (M * (true_k.get(K, K) + Nn + (Nn if kid == 7 else 0)) + Nn * K) for kid, M, Nn, K, *_ in rs)
+        fl = sum(2.0 * M * Nn * true_k.get(K, K) for _, M, Nn, K, *_ in rs)
         ach = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         return ms, {"kernel": "gemm_nt_h3_kernel<128,256,2,2,4> (embedding-MLP forward + data-gradient GEMMs, split-f16 MFMA)",
                     "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
@@ -188,8 +189,8 @@ def main():
         # written once and read once by the reduction
         rs = [r for r in recs if r[0] == 8]
         ms = sum(r[4] for r in rs)
-        by = sum(4.0 * M * (Nn + true_k.get(K, K)) for _, M, Nn, K, _ in rs)
-        fl = sum(2.0 * M * Nn * true_k.get(K, K) for _, M, Nn, K, _ in rs)
+        by = sum(4.0 * M * (Nn + true_k.get(K, K)) for _, M, Nn, K, *_ in rs)
+        fl = sum(2.0 * M * Nn * true_k.get(K, K) for _, M, Nn, K, *_ in rs)
         ach = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         return ms, {"kernel": "gemm_tn_h3_kernel (weight gradients, one slice of the rows per CU, split-f16 MFMA)",
                     "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
@@ -197,12 +198,31 @@ def main():
                     "avg_launch_ms": ms / max(len(rs), 1), "algorithmic_bytes_per_launch": by / max(len(rs), 1),
                     "fp32_equivalent_tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0, "share_of_step_time": ms / (dt * 1e3)}
 
+    def chain_line():
+        # fused layer runs (chain.hip): every fp32 product is three f16 MFMA products, and only the run's input, the
+        # saved activations / gradient rows and the masks cross HBM.  The matrix pipe is the nearer roof.
+        rs = [r for r in recs if r[0] in (9, 10)]
+        ms = sum(r[4] for r in rs)
+        by = float(sum(r[5] for r in rs))
+        fl = float(sum(r[6] for r in rs))
+        ach = 3.0 * fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        return ms, {"kernel": "mlp_chain_kernel (fused embedding-MLP runs: forward and data-gradient, split-f16 MFMA)",
+                    "bound": "mfma", "achieved": ach, "peak": F16_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / F16_MFMA_PEAK_TF,
+                    "traffic": traffic_db.get("mlp_chain_bytes_per_launch"), "launches": len(rs),
+                    "avg_launch_ms": ms / max(len(rs), 1), "algorithmic_gflop_per_launch": 3.0 * fl / max(len(rs), 1) / 1e9,
+                    "note": "flops = 3 f16 MFMA products per fp32 product (hi.hi + hi.lo + lo.hi), padded input widths",
+                    "fp32_equivalent_tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
+                    "algorithmic_bytes_per_launch": by / max(len(rs), 1),
+                    "hbm_gbs": by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0, "hbm_frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else 0.0,
+                    "share_of_step_time": ms / (dt * 1e3)}
+
     nt_ms, nt_line = mfma_line("gemm_nt_kernel<128,256,2,2> (embedding-MLP forward + data-gradient GEMMs, fp32 MFMA)", (0,),
                                "gemm_nt_128x256_bytes_per_launch")
     tn_ms, tn_line = mfma_line("gemm_tn_kernel (weight gradients, split over M, fp32 MFMA)", (4,), "gemm_tn_bytes_per_launch")
     h3_ms, h3 = h3_line()
     wg_ms, wg = wgrad_h3_line()
-    dominant = max(((nt_ms, nt_line), (tn_ms, tn_line), (h3_ms, h3), (wg_ms, wg)), key=lambda t: t[0])[1]
+    ch_ms, ch = chain_line()
+    dominant = max(((nt_ms, nt_line), (tn_ms, tn_line), (h3_ms, h3), (wg_ms, wg), (ch_ms, ch)), key=lambda t: t[0])[1]
     knn = [r for r in recs if r[0] == 5]
     knn_ms = sum(r[4] for r in knn) / max(len(knn), 1)
     knn_bytes = R * (12.0 * P + 12 + 4 * k)
@@ -220,6 +240,7 @@ def main():
         "roofline_gemm_nt_h3": h3 if h3_ms > 0 and dominant is not h3 else None,
         "roofline_wgrad": tn_line if tn_ms > 0 and dominant is not tn_line else None,
         "roofline_wgrad_h3": wg if wg_ms > 0 and dominant is not wg else None,
+        "roofline_mlp_chain": ch if ch_ms > 0 and dominant is not ch else None,
         "roofline_knn": {"kernel": "ray_knn_kernel<8,4>", "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
                          "achieved": knn_bytes / (knn_ms * 1e-3) / 1e9 if knn_ms > 0 else 0.0,
                          "frac": knn_bytes / (knn_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if knn_ms > 0 else 0.0,

@@ -197,12 +197,16 @@ int papr_attn_tail_bwd(const papr_tail_desc* d, const float* kp, const float* qp
  *             4 gemm_tn (split-M weight gradient)      5 ray_knn
  *             6 gemm_nt_h3 forward layer   7 gemm_nt_h3 data-gradient   (split-f16, 128x256 tile)
  *             8 gemm_tn_h3 (split-f16 weight gradient)
+ *             9 mlp_chain forward run   10 mlp_chain data-gradient run   (several layers in one launch; N = number of
+ *               layers, K = input width; bytes / flops below carry the algorithmic totals of the launch)
  */
 typedef struct {
     int32_t kernel;
     int32_t N, K;
     int64_t M;      /* rows (rays for kernel 5, with N = points, K = k) */
     float ms;       /* hipEventElapsedTime between the events bracketing the launch */
+    int64_t bytes;  /* kernels 9, 10: algorithmic HBM bytes of the launch (input rows + stored rows + masks read + weights); else 0 */
+    int64_t flops;  /* kernels 9, 10: fp32-equivalent 2 M N K summed over the layers (each product costs three f16 MFMA products); else 0 */
 } papr_profile_record;
 
 int papr_profile_enable(int on);

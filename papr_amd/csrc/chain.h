@@ -28,5 +28,5 @@ struct ChainArgs {
 };
 
 size_t papr_chain_lds_bytes();
-// prof_cols: sum of the widths of the stored results (+ masks read), for the profiling record
-int papr_launch_chain(const ChainArgs& a, bool dgrad, long prof_cols, hipStream_t s);
+// bytes / flops: algorithmic totals of the launch for the profiling record
+int papr_launch_chain(const ChainArgs& a, bool dgrad, long long bytes, long long flops, hipStream_t s);

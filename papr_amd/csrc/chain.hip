@@ -23,6 +23,9 @@
 namespace {
 
 constexpr int CH_BM = 64;                   // rows per tile
+#ifndef CH_START_DELAY
+#define CH_START_DELAY 1              // x 8128 cycles (s_sleep 127)
+#endif
 constexpr int CH_THREADS = 256;             // four waves, one per SIMD, each a 64 x 64 corner of the 64 x 256 tile
 constexpr int CH_AP = 264;                  // A-plane row pitch in halfs (528 B: conflict-free ds_read_b128)
 constexpr int CH_PLANE = CH_BM * CH_AP;     // halfs per plane
@@ -80,9 +83,10 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(ChainArgs p, i
         if (tid < 256) bias_tab[l * 256 + tid] = (!DGRAD && p.L[l].bias && tid < p.L[l].N) ? p.L[l].bias[tid] : 0.f;
 
     // W fragments: fragment (n-tile t, k-step s) of a layer's planes starts at ((t * ksteps + s) * 64 + lane) * 8 halfs.
-    // They come straight from L2 (~1k cycles under load, a k-step is 384): a ring of four k-steps, three in
-    // flight, and the first three of the NEXT layer are requested before this layer's row phases.
-    half8 wfh[4][2], wfl[4][2];
+    // They come straight from L2 (~1k cycles under load, a k-step is 384): a ring of WD k-steps, WD-1 in
+    // flight, and the first ones of the NEXT layer are requested before this layer's row phases.
+    constexpr int WD = 4;                        // ring depth (the k-loop below is written out for 4)
+    half8 wfh[WD][2], wfl[WD][2];
     auto load_w = [&](int l, int ks, half8 (&qh)[2], half8 (&ql)[2]) {
         const ChainLayer& L = p.L[l];
         ks = ks < L.ksteps ? ks : L.ksteps - 1;
@@ -97,28 +101,37 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(ChainArgs p, i
             ql[j] = *reinterpret_cast<const half8*>(L.w_lo + o);
         }
     };
-    load_w(0, 0, wfh[0], wfl[0]);
-    load_w(0, 1, wfh[1], wfl[1]);
-    load_w(0, 2, wfh[2], wfl[2]);
+#pragma unroll
+    for (int u = 0; u < WD - 1; ++u) load_w(0, u, wfh[u], wfl[u]);
+    constexpr int SR = 8;                        // input rows per wave and staging pass (16 per tile)
+    // Two workgroups share a CU so that one multiplies while the other is in its row phases.  Launched together and
+    // with identical timing they would run in lockstep instead (both multiplying at half speed, then both leaving the
+    // matrix pipe idle): the second wave of workgroups starts half a layer late.
+    if (blockIdx.x >= gridDim.x / 2) {
+#pragma unroll 1
+        for (int z = 0; z < CH_START_DELAY; ++z) __builtin_amdgcn_s_sleep(127);
+    }
     for (int tile = blockIdx.x; tile < tiles_m; tile += gridDim.x) {
         const long m0 = (long)tile * CH_BM;
         CH_STAMP();
-        // ---- stage the tile's input rows: one row per wave and pass, row maximum on the way ----
+        // ---- stage the tile's input rows: wave w carries rows w, w+4, ...; row maximum on the way.  (Requesting them
+        // during the previous tile's last layer bought nothing -- the other workgroup of the CU fills the wait -- and
+        // cost 64 registers.)
         {
             const int kpad = p.L[0].ksteps * 16;
             const int c = 4 * lane;
 #pragma unroll 1
-            for (int r0 = wave; r0 < CH_BM; r0 += 32) {
-                float4 v[8];
+            for (int u0 = 0; u0 < 16; u0 += SR) {
+                float4 v[SR];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    long m = m0 + r0 + 4 * u;
+                for (int u = 0; u < SR; ++u) {
+                    long m = m0 + wave + 4 * (u0 + u);
                     m = m < p.M ? m : p.M - 1;
                     v[u] = c < p.K0 ? *reinterpret_cast<const float4*>(p.A0 + m * p.lda0 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int r = r0 + 4 * u;
+                for (int u = 0; u < SR; ++u) {
+                    const int r = wave + 4 * (u0 + u);
                     float mx = fmaxf(fmaxf(fabsf(v[u].x), fabsf(v[u].y)), fmaxf(fabsf(v[u].z), fabsf(v[u].w)));
                     mx = wave64_max(mx);
                     float inv;
@@ -160,65 +173,81 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(ChainArgs p, i
             // (a load issued among the stores of phase 1 would wait for them: loads and stores share vmcnt)
             const int hh = lane >> 5;
             float4 aux[2][2][4];
-            if (DGRAD && L.mask) {
+            auto load_aux = [&](int i) {
+                long row = m0 + i * 32 + (lane & 31);
+                row = row < p.M ? row : p.M - 1;
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    long row = m0 + i * 32 + (lane & 31);
-                    row = row < p.M ? row : p.M - 1;
+                for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            int col = (wn * 2 + j) * 32 + 8 * g + 4 * hh;
-                            col = col < N ? col : 0;
-                            aux[i][j][g] = *reinterpret_cast<const float4*>(L.mask + row * L.ld_mask + col);
-                        }
-                }
-            }
+                    for (int g = 0; g < 4; ++g) {
+                        int col = (wn * 2 + j) * 32 + 8 * g + 4 * hh;
+                        col = col < N ? col : 0;
+                        aux[i][j][g] = *reinterpret_cast<const float4*>(L.mask + row * L.ld_mask + col);
+                    }
+            };
+            if (DGRAD && L.mask) { load_aux(0); load_aux(1); }
 
-            // ---- k-loop
-            auto k_step = [&](int ks, const half8 (&qh)[2], const half8 (&ql)[2]) {
-                half8 ah[2], al[2];
+            // ---- k-loop.  The A fragments of k-step s+1 are read from LDS while k-step s multiplies (hipcc does not
+            // pipeline the reads by itself: it places them right in front of their MFMAs and waits).
+            auto load_a = [&](int ks, half8 (&ah)[2], half8 (&al)[2]) {
+                ks = ks < ksteps ? ks : ksteps - 1;
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-#ifdef CH_EXP_NO_A
-                    const int o = (wm * 2 + i) * 32 * CH_AP + frag;      // experiment: always the same fragment (one LDS read hoisted out)
-#else
                     const int o = (wm * 2 + i) * 32 * CH_AP + frag + ks * 16;
-#endif
                     ah[i] = *reinterpret_cast<const half8*>(Ah + o);
                     al[i] = *reinterpret_cast<const half8*>(Al + o);
                 }
+            };
+            // W fragment as the row operand: the accumulators hold C^T (lane = row m, registers = columns n)
+            auto mma_all = [&](const half8 (&qh)[2], const half8 (&ql)[2], const half8 (&ah)[2], const half8 (&al)[2]) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh[j], al[i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ql[j], ah[i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh[j], ah[i], acc[i][j], 0, 0, 0);
+                    }
+            };
+            auto mma_live = [&](const half8 (&qh)[2], const half8 (&ql)[2], const half8 (&ah)[2], const half8 (&al)[2]) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     if (!live[j]) continue;
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
-                        // W fragment as the row operand: the accumulators hold C^T (lane = row m, registers = columns n)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh[j], al[i], acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ql[j], ah[i], acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh[j], ah[i], acc[i][j], 0, 0, 0);
                     }
                 }
             };
+            auto k_loop = [&](auto mma) {
+                half8 a0h[2], a0l[2], a1h[2], a1l[2];
+                load_a(0, a0h, a0l);
 #pragma unroll 1
-            for (int ks = 0; ks < ksteps; ks += 4) {           // ksteps is even (planes are padded to 32 columns)
-                load_w(l, ks + 3, wfh[3], wfl[3]);
-                k_step(ks, wfh[0], wfl[0]);
-                load_w(l, ks + 4, wfh[0], wfl[0]);
-                k_step(ks + 1, wfh[1], wfl[1]);
-                load_w(l, ks + 5, wfh[1], wfl[1]);
-                if (ks + 2 < ksteps) {
-                    k_step(ks + 2, wfh[2], wfl[2]);
-                    load_w(l, ks + 6, wfh[2], wfl[2]);
-                    k_step(ks + 3, wfh[3], wfl[3]);
+                for (int ks = 0; ks < ksteps; ks += 4) {       // ksteps is even (planes are padded to 32 columns)
+                    load_w(l, ks + 3, wfh[3], wfl[3]);
+                    load_a(ks + 1, a1h, a1l);
+                    mma(wfh[0], wfl[0], a0h, a0l);
+                    load_w(l, ks + 4, wfh[0], wfl[0]);
+                    load_a(ks + 2, a0h, a0l);
+                    mma(wfh[1], wfl[1], a1h, a1l);
+                    load_w(l, ks + 5, wfh[1], wfl[1]);
+                    if (ks + 2 < ksteps) {
+                        load_a(ks + 3, a1h, a1l);
+                        mma(wfh[2], wfl[2], a0h, a0l);
+                        load_w(l, ks + 6, wfh[2], wfl[2]);
+                        load_a(ks + 4, a0h, a0l);
+                        mma(wfh[3], wfl[3], a1h, a1l);
+                    }
                 }
-            }
+            };
+            if (live[1]) k_loop(mma_all);                       // both column tiles of this wave hold real columns: no tests inside
+            else if (live[0]) k_loop(mma_live);
             {   // first fragments of what comes next: the next layer, or layer 0 of the next tile
                 const int ln = l + 1 < p.n_layers ? l + 1 : 0;
-                load_w(ln, 0, wfh[0], wfl[0]);
-                load_w(ln, 1, wfh[1], wfl[1]);
-                load_w(ln, 2, wfh[2], wfl[2]);
+#pragma unroll
+                for (int u = 0; u < WD - 1; ++u) load_w(ln, u, wfh[u], wfl[u]);
             }
             CH_STAMP();
             lds_barrier();                                      // every wave is done reading the A planes
@@ -226,43 +255,50 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(ChainArgs p, i
 
             // ---- phase 1 (accumulators hold C^T: lane = row, registers = columns): un-scale, bias / activation or
             // derivative mask, 16-byte stores, row maxima
-            const float slope = L.act == PAPR_ACT_RELU ? 0.f : (L.act == PAPR_ACT_LEAKY_RELU ? 0.2f : 1.f);
+            // Instruction count matters here (one wave per SIMD and workgroup: nothing hides it).  acc * inv is exact (inv is
+            // a power of two), so fma(acc, inv, bias) equals the separate multiply and add bit for bit; ReLU is one
+            // v_max.  Columns beyond N need no masking: the weight planes are zero there, so acc is.
             const bool more = l + 1 < p.n_layers;
+            const float slope = L.act == PAPR_ACT_RELU ? 0.f : (L.act == PAPR_ACT_LEAKY_RELU ? 0.2f : 1.f);     // data-gradient: derivative on the negative side
+            auto rows_phase = [&](auto act_fn) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int rl = i * 32 + (lane & 31);
-                const long row = m0 + rl;
-                const float inv = inv_tab[rl];
-                float mx = 0.f;
+                for (int i = 0; i < 2; ++i) {
+                    const int rl = i * 32 + (lane & 31);
+                    const long row = m0 + rl;
+                    const float inv = inv_tab[rl];
+                    float mx = 0.f;
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    if (!live[j]) continue;
+                    for (int j = 0; j < 2; ++j) {
+                        if (!live[j]) continue;
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int col = (wn * 2 + j) * 32 + 8 * g + 4 * hh;
-                        const bool col_ok = col < N;
-                        float4 r = make_float4(acc[i][j][4 * g] * inv, acc[i][j][4 * g + 1] * inv, acc[i][j][4 * g + 2] * inv, acc[i][j][4 * g + 3] * inv);
-                        if (DGRAD) {
-                            if (L.mask) {
-                                const float4 a4 = aux[i][j][g];
-                                r.x *= a4.x > 0.f ? 1.f : slope; r.y *= a4.y > 0.f ? 1.f : slope;
-                                r.z *= a4.z > 0.f ? 1.f : slope; r.w *= a4.w > 0.f ? 1.f : slope;
+                        for (int g = 0; g < 4; ++g) {
+                            const int col = (wn * 2 + j) * 32 + 8 * g + 4 * hh;
+                            float4 r;
+                            if (DGRAD) {
+                                r = make_float4(acc[i][j][4 * g] * inv, acc[i][j][4 * g + 1] * inv, acc[i][j][4 * g + 2] * inv, acc[i][j][4 * g + 3] * inv);
+                                if (L.mask) {
+                                    const float4 a4 = aux[i][j][g];
+                                    r.x *= a4.x > 0.f ? 1.f : slope; r.y *= a4.y > 0.f ? 1.f : slope;
+                                    r.z *= a4.z > 0.f ? 1.f : slope; r.w *= a4.w > 0.f ? 1.f : slope;
+                                }
+                            } else {
+                                const float4 b4 = *reinterpret_cast<const float4*>(bias_tab + l * 256 + col);
+                                r.x = act_fn(__builtin_fmaf(acc[i][j][4 * g], inv, b4.x), 0.f);
+                                r.y = act_fn(__builtin_fmaf(acc[i][j][4 * g + 1], inv, b4.y), 0.f);
+                                r.z = act_fn(__builtin_fmaf(acc[i][j][4 * g + 2], inv, b4.z), 0.f);
+                                r.w = act_fn(__builtin_fmaf(acc[i][j][4 * g + 3], inv, b4.w), 0.f);
                             }
-                        } else {
-                            const float4 b4 = *reinterpret_cast<const float4*>(bias_tab + l * 256 + col);
-                            r.x += b4.x; r.y += b4.y; r.z += b4.z; r.w += b4.w;
-                            // (+0.f turns the -0 of a negative input times slope 0 into the +0 torch's relu returns)
-                            r.x = r.x > 0.f ? r.x : r.x * slope + 0.f; r.y = r.y > 0.f ? r.y : r.y * slope + 0.f;
-                            r.z = r.z > 0.f ? r.z : r.z * slope + 0.f; r.w = r.w > 0.f ? r.w : r.w * slope + 0.f;
+                            acc[i][j][4 * g] = r.x; acc[i][j][4 * g + 1] = r.y; acc[i][j][4 * g + 2] = r.z; acc[i][j][4 * g + 3] = r.w;
+                            if (L.C && col < N && row < p.M) *reinterpret_cast<float4*>(L.C + row * L.ldc + col) = r;
+                            mx = fmaxf(mx, fmaxf(fmaxf(fabsf(r.x), fabsf(r.y)), fmaxf(fabsf(r.z), fabsf(r.w))));
                         }
-                        if (!col_ok) r = make_float4(0.f, 0.f, 0.f, 0.f);
-                        acc[i][j][4 * g] = r.x; acc[i][j][4 * g + 1] = r.y; acc[i][j][4 * g + 2] = r.z; acc[i][j][4 * g + 3] = r.w;
-                        if (L.C && col_ok && row < p.M) *reinterpret_cast<float4*>(L.C + row * L.ldc + col) = r;
-                        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(r.x), fabsf(r.y)), fmaxf(fabsf(r.z), fabsf(r.w))));
                     }
+                    if (live[0]) atomicMax(rmax_tab + par * CH_BM + rl, __float_as_uint(mx));
                 }
-                if (live[0]) atomicMax(rmax_tab + par * CH_BM + rl, __float_as_uint(mx));
-            }
+            };
+            if (DGRAD || L.act == PAPR_ACT_NONE) rows_phase([](float v, float) { return v; });
+            else if (L.act == PAPR_ACT_RELU) rows_phase([](float v, float) { return fmaxf(v, 0.f); });
+            else rows_phase([](float v, float) { return fmaxf(v, 0.2f * v); });
             CH_STAMP();
             lds_barrier();                                      // row maxima complete
             CH_STAMP();
@@ -307,7 +343,7 @@ extern "C" int papr_chain_trace_read(long long* out) { return hipMemcpyFromSymbo
 
 size_t papr_chain_lds_bytes() { return CH_LDS_BYTES; }
 
-int papr_launch_chain(const ChainArgs& a, bool dgrad, long prof_cols, hipStream_t s) {
+int papr_launch_chain(const ChainArgs& a, bool dgrad, long long bytes, long long flops, hipStream_t s) {
     PAPR_REQUIRE(a.n_layers >= 1 && a.n_layers <= CHAIN_MAX_LAYERS, "mlp_chain: %d layers", a.n_layers);
     PAPR_REQUIRE(a.K0 % 4 == 0 && a.lda0 % 4 == 0 && a.K0 <= 256, "mlp_chain: input width %d", a.K0);
     if (a.M <= 0) return 0;
@@ -322,7 +358,7 @@ int papr_launch_chain(const ChainArgs& a, bool dgrad, long prof_cols, hipStream_
     }
     dim3 grid((unsigned)(tiles_m < 2 * n_cu ? tiles_m : 2 * n_cu));     // two workgroups per CU: one multiplies while the other is in its row phases
     const bool prof = papr_prof_on();
-    if (prof) papr_prof_begin(dgrad ? 10 : 9, a.M, (int)prof_cols, a.K0, s);
+    if (prof) papr_prof_begin2(dgrad ? 10 : 9, a.M, a.n_layers, a.K0, bytes, flops, s);
     if (dgrad) mlp_chain_kernel<true><<<grid, dim3(CH_THREADS), CH_LDS_BYTES, s>>>(a, tiles_m);
     else mlp_chain_kernel<false><<<grid, dim3(CH_THREADS), CH_LDS_BYTES, s>>>(a, tiles_m);
     if (prof) papr_prof_end(s);

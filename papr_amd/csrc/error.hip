@@ -25,9 +25,11 @@ bool g_on = false;
 
 bool papr_prof_on() { return g_on; }
 
-void papr_prof_begin(int kernel, long M, int N, int K, hipStream_t s) {
+void papr_prof_begin(int kernel, long M, int N, int K, hipStream_t s) { papr_prof_begin2(kernel, M, N, K, 0, 0, s); }
+
+void papr_prof_begin2(int kernel, long M, int N, int K, long long bytes, long long flops, hipStream_t s) {
     Pending p;
-    p.rec.kernel = kernel; p.rec.M = M; p.rec.N = N; p.rec.K = K; p.rec.ms = 0.f;
+    p.rec.kernel = kernel; p.rec.M = M; p.rec.N = N; p.rec.K = K; p.rec.ms = 0.f; p.rec.bytes = bytes; p.rec.flops = flops;
     (void)hipEventCreate(&p.a);
     (void)hipEventCreate(&p.b);
     (void)hipEventRecord(p.a, s);

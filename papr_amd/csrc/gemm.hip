@@ -1096,7 +1096,7 @@ extern "C" int papr_mlp_fwd(const papr_layer* layers, int n_layers, const float*
             c.rowmax0 = saved ? saved + (size_t)i * M : nullptr;
             c.M = M; c.n_layers = e - i;
             size_t used = 0;
-            long cols = 0;
+            long long bytes = 4LL * M * L.n_in, flops = 0;
             for (int l = i; l < e; ++l) {
                 ChainLayer& cl = c.L[l - i];
                 PAPR_REQUIRE(layers[l].weight && outs[l] && ld_out[l] >= layers[l].n_out, "papr_mlp_fwd: layer %d has null weight/output", l);
@@ -1104,11 +1104,13 @@ extern "C" int papr_mlp_fwd(const papr_layer* layers, int n_layers, const float*
                 PAPR_CHECK_LAUNCH("split_weight");
                 cl.bias = layers[l].bias; cl.act = layers[l].act;
                 cl.C = (saved || l == e - 1) ? outs[l] : nullptr; cl.ldc = ld_out[l];
-                if (cl.C) cols += layers[l].n_out;
+                if (cl.C) bytes += 4LL * M * layers[l].n_out;
+                bytes += 4LL * layers[l].n_out * layers[l].n_in;
+                flops += 2LL * M * layers[l].n_out * layers[l].n_in;
                 cl.rowmax = l + 1 < n_layers ? (saved ? saved + (size_t)(l + 1) * M : (l == e - 1 ? reinterpret_cast<float*>(h3.out()) : nullptr)) : nullptr;
             }
             PAPR_REQUIRE(used <= H3_PLANE_HALFS, "papr_mlp_fwd: fused run needs %zu plane halfs", used);
-            if (int err = papr_launch_chain(c, false, cols, s)) return err;
+            if (int err = papr_launch_chain(c, false, bytes, flops, s)) return err;
             if (!saved) h3.swap();
             have_amax = true;
             i = e - 1;
@@ -1226,7 +1228,7 @@ extern "C" int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float*
             c.A0 = g; c.lda0 = ldg; c.K0 = L.n_out; c.rowmax0 = runs.gmax[CHAIN_MAX_LAYERS];
             c.M = M;
             size_t used = 0;
-            long cols = 0;
+            long long bytes = 4LL * M * L.n_out, flops = 0;
             for (int l = i; l >= last; --l) {
                 const papr_layer& Ll = layers[l];
                 PAPR_REQUIRE(Ll.weight_t, "papr_mlp_bwd: layer %d needs weight_t", l);
@@ -1237,15 +1239,17 @@ extern "C" int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float*
                     cl.mask = outs[l - 1]; cl.ld_mask = ld_out[l - 1]; cl.act = layers[l - 1].act;
                     cl.C = runs.g[l - 1 - (b > 0 ? b - 1 : 0)]; cl.ldc = G_LD;
                     cl.rowmax = runs.gmax[l - 1 - (b > 0 ? b - 1 : 0)];
-                    cols += 2 * Ll.n_in;
+                    bytes += 8LL * M * Ll.n_in;
                 } else {
                     cl.C = d_x; cl.ldc = ldx; cl.act = PAPR_ACT_NONE;
-                    cols += Ll.n_in;
+                    bytes += 4LL * M * Ll.n_in;
                 }
+                bytes += 4LL * Ll.n_out * Ll.n_in;
+                flops += 2LL * M * Ll.n_out * Ll.n_in;
             }
             PAPR_REQUIRE(used <= H3_PLANE_HALFS, "papr_mlp_bwd: fused run needs %zu plane halfs", used);
             if (c.n_layers > 0)
-                if (int err = papr_launch_chain(c, true, cols, s)) return err;
+                if (int err = papr_launch_chain(c, true, bytes, flops, s)) return err;
             auto slot = [&](int l) { return l - (b > 0 ? b - 1 : 0); };
             // (the launch above leaves max |g| of the run's top rows in the last gmax slot, computed while staging them)
             if (c.n_layers == 0)

@@ -8,6 +8,7 @@
 void papr_set_error(const char* fmt, ...);
 bool papr_prof_on();
 void papr_prof_begin(int kernel, long M, int N, int K, hipStream_t s);
+void papr_prof_begin2(int kernel, long M, int N, int K, long long bytes, long long flops, hipStream_t s);
 void papr_prof_end(hipStream_t s);
 
 #define PAPR_REQUIRE(cond, ...)                \

@@ -38,7 +38,8 @@ class Layer(C.Structure):
 
 
 class ProfileRecord(C.Structure):
-    _fields_ = [("kernel", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("M", C.c_int64), ("ms", C.c_float)]
+    _fields_ = [("kernel", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("M", C.c_int64), ("ms", C.c_float),
+                ("bytes", C.c_int64), ("flops", C.c_int64)]
 
 
 class TailDesc(C.Structure):
@@ -112,10 +113,11 @@ def profile_enable(on):
 
 
 def profile_collect(cap=65536):
-    """[(kernel, M, N, K, ms), ...] of the launches timed since the last call."""
+    """[(kernel, M, N, K, ms), ...] of the launches timed since the last call (fused-run launches, kernels 9 and 10:
+    (kernel, M, n_layers, K0, ms, bytes, flops))."""
     buf = (ProfileRecord * cap)()
     n = lib().papr_profile_collect(buf, cap)
-    return [(r.kernel, r.M, r.N, r.K, r.ms) for r in buf[:min(n, cap)]]
+    return [(r.kernel, r.M, r.N, r.K, r.ms) + ((r.bytes, r.flops) if r.kernel in (9, 10) else ()) for r in buf[:min(n, cap)]]
 
 
 def check(code, what):

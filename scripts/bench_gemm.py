@@ -47,7 +47,8 @@ def rep_chain(tag, recs, kid):
     r = [x for x in recs if x[0] == kid]
     if not r: return
     ms = sum(x[4] for x in r) / len(r)
-    print("%-28s n=%3d avg %.1f us per launch (%d stored/masked columns, %.0f GB/s algorithmic)" % (tag, len(r), ms * 1e3, r[0][2], 4.0 * r[0][1] * (r[0][2] + r[0][3]) / ms / 1e6))
+    print("%-28s n=%3d avg %.1f us per launch of %d layers (%.0f GB/s algorithmic, %.0f TFLOP/s of f16 MFMA = %.0f fp32-equivalent)"
+          % (tag, len(r), ms * 1e3, r[0][2], r[0][5] / ms / 1e6, 3 * r[0][6] / ms / 1e9, r[0][6] / ms / 1e9))
 rep_chain("fwd  mlp_chain", fwd, 9)
 rep_chain("dgrad mlp_chain", bwd, 10)
 hip.profile_enable(True)
