@@ -4,21 +4,34 @@
 // data-gradient) for runs of consecutive layers without skip input and at most 256 wide.
 //
 // Why: layer by layer, the split-f16 GEMM is HBM-bound -- it reads the (M x 256) input and writes the
-// (M x 256) output of every layer.  But a workgroup's 128 x 256 output tile holds COMPLETE rows, and
-// those rows are exactly the A operand of the next layer for the same 128 rows.  So a workgroup carries
-// its 128 rows through all layers of the run: the activations stay in LDS as split f16 planes, HBM sees
-// the input once and each saved activation once (training), or only the last one (inference).
+// (M x 256) output of every layer.  But a workgroup that owns COMPLETE rows of a layer's output owns the
+// A operand of the next layer for the same rows.  So a workgroup carries 64 rows through all layers of
+// the run: the activations stay in LDS as split f16 planes, HBM sees the input once and each saved
+// activation once (training), or only the last one (inference).  The data-gradient run is the same
+// kernel walking the layers downwards with the transposed weights and the activation derivative as mask.
 //
-// Per layer and tile:   k-loop   16 k-steps x 12 MFMA per wave, A fragments from LDS (resident, no
-//                                staging barriers), W fragments straight from L2 in fragment order
-//                       phase 1  accumulators -> per-wave LDS patch -> rows: un-scale, bias/activation
-//                                (or derivative mask), 16-byte global stores, row maxima (LDS atomics)
-//                       phase 2  rows -> per-row power-of-two scale from the row maxima -> hi/lo split
-//                                -> the A planes of the next layer
-// with one LDS-only barrier between the stages (the patch aliases the then-idle A planes).
+// Shape: 4 waves (one per SIMD), each a 64-row x 64-column corner of the 64 x 256 tile; 76.5 KB of LDS,
+// so TWO workgroups share a CU and one multiplies while the other is in its row phases.
+//
+// Per layer and tile:   k-loop   16 k-steps x 12 MFMA per wave.  The MFMA takes the W fragment as its row
+//                                operand, so the accumulators hold C^T: a lane owns ONE ROW of the tile
+//                                and its registers are runs of 4 consecutive columns.  A fragments from
+//                                LDS (resident: no staging, no barriers), W fragments straight from L2 in
+//                                fragment order through a register ring (three k-steps ahead), every
+//                                request alone behind an MFMA (sched_barrier pins that; see the k-loop)
+//                       phase 1  in registers, no LDS bounce: un-scale + bias + activation (one fma, one
+//                                max) or derivative mask, 16-byte row stores, row maximum -> LDS atomic
+//                       phase 2  per-row power-of-two scale from the row maxima, hi/lo split, 8-byte LDS
+//                                writes: the rows become the A planes of the next layer
+// with one LDS-only barrier between the stages.
+//
+// Measured (512,000 rows, 256-wide layers, MI355X): 215 us per layer in inference and 290 / 350 us per
+// forward / data-gradient layer in training, against 369 / 483 us for the per-layer kernel.  Half of the
+// remaining time is not matrix work: scripts/probes/chain_trace.py (cycle stamps), mfma_filler.hip.
 #include "papr_common.h"
 #include "h3_common.h"
 #include "chain.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -127,7 +140,11 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(ChainArgs p, i
                 for (int u = 0; u < SR; ++u) {
                     long m = m0 + wave + 4 * (u0 + u);
                     m = m < p.M ? m : p.M - 1;
+#ifdef CH_EXP_NO_STAGING
+                    v[u] = make_float4((float)m, 1.f, 2.f, 3.f);
+#else
                     v[u] = c < p.K0 ? *reinterpret_cast<const float4*>(p.A0 + m * p.lda0 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
                 }
 #pragma unroll
                 for (int u = 0; u < SR; ++u) {
@@ -199,16 +216,6 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(ChainArgs p, i
                 }
             };
             // W fragment as the row operand: the accumulators hold C^T (lane = row m, registers = columns n)
-            auto mma_all = [&](const half8 (&qh)[2], const half8 (&ql)[2], const half8 (&ah)[2], const half8 (&al)[2]) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh[j], al[i], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ql[j], ah[i], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh[j], ah[i], acc[i][j], 0, 0, 0);
-                    }
-            };
             auto mma_live = [&](const half8 (&qh)[2], const half8 (&ql)[2], const half8 (&ah)[2], const half8 (&al)[2]) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
@@ -221,29 +228,90 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(ChainArgs p, i
                     }
                 }
             };
-            auto k_loop = [&](auto mma) {
+            auto k_loop = [&](auto mma) {                       // waves with a dead column tile (narrow layers): simple form
                 half8 a0h[2], a0l[2], a1h[2], a1l[2];
                 load_a(0, a0h, a0l);
 #pragma unroll 1
                 for (int ks = 0; ks < ksteps; ks += 4) {       // ksteps is even (planes are padded to 32 columns)
                     load_w(l, ks + 3, wfh[3], wfl[3]);
                     load_a(ks + 1, a1h, a1l);
+                    __builtin_amdgcn_sched_barrier(0);
                     mma(wfh[0], wfl[0], a0h, a0l);
+                    __builtin_amdgcn_sched_barrier(0);
                     load_w(l, ks + 4, wfh[0], wfl[0]);
                     load_a(ks + 2, a0h, a0l);
+                    __builtin_amdgcn_sched_barrier(0);
                     mma(wfh[1], wfl[1], a1h, a1l);
+                    __builtin_amdgcn_sched_barrier(0);
                     load_w(l, ks + 5, wfh[1], wfl[1]);
                     if (ks + 2 < ksteps) {
                         load_a(ks + 3, a1h, a1l);
+                        __builtin_amdgcn_sched_barrier(0);
                         mma(wfh[2], wfl[2], a0h, a0l);
+                        __builtin_amdgcn_sched_barrier(0);
                         load_w(l, ks + 6, wfh[2], wfl[2]);
                         load_a(ks + 4, a0h, a0l);
+                        __builtin_amdgcn_sched_barrier(0);
                         mma(wfh[3], wfl[3], a1h, a1l);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
             };
-            if (live[1]) k_loop(mma_all);                       // both column tiles of this wave hold real columns: no tests inside
+            // The hot form (both column tiles live).  One wave per SIMD and workgroup means nothing else covers this
+            // wave's issue slots: a block of ~25 load / address instructions between two k-steps leaves the matrix pipe
+            // idle for ~130 cycles per 384-cycle step (measured).  So every request sits alone behind an MFMA -- a
+            // 32-cycle MFMA hides about five issue slots -- and sched_barrier pins that order (left alone, hipcc sinks the
+            // loads to just before their use and waits with vmcnt(0)).
+            // (scalar base + 32-bit lane offset: a 64-bit VALU address computation per load costs far more than its issue
+            // slot next to MFMAs)
+            const char* wb_h[2] = {reinterpret_cast<const char*>(L.w_hi) + (size_t)((wn * 2 + 0) * ksteps) * 1024, reinterpret_cast<const char*>(L.w_hi) + (size_t)((wn * 2 + 1) * ksteps) * 1024};
+            const char* wb_l[2] = {reinterpret_cast<const char*>(L.w_lo) + (size_t)((wn * 2 + 0) * ksteps) * 1024, reinterpret_cast<const char*>(L.w_lo) + (size_t)((wn * 2 + 1) * ksteps) * 1024};
+            const unsigned lane16 = (unsigned)lane * 16u;
+#define CH_SB __builtin_amdgcn_sched_barrier(0)
+#define CH_MFMA(i, j, w, x) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[j], x[i], acc[i][j], 0, 0, 0)
+            auto step = [&](const half8 (&uh)[2], const half8 (&ul)[2], const half8 (&xh)[2], const half8 (&xl)[2],
+                            int kw, half8 (&nh)[2], half8 (&nl)[2], int ka, half8 (&yh)[2], half8 (&yl)[2]) {
+                kw = kw < ksteps ? kw : ksteps - 1;
+                ka = ka < ksteps ? ka : ksteps - 1;
+#ifdef CH_EXP_NO_W
+                const bool ldw = kw <= 2;
+#else
+                constexpr bool ldw = true;
+#endif
+#ifdef CH_EXP_NO_A
+                const bool lda = ka <= 1;
+#else
+                constexpr bool lda = true;
+#endif
+                CH_MFMA(0, 0, uh, xl); CH_SB; if (ldw) nh[0] = *reinterpret_cast<const half8*>(wb_h[0] + (size_t)kw * 1024 + lane16); CH_SB;
+                CH_MFMA(1, 0, uh, xl); CH_SB; if (ldw) nl[0] = *reinterpret_cast<const half8*>(wb_l[0] + (size_t)kw * 1024 + lane16); CH_SB;
+                CH_MFMA(0, 1, uh, xl); CH_SB; if (ldw) nh[1] = *reinterpret_cast<const half8*>(wb_h[1] + (size_t)kw * 1024 + lane16); CH_SB;
+                CH_MFMA(1, 1, uh, xl); CH_SB; if (ldw) nl[1] = *reinterpret_cast<const half8*>(wb_l[1] + (size_t)kw * 1024 + lane16); CH_SB;
+                CH_MFMA(0, 0, ul, xh); CH_SB; if (lda) yh[0] = *reinterpret_cast<const half8*>(Ah + frag + ka * 16); CH_SB;
+                CH_MFMA(1, 0, ul, xh); CH_SB; if (lda) yl[0] = *reinterpret_cast<const half8*>(Al + frag + ka * 16); CH_SB;
+                CH_MFMA(0, 1, ul, xh); CH_SB; if (lda) yh[1] = *reinterpret_cast<const half8*>(Ah + 32 * CH_AP + frag + ka * 16); CH_SB;
+                CH_MFMA(1, 1, ul, xh); CH_SB; if (lda) yl[1] = *reinterpret_cast<const half8*>(Al + 32 * CH_AP + frag + ka * 16); CH_SB;
+                CH_MFMA(0, 0, uh, xh); CH_MFMA(1, 0, uh, xh); CH_MFMA(0, 1, uh, xh); CH_MFMA(1, 1, uh, xh); CH_SB;
+            };
+            auto k_loop_full = [&]() {
+                half8 a0h[2], a0l[2], a1h[2], a1l[2];
+                load_a(0, a0h, a0l);
+#pragma unroll 1
+                for (int ks = 0; ks < ksteps; ks += 4) {
+                    step(wfh[0], wfl[0], a0h, a0l, ks + 3, wfh[3], wfl[3], ks + 1, a1h, a1l);
+                    step(wfh[1], wfl[1], a1h, a1l, ks + 4, wfh[0], wfl[0], ks + 2, a0h, a0l);
+                    if (ks + 2 < ksteps) {
+                        step(wfh[2], wfl[2], a0h, a0l, ks + 5, wfh[1], wfl[1], ks + 3, a1h, a1l);
+                        step(wfh[3], wfl[3], a1h, a1l, ks + 6, wfh[2], wfl[2], ks + 4, a0h, a0l);
+                    }
+                }
+            };
+#undef CH_MFMA
+#undef CH_SB
+#ifndef CH_EXP_NO_KLOOP
+            if (live[1]) k_loop_full();                         // both column tiles of this wave hold real columns
             else if (live[0]) k_loop(mma_live);
+#endif
             {   // first fragments of what comes next: the next layer, or layer 0 of the next tile
                 const int ln = l + 1 < p.n_layers ? l + 1 : 0;
 #pragma unroll
@@ -296,9 +364,11 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(ChainArgs p, i
                     if (live[0]) atomicMax(rmax_tab + par * CH_BM + rl, __float_as_uint(mx));
                 }
             };
+#ifndef CH_EXP_NO_PHASES
             if (DGRAD || L.act == PAPR_ACT_NONE) rows_phase([](float v, float) { return v; });
             else if (L.act == PAPR_ACT_RELU) rows_phase([](float v, float) { return fmaxf(v, 0.f); });
             else rows_phase([](float v, float) { return fmaxf(v, 0.2f * v); });
+#endif
             CH_STAMP();
             lds_barrier();                                      // row maxima complete
             CH_STAMP();
@@ -308,6 +378,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(ChainArgs p, i
                 if (L.rowmax && m0 + tid < p.M) L.rowmax[m0 + tid] = __uint_as_float(rmax_tab[par * CH_BM + tid]);
                 rmax_tab[(par ^ 1) * CH_BM + tid] = 0u;
             }
+#ifndef CH_EXP_NO_PHASES
             if (more) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
@@ -329,6 +400,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(ChainArgs p, i
                     }
                 }
             }
+#endif
             lds_barrier();
             CH_STAMP();
         }
@@ -356,7 +428,8 @@ int papr_launch_chain(const ChainArgs& a, bool dgrad, long long bytes, long long
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_chain_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CH_LDS_BYTES);
         attr_set = true;
     }
-    dim3 grid((unsigned)(tiles_m < 2 * n_cu ? tiles_m : 2 * n_cu));     // two workgroups per CU: one multiplies while the other is in its row phases
+    static const int wgs_per_cu = getenv("PAPR_CHAIN_WGS_PER_CU") ? atoi(getenv("PAPR_CHAIN_WGS_PER_CU")) : 2;   // (A/B switch)
+    dim3 grid((unsigned)(tiles_m < wgs_per_cu * n_cu ? tiles_m : wgs_per_cu * n_cu));     // two workgroups per CU: one multiplies while the other is in its row phases
     const bool prof = papr_prof_on();
     if (prof) papr_prof_begin2(dgrad ? 10 : 9, a.M, a.n_layers, a.K0, bytes, flops, s);
     if (dgrad) mlp_chain_kernel<true><<<grid, dim3(CH_THREADS), CH_LDS_BYTES, s>>>(a, tiles_m);
