@@ -58,9 +58,11 @@ __device__ __forceinline__ float wave64_max(float v) {
     v = seg8_max(v);
     int x = __float_as_int(v);
     v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x140, 0xf, 0xf, false)));   // row_mirror: 16 lanes
-    v = fmaxf(v, __shfl_xor(v, 16, 64));
-    v = fmaxf(v, __shfl_xor(v, 32, 64));
-    return v;
+    // the four 16-lane rows meet on the scalar unit (a ds_bpermute butterfly costs two LDS round trips per row)
+    const int r = __float_as_int(v);
+    const float a = __int_as_float(__builtin_amdgcn_readlane(r, 0)), b = __int_as_float(__builtin_amdgcn_readlane(r, 16));
+    const float c = __int_as_float(__builtin_amdgcn_readlane(r, 32)), d = __int_as_float(__builtin_amdgcn_readlane(r, 48));
+    return fmaxf(fmaxf(a, b), fmaxf(c, d));
 }
 
 __device__ __forceinline__ float scale_from_max(unsigned bits, float& inv) {      // row max -> [2^13, 2^14)
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(ChainArgs p, i
     };
 #pragma unroll
     for (int u = 0; u < WD - 1; ++u) load_w(0, u, wfh[u], wfl[u]);
-    constexpr int SR = 8;                        // input rows per wave and staging pass (16 per tile)
+    constexpr int SR = 8;                        // input rows per wave and staging pass (16 per tile; one pass of 16 is no faster)
     // Two workgroups share a CU so that one multiplies while the other is in its row phases.  Launched together and
     // with identical timing they would run in lockstep instead (both multiplying at half speed, then both leaving the
     // matrix pipe idle): the second wave of workgroups starts half a layer late.
@@ -357,6 +359,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(ChainArgs p, i
                                 r.w = act_fn(__builtin_fmaf(acc[i][j][4 * g + 3], inv, b4.w), 0.f);
                             }
                             acc[i][j][4 * g] = r.x; acc[i][j][4 * g + 1] = r.y; acc[i][j][4 * g + 2] = r.z; acc[i][j][4 * g + 3] = r.w;
+                            // (plain stores: the 32-byte pieces of a line meet in L2; non-temporal stores double the run time)
                             if (L.C && col < N && row < p.M) *reinterpret_cast<float4*>(L.C + row * L.ldc + col) = r;
                             mx = fmaxf(mx, fmaxf(fmaxf(fabsf(r.x), fabsf(r.y)), fmaxf(fabsf(r.z), fabsf(r.w))));
                         }

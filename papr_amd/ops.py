@@ -82,10 +82,10 @@ def prepare_mlp_weights(spec, weights, biases, ln_in=None):
         if ln_in is not None:
             a, sh = ln_in
             if i == 0:
-                b = b + main @ sh
+                b = b + (main * sh).sum(1)      # (not `main @ sh`: rocBLAS' gemv takes 58 us for a 256 x 117 matrix)
                 main = main * a
             if extra is not None:
-                b = b + extra @ sh
+                b = b + (extra * sh).sum(1)
                 extra = extra * a
         main = F.pad(main, (0, L["n_in"] - main.shape[1]))
         if extra is not None:
