@@ -20,7 +20,7 @@ from . import dist as pdist
 from .config import as_node
 from .ops import RenderPath, prepare_mlp_weights, render_rays
 from .pointcloud import grow_points
-from .schedule import create_learning_rate_fn
+from .schedule import create_learning_rate_fn, fast_forward
 from .unet import get_generator
 
 
@@ -224,11 +224,10 @@ class PAPR(nn.Module):
                 print("Fixing {}".format(name))
                 self.optimizers.pop(name)
                 self.schedulers.pop(name)
-        if total_steps > 0:
-            for sched in self.schedulers.values():
-                if sched is not None:
-                    for _ in range(total_steps):
-                        sched.step()
+        if total_steps > 0:                          # closed form instead of the reference's replay loop (schedule.fast_forward)
+            opts = {name: opt for name, _, opt in self._groups()}
+            for name, sched in self.schedulers.items():
+                fast_forward(sched, opts[name], self.args.training.steps, total_steps, lr.lr_factor)
 
     def clear_optimizer(self):
         self.optimizers.clear()

@@ -22,7 +22,7 @@ def seed_all(s):
 def build(tag="chair1k", seed=1):
     from papr_amd import get_model
     seed_all(seed)
-    return get_model(case_cfg(tag), device="cpu")
+    return get_model(tag if isinstance(tag, dict) else case_cfg(tag), device="cpu")
 
 
 def stats(t):
@@ -100,16 +100,32 @@ def test_schedules_follow_reference_trajectory():
 
 
 def test_init_optimizers_fast_forward_equals_stepping():
-    m = build()
-    for step in range(25):
-        for s in m.schedulers.values():
-            s.step()
-    lrs = {n: o.param_groups[0]["lr"] for n, o in m.optimizers.items()}
-    m.clear_optimizer(); m.clear_scheduler()
-    m.init_optimizers(25)
-    for n, o in m.optimizers.items():
-        assert o.param_groups[0]["lr"] == pytest.approx(lrs[n], rel=1e-12)
-
+    """init_optimizers(n) jumps to step n in closed form; the state must be the one n scheduler steps leave behind,
+    and stepping on from there must follow the same trajectory (below, inside and right at the end of the warm-up)."""
+    import warnings
+    cfg = case_cfg("chair1k")
+    cfg["training"]["lr"]["attn"]["warmup"] = 40
+    cfg["training"]["lr"]["points"]["warmup"] = 0
+    cfg["training"]["steps"] = 300
+    for n in (1, 25, 39, 40, 41, 120):
+        m = build(cfg)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for step in range(n):
+                for s_ in m.schedulers.values():
+                    s_.step()
+        m2 = build(cfg)
+        m2.clear_optimizer(); m2.clear_scheduler()
+        m2.init_optimizers(n)
+        for extra in range(5):
+            for name in m.optimizers:
+                a_, b_ = m.optimizers[name].param_groups[0]["lr"], m2.optimizers[name].param_groups[0]["lr"]
+                assert b_ == pytest.approx(a_, rel=1e-9, abs=1e-30), (n, extra, name)
+                assert m2.schedulers[name].get_last_lr()[0] == pytest.approx(m.schedulers[name].get_last_lr()[0], rel=1e-9, abs=1e-30)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                for s_ in list(m.schedulers.values()) + list(m2.schedulers.values()):
+                    s_.step()
 
 def test_prune_keeps_strictly_greater_and_drops_untouched_points():
     m = build()
