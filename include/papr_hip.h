@@ -135,10 +135,13 @@ typedef struct {
  * the split-f16 GEMM; see gemm.hip).  Arithmetic: fp32 in, fp32 out; wide layers multiply on the f16
  * matrix pipe with every fp32 operand split into two halves (22 mantissa bits, fp32 accumulation) unless
  * the environment variable PAPR_GEMM_MODE=f32 selects fp32 MFMA everywhere.
- * row_absmax: NULL, or (n_layers, M) floats that receive max_k |input row m of layer i| at [i*M + m] for
- * every layer that ran on the split-f16 kernel (other entries undefined).  Pass the same buffer to
- * papr_mlp_bwd: the weight-gradient GEMM of such a layer then also runs with split-f16 operands, scaled
- * by these maxima (without it, weight-gradients use fp32 MFMA). */
+ * row_absmax: NULL (inference: nothing is kept for a backward pass, and only outs[n_layers-1] is defined
+ * afterwards), or papr_mlp_saved_floats(n_layers, M) floats of state for papr_mlp_bwd: max_k |input row m
+ * of layer i| at [i*M + m] for every layer that ran on a split-f16 kernel (other entries undefined),
+ * followed by one sign bit per activation of the layers a fused run produced.  Pass the same buffer to
+ * papr_mlp_bwd: weight-gradients then run with split-f16 operands scaled by the maxima (fp32 MFMA
+ * without it), and the data-gradient run reads the sign bits instead of the fp32 activations. */
+size_t papr_mlp_saved_floats(int32_t n_layers, int64_t M);
 size_t papr_mlp_fwd_workspace_bytes(int64_t M);
 int papr_mlp_fwd(const papr_layer* layers, int n_layers, const float* x, int ldx, int64_t M,
                  float* const* outs, const int32_t* ld_out, float* row_absmax, void* workspace,

@@ -11,6 +11,8 @@ struct ChainLayer {
     const float* bias;         // forward: (N) or null
     const float* mask;         // data-gradient: activation outputs whose derivative multiplies this layer's result, or null
     long ld_mask;
+    unsigned* sign_bits;       // (8, M) words: forward = written (bit set where the result is > 0), data-gradient = read in place of mask; or null.
+                               // word [(2 wn + h) * M + m] holds the 32 columns 64 wn + 32 j + 8 g + 4 h + c of row m, (j, g, c) = 0 first, in the top bit
     float* C;                  // (M, ldc) result rows, or null when nobody needs them in memory
     long ldc;
     float* rowmax;             // (M) max |.| of every result row, or null

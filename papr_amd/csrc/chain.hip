@@ -78,7 +78,10 @@ __device__ long long g_chain_trace[256];
 #define CH_STAMP() do {} while (0)
 #endif
 
-template <bool DGRAD>
+// BITS (data-gradient only): the activation derivative comes from the sign words the forward run left behind
+// (L.sign_bits) instead of the fp32 activation rows (L.mask): 16 MB instead of 524 MB per layer, and 2 registers
+// instead of 64.
+template <bool DGRAD, bool BITS>
 __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(ChainArgs p, int tiles_m) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     _Float16* Ah = reinterpret_cast<_Float16*>(smem);
@@ -192,9 +195,14 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(ChainArgs p, i
             // (a load issued among the stores of phase 1 would wait for them: loads and stores share vmcnt)
             const int hh = lane >> 5;
             float4 aux[2][2][4];
+            unsigned mbits[2] = {0u, 0u};
             auto load_aux = [&](int i) {
                 long row = m0 + i * 32 + (lane & 31);
                 row = row < p.M ? row : p.M - 1;
+                if (BITS) {
+                    mbits[i] = L.sign_bits[(long)(wn * 2 + hh) * p.M + row];
+                    return;
+                }
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -204,7 +212,8 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(ChainArgs p, i
                         aux[i][j][g] = *reinterpret_cast<const float4*>(L.mask + row * L.ld_mask + col);
                     }
             };
-            if (DGRAD && L.mask) { load_aux(0); load_aux(1); }
+            const bool masked = DGRAD && (BITS ? L.sign_bits != nullptr : L.mask != nullptr);
+            if (masked) { load_aux(0); load_aux(1); }
 
             // ---- k-loop.  The A fragments of k-step s+1 are read from LDS while k-step s multiplies (hipcc does not
             // pipeline the reads by itself: it places them right in front of their MFMAs and waits).
@@ -330,6 +339,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(ChainArgs p, i
             // v_max.  Columns beyond N need no masking: the weight planes are zero there, so acc is.
             const bool more = l + 1 < p.n_layers;
             const float slope = L.act == PAPR_ACT_RELU ? 0.f : (L.act == PAPR_ACT_LEAKY_RELU ? 0.2f : 1.f);     // data-gradient: derivative on the negative side
+            const bool want_bits = !DGRAD && L.sign_bits != nullptr;      // forward: leave the signs for the data-gradient run
             auto rows_phase = [&](auto act_fn) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
@@ -337,19 +347,27 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(ChainArgs p, i
                     const long row = m0 + rl;
                     const float inv = inv_tab[rl];
                     float mx = 0.f;
+                    unsigned sb = 0u;                           // forward: sign word of this lane's 32 values, first value in the top bit
+                    unsigned mb = mbits[i];
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        if (!live[j]) continue;
+                        if (!live[j]) { sb <<= 16; mb <<= 16; continue; }
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
                             const int col = (wn * 2 + j) * 32 + 8 * g + 4 * hh;
                             float4 r;
                             if (DGRAD) {
                                 r = make_float4(acc[i][j][4 * g] * inv, acc[i][j][4 * g + 1] * inv, acc[i][j][4 * g + 2] * inv, acc[i][j][4 * g + 3] * inv);
-                                if (L.mask) {
-                                    const float4 a4 = aux[i][j][g];
-                                    r.x *= a4.x > 0.f ? 1.f : slope; r.y *= a4.y > 0.f ? 1.f : slope;
-                                    r.z *= a4.z > 0.f ? 1.f : slope; r.w *= a4.w > 0.f ? 1.f : slope;
+                                if (masked) {
+                                    if (BITS) {
+                                        r.x *= (int)mb < 0 ? 1.f : slope; r.y *= (int)(mb << 1) < 0 ? 1.f : slope;
+                                        r.z *= (int)(mb << 2) < 0 ? 1.f : slope; r.w *= (int)(mb << 3) < 0 ? 1.f : slope;
+                                        mb <<= 4;
+                                    } else {
+                                        const float4 a4 = aux[i][j][g];
+                                        r.x *= a4.x > 0.f ? 1.f : slope; r.y *= a4.y > 0.f ? 1.f : slope;
+                                        r.z *= a4.z > 0.f ? 1.f : slope; r.w *= a4.w > 0.f ? 1.f : slope;
+                                    }
                                 }
                             } else {
                                 const float4 b4 = *reinterpret_cast<const float4*>(bias_tab + l * 256 + col);
@@ -357,6 +375,8 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(ChainArgs p, i
                                 r.y = act_fn(__builtin_fmaf(acc[i][j][4 * g + 1], inv, b4.y), 0.f);
                                 r.z = act_fn(__builtin_fmaf(acc[i][j][4 * g + 2], inv, b4.z), 0.f);
                                 r.w = act_fn(__builtin_fmaf(acc[i][j][4 * g + 3], inv, b4.w), 0.f);
+                                if (want_bits)
+                                    sb = (sb << 4) | (r.x > 0.f ? 8u : 0u) | (r.y > 0.f ? 4u : 0u) | (r.z > 0.f ? 2u : 0u) | (r.w > 0.f ? 1u : 0u);
                             }
                             acc[i][j][4 * g] = r.x; acc[i][j][4 * g + 1] = r.y; acc[i][j][4 * g + 2] = r.z; acc[i][j][4 * g + 3] = r.w;
                             // (plain stores: the 32-byte pieces of a line meet in L2; non-temporal stores double the run time)
@@ -364,6 +384,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(ChainArgs p, i
                             mx = fmaxf(mx, fmaxf(fmaxf(fabsf(r.x), fabsf(r.y)), fmaxf(fabsf(r.z), fabsf(r.w))));
                         }
                     }
+                    if (want_bits && row < p.M) L.sign_bits[(long)(wn * 2 + hh) * p.M + row] = sb;
                     if (live[0]) atomicMax(rmax_tab + par * CH_BM + rl, __float_as_uint(mx));
                 }
             };
@@ -427,16 +448,21 @@ int papr_launch_chain(const ChainArgs& a, bool dgrad, long long bytes, long long
     if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu <= 0) n_cu = 256; }
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_chain_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CH_LDS_BYTES);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_chain_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CH_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_chain_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CH_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_chain_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CH_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_chain_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CH_LDS_BYTES);
         attr_set = true;
     }
     static const int wgs_per_cu = getenv("PAPR_CHAIN_WGS_PER_CU") ? atoi(getenv("PAPR_CHAIN_WGS_PER_CU")) : 2;   // (A/B switch)
     dim3 grid((unsigned)(tiles_m < wgs_per_cu * n_cu ? tiles_m : wgs_per_cu * n_cu));     // two workgroups per CU: one multiplies while the other is in its row phases
     const bool prof = papr_prof_on();
     if (prof) papr_prof_begin2(dgrad ? 10 : 9, a.M, a.n_layers, a.K0, bytes, flops, s);
-    if (dgrad) mlp_chain_kernel<true><<<grid, dim3(CH_THREADS), CH_LDS_BYTES, s>>>(a, tiles_m);
-    else mlp_chain_kernel<false><<<grid, dim3(CH_THREADS), CH_LDS_BYTES, s>>>(a, tiles_m);
+    // a data-gradient run reads sign words when every masked layer has them, fp32 activation rows otherwise
+    bool bits = dgrad;
+    for (int l = 0; l < a.n_layers; ++l) bits = bits && (a.L[l].mask == nullptr || a.L[l].sign_bits != nullptr);
+    if (dgrad && bits) mlp_chain_kernel<true, true><<<grid, dim3(CH_THREADS), CH_LDS_BYTES, s>>>(a, tiles_m);
+    else if (dgrad) mlp_chain_kernel<true, false><<<grid, dim3(CH_THREADS), CH_LDS_BYTES, s>>>(a, tiles_m);
+    else mlp_chain_kernel<false, false><<<grid, dim3(CH_THREADS), CH_LDS_BYTES, s>>>(a, tiles_m);
     if (prof) papr_prof_end(s);
     PAPR_CHECK_LAUNCH("mlp_chain");
     return 0;

@@ -1037,6 +1037,13 @@ __global__ __launch_bounds__(256) void act_grad_kernel(float* g, long ldg, const
 constexpr size_t TN_SLAB_BYTES = (size_t)MAX_SLICES * (SLAB * SLAB + SLAB) * sizeof(float);
 
 extern "C" size_t papr_mlp_fwd_workspace_bytes(int64_t M) { return H3Scratch::bytes(M); }
+extern "C" size_t papr_mlp_saved_floats(int32_t n_layers, int64_t M) { return (size_t)n_layers * M * 9; }
+
+// Layout of the `row_absmax` buffer of papr_mlp_fwd / papr_mlp_bwd (papr_mlp_saved_floats(n_layers, M) floats):
+// [n_layers][M] row maxima, then [n_layers][8][M] sign words of the layer outputs (fused runs, chain.h).
+static unsigned* saved_sign_words(const float* saved, int n_layers, long M, int layer) {
+    return reinterpret_cast<unsigned*>(const_cast<float*>(saved)) + (size_t)n_layers * M + (size_t)layer * 8 * M;
+}
 
 // layer i runs on the split-f16 forward kernel (and so leaves the row maxima of its input behind)
 static bool layer_on_h3(const papr_layer& L) { return GEMM_H3_FWD && L.n_out > 128 && L.n_skip == 0; }
@@ -1104,6 +1111,7 @@ extern "C" int papr_mlp_fwd(const papr_layer* layers, int n_layers, const float*
                 PAPR_CHECK_LAUNCH("split_weight");
                 cl.bias = layers[l].bias; cl.act = layers[l].act;
                 cl.C = (saved || l == e - 1) ? outs[l] : nullptr; cl.ldc = ld_out[l];
+                cl.sign_bits = saved && layers[l].act != PAPR_ACT_NONE ? saved_sign_words(saved, n_layers, M, l) : nullptr;
                 if (cl.C) bytes += 4LL * M * layers[l].n_out;
                 bytes += 4LL * layers[l].n_out * layers[l].n_in;
                 flops += 2LL * M * layers[l].n_out * layers[l].n_in;
@@ -1236,10 +1244,15 @@ extern "C" int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float*
                 used += chain_split_weight(Ll.weight_t, Ll.n_in, Ll.n_out, Ll.ldwt, h3.planes + used, cl, s);
                 PAPR_CHECK_LAUNCH("split_weight");
                 if (l > 0) {
-                    cl.mask = outs[l - 1]; cl.ld_mask = ld_out[l - 1]; cl.act = layers[l - 1].act;
+                    cl.act = layers[l - 1].act;
+                    if (cl.act != PAPR_ACT_NONE) {
+                        cl.mask = outs[l - 1]; cl.ld_mask = ld_out[l - 1];
+                        // the forward run of layer l-1 left one bit per activation: read those instead of the fp32 rows
+                        if (row_absmax && run_begin[l - 1] >= 0) cl.sign_bits = saved_sign_words(row_absmax, n_layers, M, l - 1);
+                    }
                     cl.C = runs.g[l - 1 - (b > 0 ? b - 1 : 0)]; cl.ldc = G_LD;
                     cl.rowmax = runs.gmax[l - 1 - (b > 0 ? b - 1 : 0)];
-                    bytes += 8LL * M * Ll.n_in;
+                    bytes += (cl.sign_bits ? 4LL * M * Ll.n_in + 32LL * M : cl.mask ? 8LL * M * Ll.n_in : 4LL * M * Ll.n_in);
                 } else {
                     cl.C = d_x; cl.ldc = ldx; cl.act = PAPR_ACT_NONE;
                     bytes += 4LL * M * Ll.n_in;

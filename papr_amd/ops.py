@@ -126,7 +126,7 @@ def mlp_forward(spec, ws, bs, x, M, keep=True):
     outs = LayerOutputs()
     if keep:
         outs.extend(torch.empty((M, ld), device=dev, dtype=torch.float32) for ld in spec.ld_out)
-        outs.row_absmax = torch.empty((spec.n_layer, M), device=dev, dtype=torch.float32)
+        outs.row_absmax = torch.empty(hip.lib().papr_mlp_saved_floats(spec.n_layer, M), device=dev, dtype=torch.float32)
     else:
         pool = [torch.empty(M * max(spec.ld_out), device=dev, dtype=torch.float32) for _ in range(2)]
         outs.extend(pool[i & 1][:M * ld].view(M, ld) for i, ld in enumerate(spec.ld_out))
