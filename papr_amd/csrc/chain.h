@@ -4,6 +4,7 @@
 #include <stddef.h>
 
 constexpr int CHAIN_MAX_LAYERS = 8;
+constexpr int CHAIN_SIGN_WORDS = 16;       // sign words per row and layer (one per wave and half-wave: 8 or 16 are used)
 
 struct ChainLayer {
     const _Float16* w_hi;      // weight planes in MFMA fragment order (split_weight_kernel): n_tiles x ksteps fragments
@@ -11,7 +12,7 @@ struct ChainLayer {
     const float* bias;         // forward: (N) or null
     const float* mask;         // data-gradient: activation outputs whose derivative multiplies this layer's result, or null
     long ld_mask;
-    unsigned* sign_bits;       // (8, M) words: forward = written (bit set where the result is > 0), data-gradient = read in place of mask; or null.
+    unsigned* sign_bits;       // (CHAIN_SIGN_WORDS, M) words: forward = written (bit set where the result is > 0), data-gradient = read in place of mask; or null.
                                // word [(2 wn + h) * M + m] holds the 32 columns 64 wn + 32 j + 8 g + 4 h + c of row m, (j, g, c) = 0 first, in the top bit
     float* C;                  // (M, ldc) result rows, or null when nobody needs them in memory
     long ldc;

@@ -35,11 +35,25 @@
 
 namespace {
 
-constexpr int CH_BM = 64;                   // rows per tile
+#ifndef CH_NI
+#define CH_NI 2                         // 32-row tiles per wave = rows per workgroup tile / 32 (2: two workgroups fit a CU; 4: one)
+#endif
+constexpr int NI = CH_NI;
+constexpr int CH_BM = 32 * NI;              // rows per tile
 #ifndef CH_START_DELAY
 #define CH_START_DELAY 1              // x 8128 cycles (s_sleep 127)
 #endif
-constexpr int CH_THREADS = 256;             // four waves, one per SIMD, each a 64 x 64 corner of the 64 x 256 tile
+// Tile shape (compile-time, A/B-tested on 512,000 x 256 x 256 x 4 layers; forward / data-gradient / inference run in us):
+//   NJ=2 NI=2  4 waves of 64 x 64, two workgroups per CU      1165 / 1177 / 884   <- default
+//   NJ=1 NI=2  8 waves of 64 x 32, two workgroups per CU      1221 / 1111 / 904   (twice the waves: no gain)
+//   NJ=1 NI=4  8 waves of 128 x 32, one workgroup per CU      1181 / 1135 / 942   (half the W traffic through L1: no gain)
+//   NJ=2 NI=4  4 waves of 128 x 64, one workgroup per CU      1354 / 1240 / 1107  (nothing overlaps the row phases)
+#ifndef CH_NJ
+#define CH_NJ 2                         // 32-column tiles per wave: 2 = four waves of 64 x 64 (one per SIMD), 1 = eight waves of 64 x 32 (two per SIMD)
+#endif
+constexpr int NJ = CH_NJ;
+constexpr int CH_WAVES = 8 / NJ;
+constexpr int CH_THREADS = 64 * CH_WAVES;
 constexpr int CH_AP = 264;                  // A-plane row pitch in halfs (528 B: conflict-free ds_read_b128)
 constexpr int CH_PLANE = CH_BM * CH_AP;     // halfs per plane
 constexpr size_t CH_LDS_BYTES = (size_t)2 * CH_PLANE * sizeof(_Float16) + CH_BM * sizeof(float) + 2 * CH_BM * sizeof(unsigned) + CHAIN_MAX_LAYERS * 256 * sizeof(float);
@@ -82,7 +96,7 @@ __device__ long long g_chain_trace[256];
 // (L.sign_bits) instead of the fp32 activation rows (L.mask): 16 MB instead of 524 MB per layer, and 2 registers
 // instead of 64.
 template <bool DGRAD, bool BITS>
-__global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(ChainArgs p, int tiles_m) {
+__global__ __launch_bounds__(CH_THREADS, (NI == 2 ? 2 : 1) * CH_WAVES / 4) void mlp_chain_kernel(ChainArgs p, int tiles_m) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     _Float16* Ah = reinterpret_cast<_Float16*>(smem);
     _Float16* Al = Ah + CH_PLANE;
@@ -91,7 +105,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(ChainArgs p, i
     float* bias_tab = reinterpret_cast<float*>(rmax_tab + 2 * CH_BM);    // [layers][256]: a global load in phase 1 would wait for the stores before it (loads and stores share vmcnt)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int wm = 0;                        // (one wave row: the tile is 64 rows)
-    const int wn = wave;                         // wave tile: all 64 rows, columns 64 wn .. +63
+    const int wn = wave;                         // wave tile: all 64 rows, columns 32 NJ wn .. + 32 NJ - 1
     const int frag = (lane & 31) * CH_AP + 8 * (lane >> 5);
 
 #ifdef PAPR_H3_TRACE
@@ -104,16 +118,16 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(ChainArgs p, i
     // They come straight from L2 (~1k cycles under load, a k-step is 384): a ring of WD k-steps, WD-1 in
     // flight, and the first ones of the NEXT layer are requested before this layer's row phases.
     constexpr int WD = 4;                        // ring depth (the k-loop below is written out for 4)
-    half8 wfh[WD][2], wfl[WD][2];
-    auto load_w = [&](int l, int ks, half8 (&qh)[2], half8 (&ql)[2]) {
+    half8 wfh[WD][NJ], wfl[WD][NJ];
+    auto load_w = [&](int l, int ks, half8 (&qh)[NJ], half8 (&ql)[NJ]) {
         const ChainLayer& L = p.L[l];
         ks = ks < L.ksteps ? ks : L.ksteps - 1;
 #ifdef CH_EXP_NO_W
         if (ks > 2) return;                  // experiment: only the first fragments are ever loaded
 #endif
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int t = 32 * (wn * 2 + j) < L.N ? wn * 2 + j : 0;
+        for (int j = 0; j < NJ; ++j) {
+            const int t = 32 * (wn * NJ + j) < L.N ? wn * NJ + j : 0;
             const long o = ((long)(t * L.ksteps + ks) * 64 + lane) * 8;
             qh[j] = *reinterpret_cast<const half8*>(L.w_hi + o);
             ql[j] = *reinterpret_cast<const half8*>(L.w_lo + o);
@@ -139,11 +153,11 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(ChainArgs p, i
             const int kpad = p.L[0].ksteps * 16;
             const int c = 4 * lane;
 #pragma unroll 1
-            for (int u0 = 0; u0 < 16; u0 += SR) {
+            for (int u0 = 0; u0 < CH_BM / CH_WAVES; u0 += SR) {
                 float4 v[SR];
 #pragma unroll
                 for (int u = 0; u < SR; ++u) {
-                    long m = m0 + wave + 4 * (u0 + u);
+                    long m = m0 + wave + CH_WAVES * (u0 + u);
                     m = m < p.M ? m : p.M - 1;
 #ifdef CH_EXP_NO_STAGING
                     v[u] = make_float4((float)m, 1.f, 2.f, 3.f);
@@ -153,7 +167,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(ChainArgs p, i
                 }
 #pragma unroll
                 for (int u = 0; u < SR; ++u) {
-                    const int r = wave + 4 * (u0 + u);
+                    const int r = wave + CH_WAVES * (u0 + u);
                     float mx = fmaxf(fmaxf(fabsf(v[u].x), fabsf(v[u].y)), fmaxf(fabsf(v[u].z), fabsf(v[u].w)));
                     mx = wave64_max(mx);
                     float inv;
@@ -170,7 +184,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(ChainArgs p, i
                     }
                 }
             }
-            if (tid < CH_BM) rmax_tab[tid] = 0u;
+            for (int t = tid; t < CH_BM; t += CH_THREADS) rmax_tab[t] = 0u;
         }
         lds_barrier();
         CH_STAMP();
@@ -180,22 +194,22 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(ChainArgs p, i
             const ChainLayer& L = p.L[l];
             const int par = l & 1;
             const int N = L.N, ksteps = L.ksteps;
-            bool live[2];
+            bool live[NJ];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) live[j] = 32 * (wn * 2 + j) < N;
-            f32x16 acc[2][2];
+            for (int j = 0; j < NJ; ++j) live[j] = 32 * (wn * NJ + j) < N;
+            f32x16 acc[NI][NJ];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < NJ; ++j)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
             // data-gradient: the activation rows whose derivative masks the result are requested before the k-loop
             // (a load issued among the stores of phase 1 would wait for them: loads and stores share vmcnt)
             const int hh = lane >> 5;
-            float4 aux[2][2][4];
-            unsigned mbits[2] = {0u, 0u};
+            float4 aux[NI][NJ][4];
+            unsigned mbits[NI] = {};
             auto load_aux = [&](int i) {
                 long row = m0 + i * 32 + (lane & 31);
                 row = row < p.M ? row : p.M - 1;
@@ -204,35 +218,38 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(ChainArgs p, i
                     return;
                 }
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < NJ; ++j)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        int col = (wn * 2 + j) * 32 + 8 * g + 4 * hh;
+                        int col = (wn * NJ + j) * 32 + 8 * g + 4 * hh;
                         col = col < N ? col : 0;
                         aux[i][j][g] = *reinterpret_cast<const float4*>(L.mask + row * L.ld_mask + col);
                     }
             };
             const bool masked = DGRAD && (BITS ? L.sign_bits != nullptr : L.mask != nullptr);
-            if (masked) { load_aux(0); load_aux(1); }
+            if (masked) {
+#pragma unroll
+                for (int i = 0; i < NI; ++i) load_aux(i);
+            }
 
             // ---- k-loop.  The A fragments of k-step s+1 are read from LDS while k-step s multiplies (hipcc does not
             // pipeline the reads by itself: it places them right in front of their MFMAs and waits).
-            auto load_a = [&](int ks, half8 (&ah)[2], half8 (&al)[2]) {
+            auto load_a = [&](int ks, half8 (&ah)[NI], half8 (&al)[NI]) {
                 ks = ks < ksteps ? ks : ksteps - 1;
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
+                for (int i = 0; i < NI; ++i) {
                     const int o = (wm * 2 + i) * 32 * CH_AP + frag + ks * 16;
                     ah[i] = *reinterpret_cast<const half8*>(Ah + o);
                     al[i] = *reinterpret_cast<const half8*>(Al + o);
                 }
             };
             // W fragment as the row operand: the accumulators hold C^T (lane = row m, registers = columns n)
-            auto mma_live = [&](const half8 (&qh)[2], const half8 (&ql)[2], const half8 (&ah)[2], const half8 (&al)[2]) {
+            auto mma_live = [&](const half8 (&qh)[NJ], const half8 (&ql)[NJ], const half8 (&ah)[NI], const half8 (&al)[NI]) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < NJ; ++j) {
                     if (!live[j]) continue;
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) {
+                    for (int i = 0; i < NI; ++i) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh[j], al[i], acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ql[j], ah[i], acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh[j], ah[i], acc[i][j], 0, 0, 0);
@@ -240,7 +257,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(ChainArgs p, i
                 }
             };
             auto k_loop = [&](auto mma) {                       // waves with a dead column tile (narrow layers): simple form
-                half8 a0h[2], a0l[2], a1h[2], a1l[2];
+                half8 a0h[NI], a0l[NI], a1h[NI], a1l[NI];
                 load_a(0, a0h, a0l);
 #pragma unroll 1
                 for (int ks = 0; ks < ksteps; ks += 4) {       // ksteps is even (planes are padded to 32 columns)
@@ -275,13 +292,18 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(ChainArgs p, i
             // loads to just before their use and waits with vmcnt(0)).
             // (scalar base + 32-bit lane offset: a 64-bit VALU address computation per load costs far more than its issue
             // slot next to MFMAs)
-            const char* wb_h[2] = {reinterpret_cast<const char*>(L.w_hi) + (size_t)((wn * 2 + 0) * ksteps) * 1024, reinterpret_cast<const char*>(L.w_hi) + (size_t)((wn * 2 + 1) * ksteps) * 1024};
-            const char* wb_l[2] = {reinterpret_cast<const char*>(L.w_lo) + (size_t)((wn * 2 + 0) * ksteps) * 1024, reinterpret_cast<const char*>(L.w_lo) + (size_t)((wn * 2 + 1) * ksteps) * 1024};
+            const char* wb_h[NJ];
+            const char* wb_l[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                wb_h[j] = reinterpret_cast<const char*>(L.w_hi) + (size_t)((wn * NJ + j) * ksteps) * 1024;
+                wb_l[j] = reinterpret_cast<const char*>(L.w_lo) + (size_t)((wn * NJ + j) * ksteps) * 1024;
+            }
             const unsigned lane16 = (unsigned)lane * 16u;
 #define CH_SB __builtin_amdgcn_sched_barrier(0)
 #define CH_MFMA(i, j, w, x) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[j], x[i], acc[i][j], 0, 0, 0)
-            auto step = [&](const half8 (&uh)[2], const half8 (&ul)[2], const half8 (&xh)[2], const half8 (&xl)[2],
-                            int kw, half8 (&nh)[2], half8 (&nl)[2], int ka, half8 (&yh)[2], half8 (&yl)[2]) {
+            auto step = [&](const half8 (&uh)[NJ], const half8 (&ul)[NJ], const half8 (&xh)[NI], const half8 (&xl)[NI],
+                            int kw, half8 (&nh)[NJ], half8 (&nl)[NJ], int ka, half8 (&yh)[NI], half8 (&yl)[NI]) {
                 kw = kw < ksteps ? kw : ksteps - 1;
                 ka = ka < ksteps ? ka : ksteps - 1;
 #ifdef CH_EXP_NO_W
@@ -294,18 +316,37 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(ChainArgs p, i
 #else
                 constexpr bool lda = true;
 #endif
-                CH_MFMA(0, 0, uh, xl); CH_SB; if (ldw) nh[0] = *reinterpret_cast<const half8*>(wb_h[0] + (size_t)kw * 1024 + lane16); CH_SB;
-                CH_MFMA(1, 0, uh, xl); CH_SB; if (ldw) nl[0] = *reinterpret_cast<const half8*>(wb_l[0] + (size_t)kw * 1024 + lane16); CH_SB;
-                CH_MFMA(0, 1, uh, xl); CH_SB; if (ldw) nh[1] = *reinterpret_cast<const half8*>(wb_h[1] + (size_t)kw * 1024 + lane16); CH_SB;
-                CH_MFMA(1, 1, uh, xl); CH_SB; if (ldw) nl[1] = *reinterpret_cast<const half8*>(wb_l[1] + (size_t)kw * 1024 + lane16); CH_SB;
-                CH_MFMA(0, 0, ul, xh); CH_SB; if (lda) yh[0] = *reinterpret_cast<const half8*>(Ah + frag + ka * 16); CH_SB;
-                CH_MFMA(1, 0, ul, xh); CH_SB; if (lda) yl[0] = *reinterpret_cast<const half8*>(Al + frag + ka * 16); CH_SB;
-                CH_MFMA(0, 1, ul, xh); CH_SB; if (lda) yh[1] = *reinterpret_cast<const half8*>(Ah + 32 * CH_AP + frag + ka * 16); CH_SB;
-                CH_MFMA(1, 1, ul, xh); CH_SB; if (lda) yl[1] = *reinterpret_cast<const half8*>(Al + 32 * CH_AP + frag + ka * 16); CH_SB;
-                CH_MFMA(0, 0, uh, xh); CH_MFMA(1, 0, uh, xh); CH_MFMA(0, 1, uh, xh); CH_MFMA(1, 1, uh, xh); CH_SB;
+                // request q of this step: the 2 NJ W fragments of k-step kw, then the 2 NI A fragments of k-step ka
+                auto request = [&](int q) {
+                    if (q < 2 * NJ) {
+                        if (!ldw) return;
+                        const int j = q >> 1;
+                        if (q & 1) nl[j] = *reinterpret_cast<const half8*>(wb_l[j] + (size_t)kw * 1024 + lane16);
+                        else nh[j] = *reinterpret_cast<const half8*>(wb_h[j] + (size_t)kw * 1024 + lane16);
+                    } else if (q < 2 * NJ + 2 * NI) {
+                        if (!lda) return;
+                        const int a = q - 2 * NJ, i = a >> 1;
+                        if (a & 1) yl[i] = *reinterpret_cast<const half8*>(Al + i * 32 * CH_AP + frag + ka * 16);
+                        else yh[i] = *reinterpret_cast<const half8*>(Ah + i * 32 * CH_AP + frag + ka * 16);
+                    }
+                };
+                int q = 0;                                      // (everything below unrolls: q is a compile-time constant at each use)
+#pragma unroll
+                for (int term = 0; term < 3; ++term)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                        for (int i = 0; i < NI; ++i) {
+                            if (term == 0) CH_MFMA(i, j, uh, xl);
+                            else if (term == 1) CH_MFMA(i, j, ul, xh);
+                            else CH_MFMA(i, j, uh, xh);
+                            CH_SB;
+                            request(q++);
+                            CH_SB;
+                        }
             };
             auto k_loop_full = [&]() {
-                half8 a0h[2], a0l[2], a1h[2], a1l[2];
+                half8 a0h[NI], a0l[NI], a1h[NI], a1l[NI];
                 load_a(0, a0h, a0l);
 #pragma unroll 1
                 for (int ks = 0; ks < ksteps; ks += 4) {
@@ -320,7 +361,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(ChainArgs p, i
 #undef CH_MFMA
 #undef CH_SB
 #ifndef CH_EXP_NO_KLOOP
-            if (live[1]) k_loop_full();                         // both column tiles of this wave hold real columns
+            if (live[NJ - 1]) k_loop_full();                    // every column tile of this wave holds real columns
             else if (live[0]) k_loop(mma_live);
 #endif
             {   // first fragments of what comes next: the next layer, or layer 0 of the next tile
@@ -342,7 +383,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(ChainArgs p, i
             const bool want_bits = !DGRAD && L.sign_bits != nullptr;      // forward: leave the signs for the data-gradient run
             auto rows_phase = [&](auto act_fn) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
+                for (int i = 0; i < NI; ++i) {
                     const int rl = i * 32 + (lane & 31);
                     const long row = m0 + rl;
                     const float inv = inv_tab[rl];
@@ -350,11 +391,11 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(ChainArgs p, i
                     unsigned sb = 0u;                           // forward: sign word of this lane's 32 values, first value in the top bit
                     unsigned mb = mbits[i];
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
+                    for (int j = 0; j < NJ; ++j) {
                         if (!live[j]) { sb <<= 16; mb <<= 16; continue; }
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
-                            const int col = (wn * 2 + j) * 32 + 8 * g + 4 * hh;
+                            const int col = (wn * NJ + j) * 32 + 8 * g + 4 * hh;
                             float4 r;
                             if (DGRAD) {
                                 r = make_float4(acc[i][j][4 * g] * inv, acc[i][j][4 * g + 1] * inv, acc[i][j][4 * g + 2] * inv, acc[i][j][4 * g + 3] * inv);
@@ -384,7 +425,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(ChainArgs p, i
                             mx = fmaxf(mx, fmaxf(fmaxf(fabsf(r.x), fabsf(r.y)), fmaxf(fabsf(r.z), fabsf(r.w))));
                         }
                     }
-                    if (want_bits && row < p.M) L.sign_bits[(long)(wn * 2 + hh) * p.M + row] = sb;
+                    if (want_bits && row < p.M) L.sign_bits[(long)(wn * 2 + hh) * p.M + row] = sb << (32 - 16 * NJ);
                     if (live[0]) atomicMax(rmax_tab + par * CH_BM + rl, __float_as_uint(mx));
                 }
             };
@@ -398,24 +439,24 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain_kernel(ChainArgs p, i
             CH_STAMP();
 
             // ---- phase 2: the rows become the A planes of the next layer
-            if (tid < CH_BM) {
-                if (L.rowmax && m0 + tid < p.M) L.rowmax[m0 + tid] = __uint_as_float(rmax_tab[par * CH_BM + tid]);
-                rmax_tab[(par ^ 1) * CH_BM + tid] = 0u;
+            for (int t = tid; t < CH_BM; t += CH_THREADS) {
+                if (L.rowmax && m0 + t < p.M) L.rowmax[m0 + t] = __uint_as_float(rmax_tab[par * CH_BM + t]);
+                rmax_tab[(par ^ 1) * CH_BM + t] = 0u;
             }
 #ifndef CH_EXP_NO_PHASES
             if (more) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
+                for (int i = 0; i < NI; ++i) {
                     const int rl = i * 32 + (lane & 31);
                     float inv;
                     const float sc = scale_from_max(rmax_tab[par * CH_BM + rl], inv);
                     if (wn == 0 && hh == 0) inv_tab[rl] = inv;
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
+                    for (int j = 0; j < NJ; ++j) {
                         if (!live[j]) continue;
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
-                            const int col = (wn * 2 + j) * 32 + 8 * g + 4 * hh;
+                            const int col = (wn * NJ + j) * 32 + 8 * g + 4 * hh;
                             half4 hi, lo;
                             split4(make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]), sc, hi, lo);
                             *reinterpret_cast<half4*>(Ah + rl * CH_AP + col) = hi;
@@ -453,7 +494,7 @@ int papr_launch_chain(const ChainArgs& a, bool dgrad, long long bytes, long long
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_chain_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CH_LDS_BYTES);
         attr_set = true;
     }
-    static const int wgs_per_cu = getenv("PAPR_CHAIN_WGS_PER_CU") ? atoi(getenv("PAPR_CHAIN_WGS_PER_CU")) : 2;   // (A/B switch)
+    static const int wgs_per_cu = getenv("PAPR_CHAIN_WGS_PER_CU") ? atoi(getenv("PAPR_CHAIN_WGS_PER_CU")) : (NI == 2 ? 2 : 1);   // (A/B switch)
     dim3 grid((unsigned)(tiles_m < wgs_per_cu * n_cu ? tiles_m : wgs_per_cu * n_cu));     // two workgroups per CU: one multiplies while the other is in its row phases
     const bool prof = papr_prof_on();
     if (prof) papr_prof_begin2(dgrad ? 10 : 9, a.M, a.n_layers, a.K0, bytes, flops, s);
