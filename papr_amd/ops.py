@@ -256,6 +256,9 @@ class RenderPath:
             raise NotImplementedError("papr_amd: d_model must be a multiple of 4 and <= 256")
         self.wk = one("w_k", self.key.d_out)
         self.wq = one("w_q", self.qry.d_out)
+        # g = q' W_k seen as a Linear layer (weight W_k^T): its backward runs on the library's own GEMMs
+        self.wk_fold = MlpSpec("w_k_fold", self.d_model, dict(n_ff_layer=1, d_ff=self.key.d_out, d_ff_out=self.key.d_out, norm="none",
+                                                              ff_act="none", ff_last_act="none"))
         d = hip.FeatureDesc()
         d.feat_dim = self.feat_dim
         d.L_key = (C.c_int32 * 3)(*e["k_L"])
@@ -399,14 +402,17 @@ class _RenderFn(torch.autograd.Function):
         hip.check(lib.papr_attn_tail_bwd(C.byref(td), hip.ptr(K), hip.ptr(s["g"]), hip.ptr(V), hip.ptr(s["influ"]), hip.ptr(idx),
                                          R, hip.ptr(s["scores"]), hip.ptr(s["attn"]), hip.ptr(d_fused), hip.ptr(d_attn), hip.ptr(d_K),
                                          hip.ptr(d_g), hip.ptr(d_V), None, hip.ptr(d_c0), hip.ptr(pair_influ), hip.stream_ptr()), "papr_attn_tail_bwd")
-        # backward of g = q' W_k, c0 = q'.b_k (R-row library GEMMs)
+        # backward of g = q' W_k, c0 = q'.b_k: R-row products on the library's GEMMs (rocBLAS / hipBLASLt pick 130-270 us
+        # kernels for these 25,600 x 256 shapes; the same work is ~100 us here)
         qp = s["qp"]
-        d_g = d_g[:, :plan.key.d_out]                        # the tail kernel fills d_model = key.d_out columns
-        d_qp = torch.addmm(torch.outer(d_c0, wkb[0]), d_g, wkw[0].t())
-        d_wk = [torch.matmul(qp.t(), d_g)]
-        d_wkb = [torch.mv(qp.t(), d_c0)]
         wmax = max(plan.key.width, plan.qry.width, plan.val.width, plan.key.ld_in, plan.val.ld_in, plan.d_model)
         scratch = [torch.empty((M, wmax), device=dev, dtype=torch.float32) for _ in range(2)]
+        d_g = d_g[:, :plan.key.d_out].contiguous()           # the tail kernel fills d_model = key.d_out columns
+        d_wkT, _, d_qp = mlp_backward(plan.wk_fold, [wkw[0].t().contiguous()], [wkb[0].new_zeros(plan.key.d_out)], qp, R, [d_g], d_g,
+                                      [t[:R] for t in scratch], True)
+        d_qp.addcmul_(d_c0[:, None], wkb[0][None, :])
+        d_wk = [d_wkT[0].t()]
+        d_wkb = [(qp * d_c0[:, None]).sum(0)]
         # key branch
         if plan.kq_norm:
             rownorm_bwd_(d_K, K, s["kst2"], plan.key.d_out, eps)
