@@ -14,6 +14,7 @@
 // d/dx [x, sin(f x), cos(f x)] = [1, f cos(f x), -f sin(f x)] and the geometry Jacobian into a
 // single atomic scatter onto the point gradients.
 #include "papr_common.h"
+#include <algorithm>
 
 namespace {
 
@@ -63,45 +64,98 @@ __device__ __forceinline__ RayGeom load_ray(const float* __restrict__ rays_o, co
     return g;
 }
 
+// Rows are 117-142 floats: a thread that owns a row and reads or writes it directly touches 64 different cache lines
+// per instruction (PMC: 2.5-3x the algorithmic traffic, 4-byte pieces).  So each wave stages one encoding block
+// (39 floats for L = 6) of its 64 rows in LDS -- odd row pitch, conflict-free for "same column, 64 rows" -- and moves
+// it to / from memory with consecutive lanes on consecutive addresses.
+__device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// buf[r][c], r < 64, c < w  ->  dst[(m0 + r) * ld + c0 + c]
+__device__ __forceinline__ void wave_flush(const float* buf, int pitch, int w, float* __restrict__ dst, long ld, int c0, long m0, long M) {
+    const int lane = threadIdx.x & 63, total = 64 * w;
+    const float inv_w = 1.0f / (float)w;
+    for (int e = lane; e < total; e += 64) {
+        const int r = (int)(((float)e + 0.5f) * inv_w), c = e - r * w;
+        if (m0 + r < M) dst[(m0 + r) * ld + c0 + c] = buf[r * pitch + c];
+    }
+}
+// src[(m0 + r) * ld + c0 + c]  ->  buf[r][c]   (rows beyond M read row M-1)
+__device__ __forceinline__ void wave_fetch(float* buf, int pitch, int w, const float* __restrict__ src, long ld, int c0, long m0, long M) {
+    const int lane = threadIdx.x & 63, total = 64 * w;
+    const float inv_w = 1.0f / (float)w;
+    for (int e = lane; e < total; e += 64) {
+        const int r = (int)(((float)e + 0.5f) * inv_w), c = e - r * w;
+        const long m = m0 + r < M ? m0 + r : M - 1;
+        buf[r * pitch + c] = src[m * ld + c0 + c];
+    }
+}
+// feature rows of the 64 selected points -> dst[(m0 + r) * ld + c0 + 0..feat_dim)
+__device__ __forceinline__ void wave_copy_feats(const float* __restrict__ pc_feats, int feat_dim, int pi, float* __restrict__ dst, long ld, int c0,
+                                                long m0, long M) {
+    const int lane = threadIdx.x & 63;
+    for (int r = 0; r < 64; ++r) {
+        const int pr = __builtin_amdgcn_readlane(pi, r);
+        if (m0 + r >= M) break;
+        for (int c = lane; c < feat_dim; c += 64) dst[(m0 + r) * ld + c0 + c] = pc_feats[(long)pr * feat_dim + c];
+    }
+}
+// zero columns [c0, c1) of the 64 rows
+__device__ __forceinline__ void wave_zero_cols(float* __restrict__ dst, long ld, int c0, int c1, long m0, long M) {
+    const int lane = threadIdx.x & 63, w = c1 - c0;
+    if (w <= 0) return;
+    for (int e = lane; e < 64 * w; e += 64) {
+        const int r = e / w, c = e - r * w;
+        if (m0 + r < M) dst[(m0 + r) * ld + c0 + c] = 0.f;
+    }
+}
+
 __global__ __launch_bounds__(256) void features_fwd_kernel(FeatParams fp, const float* __restrict__ points,
                                                            const float* __restrict__ pc_feats,
                                                            const float* __restrict__ rays_o,
                                                            const float* __restrict__ rays_d, long R,
                                                            long rays_per_image, const int* __restrict__ idx,
                                                            float* __restrict__ key, float* __restrict__ val,
-                                                           float* __restrict__ sel_points) {
+                                                           float* __restrict__ sel_points, int pitch) {
+    extern __shared__ float feat_lds[];
     const papr_feature_desc& d = fp.d;
-    long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    long M = R * d.k;
-    if (m >= M) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* buf = feat_lds + wave * 64 * pitch;
+    float* row = buf + lane * pitch;
+    const long M = R * d.k;
+    const long m0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) - lane;     // first pair of this wave
+    if (m0 >= M) return;                                                        // (whole wave)
+    const long mreal = m0 + lane;
+    const long m = mreal < M ? mreal : M - 1;                                   // idle lanes shadow the last pair: the wave works as one
     long r = m / d.k;
     RayGeom g = load_ray(rays_o, rays_d, r, rays_per_image, d.eps);
     int pi = idx[m];
     float p[3] = {points[pi * 3 + 0], points[pi * 3 + 1], points[pi * 3 + 2]};
-    if (sel_points) { sel_points[m * 3 + 0] = p[0]; sel_points[m * 3 + 1] = p[1]; sel_points[m * 3 + 2] = p[2]; }
+    if (sel_points && mreal < M) { sel_points[m * 3 + 0] = p[0]; sel_points[m * 3 + 1] = p[1]; sel_points[m * 3 + 2] = p[2]; }
     float vx = p[0] - g.ox, vy = p[1] - g.oy, vz = p[2] - g.oz;
     float t = ((vx * g.rx + vy * g.ry) + vz * g.rz) / g.rr;
     float s[3] = {g.rx * t, g.ry * t, g.rz * t};
     float u[3] = {vx - s[0], vy - s[1], vz - s[2]};
 
-    float* krow = key + m * d.ld_key;
+    auto emit = [&](const float x[3], int L, float* dst, long ld, int c0) -> int {
+        const int w = write_pe(row, x, L, d.with_self, d.pe_factor, d.pe_mult);
+        wave_lds_sync();
+        wave_flush(buf, pitch, w, dst, ld, c0, m0, M);
+        wave_lds_sync();
+        return w;
+    };
     int c = 0;
-    c += write_pe(krow + c, p, d.L_key[0], d.with_self, d.pe_factor, d.pe_mult);
-    c += write_pe(krow + c, s, d.L_key[1], d.with_self, d.pe_factor, d.pe_mult);
-    c += write_pe(krow + c, u, d.L_key[2], d.with_self, d.pe_factor, d.pe_mult);
-    const float* frow = pc_feats ? pc_feats + (long)pi * d.feat_dim : nullptr;
-    if (d.key_has_feats)
-        for (int j = 0; j < d.feat_dim; ++j) krow[c++] = frow[j];
-    for (; c < d.ld_key; ++c) krow[c] = 0.f;
+    c += emit(p, d.L_key[0], key, d.ld_key, c);
+    c += emit(s, d.L_key[1], key, d.ld_key, c);
+    c += emit(u, d.L_key[2], key, d.ld_key, c);
+    if (d.key_has_feats) { wave_copy_feats(pc_feats, d.feat_dim, pi, key, d.ld_key, c, m0, M); c += d.feat_dim; }
+    wave_zero_cols(key, d.ld_key, c, d.ld_key, m0, M);
 
-    float* vrow = val + m * d.ld_val;
     c = 0;
     // pe(s), pe(u) are shared with the key when the orders agree; recomputing keeps the kernel simple
-    c += write_pe(vrow + c, s, d.L_val[0], d.with_self, d.pe_factor, d.pe_mult);
-    c += write_pe(vrow + c, u, d.L_val[1], d.with_self, d.pe_factor, d.pe_mult);
-    if (d.val_has_feats)
-        for (int j = 0; j < d.feat_dim; ++j) vrow[c++] = frow[j];
-    for (; c < d.ld_val; ++c) vrow[c] = 0.f;
+    c += emit(s, d.L_val[0], val, d.ld_val, c);
+    c += emit(u, d.L_val[1], val, d.ld_val, c);
+    if (d.val_has_feats) { wave_copy_feats(pc_feats, d.feat_dim, pi, val, d.ld_val, c, m0, M); c += d.feat_dim; }
+    wave_zero_cols(val, d.ld_val, c, d.ld_val, m0, M);
 }
 
 __global__ __launch_bounds__(256) void query_fwd_kernel(FeatParams fp, const float* __restrict__ rays_d, long R,
@@ -141,11 +195,17 @@ __global__ __launch_bounds__(256) void features_bwd_kernel(FeatParams fp, const 
                                                            long rays_per_image, const int* __restrict__ idx,
                                                            const float* __restrict__ d_key,
                                                            const float* __restrict__ d_val,
-                                                           float* __restrict__ d_points, float4* __restrict__ d_pair) {
+                                                           float* __restrict__ d_points, float4* __restrict__ d_pair, int pitch) {
+    extern __shared__ float feat_lds[];
     const papr_feature_desc& d = fp.d;
-    long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    long M = R * d.k;
-    if (m >= M) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* buf = feat_lds + wave * 64 * pitch;
+    const float* row = buf + lane * pitch;
+    const long M = R * d.k;
+    const long m0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) - lane;
+    if (m0 >= M) return;
+    const long mreal = m0 + lane;
+    const long m = mreal < M ? mreal : M - 1;
     long r = m / d.k;
     RayGeom g = load_ray(rays_o, rays_d, r, rays_per_image, d.eps);
     int pi = idx[m];
@@ -154,16 +214,25 @@ __global__ __launch_bounds__(256) void features_bwd_kernel(FeatParams fp, const 
     float s[3] = {g.rx * t, g.ry * t, g.rz * t};
     float u[3] = {vx - s[0], vy - s[1], vz - s[2]};
     float gs[3] = {0.f, 0.f, 0.f}, gu[3] = {0.f, 0.f, 0.f};
+    // one encoding block of the 64 gradient rows at a time through LDS (see features_fwd_kernel)
+    auto absorb = [&](const float* src, long ld, int c0, const float x[3], int L, float out[3]) -> int {
+        const int w = pe_width(L, d.with_self);
+        wave_fetch(buf, pitch, w, src, ld, c0, m0, M);
+        wave_lds_sync();
+        pe_grad(row, x, L, d.with_self, d.pe_factor, d.pe_mult, out);
+        wave_lds_sync();
+        return w;
+    };
     if (d_key) {
-        const float* kr = d_key + m * d.ld_key + pe_width(d.L_key[0], d.with_self);  // skip pe(p): detached
-        pe_grad(kr, s, d.L_key[1], d.with_self, d.pe_factor, d.pe_mult, gs);
-        pe_grad(kr + pe_width(d.L_key[1], d.with_self), u, d.L_key[2], d.with_self, d.pe_factor, d.pe_mult, gu);
+        int c = pe_width(d.L_key[0], d.with_self);                       // skip pe(p): detached
+        c += absorb(d_key, d.ld_key, c, s, d.L_key[1], gs);
+        absorb(d_key, d.ld_key, c, u, d.L_key[2], gu);
     }
     if (d_val) {
-        const float* vr = d_val + m * d.ld_val;
-        pe_grad(vr, s, d.L_val[0], d.with_self, d.pe_factor, d.pe_mult, gs);
-        pe_grad(vr + pe_width(d.L_val[0], d.with_self), u, d.L_val[1], d.with_self, d.pe_factor, d.pe_mult, gu);
+        int c = absorb(d_val, d.ld_val, 0, s, d.L_val[0], gs);
+        absorb(d_val, d.ld_val, c, u, d.L_val[1], gu);
     }
+    if (mreal >= M) return;
     // s = r t, u = v - r t, t = (v.r)/(r.r+eps)  =>  dL/dv = gu + r * (r.(gs - gu)) / (r.r+eps)
     float w = (g.rx * (gs[0] - gu[0]) + g.ry * (gs[1] - gu[1]) + g.rz * (gs[2] - gu[2])) / g.rr;
     if (d_pair) {           // per-pair rows for the deterministic segmented reduction (papr_segment_reduce)
@@ -257,6 +326,14 @@ __global__ __launch_bounds__(256) void segment_reduce_kernel(const long* __restr
     flush(cur);
 }
 
+// LDS row pitch of the per-wave staging buffer: the widest encoding block, made odd
+int stage_pitch(const papr_feature_desc* d) {
+    int w = 1;
+    for (int i = 0; i < 3; ++i) w = std::max(w, 3 * (d->with_self + 2 * d->L_key[i]));
+    for (int i = 0; i < 2; ++i) w = std::max(w, 3 * (d->with_self + 2 * d->L_val[i]));
+    return w | 1;
+}
+
 int fill_params(const papr_feature_desc* d, FeatParams* fp) {
     fp->d = *d;
     fp->key_w = 0;
@@ -303,8 +380,10 @@ extern "C" int papr_build_features_fwd(const papr_feature_desc* d, const float* 
     if (R <= 0) return 0;
     hipStream_t s = as_stream(stream);
     long M = R * d->k;
-    features_fwd_kernel<<<dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s>>>(fp, points, pc_feats, rays_o, rays_d, R,
-                                                                             rays_per_image, idx, key, val, sel_points);
+    const int pitch = stage_pitch(d);
+    PAPR_REQUIRE(pitch <= 129, "papr_build_features_fwd: encoding orders too large for the staging buffer");
+    features_fwd_kernel<<<dim3((unsigned)((M + 255) / 256)), dim3(256), (size_t)4 * 64 * pitch * sizeof(float), s>>>(
+        fp, points, pc_feats, rays_o, rays_d, R, rays_per_image, idx, key, val, sel_points, pitch);
     PAPR_CHECK_LAUNCH("features_fwd");
     query_fwd_kernel<<<dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s>>>(fp, rays_d, R, qry);
     PAPR_CHECK_LAUNCH("query_fwd");
@@ -322,8 +401,10 @@ extern "C" int papr_build_features_bwd(const papr_feature_desc* d, const float* 
     if (R <= 0) return 0;
     hipStream_t s = as_stream(stream);
     long M = R * d->k;
-    features_bwd_kernel<<<dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s>>>(fp, points, rays_o, rays_d, R,
-                                                                             rays_per_image, idx, d_key, d_val, d_points, nullptr);
+    const int pitch = stage_pitch(d);
+    PAPR_REQUIRE(pitch <= 129, "papr_build_features_bwd: encoding orders too large for the staging buffer");
+    features_bwd_kernel<<<dim3((unsigned)((M + 255) / 256)), dim3(256), (size_t)4 * 64 * pitch * sizeof(float), s>>>(
+        fp, points, rays_o, rays_d, R, rays_per_image, idx, d_key, d_val, d_points, nullptr, pitch);
     PAPR_CHECK_LAUNCH("features_bwd");
     if (d_pc_feats) {
         long n = M * (d->feat_dim / 4);
@@ -351,8 +432,10 @@ extern "C" int papr_build_features_bwd_pairs(const papr_feature_desc* d, const f
     if (int e = check_desc(d, fp, "papr_build_features_bwd_pairs")) return e;
     if (R <= 0) return 0;
     long M = R * d->k;
-    features_bwd_kernel<<<dim3((unsigned)((M + 255) / 256)), dim3(256), 0, as_stream(stream)>>>(
-        fp, points, rays_o, rays_d, R, rays_per_image, idx, d_key, d_val, nullptr, reinterpret_cast<float4*>(d_pair_points));
+    const int pitch = stage_pitch(d);
+    PAPR_REQUIRE(pitch <= 129, "papr_build_features_bwd_pairs: encoding orders too large for the staging buffer");
+    features_bwd_kernel<<<dim3((unsigned)((M + 255) / 256)), dim3(256), (size_t)4 * 64 * pitch * sizeof(float), as_stream(stream)>>>(
+        fp, points, rays_o, rays_d, R, rays_per_image, idx, d_key, d_val, nullptr, reinterpret_cast<float4*>(d_pair_points), pitch);
     PAPR_CHECK_LAUNCH("features_bwd(pairs)");
     return 0;
 }
