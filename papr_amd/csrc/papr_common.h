@@ -42,13 +42,26 @@ __device__ __forceinline__ float papr_act_grad(float y, int act) {
     return 1.f;
 }
 
+// Wave-wide reductions, result in every lane.  16 lanes meet on the DPP network (four steps, no LDS traffic), the four
+// 16-lane rows on the scalar unit; a __shfl_xor butterfly is six ds_bpermute round trips through the LDS pipe.
+#define PAPR_DPP_F(v, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), ctrl, 0xf, 0xf, false))
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += PAPR_DPP_F(v, 0xB1);      // quad_perm [1,0,3,2]
+    v += PAPR_DPP_F(v, 0x4E);      // quad_perm [2,3,0,1]
+    v += PAPR_DPP_F(v, 0x141);     // row_half_mirror
+    v += PAPR_DPP_F(v, 0x140);     // row_mirror
+    const int r = __float_as_int(v);
+    const float a = __int_as_float(__builtin_amdgcn_readlane(r, 0)), b = __int_as_float(__builtin_amdgcn_readlane(r, 16));
+    const float c = __int_as_float(__builtin_amdgcn_readlane(r, 32)), d = __int_as_float(__builtin_amdgcn_readlane(r, 48));
+    return (a + b) + (c + d);
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, PAPR_DPP_F(v, 0xB1));
+    v = fmaxf(v, PAPR_DPP_F(v, 0x4E));
+    v = fmaxf(v, PAPR_DPP_F(v, 0x141));
+    v = fmaxf(v, PAPR_DPP_F(v, 0x140));
+    const int r = __float_as_int(v);
+    const float a = __int_as_float(__builtin_amdgcn_readlane(r, 0)), b = __int_as_float(__builtin_amdgcn_readlane(r, 16));
+    const float c = __int_as_float(__builtin_amdgcn_readlane(r, 32)), d = __int_as_float(__builtin_amdgcn_readlane(r, 48));
+    return fmaxf(fmaxf(a, b), fmaxf(c, d));
 }
