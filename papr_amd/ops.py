@@ -11,6 +11,7 @@ Reference call sites this file stands in for: PAPR._get_points / _get_kqv / eval
 """
 import ctypes as C
 
+import os
 import torch
 import torch.nn.functional as F
 
@@ -77,7 +78,8 @@ def prepare_mlp_weights(spec, weights, biases, ln_in=None):
     eff_w, eff_b = [], []
     for i, (w, b) in enumerate(zip(weights, biases)):
         L = spec.layers[i]
-        main = w[:, :L["raw_in"]]
+        # (no slice when the layer has no skip block: its backward would zero-fill and copy a full-size gradient)
+        main = w[:, :L["raw_in"]] if L["skip"] else w
         extra = w[:, L["raw_in"]:] if L["skip"] else None
         if ln_in is not None:
             a, sh = ln_in
