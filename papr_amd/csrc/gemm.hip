@@ -41,6 +41,7 @@ struct NTArgs {
     float* C; long ldc;
     long M; int N;
     const unsigned* amax_in;   // split-f16 mode: per row m, the bit pattern of max_k |A[m][k]| (M words); 0 -> scale 1
+    const unsigned* amax_in2;  // split-f16 mode with a second K segment: the same for A2 (the row's scale covers both), or NULL
     _Float16* planes;          // split-f16 mode: scratch for the pre-split weight (H3_PLANE_HALFS halfs)
     unsigned* amax_out;        // split-f16 mode: per row, atomicMax'ed with the bit pattern of max_n |C[m][n]| (M words, zeroed) or NULL
 };
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_h3_kernel(NTArgs p, int tiles_
             m = m < p.M ? m : p.M - 1;
             int kk = k0 + a_kq[i] < klim ? k0 + a_kq[i] : 0;
             qa[i] = *reinterpret_cast<const float4*>(src + m * ld + kk);
-            qs[i] = p.amax_in[m];
+            qs[i] = p.amax_in2 ? max(p.amax_in[m], p.amax_in2[m]) : p.amax_in[m];
         }
         (void)wcol;
     };
@@ -534,14 +535,16 @@ static const bool GEMM_H3_FWD = GEMM_MODE >= 1, GEMM_H3 = GEMM_MODE >= 2, GEMM_H
 constexpr size_t H3_PLANE_HALFS = (size_t)CHAIN_MAX_LAYERS * 2 * 256 * 256;      // hi + lo planes of a weight up to 512 x 704, or of a fused run of up to 8 layers of 256 x 256
 struct H3Scratch {
     unsigned* amax[2];
+    unsigned* amax_x;            // row maxima of the chain's input x (skip layers read x again)
     _Float16* planes;
     int cur = 0;
     H3Scratch(void* ws, long M) {
         amax[0] = static_cast<unsigned*>(ws);
         amax[1] = amax[0] + M;
-        planes = reinterpret_cast<_Float16*>(amax[1] + M);
+        amax_x = amax[1] + M;
+        planes = reinterpret_cast<_Float16*>(amax_x + M);
     }
-    static size_t bytes(long M) { return ((size_t)2 * M * sizeof(unsigned) + H3_PLANE_HALFS * sizeof(_Float16) + 255) / 256 * 256; }
+    static size_t bytes(long M) { return ((size_t)3 * M * sizeof(unsigned) + H3_PLANE_HALFS * sizeof(_Float16) + 255) / 256 * 256; }
     unsigned* in() { return amax[cur]; }
     unsigned* out() { return amax[cur ^ 1]; }
     void swap() { cur ^= 1; }
@@ -1131,8 +1134,13 @@ extern "C" int papr_mlp_fwd(const papr_layer* layers, int n_layers, const float*
         if (L.n_skip > 0) { a.A2 = x; a.lda2 = ldx; a.K2 = L.n_skip; a.wcol2 = L.skip_col; }
         a.W = L.weight; a.ldw = L.ldw; a.bias = L.bias; a.act = L.act;
         a.C = outs[i]; a.ldc = ld_out[i]; a.M = M; a.N = L.n_out;
-        if (layer_on_h3(L)) {
+        const bool skip_h3 = GEMM_H3_FWD && L.n_skip > 0 && L.n_out > 128 && L.n_in % 32 == 0 && L.skip_col % 32 == 0;
+        if (layer_on_h3(L) || skip_h3) {
             // with row_absmax the maxima of layer i's input rows stay in row_absmax[i*M ..) for papr_mlp_bwd
+            if (skip_h3) {                  // the row's scale must cover both K segments: maxima of x as well
+                if (int e = launch_row_absmax(x, M, L.n_skip, ldx, h3.amax_x, s)) return e;
+                a.amax_in2 = h3.amax_x;
+            }
             unsigned* saved = reinterpret_cast<unsigned*>(row_absmax);
             unsigned* in = saved ? saved + (size_t)i * M : h3.in();
             if (!have_amax)

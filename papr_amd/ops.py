@@ -308,14 +308,16 @@ class _RenderFn(torch.autograd.Function):
     """fused (R,C), attn (R,k+1) = path(points, pc_feats, influ, effective weights; rays, idx)."""
 
     @staticmethod
-    def forward(ctx, plan, rays_o, rays_d, rays_per_image, idx, points, pc_feats, influ, n_k, n_q, n_v, *wb):
+    def forward(ctx, plan, rays_o, rays_d, rays_per_image, track, idx, points, pc_feats, influ, n_k, n_q, n_v, *wb):
         lib = hip.lib()
         R, k = idx.shape
         M = R * k
         if k > 63:
             raise NotImplementedError("papr_amd: %d neighbours per ray > 63 is not supported by the HIP kernels" % k)
         dev = points.device
-        keep = ctx.needs_input_grad[5] or ctx.needs_input_grad[6] or ctx.needs_input_grad[7] or any(ctx.needs_input_grad[11:])
+        # track: grad mode of the caller (always off in here, and needs_input_grad ignores torch.no_grad()): under no_grad
+        # nothing is kept for a backward pass -- no saved activations, no pair sort
+        keep = track and (ctx.needs_input_grad[6] or ctx.needs_input_grad[7] or ctx.needs_input_grad[8] or any(ctx.needs_input_grad[12:]))
         # unpack effective weights: key MLP, w_k, query MLP, w_q, value MLP  (each: weights then biases)
         it = iter(wb)
         take = lambda n: [next(it) for _ in range(n)]
@@ -418,7 +420,7 @@ class _RenderFn(torch.autograd.Function):
         # key branch
         if plan.kq_norm:
             rownorm_bwd_(d_K, K, s["kst2"], plan.key.d_out, eps)
-        need_pts = ctx.needs_input_grad[5]
+        need_pts = ctx.needs_input_grad[6]
         d_kw, d_kb, d_key = mlp_backward(plan.key, kw, kb, s["key_in"], M, s["k_outs"], d_K, scratch, need_pts)
         if plan.kq_norm and d_key is not None:
             rownorm_bwd_(d_key, s["key_in"], s["kst"], plan.key_w, eps)
@@ -429,11 +431,11 @@ class _RenderFn(torch.autograd.Function):
             rownorm_bwd_(d_Q, Q, s["qst2"], plan.qry.d_out, eps)
         d_qw, d_qb, _ = mlp_backward(plan.qry, qw, qb, s["qry_in"], R, s["q_outs"], d_Q, qscratch, False)
         # value branch
-        need_val_dx = need_pts or ctx.needs_input_grad[6]
+        need_val_dx = need_pts or ctx.needs_input_grad[7]
         d_vw, d_vb, d_val = mlp_backward(plan.val, vw, vb, s["val_in"], M, s["v_outs"], d_V, scratch, need_val_dx)
         # gather / geometry / encoding backward: per-pair gradient rows, then one segmented sum per point
         d_points = d_feats = pair_pts = None
-        need_geo = need_pts or ctx.needs_input_grad[6]
+        need_geo = need_pts or ctx.needs_input_grad[7]
         if need_geo:
             pair_pts = torch.empty((M, 4), device=dev, dtype=torch.float32)
             fd = plan.feature_desc(k)
@@ -458,7 +460,7 @@ class _RenderFn(torch.autograd.Function):
                                               hip.stream_ptr()), "papr_segment_reduce")
         ctx.saved = None
         grads_wb = d_kw + d_kb + d_wk + d_wkb + d_qw + d_qb + d_wq + d_wqb + d_vw + d_vb
-        return (None, None, None, None, None, d_points, d_feats, d_influ, None, None, None) + tuple(grads_wb)
+        return (None, None, None, None, None, None, d_points, d_feats, d_influ, None, None, None) + tuple(grads_wb)
 
 
 def render_rays(plan, rays_o, rays_d, rays_per_image, idx, points, pc_feats, influ, weights):
@@ -467,4 +469,4 @@ def render_rays(plan, rays_o, rays_d, rays_per_image, idx, points, pc_feats, inf
     qw, qb = weights["query"]
     vw, vb = weights["value"]
     flat = kw + kb + weights["wk"][0] + weights["wk"][1] + qw + qb + weights["wq"][0] + weights["wq"][1] + vw + vb
-    return _RenderFn.apply(plan, rays_o, rays_d, rays_per_image, idx, points, pc_feats, influ, len(kw), len(qw), len(vw), *flat)
+    return _RenderFn.apply(plan, rays_o, rays_d, rays_per_image, torch.is_grad_enabled(), idx, points, pc_feats, influ, len(kw), len(qw), len(vw), *flat)
