@@ -48,6 +48,7 @@ constexpr int CH_BM = 32 * NI;              // rows per tile
 //   NJ=1 NI=2  8 waves of 64 x 32, two workgroups per CU      1221 / 1111 / 904   (twice the waves: no gain)
 //   NJ=1 NI=4  8 waves of 128 x 32, one workgroup per CU      1181 / 1135 / 942   (half the W traffic through L1: no gain)
 //   NJ=2 NI=4  4 waves of 128 x 64, one workgroup per CU      1354 / 1240 / 1107  (nothing overlaps the row phases)
+//   NJ=2 NI=1  4 waves of 32 x 64, three workgroups per CU    1336 / 1281 / 986   (twice the W traffic per MFMA)
 #ifndef CH_NJ
 #define CH_NJ 2                         // 32-column tiles per wave: 2 = four waves of 64 x 64 (one per SIMD), 1 = eight waves of 64 x 32 (two per SIMD)
 #endif
@@ -95,8 +96,9 @@ __device__ long long g_chain_trace[256];
 // BITS (data-gradient only): the activation derivative comes from the sign words the forward run left behind
 // (L.sign_bits) instead of the fp32 activation rows (L.mask): 16 MB instead of 524 MB per layer, and 2 registers
 // instead of 64.
+constexpr int CH_WGS_PER_CU = NI == 1 ? 3 : (NI == 2 ? 2 : 1);     // what fits the LDS (42 / 76.5 / 144 KB per workgroup)
 template <bool DGRAD, bool BITS>
-__global__ __launch_bounds__(CH_THREADS, (NI == 2 ? 2 : 1) * CH_WAVES / 4) void mlp_chain_kernel(ChainArgs p, int tiles_m) {
+__global__ __launch_bounds__(CH_THREADS, CH_WGS_PER_CU * CH_WAVES / 4) void mlp_chain_kernel(ChainArgs p, int tiles_m) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     _Float16* Ah = reinterpret_cast<_Float16*>(smem);
     _Float16* Al = Ah + CH_PLANE;
@@ -494,7 +496,7 @@ int papr_launch_chain(const ChainArgs& a, bool dgrad, long long bytes, long long
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_chain_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CH_LDS_BYTES);
         attr_set = true;
     }
-    static const int wgs_per_cu = getenv("PAPR_CHAIN_WGS_PER_CU") ? atoi(getenv("PAPR_CHAIN_WGS_PER_CU")) : (NI == 2 ? 2 : 1);   // (A/B switch)
+    static const int wgs_per_cu = getenv("PAPR_CHAIN_WGS_PER_CU") ? atoi(getenv("PAPR_CHAIN_WGS_PER_CU")) : CH_WGS_PER_CU;   // (A/B switch)
     dim3 grid((unsigned)(tiles_m < wgs_per_cu * n_cu ? tiles_m : wgs_per_cu * n_cu));     // two workgroups per CU: one multiplies while the other is in its row phases
     const bool prof = papr_prof_on();
     if (prof) papr_prof_begin2(dgrad ? 10 : 9, a.M, a.n_layers, a.K0, bytes, flops, s);
