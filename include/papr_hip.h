@@ -153,6 +153,9 @@ int papr_mlp_fwd(const papr_layer* layers, int n_layers, const float* x, int ldx
  * workspace: papr_mlp_bwd_workspace_bytes(M) bytes (split-M slabs of the weight-gradient GEMMs + the
  * split-f16 scratch). */
 size_t papr_mlp_bwd_workspace_bytes(int64_t M);
+/* 1 if papr_mlp_bwd will read layers[i].weight_t for some layer (weight_t itself is not inspected), 0 if every
+ * data-gradient runs inside a fused launch, which reads the transpose out of `weight` in place. */
+int papr_mlp_bwd_needs_weight_t(const papr_layer* layers, int n_layers, int need_dx);
 int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float* x, int ldx, int64_t M,
                  float* const* outs, const int32_t* ld_out, const float* row_absmax, float* d_out,
                  float* scratch0, float* scratch1, int ld_scratch, float* const* d_weight,

@@ -23,6 +23,7 @@
 #include "h3_common.h"
 #include "chain.h"
 #include <stdlib.h>
+#include <algorithm>
 #include <string.h>
 
 namespace {
@@ -1078,12 +1079,39 @@ static bool layer_rowmax_saved(const papr_layer* layers, int n_layers, int i) {
 }
 
 // pre-split W (N x K, leading dimension ldw) into fragment-order planes at `planes`; returns the halfs used
-static size_t chain_split_weight(const float* W, int N, int K, int ldw, _Float16* planes, ChainLayer& L, hipStream_t s) {
+// All weights of a fused run are split by ONE launch (grid.y = layer).  transposed: the planes hold W^T (the
+// data-gradient run multiplies with the transposed weights; reading W column-wise here saves the caller a transpose).
+struct SplitJob { const float* W; int N, K, ldw, transposed, n_tiles, ksteps; _Float16* hi; _Float16* lo; };
+struct SplitBatch { SplitJob job[CHAIN_MAX_LAYERS]; };
+
+__global__ __launch_bounds__(256) void split_weight_batch_kernel(SplitBatch b) {
+    const SplitJob& j = b.job[blockIdx.y];
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= j.n_tiles * j.ksteps * 512) return;
+    const int e = idx & 7, l = (idx >> 3) & 63, f = idx >> 9;
+    const int t = f / j.ksteps, ks = f - t * j.ksteps;
+    const int n = 32 * t + (l & 31), c = 16 * ks + 8 * (l >> 5) + e;
+    float x = 0.f;
+    if (n < j.N && c < j.K) x = j.transposed ? j.W[(long)c * j.ldw + n] : j.W[(long)n * j.ldw + c];
+    const _Float16 h = (_Float16)x;
+    j.hi[idx] = h;
+    j.lo[idx] = (_Float16)(x - (float)h);
+}
+
+// queue W (N x K result-by-input, or its transpose stored K x N with leading dimension ldw) for the run's split launch
+static size_t chain_queue_weight(SplitBatch& b, int slot, const float* W, int N, int K, int ldw, int transposed, _Float16* planes, ChainLayer& L) {
     const int pitch = (K + 31) / 32 * 32, n_tiles = (N + 31) / 32;
     const size_t plane = (size_t)n_tiles * 32 * pitch;
-    split_weight_kernel<<<dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, s>>>(W, N, K, ldw, n_tiles, pitch / 16, planes, planes + plane);
+    b.job[slot] = SplitJob{W, N, K, ldw, transposed, n_tiles, pitch / 16, planes, planes + plane};
     L.w_hi = planes; L.w_lo = planes + plane; L.ksteps = pitch / 16; L.N = N;
     return 2 * plane;
+}
+static int chain_split_launch(const SplitBatch& b, int n, hipStream_t s) {
+    int most = 0;
+    for (int i = 0; i < n; ++i) most = std::max(most, b.job[i].n_tiles * b.job[i].ksteps * 512);
+    split_weight_batch_kernel<<<dim3((unsigned)((most + 255) / 256), (unsigned)n), dim3(256), 0, s>>>(b);
+    PAPR_CHECK_LAUNCH("split_weight");
+    return 0;
 }
 
 extern "C" int papr_mlp_fwd(const papr_layer* layers, int n_layers, const float* x, int ldx, int64_t M,
@@ -1106,12 +1134,12 @@ extern "C" int papr_mlp_fwd(const papr_layer* layers, int n_layers, const float*
             c.rowmax0 = saved ? saved + (size_t)i * M : nullptr;
             c.M = M; c.n_layers = e - i;
             size_t used = 0;
+            SplitBatch split = {};
             long long bytes = 4LL * M * L.n_in, flops = 0;
             for (int l = i; l < e; ++l) {
                 ChainLayer& cl = c.L[l - i];
                 PAPR_REQUIRE(layers[l].weight && outs[l] && ld_out[l] >= layers[l].n_out, "papr_mlp_fwd: layer %d has null weight/output", l);
-                used += chain_split_weight(layers[l].weight, layers[l].n_out, layers[l].n_in, layers[l].ldw, h3.planes + used, cl, s);
-                PAPR_CHECK_LAUNCH("split_weight");
+                used += chain_queue_weight(split, l - i, layers[l].weight, layers[l].n_out, layers[l].n_in, layers[l].ldw, 0, h3.planes + used, cl);
                 cl.bias = layers[l].bias; cl.act = layers[l].act;
                 cl.C = (saved || l == e - 1) ? outs[l] : nullptr; cl.ldc = ld_out[l];
                 cl.sign_bits = saved && layers[l].act != PAPR_ACT_NONE ? saved_sign_words(saved, n_layers, M, l) : nullptr;
@@ -1121,6 +1149,7 @@ extern "C" int papr_mlp_fwd(const papr_layer* layers, int n_layers, const float*
                 cl.rowmax = l + 1 < n_layers ? (saved ? saved + (size_t)(l + 1) * M : (l == e - 1 ? reinterpret_cast<float*>(h3.out()) : nullptr)) : nullptr;
             }
             PAPR_REQUIRE(used <= H3_PLANE_HALFS, "papr_mlp_fwd: fused run needs %zu plane halfs", used);
+            if (int err = chain_split_launch(split, e - i, s)) return err;
             if (int err = papr_launch_chain(c, false, bytes, flops, s)) return err;
             if (!saved) h3.swap();
             have_amax = true;
@@ -1174,6 +1203,20 @@ struct BwdRunScratch {
     }
     static size_t bytes(long M) { return GEMM_CHAIN ? ((size_t)CHAIN_MAX_LAYERS * M * G_LD + (size_t)(CHAIN_MAX_LAYERS + 1) * M) * sizeof(float) : 0; }
 };
+
+extern "C" int papr_mlp_bwd_needs_weight_t(const papr_layer* layers, int n_layers, int need_dx) {
+    if (!layers || n_layers < 1) return 1;
+    bool any_skip = false;
+    for (int i = 0; i < n_layers; ++i) any_skip |= layers[i].n_skip > 0;
+    if (any_skip) return 1;                         // (skip layers and the accumulating layer-0 data-gradient read weight_t)
+    for (int b = 0; b < n_layers;) {
+        const int e = chain_run_end(layers, n_layers, b);
+        if (e - b >= 2) { b = e; continue; }        // fused run: reads W^T out of `weight`
+        if (b > 0 || need_dx) return 1;
+        ++b;
+    }
+    return 0;
+}
 
 extern "C" size_t papr_mlp_bwd_workspace_bytes(int64_t M) { return TN_SLAB_BYTES + H3Scratch::bytes(M) + BwdRunScratch::bytes(M); }
 
@@ -1244,13 +1287,13 @@ extern "C" int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float*
             c.A0 = g; c.lda0 = ldg; c.K0 = L.n_out; c.rowmax0 = runs.gmax[CHAIN_MAX_LAYERS];
             c.M = M;
             size_t used = 0;
+            SplitBatch split = {};
             long long bytes = 4LL * M * L.n_out, flops = 0;
             for (int l = i; l >= last; --l) {
                 const papr_layer& Ll = layers[l];
-                PAPR_REQUIRE(Ll.weight_t, "papr_mlp_bwd: layer %d needs weight_t", l);
-                ChainLayer& cl = c.L[c.n_layers++];
-                used += chain_split_weight(Ll.weight_t, Ll.n_in, Ll.n_out, Ll.ldwt, h3.planes + used, cl, s);
-                PAPR_CHECK_LAUNCH("split_weight");
+                ChainLayer& cl = c.L[c.n_layers];
+                used += chain_queue_weight(split, c.n_layers, Ll.weight, Ll.n_in, Ll.n_out, Ll.ldw, 1, h3.planes + used, cl);   // W^T read in place
+                ++c.n_layers;
                 if (l > 0) {
                     cl.act = layers[l - 1].act;
                     if (cl.act != PAPR_ACT_NONE) {
@@ -1269,8 +1312,10 @@ extern "C" int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float*
                 flops += 2LL * M * Ll.n_out * Ll.n_in;
             }
             PAPR_REQUIRE(used <= H3_PLANE_HALFS, "papr_mlp_bwd: fused run needs %zu plane halfs", used);
-            if (c.n_layers > 0)
+            if (c.n_layers > 0) {
+                if (int err = chain_split_launch(split, c.n_layers, s)) return err;
                 if (int err = papr_launch_chain(c, true, bytes, flops, s)) return err;
+            }
             auto slot = [&](int l) { return l - (b > 0 ? b - 1 : 0); };
             // (the launch above leaves max |g| of the run's top rows in the last gmax slot, computed while staging them)
             if (c.n_layers == 0)

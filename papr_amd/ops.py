@@ -155,8 +155,10 @@ def _workspace(dev, kind, M):
 def mlp_backward(spec, ws, bs, x, M, outs, d_out, scratch, need_dx):
     """Returns (d_ws, d_bs, d_x or None).  d_out is consumed."""
     dev = x.device
-    wts = [w.t().contiguous() for w in ws]
-    tab = _layer_table(spec, ws, bs, wts)
+    tab = _layer_table(spec, ws, bs)
+    if hip.lib().papr_mlp_bwd_needs_weight_t(tab, spec.n_layer, 1 if need_dx else 0):     # (fused runs read W^T in place)
+        wts = [w.t().contiguous() for w in ws]
+        tab = _layer_table(spec, ws, bs, wts)
     d_ws = [torch.empty_like(w) for w in ws]
     d_bs = [torch.empty_like(b) for b in bs]
     d_x = torch.empty_like(x) if need_dx else None
