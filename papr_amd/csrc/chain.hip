@@ -41,7 +41,7 @@ namespace {
 constexpr int NI = CH_NI;
 constexpr int CH_BM = 32 * NI;              // rows per tile
 #ifndef CH_START_DELAY
-#define CH_START_DELAY 1              // x 8128 cycles (s_sleep 127)
+#define CH_START_DELAY 0              // x 8128 cycles (s_sleep 127); 0, 1 and 2 measured the same
 #endif
 // Tile shape (compile-time, A/B-tested on 512,000 x 256 x 256 x 4 layers; forward / data-gradient / inference run in us):
 //   NJ=2 NI=2  4 waves of 64 x 64, two workgroups per CU      1165 / 1177 / 884   <- default
@@ -138,9 +138,8 @@ __global__ __launch_bounds__(CH_THREADS, CH_WGS_PER_CU * CH_WAVES / 4) void mlp_
 #pragma unroll
     for (int u = 0; u < WD - 1; ++u) load_w(0, u, wfh[u], wfl[u]);
     constexpr int SR = 8;                        // input rows per wave and staging pass (16 per tile; one pass of 16 is no faster)
-    // Two workgroups share a CU so that one multiplies while the other is in its row phases.  Launched together and
-    // with identical timing they would run in lockstep instead (both multiplying at half speed, then both leaving the
-    // matrix pipe idle): the second wave of workgroups starts half a layer late.
+    // Two workgroups share a CU so that one multiplies while the other is in its row phases.  (Experiment: start the
+    // second half of the grid late, in case equal timing keeps the pairs in lockstep.  No effect: off.)
     if (blockIdx.x >= gridDim.x / 2) {
 #pragma unroll 1
         for (int z = 0; z < CH_START_DELAY; ++z) __builtin_amdgcn_s_sleep(127);
