@@ -275,6 +275,14 @@ def test_mlp_forward_backward_vs_torch(M, d_in, width, d_out, n, act, skips):
         np.testing.assert_allclose(bd[i].grad.cpu().numpy(), bs[i].grad.numpy(), rtol=0, atol=3e-5 * sb, err_msg="db%d" % i)
     sx = x.grad.abs().max().item()
     np.testing.assert_allclose(d_x.cpu()[:, :d_in].numpy(), x.grad.numpy(), rtol=0, atol=3e-5 * sx)
+    # without the state of the forward call (row maxima, sign words) the backward pass takes its other route -- fp32
+    # activation rows as masks, fp32 MFMA weight-gradients -- and must land on the same gradients
+    d_ws2, d_bs2, d_x2 = ops.mlp_backward(spec, [w.detach() for w in ew], [b.detach() for b in eb], xd, M, list(outs), gp.to(d), scratch, True)
+    torch.cuda.synchronize()
+    for i in range(n):
+        sw = d_ws[i].abs().max().item() + 1e-12
+        np.testing.assert_allclose(d_ws2[i].cpu().numpy(), d_ws[i].cpu().numpy(), rtol=0, atol=3e-5 * sw, err_msg="dW%d (no saved state)" % i)
+    np.testing.assert_allclose(d_x2.cpu().numpy(), d_x.cpu().numpy(), rtol=0, atol=3e-5 * sx)
 
 
 # ------------------------------------------------------------------------------------------- K4
