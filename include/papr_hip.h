@@ -142,10 +142,21 @@ typedef struct {
  * papr_mlp_bwd: weight-gradients then run with split-f16 operands scaled by the maxima (fp32 MFMA
  * without it), and the data-gradient run reads the sign bits instead of the fp32 activations. */
 size_t papr_mlp_saved_floats(int32_t n_layers, int64_t M);
+/* Optional LayerNorm core behind the last layer (the reference's FeedForward.outnorm, models/attn.py:113-117, without
+ * its affine part, which the host folds into the next Linear): outs[n_layers-1] receives the standardised rows
+ * y = (x - mean) / (std_unbiased + eps) and stats[2m], stats[2m+1] = 1 / (std + eps), std -- the layout papr_rownorm_fwd
+ * writes and papr_rownorm_bwd reads.  A fused run applies it in its last row phase (no extra pass over the rows);
+ * otherwise the library runs papr_rownorm_fwd in place after the last layer. */
+typedef struct {
+    float eps;
+    int32_t width;      /* logical row width (= n_out of the last layer) */
+    float* stats;       /* (M, 2) */
+} papr_row_norm;
+
 size_t papr_mlp_fwd_workspace_bytes(int64_t M);
 int papr_mlp_fwd(const papr_layer* layers, int n_layers, const float* x, int ldx, int64_t M,
-                 float* const* outs, const int32_t* ld_out, float* row_absmax, void* workspace,
-                 papr_stream_t stream);
+                 float* const* outs, const int32_t* ld_out, float* row_absmax, const papr_row_norm* out_norm,
+                 void* workspace, papr_stream_t stream);
 
 /* Backward.  d_out: gradient w.r.t. the last layer's output (M, ld_out[n-1]); it is consumed
  * (overwritten).  scratch0/scratch1: two (M, max width) buffers.  d_weight[i] (n_out, ldw) and

@@ -27,6 +27,8 @@ struct ChainArgs {
     float* rowmax0;                       // (M) receives max |.| of every input row, or null
     long M;
     int n_layers;
+    float norm_eps;                       // forward: with norm_stats, the LAST layer's rows are standardised (LayerNorm core,
+    float* norm_stats;                    // papr_row_norm in papr_hip.h) before they are stored; (M, 2) = 1/(std+eps), std
     ChainLayer L[CHAIN_MAX_LAYERS];
 };
 

@@ -431,7 +431,87 @@ __global__ __launch_bounds__(CH_THREADS, CH_WGS_PER_CU * CH_WAVES / 4) void mlp_
                 }
             };
 #ifndef CH_EXP_NO_PHASES
-            if (DGRAD || L.act == PAPR_ACT_NONE) rows_phase([](float v, float) { return v; });
+            if (!DGRAD && !more && p.norm_stats) {
+                // ---- last layer with LayerNorm core behind it (act = none): the rows are complete in this workgroup, so
+                // they are standardised before they ever reach memory.  Two-pass mean / unbiased std like papr_rownorm_fwd;
+                // the partial sums of a row's 2 x CH_WAVES lanes meet in LDS in a FIXED order (atomics would make the last
+                // bits, and with them the chunk-invariance of evaluate, depend on timing).  The tables alias the A planes,
+                // which nobody reads after the barrier above.
+                constexpr int PW = 2 * CH_WAVES;
+                float* part0 = smem;
+                float* part1 = smem + CH_BM * PW;
+                float mean[NI];
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int rl = i * 32 + (lane & 31);
+                    const float inv = inv_tab[rl];
+                    float sum = 0.f;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        if (!live[j]) continue;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int col = (wn * NJ + j) * 32 + 8 * g + 4 * hh;
+                            const float4 b4 = *reinterpret_cast<const float4*>(bias_tab + l * 256 + col);
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                const float r = __builtin_fmaf(acc[i][j][4 * g + c], inv, c == 0 ? b4.x : c == 1 ? b4.y : c == 2 ? b4.z : b4.w);
+                                acc[i][j][4 * g + c] = r;
+                                sum += col + c < N ? r : 0.f;
+                            }
+                        }
+                    }
+                    part0[rl * PW + wn * 2 + hh] = sum;
+                }
+                lds_barrier();
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int rl = i * 32 + (lane & 31);
+                    float tot = 0.f;
+#pragma unroll
+                    for (int q = 0; q < PW; ++q) tot += part0[rl * PW + q];
+                    mean[i] = tot / (float)N;
+                    float ss = 0.f;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        if (!live[j]) continue;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int col = (wn * NJ + j) * 32 + 8 * g + 4 * hh;
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                const float dlt = acc[i][j][4 * g + c] - mean[i];
+                                acc[i][j][4 * g + c] = dlt;
+                                ss += col + c < N ? dlt * dlt : 0.f;
+                            }
+                        }
+                    }
+                    part1[rl * PW + wn * 2 + hh] = ss;
+                }
+                lds_barrier();
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int rl = i * 32 + (lane & 31);
+                    const long row = m0 + rl;
+                    float tot = 0.f;
+#pragma unroll
+                    for (int q = 0; q < PW; ++q) tot += part1[rl * PW + q];
+                    const float sigma = sqrtf(tot / (float)(N - 1));
+                    const float rinv = 1.0f / (sigma + p.norm_eps);
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        if (!live[j]) continue;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int col = (wn * NJ + j) * 32 + 8 * g + 4 * hh;
+                            const float4 y = make_float4(acc[i][j][4 * g] * rinv, acc[i][j][4 * g + 1] * rinv, acc[i][j][4 * g + 2] * rinv, acc[i][j][4 * g + 3] * rinv);
+                            if (L.C && col < N && row < p.M) *reinterpret_cast<float4*>(L.C + row * L.ldc + col) = y;
+                        }
+                    }
+                    if (wn == 0 && hh == 0 && row < p.M) { p.norm_stats[row * 2] = rinv; p.norm_stats[row * 2 + 1] = sigma; }
+                }
+            }
+            else if (DGRAD || L.act == PAPR_ACT_NONE) rows_phase([](float v, float) { return v; });
             else if (L.act == PAPR_ACT_RELU) rows_phase([](float v, float) { return fmaxf(v, 0.f); });
             else rows_phase([](float v, float) { return fmaxf(v, 0.2f * v); });
 #endif

@@ -1115,11 +1115,13 @@ static int chain_split_launch(const SplitBatch& b, int n, hipStream_t s) {
 }
 
 extern "C" int papr_mlp_fwd(const papr_layer* layers, int n_layers, const float* x, int ldx, int64_t M,
-                            float* const* outs, const int32_t* ld_out, float* row_absmax, void* workspace,
-                            papr_stream_t stream) {
+                            float* const* outs, const int32_t* ld_out, float* row_absmax, const papr_row_norm* out_norm,
+                            void* workspace, papr_stream_t stream) {
     PAPR_REQUIRE(layers && x && outs && ld_out && n_layers >= 1, "papr_mlp_fwd: bad arguments");
     hipStream_t s = as_stream(stream);
     bool have_amax = false;                 // split-f16 mode: row maxima of the current layer's input are in h3.in()
+    bool norm_done = false;
+    PAPR_REQUIRE(!out_norm || (out_norm->stats && out_norm->width >= 2), "papr_mlp_fwd: out_norm needs stats and a width");
     PAPR_REQUIRE(!GEMM_H3_FWD || workspace, "papr_mlp_fwd: workspace required (papr_mlp_fwd_workspace_bytes)");
     H3Scratch h3(workspace, M);
     for (int i = 0; i < n_layers; ++i) {
@@ -1149,6 +1151,10 @@ extern "C" int papr_mlp_fwd(const papr_layer* layers, int n_layers, const float*
                 cl.rowmax = l + 1 < n_layers ? (saved ? saved + (size_t)(l + 1) * M : (l == e - 1 ? reinterpret_cast<float*>(h3.out()) : nullptr)) : nullptr;
             }
             PAPR_REQUIRE(used <= H3_PLANE_HALFS, "papr_mlp_fwd: fused run needs %zu plane halfs", used);
+            if (out_norm && e == n_layers && layers[e - 1].act == PAPR_ACT_NONE && out_norm->width == layers[e - 1].n_out) {
+                c.norm_eps = out_norm->eps; c.norm_stats = out_norm->stats;      // standardised in the run's last row phase
+                norm_done = true;
+            }
             if (int err = chain_split_launch(split, e - i, s)) return err;
             if (int err = papr_launch_chain(c, false, bytes, flops, s)) return err;
             if (!saved) h3.swap();
@@ -1186,6 +1192,9 @@ extern "C" int papr_mlp_fwd(const papr_layer* layers, int n_layers, const float*
         have_amax = false;
         if (int e = gemm_nt(a, s)) return e;
     }
+    if (out_norm && !norm_done)             // not inside a fused run: one more pass over the rows
+        return papr_rownorm_fwd(outs[n_layers - 1], M, out_norm->width, ld_out[n_layers - 1], out_norm->eps, outs[n_layers - 1],
+                                out_norm->stats, stream);
     return 0;
 }
 
