@@ -19,6 +19,8 @@ struct ChainLayer {
     float* rowmax;             // (M) max |.| of every result row, or null
     int N;                     // result width (<= 256; a multiple of 32 unless this is the last layer of the run)
     int ksteps;                // input width / 16, planes padded to a multiple of 32 columns (even)
+    int k1steps;               // = ksteps, or for a skip layer ([previous output | x] as input): the k-steps of the first
+                               // segment (a multiple of 4); the remaining ones multiply the run's input rows A0 again
     int act;                   // forward: activation; data-gradient: activation whose derivative is applied
 };
 

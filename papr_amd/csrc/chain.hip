@@ -32,6 +32,7 @@
 #include "h3_common.h"
 #include "chain.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -57,7 +58,7 @@ constexpr int CH_WAVES = 8 / NJ;
 constexpr int CH_THREADS = 64 * CH_WAVES;
 constexpr int CH_AP = 264;                  // A-plane row pitch in halfs (528 B: conflict-free ds_read_b128)
 constexpr int CH_PLANE = CH_BM * CH_AP;     // halfs per plane
-constexpr size_t CH_LDS_BYTES = (size_t)2 * CH_PLANE * sizeof(_Float16) + CH_BM * sizeof(float) + 2 * CH_BM * sizeof(unsigned) + CHAIN_MAX_LAYERS * 256 * sizeof(float);
+constexpr size_t CH_LDS_BYTES = (size_t)2 * CH_PLANE * sizeof(_Float16) + 3 * CH_BM * sizeof(float) + 2 * CH_BM * sizeof(unsigned) + CHAIN_MAX_LAYERS * 256 * sizeof(float);
 
 // max over the 8 lanes that share a row segment (lanes 8q .. 8q+7), on the DPP network
 __device__ __forceinline__ float seg8_max(float v) {
@@ -97,14 +98,18 @@ __device__ long long g_chain_trace[256];
 // (L.sign_bits) instead of the fp32 activation rows (L.mask): 16 MB instead of 524 MB per layer, and 2 registers
 // instead of 64.
 constexpr int CH_WGS_PER_CU = NI == 1 ? 3 : (NI == 2 ? 2 : 1);     // what fits the LDS (42 / 76.5 / 144 KB per workgroup)
-template <bool DGRAD, bool BITS>
+// SKIP (forward only): the run contains a skip layer (second K segment = the run's input); a separate instantiation, so
+// that the extra control flow around the k-loop does not cost the common kernels registers.
+template <bool DGRAD, bool BITS, bool SKIP = false>
 __global__ __launch_bounds__(CH_THREADS, CH_WGS_PER_CU * CH_WAVES / 4) void mlp_chain_kernel(ChainArgs p, int tiles_m) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     _Float16* Ah = reinterpret_cast<_Float16*>(smem);
     _Float16* Al = Ah + CH_PLANE;
     float* inv_tab = reinterpret_cast<float*>(Al + CH_PLANE);            // [64] 1/scale of the rows of the A planes
     unsigned* rmax_tab = reinterpret_cast<unsigned*>(inv_tab + CH_BM);   // [2][64] max|C| bit patterns, by layer parity
-    float* bias_tab = reinterpret_cast<float*>(rmax_tab + 2 * CH_BM);    // [layers][256]: a global load in phase 1 would wait for the stores before it (loads and stores share vmcnt)
+    float* scl_tab = reinterpret_cast<float*>(rmax_tab + 2 * CH_BM);      // [rows] scale of the rows of the A planes (= 1 / inv_tab)
+    unsigned* xmax_tab = reinterpret_cast<unsigned*>(scl_tab + CH_BM);    // [rows] max |x| bits of the tile's input rows (skip layers multiply x again)
+    float* bias_tab = reinterpret_cast<float*>(xmax_tab + CH_BM);    // [layers][256]: a global load in phase 1 would wait for the stores before it (loads and stores share vmcnt)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int wm = 0;                        // (one wave row: the tile is 64 rows)
     const int wn = wave;                         // wave tile: all 64 rows, columns 32 NJ wn .. + 32 NJ - 1
@@ -137,7 +142,6 @@ __global__ __launch_bounds__(CH_THREADS, CH_WGS_PER_CU * CH_WAVES / 4) void mlp_
     };
 #pragma unroll
     for (int u = 0; u < WD - 1; ++u) load_w(0, u, wfh[u], wfl[u]);
-    constexpr int SR = 8;                        // input rows per wave and staging pass (16 per tile; one pass of 16 is no faster)
     // Two workgroups share a CU so that one multiplies while the other is in its row phases.  (Experiment: start the
     // second half of the grid late, in case equal timing keeps the pairs in lockstep.  No effect: off.)
     if (blockIdx.x >= gridDim.x / 2) {
@@ -147,11 +151,11 @@ __global__ __launch_bounds__(CH_THREADS, CH_WGS_PER_CU * CH_WAVES / 4) void mlp_
     for (int tile = blockIdx.x; tile < tiles_m; tile += gridDim.x) {
         const long m0 = (long)tile * CH_BM;
         CH_STAMP();
-        // ---- stage the tile's input rows: wave w carries rows w, w+4, ...; row maximum on the way.  (Requesting them
-        // during the previous tile's last layer bought nothing -- the other workgroup of the CU fills the wait -- and
-        // cost 64 registers.)
-        {
-            const int kpad = p.L[0].ksteps * 16;
+        // ---- stage the tile's input rows: wave w carries rows w, w + CH_WAVES, ...; row maximum on the way.  (Requesting
+        // them during the previous tile's last layer bought nothing -- the other workgroup of the CU fills the wait -- and
+        // cost 64 registers.)  first = false: a skip layer multiplies x again, with the scale its rows already carry.
+        auto stage_rows = [&](int kpad, bool first, auto batch) {
+            constexpr int SR = decltype(batch)::value;            // rows in flight per wave: 8, or 4 where the accumulators are live
             const int c = 4 * lane;
 #pragma unroll 1
             for (int u0 = 0; u0 < CH_BM / CH_WAVES; u0 += SR) {
@@ -169,24 +173,33 @@ __global__ __launch_bounds__(CH_THREADS, CH_WGS_PER_CU * CH_WAVES / 4) void mlp_
 #pragma unroll
                 for (int u = 0; u < SR; ++u) {
                     const int r = wave + CH_WAVES * (u0 + u);
-                    float mx = fmaxf(fmaxf(fabsf(v[u].x), fabsf(v[u].y)), fmaxf(fabsf(v[u].z), fabsf(v[u].w)));
-                    mx = wave64_max(mx);
-                    float inv;
-                    const float sc = scale_from_max(__float_as_uint(mx), inv);
+                    float sc;
+                    if (first) {
+                        float mx = fmaxf(fmaxf(fabsf(v[u].x), fabsf(v[u].y)), fmaxf(fabsf(v[u].z), fabsf(v[u].w)));
+                        mx = wave64_max(mx);
+                        // (when layer 0 feeds a skip layer later, that layer rescales; layer 0 itself only sees x)
+                        float inv;
+                        sc = scale_from_max(__float_as_uint(mx), inv);
+                        if (lane == 0) {
+                            inv_tab[r] = inv;
+                            scl_tab[r] = sc;
+                            xmax_tab[r] = __float_as_uint(mx);
+                            if (p.rowmax0 && m0 + r < p.M) p.rowmax0[m0 + r] = mx;
+                        }
+                    } else {
+                        sc = scl_tab[r];
+                    }
                     if (c < kpad) {
                         half4 hi, lo;
                         split4(v[u], sc, hi, lo);
                         *reinterpret_cast<half4*>(Ah + r * CH_AP + c) = hi;
                         *reinterpret_cast<half4*>(Al + r * CH_AP + c) = lo;
                     }
-                    if (lane == 0) {
-                        inv_tab[r] = inv;
-                        if (p.rowmax0 && m0 + r < p.M) p.rowmax0[m0 + r] = mx;
-                    }
                 }
             }
-            for (int t = tid; t < CH_BM; t += CH_THREADS) rmax_tab[t] = 0u;
-        }
+        };
+        stage_rows(p.L[0].k1steps * 16, true, std::integral_constant<int, 8>());
+        for (int t = tid; t < CH_BM; t += CH_THREADS) rmax_tab[t] = 0u;
         lds_barrier();
         CH_STAMP();
 
@@ -235,8 +248,12 @@ __global__ __launch_bounds__(CH_THREADS, CH_WGS_PER_CU * CH_WAVES / 4) void mlp_
 
             // ---- k-loop.  The A fragments of k-step s+1 are read from LDS while k-step s multiplies (hipcc does not
             // pipeline the reads by itself: it places them right in front of their MFMAs and waits).
+            // (kb, ke): the k-steps of one K segment -- all of them, or [0, k1steps) and [k1steps, ksteps) of a skip layer.  W
+            // fragments are indexed by the layer-wide k-step, A fragments by the step inside the segment (the A planes hold
+            // one segment at a time).
+            int kb = 0, ke = SKIP ? L.k1steps : ksteps;
             auto load_a = [&](int ks, half8 (&ah)[NI], half8 (&al)[NI]) {
-                ks = ks < ksteps ? ks : ksteps - 1;
+                ks = (ks < ke ? ks : ke - 1) - kb;
 #pragma unroll
                 for (int i = 0; i < NI; ++i) {
                     const int o = (wm * 2 + i) * 32 * CH_AP + frag + ks * 16;
@@ -259,9 +276,9 @@ __global__ __launch_bounds__(CH_THREADS, CH_WGS_PER_CU * CH_WAVES / 4) void mlp_
             };
             auto k_loop = [&](auto mma) {                       // waves with a dead column tile (narrow layers): simple form
                 half8 a0h[NI], a0l[NI], a1h[NI], a1l[NI];
-                load_a(0, a0h, a0l);
+                load_a(kb, a0h, a0l);
 #pragma unroll 1
-                for (int ks = 0; ks < ksteps; ks += 4) {       // ksteps is even (planes are padded to 32 columns)
+                for (int ks = kb; ks < ke; ks += 4) {          // segment lengths are even (planes are padded to 32 columns)
                     load_w(l, ks + 3, wfh[3], wfl[3]);
                     load_a(ks + 1, a1h, a1l);
                     __builtin_amdgcn_sched_barrier(0);
@@ -273,7 +290,7 @@ __global__ __launch_bounds__(CH_THREADS, CH_WGS_PER_CU * CH_WAVES / 4) void mlp_
                     mma(wfh[1], wfl[1], a1h, a1l);
                     __builtin_amdgcn_sched_barrier(0);
                     load_w(l, ks + 5, wfh[1], wfl[1]);
-                    if (ks + 2 < ksteps) {
+                    if (ks + 2 < ke) {
                         load_a(ks + 3, a1h, a1l);
                         __builtin_amdgcn_sched_barrier(0);
                         mma(wfh[2], wfl[2], a0h, a0l);
@@ -306,7 +323,7 @@ __global__ __launch_bounds__(CH_THREADS, CH_WGS_PER_CU * CH_WAVES / 4) void mlp_
             auto step = [&](const half8 (&uh)[NJ], const half8 (&ul)[NJ], const half8 (&xh)[NI], const half8 (&xl)[NI],
                             int kw, half8 (&nh)[NJ], half8 (&nl)[NJ], int ka, half8 (&yh)[NI], half8 (&yl)[NI]) {
                 kw = kw < ksteps ? kw : ksteps - 1;
-                ka = ka < ksteps ? ka : ksteps - 1;
+                ka = (ka < ke ? ka : ke - 1) - kb;
 #ifdef CH_EXP_NO_W
                 const bool ldw = kw <= 2;
 #else
@@ -348,12 +365,12 @@ __global__ __launch_bounds__(CH_THREADS, CH_WGS_PER_CU * CH_WAVES / 4) void mlp_
             };
             auto k_loop_full = [&]() {
                 half8 a0h[NI], a0l[NI], a1h[NI], a1l[NI];
-                load_a(0, a0h, a0l);
+                load_a(kb, a0h, a0l);
 #pragma unroll 1
-                for (int ks = 0; ks < ksteps; ks += 4) {
+                for (int ks = kb; ks < ke; ks += 4) {
                     step(wfh[0], wfl[0], a0h, a0l, ks + 3, wfh[3], wfl[3], ks + 1, a1h, a1l);
                     step(wfh[1], wfl[1], a1h, a1l, ks + 4, wfh[0], wfl[0], ks + 2, a0h, a0l);
-                    if (ks + 2 < ksteps) {
+                    if (ks + 2 < ke) {
                         step(wfh[2], wfl[2], a0h, a0l, ks + 5, wfh[1], wfl[1], ks + 3, a1h, a1l);
                         step(wfh[3], wfl[3], a1h, a1l, ks + 6, wfh[2], wfl[2], ks + 4, a0h, a0l);
                     }
@@ -362,8 +379,22 @@ __global__ __launch_bounds__(CH_THREADS, CH_WGS_PER_CU * CH_WAVES / 4) void mlp_
 #undef CH_MFMA
 #undef CH_SB
 #ifndef CH_EXP_NO_KLOOP
-            if (live[NJ - 1]) k_loop_full();                    // every column tile of this wave holds real columns
-            else if (live[0]) k_loop(mma_live);
+            // A skip layer has a second K segment: the run's own input x (reference MLP skip_layers, models/mlp.py:54-55).  Its
+            // rows come into the A planes again -- split with the scale the rows already carry, which the previous layer's
+            // phase 2 chose from max(row max of its output, row max of x) -- and the k-loop goes on.  k1steps is a multiple
+            // of 4: the W ring is back at set 0 and already holds k-steps k1steps, +1, +2.  (One loop, so that the k-loop code
+            // exists once: a second copy costs registers.)
+#pragma unroll 1
+            for (int seg = 0; seg < (SKIP && L.k1steps < ksteps ? 2 : 1); ++seg) {
+                if (SKIP && seg) {
+                    lds_barrier();                              // everyone is done with the first segment's A planes
+                    stage_rows((ksteps - L.k1steps) * 16, false, std::integral_constant<int, 4>());
+                    lds_barrier();
+                    kb = L.k1steps; ke = ksteps;
+                }
+                if (live[NJ - 1]) k_loop_full();                // every column tile of this wave holds real columns
+                else if (live[0]) k_loop(mma_live);
+            }
 #endif
             {   // first fragments of what comes next: the next layer, or layer 0 of the next tile
                 const int ln = l + 1 < p.n_layers ? l + 1 : 0;
@@ -530,8 +561,10 @@ __global__ __launch_bounds__(CH_THREADS, CH_WGS_PER_CU * CH_WAVES / 4) void mlp_
                 for (int i = 0; i < NI; ++i) {
                     const int rl = i * 32 + (lane & 31);
                     float inv;
-                    const float sc = scale_from_max(rmax_tab[par * CH_BM + rl], inv);
-                    if (wn == 0 && hh == 0) inv_tab[rl] = inv;
+                    unsigned mxb = rmax_tab[par * CH_BM + rl];
+                    if (SKIP && p.L[l + 1].k1steps < p.L[l + 1].ksteps) mxb = max(mxb, xmax_tab[rl]);      // next layer also multiplies x
+                    const float sc = scale_from_max(mxb, inv);
+                    if (wn == 0 && hh == 0) { inv_tab[rl] = inv; scl_tab[rl] = sc; }
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) {
                         if (!live[j]) continue;
@@ -573,6 +606,7 @@ int papr_launch_chain(const ChainArgs& a, bool dgrad, long long bytes, long long
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_chain_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CH_LDS_BYTES);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_chain_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CH_LDS_BYTES);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_chain_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CH_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_chain_kernel<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CH_LDS_BYTES);
         attr_set = true;
     }
     static const int wgs_per_cu = getenv("PAPR_CHAIN_WGS_PER_CU") ? atoi(getenv("PAPR_CHAIN_WGS_PER_CU")) : CH_WGS_PER_CU;   // (A/B switch)
@@ -584,7 +618,12 @@ int papr_launch_chain(const ChainArgs& a, bool dgrad, long long bytes, long long
     for (int l = 0; l < a.n_layers; ++l) bits = bits && (a.L[l].mask == nullptr || a.L[l].sign_bits != nullptr);
     if (dgrad && bits) mlp_chain_kernel<true, true><<<grid, dim3(CH_THREADS), CH_LDS_BYTES, s>>>(a, tiles_m);
     else if (dgrad) mlp_chain_kernel<true, false><<<grid, dim3(CH_THREADS), CH_LDS_BYTES, s>>>(a, tiles_m);
-    else mlp_chain_kernel<false, false><<<grid, dim3(CH_THREADS), CH_LDS_BYTES, s>>>(a, tiles_m);
+    else {
+        bool skip = false;
+        for (int l = 0; l < a.n_layers; ++l) skip = skip || a.L[l].k1steps < a.L[l].ksteps;
+        if (skip) mlp_chain_kernel<false, false, true><<<grid, dim3(CH_THREADS), CH_LDS_BYTES, s>>>(a, tiles_m);
+        else mlp_chain_kernel<false, false><<<grid, dim3(CH_THREADS), CH_LDS_BYTES, s>>>(a, tiles_m);
+    }
     if (prof) papr_prof_end(s);
     PAPR_CHECK_LAUNCH("mlp_chain");
     return 0;

@@ -1054,12 +1054,16 @@ static bool layer_on_h3(const papr_layer& L) { return GEMM_H3_FWD && L.n_out > 1
 
 // Layers [b, e) that one fused launch (chain.hip) can carry: no skip inputs, at most 256 wide, the widths between
 // two fused layers multiples of 32.  Returns e (e - b < 2: no fusion).
-static int chain_run_end(const papr_layer* layers, int n_layers, int b) {
+static int chain_run_end(const papr_layer* layers, int n_layers, int b, bool allow_skip = false) {
     if (!GEMM_CHAIN) return b;
     int e = b;
     while (e < n_layers && e - b < CHAIN_MAX_LAYERS) {
         const papr_layer& L = layers[e];
-        if (L.n_skip > 0 || L.n_in > 256 || L.n_out > 256 || L.n_in % 4 || L.n_out % 4) break;
+        if (L.n_skip > 0) {
+            // a skip layer rides in a FORWARD run that starts at layer 0 (its second K segment is the run's own input)
+            if (!(allow_skip && b == 0 && e > 0 && L.n_skip == layers[0].n_in && L.skip_col == L.n_in && L.n_in % 64 == 0)) break;
+        }
+        if (L.n_in > 256 || L.n_out > 256 || L.n_in % 4 || L.n_out % 4 || L.n_skip > 256) break;
         if (e > b && (layers[e - 1].n_out % 32 || layers[e - 1].n_out != L.n_in)) break;
         ++e;
     }
@@ -1069,7 +1073,7 @@ static int chain_run_end(const papr_layer* layers, int n_layers, int b) {
 // the forward pass left max |input row| of layer i in row_absmax: split-f16 layers and members of fused runs
 static bool layer_rowmax_saved(const papr_layer* layers, int n_layers, int i) {
     for (int b = 0; b < n_layers;) {
-        const int e = chain_run_end(layers, n_layers, b);
+        const int e = chain_run_end(layers, n_layers, b, true);
         if (e - b >= 2) {
             if (i >= b && i < e) return true;
             b = e;
@@ -1103,7 +1107,7 @@ static size_t chain_queue_weight(SplitBatch& b, int slot, const float* W, int N,
     const int pitch = (K + 31) / 32 * 32, n_tiles = (N + 31) / 32;
     const size_t plane = (size_t)n_tiles * 32 * pitch;
     b.job[slot] = SplitJob{W, N, K, ldw, transposed, n_tiles, pitch / 16, planes, planes + plane};
-    L.w_hi = planes; L.w_lo = planes + plane; L.ksteps = pitch / 16; L.N = N;
+    L.w_hi = planes; L.w_lo = planes + plane; L.ksteps = pitch / 16; L.k1steps = pitch / 16; L.N = N;
     return 2 * plane;
 }
 static int chain_split_launch(const SplitBatch& b, int n, hipStream_t s) {
@@ -1128,7 +1132,7 @@ extern "C" int papr_mlp_fwd(const papr_layer* layers, int n_layers, const float*
         const papr_layer& L = layers[i];
         PAPR_REQUIRE(L.weight && outs[i], "papr_mlp_fwd: layer %d has null weight/output", i);
         PAPR_REQUIRE(ld_out[i] >= L.n_out, "papr_mlp_fwd: layer %d output stride %d < %d", i, ld_out[i], L.n_out);
-        if (const int e = chain_run_end(layers, n_layers, i); e - i >= 2) {
+        if (const int e = chain_run_end(layers, n_layers, i, true); e - i >= 2) {
             // layers [i, e) in one launch; without row_absmax (inference) only the run's last result reaches memory
             float* saved = row_absmax;
             ChainArgs c = {};
@@ -1141,13 +1145,14 @@ extern "C" int papr_mlp_fwd(const papr_layer* layers, int n_layers, const float*
             for (int l = i; l < e; ++l) {
                 ChainLayer& cl = c.L[l - i];
                 PAPR_REQUIRE(layers[l].weight && outs[l] && ld_out[l] >= layers[l].n_out, "papr_mlp_fwd: layer %d has null weight/output", l);
-                used += chain_queue_weight(split, l - i, layers[l].weight, layers[l].n_out, layers[l].n_in, layers[l].ldw, 0, h3.planes + used, cl);
+                used += chain_queue_weight(split, l - i, layers[l].weight, layers[l].n_out, layers[l].n_in + layers[l].n_skip, layers[l].ldw, 0, h3.planes + used, cl);
+                if (layers[l].n_skip > 0) cl.k1steps = layers[l].n_in / 16;      // [previous output | x]: the second segment multiplies the run's input again
                 cl.bias = layers[l].bias; cl.act = layers[l].act;
                 cl.C = (saved || l == e - 1) ? outs[l] : nullptr; cl.ldc = ld_out[l];
                 cl.sign_bits = saved && layers[l].act != PAPR_ACT_NONE ? saved_sign_words(saved, n_layers, M, l) : nullptr;
                 if (cl.C) bytes += 4LL * M * layers[l].n_out;
-                bytes += 4LL * layers[l].n_out * layers[l].n_in;
-                flops += 2LL * M * layers[l].n_out * layers[l].n_in;
+                bytes += 4LL * layers[l].n_out * (layers[l].n_in + layers[l].n_skip) + 4LL * M * layers[l].n_skip;
+                flops += 2LL * M * layers[l].n_out * (layers[l].n_in + layers[l].n_skip);
                 cl.rowmax = l + 1 < n_layers ? (saved ? saved + (size_t)(l + 1) * M : (l == e - 1 ? reinterpret_cast<float*>(h3.out()) : nullptr)) : nullptr;
             }
             PAPR_REQUIRE(used <= H3_PLANE_HALFS, "papr_mlp_fwd: fused run needs %zu plane halfs", used);
