@@ -1,7 +1,8 @@
 // K3b: a whole run of embedding-MLP layers in ONE kernel (split-f16 MFMA, see gemm.hip for the arithmetic).
 //
 // Replaces the same reference lines as gemm_nt (MLP.forward, models/mlp.py:47-59, and its autograd
-// data-gradient) for runs of consecutive layers without skip input and at most 256 wide.
+// data-gradient) for runs of consecutive layers at most 256 wide (a forward run may contain skip layers: their second
+// K segment is the run's own input; data-gradient runs stop at them).
 //
 // Why: layer by layer, the split-f16 GEMM is HBM-bound -- it reads the (M x 256) input and writes the
 // (M x 256) output of every layer.  But a workgroup that owns COMPLETE rows of a layer's output owns the
@@ -20,12 +21,14 @@
 //                                fragment order through a register ring (three k-steps ahead), every
 //                                request alone behind an MFMA (sched_barrier pins that; see the k-loop)
 //                       phase 1  in registers, no LDS bounce: un-scale + bias + activation (one fma, one
-//                                max) or derivative mask, 16-byte row stores, row maximum -> LDS atomic
+//                                max) or derivative mask (sign words the forward run left: one bit per
+//                                activation), 16-byte row stores, row maximum -> LDS atomic
 //                       phase 2  per-row power-of-two scale from the row maxima, hi/lo split, 8-byte LDS
 //                                writes: the rows become the A planes of the next layer
-// with one LDS-only barrier between the stages.
+// with one LDS-only barrier between the stages.  The last layer of a forward run can standardise its rows
+// (LayerNorm core of the key / query embeddings) before they are stored.
 //
-// Measured (512,000 rows, 256-wide layers, MI355X): 215 us per layer in inference and 290 / 350 us per
+// Measured (512,000 rows, 256-wide layers, MI355X): 215 us per layer in inference and 285 / 280 us per
 // forward / data-gradient layer in training, against 369 / 483 us for the per-layer kernel.  Half of the
 // remaining time is not matrix work: scripts/probes/chain_trace.py (cycle stamps), mfma_filler.hip.
 #include "papr_common.h"
