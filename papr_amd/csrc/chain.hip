@@ -405,7 +405,9 @@ __global__ __launch_bounds__(CH_THREADS, CH_WGS_PER_CU * CH_WAVES / 4) void mlp_
                 for (int u = 0; u < WD - 1; ++u) load_w(ln, u, wfh[u], wfl[u]);
             }
             CH_STAMP();
-            lds_barrier();                                      // every wave is done reading the A planes
+            // Phase 1 touches no LDS the k-loop reads (row-maximum table, bias table, 1/scale table): it may start while
+            // other waves still multiply.  Only the standardising last layer puts its partial sums where the A planes are.
+            if (!DGRAD && l + 1 == p.n_layers && p.norm_stats) lds_barrier();
             CH_STAMP();
 
             // ---- phase 1 (accumulators hold C^T: lane = row, registers = columns): un-scale, bias / activation or
