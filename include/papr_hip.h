@@ -154,9 +154,12 @@ typedef struct {
 } papr_row_norm;
 
 size_t papr_mlp_fwd_workspace_bytes(int64_t M);
-int papr_mlp_fwd(const papr_layer* layers, int n_layers, const float* x, int ldx, int64_t M,
-                 float* const* outs, const int32_t* ld_out, float* row_absmax, const papr_row_norm* out_norm,
-                 void* workspace, papr_stream_t stream);
+/* in_norm (optional): the same LayerNorm core in FRONT of layer 0 (FeedForward.innorm) over the first in_norm->width
+ * columns of x.  x is then overwritten with its standardised rows (papr_mlp_bwd and papr_rownorm_bwd read them),
+ * except in inference (row_absmax == NULL) inside a fused run without skip layers, where nobody reads x again. */
+int papr_mlp_fwd(const papr_layer* layers, int n_layers, float* x, int ldx, int64_t M,
+                 float* const* outs, const int32_t* ld_out, float* row_absmax, const papr_row_norm* in_norm,
+                 const papr_row_norm* out_norm, void* workspace, papr_stream_t stream);
 
 /* Backward.  d_out: gradient w.r.t. the last layer's output (M, ld_out[n-1]); it is consumed
  * (overwritten).  scratch0/scratch1: two (M, max width) buffers.  d_weight[i] (n_out, ldw) and

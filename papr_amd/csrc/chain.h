@@ -25,10 +25,14 @@ struct ChainLayer {
 };
 
 struct ChainArgs {
-    const float* A0; long lda0; int K0;   // input rows (M, lda0), K0 <= 256 real columns
+    float* A0; long lda0; int K0;         // input rows (M, lda0), K0 <= 256 real columns (written only with in_norm_writeback)
     float* rowmax0;                       // (M) receives max |.| of every input row, or null
     long M;
     int n_layers;
+    int in_norm_width;                    // forward: with in_norm_stats, the input rows are standardised over their first
+    float in_norm_eps;                    // in_norm_width columns while they are staged (LayerNorm core in front of the run);
+    float* in_norm_stats;                 // (M, 2) = 1/(std+eps), std; in_norm_writeback: the standardised rows replace A0 in
+    int in_norm_writeback;                // memory as well (training: the backward pass reads them; runs with a skip layer)
     float norm_eps;                       // forward: with norm_stats, the LAST layer's rows are standardised (LayerNorm core,
     float* norm_stats;                    // papr_row_norm in papr_hip.h) before they are stored; (M, 2) = 1/(std+eps), std
     ChainLayer L[CHAIN_MAX_LAYERS];

@@ -178,6 +178,21 @@ __global__ __launch_bounds__(CH_THREADS, CH_WGS_PER_CU * CH_WAVES / 4) void mlp_
                     const int r = wave + CH_WAVES * (u0 + u);
                     float sc;
                     if (first) {
+                        if (!DGRAD && p.in_norm_stats) {
+                            // LayerNorm core in front of the run (FeedForward.innorm): the wave holds the whole row
+                            const int wdt = p.in_norm_width;
+                            const bool i0 = c < wdt, i1 = c + 1 < wdt, i2 = c + 2 < wdt, i3 = c + 3 < wdt;
+                            const float mean = wave_sum(((i0 ? v[u].x : 0.f) + (i1 ? v[u].y : 0.f)) + ((i2 ? v[u].z : 0.f) + (i3 ? v[u].w : 0.f))) / (float)wdt;
+                            float4 dl = make_float4(i0 ? v[u].x - mean : 0.f, i1 ? v[u].y - mean : 0.f, i2 ? v[u].z - mean : 0.f, i3 ? v[u].w - mean : 0.f);
+                            const float sigma = sqrtf(wave_sum((dl.x * dl.x + dl.y * dl.y) + (dl.z * dl.z + dl.w * dl.w)) / (float)(wdt - 1));
+                            const float rinv = 1.0f / (sigma + p.in_norm_eps);
+                            v[u] = make_float4(dl.x * rinv, dl.y * rinv, dl.z * rinv, dl.w * rinv);
+                            const long mrow = m0 + r;
+                            if (mrow < p.M) {
+                                if (p.in_norm_writeback && c < p.K0) *reinterpret_cast<float4*>(p.A0 + mrow * p.lda0 + c) = v[u];
+                                if (lane == 0) { p.in_norm_stats[mrow * 2] = rinv; p.in_norm_stats[mrow * 2 + 1] = sigma; }
+                            }
+                        }
                         float mx = fmaxf(fmaxf(fabsf(v[u].x), fabsf(v[u].y)), fmaxf(fabsf(v[u].z), fabsf(v[u].w)));
                         mx = wave64_max(mx);
                         // (when layer 0 feeds a skip layer later, that layer rescales; layer 0 itself only sees x)

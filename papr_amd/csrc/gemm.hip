@@ -1118,14 +1118,17 @@ static int chain_split_launch(const SplitBatch& b, int n, hipStream_t s) {
     return 0;
 }
 
-extern "C" int papr_mlp_fwd(const papr_layer* layers, int n_layers, const float* x, int ldx, int64_t M,
-                            float* const* outs, const int32_t* ld_out, float* row_absmax, const papr_row_norm* out_norm,
-                            void* workspace, papr_stream_t stream) {
+extern "C" int papr_mlp_fwd(const papr_layer* layers, int n_layers, float* x, int ldx, int64_t M,
+                            float* const* outs, const int32_t* ld_out, float* row_absmax, const papr_row_norm* in_norm,
+                            const papr_row_norm* out_norm, void* workspace, papr_stream_t stream) {
     PAPR_REQUIRE(layers && x && outs && ld_out && n_layers >= 1, "papr_mlp_fwd: bad arguments");
     hipStream_t s = as_stream(stream);
     bool have_amax = false;                 // split-f16 mode: row maxima of the current layer's input are in h3.in()
     bool norm_done = false;
     PAPR_REQUIRE(!out_norm || (out_norm->stats && out_norm->width >= 2), "papr_mlp_fwd: out_norm needs stats and a width");
+    PAPR_REQUIRE(!in_norm || (in_norm->stats && in_norm->width >= 2 && in_norm->width <= ldx), "papr_mlp_fwd: in_norm needs stats and a width <= ldx");
+    if (in_norm && !(chain_run_end(layers, n_layers, 0, true) >= 2))      // not staged by a fused run: one pass over x first
+        if (int e = papr_rownorm_fwd(x, M, in_norm->width, ldx, in_norm->eps, x, in_norm->stats, stream)) return e;
     PAPR_REQUIRE(!GEMM_H3_FWD || workspace, "papr_mlp_fwd: workspace required (papr_mlp_fwd_workspace_bytes)");
     H3Scratch h3(workspace, M);
     for (int i = 0; i < n_layers; ++i) {
@@ -1137,6 +1140,12 @@ extern "C" int papr_mlp_fwd(const papr_layer* layers, int n_layers, const float*
             float* saved = row_absmax;
             ChainArgs c = {};
             c.A0 = i == 0 ? x : outs[i - 1]; c.lda0 = i == 0 ? ldx : ld_out[i - 1]; c.K0 = L.n_in;
+            if (i == 0 && in_norm) {                // standardised while the rows are staged
+                bool run_has_skip = false;
+                for (int l = i; l < e; ++l) run_has_skip |= layers[l].n_skip > 0;
+                c.in_norm_width = in_norm->width; c.in_norm_eps = in_norm->eps; c.in_norm_stats = in_norm->stats;
+                c.in_norm_writeback = (row_absmax != nullptr || run_has_skip || e < n_layers) ? 1 : 0;
+            }
             c.rowmax0 = saved ? saved + (size_t)i * M : nullptr;
             c.M = M; c.n_layers = e - i;
             size_t used = 0;

@@ -88,7 +88,7 @@ def lib():
     L.papr_mlp_bwd_needs_weight_t.argtypes = [C.POINTER(Layer), i32, i32]
     L.papr_mlp_saved_floats.restype = C.c_size_t
     L.papr_mlp_saved_floats.argtypes = [i32, i64]
-    L.papr_mlp_fwd.argtypes = [C.POINTER(Layer), i32, vp, i32, i64, C.POINTER(vp), C.POINTER(C.c_int32), vp, C.POINTER(RowNorm), vp, vp]
+    L.papr_mlp_fwd.argtypes = [C.POINTER(Layer), i32, vp, i32, i64, C.POINTER(vp), C.POINTER(C.c_int32), vp, C.POINTER(RowNorm), C.POINTER(RowNorm), vp, vp]
     L.papr_mlp_bwd.argtypes = [C.POINTER(Layer), i32, vp, i32, i64, C.POINTER(vp), C.POINTER(C.c_int32), vp, vp, vp, vp,
                                i32, C.POINTER(vp), C.POINTER(vp), vp, vp, vp]
     L.papr_attn_tail_fwd.argtypes = [C.POINTER(TailDesc), vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp]

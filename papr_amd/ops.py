@@ -121,12 +121,14 @@ class LayerOutputs(list):
     """The saved activations of one chain plus the per-row input maxima papr_mlp_fwd leaves for papr_mlp_bwd."""
     row_absmax = None
     norm_stats = None
+    in_stats = None
 
 
-def mlp_forward(spec, ws, bs, x, M, keep=True, out_norm=None):
+def mlp_forward(spec, ws, bs, x, M, keep=True, out_norm=None, in_norm=None):
     """Run the chain; returns the list of layer outputs (all kept, or two ping-pong buffers).
     out_norm = (width, eps): the last output comes back row-standardised (LayerNorm core), outs.norm_stats holds
-    the (M, 2) statistics papr_rownorm_bwd needs."""
+    the (M, 2) statistics papr_rownorm_bwd needs.  in_norm = (width, eps): x is standardised first (outs.in_stats; x itself
+    is overwritten, except in inference inside a fused run, where nobody reads it again)."""
     dev = x.device
     outs = LayerOutputs()
     if keep:
@@ -136,12 +138,15 @@ def mlp_forward(spec, ws, bs, x, M, keep=True, out_norm=None):
         pool = [torch.empty(M * max(spec.ld_out), device=dev, dtype=torch.float32) for _ in range(2)]
         outs.extend(pool[i & 1][:M * ld].view(M, ld) for i, ld in enumerate(spec.ld_out))
     tab = _layer_table(spec, ws, bs)
-    norm = None
+    norm = inorm = None
+    if in_norm is not None:
+        outs.in_stats = torch.empty((M, 2), device=dev, dtype=torch.float32)
+        inorm = C.byref(hip.RowNorm(in_norm[1], in_norm[0], outs.in_stats.data_ptr()))
     if out_norm is not None:
         outs.norm_stats = torch.empty((M, 2), device=dev, dtype=torch.float32)
         norm = C.byref(hip.RowNorm(out_norm[1], out_norm[0], outs.norm_stats.data_ptr()))
     hip.check(hip.lib().papr_mlp_fwd(tab, spec.n_layer, hip.ptr(x), x.shape[1], M, hip.ptr_array(outs),
-                                     hip.i32_array(spec.ld_out), hip.ptr(outs.row_absmax), norm,
+                                     hip.i32_array(spec.ld_out), hip.ptr(outs.row_absmax), inorm, norm,
                                      hip.ptr(_workspace(dev, "fwd", M)), hip.stream_ptr()), "papr_mlp_fwd")
     return outs
 
@@ -188,7 +193,7 @@ def linear_rows(x, w):
     t.weight, t.weight_t, t.bias = w.data_ptr(), None, None
     t.n_in, t.n_out, t.ldw, t.ldwt, t.n_skip, t.skip_col, t.act = x.shape[1], n_out, w.shape[1], 0, 0, 0, 0
     hip.check(hip.lib().papr_mlp_fwd(tab, 1, hip.ptr(x), x.shape[1], M, hip.ptr_array([out]), hip.i32_array([n_out]),
-                                     None, None, hip.ptr(_workspace(x.device, "fwd", M)), hip.stream_ptr()), "papr_mlp_fwd")
+                                     None, None, None, hip.ptr(_workspace(x.device, "fwd", M)), hip.stream_ptr()), "papr_mlp_fwd")
     return out
 
 
@@ -346,15 +351,14 @@ class _RenderFn(torch.autograd.Function):
                                               rays_per_image, hip.ptr(idx), hip.ptr(key_in), hip.ptr(qry_in), hip.ptr(val_in),
                                               hip.ptr(sel), hip.stream_ptr()), "papr_build_features_fwd")
         eps = plan.eps
-        kst = qst = kst2 = qst2 = None
-        if plan.kq_norm:
-            kst = rownorm_(key_in, plan.key_w, eps)
-            qst = rownorm_(qry_in, plan.qry_w, eps)
-        # (the LayerNorm core behind the key / query MLPs rides in the fused run's last row phase)
-        k_outs = mlp_forward(plan.key, kw, kb, key_in, M, keep, (plan.key.d_out, eps) if plan.kq_norm else None)
-        q_outs = mlp_forward(plan.qry, qw, qb, qry_in, R, keep, (plan.qry.d_out, eps) if plan.kq_norm else None)
+        # (the LayerNorm cores in front of and behind the key / query MLPs ride in the fused runs: rows are standardised
+        # while they are staged, and again in the last row phase)
+        k_outs = mlp_forward(plan.key, kw, kb, key_in, M, keep, (plan.key.d_out, eps) if plan.kq_norm else None,
+                             (plan.key_w, eps) if plan.kq_norm else None)
+        q_outs = mlp_forward(plan.qry, qw, qb, qry_in, R, keep, (plan.qry.d_out, eps) if plan.kq_norm else None,
+                             (plan.qry_w, eps) if plan.kq_norm else None)
         K, Q = k_outs[-1], q_outs[-1]
-        kst2, qst2 = k_outs.norm_stats, q_outs.norm_stats
+        kst, qst, kst2, qst2 = k_outs.in_stats, q_outs.in_stats, k_outs.norm_stats, q_outs.norm_stats
         # score_j = (W_q Q + b_q).(W_k K_j + b_k) = K_j.(W_k^T q') + b_k.q'  with q' = W_q Q + b_q: the R*k-row w_k
         # product of the reference (models/attn.py:217) becomes two R-row products (plain library GEMMs)
         qp = mlp_forward(plan.wq, wqw, wqb, Q, R, True)[0]

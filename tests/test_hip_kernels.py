@@ -23,7 +23,7 @@ def dev():
 
 def test_library_loads_on_device():
     from papr_amd import hip
-    assert hip.lib().papr_abi_version() == 5
+    assert hip.lib().papr_abi_version() == 6
 
 
 # ------------------------------------------------------------------------------------------- K1
