@@ -182,6 +182,44 @@ def mlp_backward(spec, ws, bs, x, M, outs, d_out, scratch, need_dx):
     return d_ws, d_bs, d_x
 
 
+class _MlpRowsFn(torch.autograd.Function):
+    """y (M, ld_out) = MLP(x (M, ld_in)) on the library's GEMM kernels, for modules that are just an MLP over rows
+    (the per-pixel MLPGenerator render head).  Weights arrive prepared (prepare_mlp_weights), so their gradients flow on
+    through ordinary autograd."""
+
+    @staticmethod
+    def forward(ctx, spec, track, x, n, *wb):
+        ws, bs = list(wb[:n]), list(wb[n:])
+        M = x.shape[0]
+        keep = track and (ctx.needs_input_grad[2] or any(ctx.needs_input_grad[4:]))
+        outs = mlp_forward(spec, ws, bs, x, M, keep)
+        ctx.spec, ctx.n = spec, n
+        if keep:
+            ctx.saved = (x, outs, ws, bs)
+        return outs[-1] if keep else outs[-1].clone()
+
+    @staticmethod
+    def backward(ctx, d_y):
+        spec, n = ctx.spec, ctx.n
+        x, outs, ws, bs = ctx.saved
+        M = x.shape[0]
+        wmax = max([spec.width, spec.ld_in] + list(spec.ld_out))
+        scratch = [torch.empty((M, wmax), device=x.device, dtype=torch.float32) for _ in range(2)]
+        d_ws, d_bs, d_x = mlp_backward(spec, ws, bs, x, M, outs, d_y.contiguous().clone(), scratch, ctx.needs_input_grad[2])
+        ctx.saved = None
+        return (None, None, d_x, None) + tuple(d_ws) + tuple(d_bs)
+
+
+def mlp_rows(spec, x, weights, biases):
+    """Differentiable MLP over the rows of x (M, d_in) with reference-shaped Linear parameters; returns (M, d_out)."""
+    if not x.is_cuda:
+        raise RuntimeError("papr_amd: the MLP kernels run only on a ROCm device (HIP); there is no CPU fallback")
+    ew, eb = prepare_mlp_weights(spec, weights, biases)
+    xp = x if x.shape[1] == spec.ld_in else F.pad(x, (0, spec.ld_in - x.shape[1]))
+    y = _MlpRowsFn.apply(spec, torch.is_grad_enabled(), xp.contiguous(), len(ew), *ew, *eb)
+    return y[:, :spec.d_out]
+
+
 def linear_rows(x, w):
     """out = x @ w.T on the MFMA GEMM (no bias, no activation).  x (M, ldx), w (n_out, ldx) with n_out % 4 == 0.
     Row results do not depend on M (unlike a library GEMM, whose tiling follows the problem size), which keeps

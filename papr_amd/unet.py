@@ -71,6 +71,34 @@ class SmallUNet(nn.Module):
             return self.outc(y)
 
 
+class MLPGenerator(nn.Module):
+    """Per-pixel MLP render head on the HIP MLP kernels -- counterpart of the reference's MLPGenerator
+    (models/renderer.py:6-17: an MLP, models/mlp.py:12-59, over the channels of every pixel).  Same parameter names
+    (`mlp.model.{2i+1}.weight/bias`), same options as far as the kernels' epilogues go: relu / leakyrelu / none,
+    skip layers, bias; weight-norm, half / residual layers and the exotic activations raise."""
+
+    def __init__(self, inp_dim, num_layers, num_channels, out_dim, act_type="leakyrelu", last_act_type="none", use_wn=False,
+                 skip_layers=(), bias=True, half_layers=(), residual_layers=(), residual_dims=()):
+        super().__init__()
+        from .model import _MlpParams
+        from .ops import MlpSpec
+        if use_wn or not bias or half_layers or residual_layers or residual_dims:
+            raise NotImplementedError("papr_amd: MLPGenerator supports use_wn=false, bias=true, no half / residual layers")
+        ecfg = dict(n_ff_layer=num_layers, d_ff=num_channels, d_ff_out=out_dim, norm="none", ff_act=act_type,
+                    ff_last_act=last_act_type, skip_layers=list(skip_layers))
+        self.spec = MlpSpec("generator", inp_dim, ecfg)     # raises for activations without a HIP epilogue
+        self.mlp = _MlpParams(inp_dim, ecfg)
+        self.out_dim = out_dim
+
+    def forward(self, x, residuals=(), gamma=None, beta=None):      # (N, C, H, W) -> (N, out, H, W)
+        from .ops import mlp_rows
+        N, C, H, W = x.shape
+        lin = self.mlp.linears()
+        rows = x.permute(0, 2, 3, 1).reshape(-1, C)
+        y = mlp_rows(self.spec, rows, [m.weight for m in lin], [m.bias for m in lin])
+        return y.reshape(N, H, W, self.out_dim).permute(0, 3, 1, 2)
+
+
 def get_generator(gcfg, in_c, out_c, use_amp=False, amp_dtype=torch.float16):
     """Counterpart of models/renderer.py:21-34."""
     if gcfg["type"] == "small-unet":
@@ -78,4 +106,12 @@ def get_generator(gcfg, in_c, out_c, use_amp=False, amp_dtype=torch.float16):
         if o["bilinear"] or not o["single"] or o["norm"] != "none" or o["affine_layer"] >= 0 or o["last_act"] != "none":
             raise NotImplementedError("papr_amd: only the shipped small-unet variant (transposed-conv, single, no norm/affine) is built")
         return SmallUNet(in_c, out_c, use_amp=use_amp, amp_dtype=amp_dtype)
+    if gcfg["type"] == "mlp":
+        o = gcfg["mlp"]
+        if float(o.get("act_a", 1.0)) != 1.0 or float(o.get("act_b", 1.0)) != 1.0 or o.get("act_trainable", False):
+            raise NotImplementedError("papr_amd: MLPGenerator activations take no parameters (act_a / act_b / act_trainable)")
+        return MLPGenerator(in_c, o["num_layers"], o["num_channels"], out_c, act_type=o["act_type"], last_act_type=o["last_act_type"],
+                            use_wn=o.get("use_wn", False), skip_layers=o.get("skip_layers", []) or [], bias=o.get("bias", True),
+                            half_layers=o.get("half_layers", []) or [], residual_layers=o.get("residual_layers", []) or [],
+                            residual_dims=o.get("residual_dims", []) or [])
     raise NotImplementedError("generator type [%s] is not supported by papr_amd" % gcfg["type"])

@@ -228,3 +228,22 @@ def test_c_abi_library_exports_every_declared_symbol():
     lib.papr_mlp_fwd_workspace_bytes.argtypes = [ctypes.c_int64]
     assert lib.papr_mlp_bwd_workspace_bytes(1000) >= 256 * (256 * 256 + 256) * 4 + lib.papr_mlp_fwd_workspace_bytes(1000)
     assert lib.papr_mlp_fwd_workspace_bytes(1000) >= 2 * 1000 * 4 + 2 * 512 * 704 * 2
+
+
+def test_mlp_generator_surface():
+    """The per-pixel MLP render head (reference models/renderer.py:6-17) keeps the reference's parameter names, refuses
+    what the kernels cannot do, and -- like the rest of the path -- has no CPU fallback."""
+    from papr_amd.unet import MLPGenerator, get_generator
+    seed_all(3)
+    m = MLPGenerator(32, 3, 128, 3, act_type="leakyrelu", last_act_type="none")
+    assert sorted(m.state_dict().keys()) == ["mlp.model.%d.%s" % (i, k) for i in (1, 3, 5) for k in ("bias", "weight")]
+    assert m.state_dict()["mlp.model.1.weight"].shape == (128, 32) and m.state_dict()["mlp.model.5.weight"].shape == (3, 128)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 32, 4, 4))
+    opt = dict(num_layers=3, num_channels=64, act_type="relu", last_act_type="none", use_wn=False, act_a=1.0, act_b=1.0,
+               act_trainable=False, skip_layers=[1], bias=True, half_layers=[], residual_layers=[], residual_dims=[])
+    g = get_generator({"type": "mlp", "mlp": opt}, 32, 3)
+    assert g.state_dict()["mlp.model.3.weight"].shape == (64, 64 + 32)          # skip layer: [hidden | input]
+    for bad in (dict(use_wn=True), dict(bias=False), dict(half_layers=[1]), dict(act_type="gelu"), dict(act_a=2.0)):
+        with pytest.raises(NotImplementedError):
+            get_generator({"type": "mlp", "mlp": dict(opt, **bad)}, 32, 3)
