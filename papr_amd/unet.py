@@ -107,6 +107,9 @@ def get_generator(gcfg, in_c, out_c, use_amp=False, amp_dtype=torch.float16):
             raise NotImplementedError("papr_amd: only the shipped small-unet variant (transposed-conv, single, no norm/affine) is built")
         return SmallUNet(in_c, out_c, use_amp=use_amp, amp_dtype=amp_dtype)
     if gcfg["type"] == "mlp":
+        if "mlp" not in gcfg:
+            raise KeyError("models.renderer.generator.mlp: option block missing (the reference reads num_layers, num_channels, "
+                           "act_type, ... from it, models/renderer.py:26-31; its default.yml ships none)")
         o = gcfg["mlp"]
         if float(o.get("act_a", 1.0)) != 1.0 or float(o.get("act_b", 1.0)) != 1.0 or o.get("act_trainable", False):
             raise NotImplementedError("papr_amd: MLPGenerator activations take no parameters (act_a / act_b / act_trainable)")

@@ -202,10 +202,12 @@ def test_unsupported_options_fail_at_construction():
     for over in ({"models": {"attn": {"embed": {"key": {"ff_act": "gelu"}}}}},
                  {"models": {"attn": {"embed": {"value": {"use_wn": True}}}}},
                  {"exposure_control": {"use": True}},
-                 {"models": {"renderer": {"generator": {"type": "mlp"}}}}):
+                 {"models": {"renderer": {"generator": {"type": "big-unet"}}}}):
         cfg = deep_merge(case_cfg("chair1k"), over)
         with pytest.raises(NotImplementedError):
             get_model(cfg, device="cpu")
+    with pytest.raises(KeyError, match="generator.mlp"):          # `type: mlp` needs its option block (default.yml ships none)
+        get_model(deep_merge(case_cfg("chair1k"), {"models": {"renderer": {"generator": {"type": "mlp"}}}}), device="cpu")
     with pytest.raises(NotImplementedError):
         from papr_amd import get_loss
         get_loss({"mse": 1.0, "lpips": 0.01})
