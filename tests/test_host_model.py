@@ -249,3 +249,19 @@ def test_mlp_generator_surface():
     for bad in (dict(use_wn=True), dict(bias=False), dict(half_layers=[1]), dict(act_type="gelu"), dict(act_a=2.0)):
         with pytest.raises(NotImplementedError):
             get_generator({"type": "mlp", "mlp": dict(opt, **bad)}, 32, 3)
+
+
+def test_ssim_restatement_properties():
+    """papr_amd/metrics.py: SSIM as the reference calls it (uniform 11 x 11 window, sample covariance, data_range 1)."""
+    from papr_amd.metrics import psnr, ssim
+    rng = np.random.default_rng(0)
+    a = rng.random((40, 37, 3))
+    assert ssim(a, a) == pytest.approx(1.0, abs=1e-12)
+    b = np.clip(a + 0.05 * rng.standard_normal(a.shape), 0, 1)
+    s_ab = ssim(a, b)
+    assert 0.0 < s_ab < 1.0 and s_ab == pytest.approx(ssim(b, a), abs=1e-12)          # symmetric
+    assert ssim(a, np.clip(a + 0.2 * rng.standard_normal(a.shape), 0, 1)) < s_ab           # more noise, less similar
+    # two constant images: means only.  SSIM = (2 x y + C1) / (x^2 + y^2 + C1) with C1 = 1e-4 (variances are exactly 0)
+    x, y = np.full((20, 20, 1), 0.3), np.full((20, 20, 1), 0.6)
+    assert ssim(x, y) == pytest.approx((2 * 0.3 * 0.6 + 1e-4) / (0.09 + 0.36 + 1e-4), rel=1e-9)
+    assert psnr(x, y) == pytest.approx(-10 * np.log10(0.09), rel=1e-12)
