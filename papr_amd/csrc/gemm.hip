@@ -836,7 +836,9 @@ __device__ __forceinline__ half8 lds_read8(const _Float16* q) {
 }
 
 // FULL: every 32-column tile holds real columns (N, K > 131): the hot loop has no tile tests
-template <bool FULL>
+__device__ __forceinline__ float comp4(const float4& v, int j) { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); }
+
+template <bool FULL, bool PIPE>
 __global__ __launch_bounds__(512, 2) void gemm_tn_h3_kernel(TNH3Args p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     _Float16* lds = reinterpret_cast<_Float16*>(smem);
@@ -958,11 +960,100 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_h3_kernel(TNH3Args p) {
     store_stage(0, rg, rx);
     load_stage(1, rg, rx);
     lds_barrier();
-    for (long st = 0; st < nst; ++st) {
-        multiply(st);
-        if (st + 1 < nst) store_stage(st + 1, rg, rx);
-        load_stage(st + 2, rg, rx);
-        lds_barrier();
+    if (!PIPE) {
+        for (long st = 0; st < nst; ++st) {
+            multiply(st);
+            if (st + 1 < nst) store_stage(st + 1, rg, rx);
+            load_stage(st + 2, rg, rx);
+            lds_barrier();
+        }
+    } else {
+        // The split of stage st+1 rides between the matrix instructions of stage st.  A wave issues in order and a
+        // matrix instruction waits for its pipe (32 cycles each), so vector work placed behind a run of matrix
+        // instructions only starts when the last of them has been issued: the two kinds of work overlap only when
+        // they alternate instruction by instruction.  A stage is cut into eight pieces -- (operand, column j of the
+        // thread's 4 x 4 block) -- one per group of six matrix instructions, and each piece into six steps, one behind
+        // each instruction (sched_barrier pins the order).  The two accumulators of a group alternate, so that no
+        // instruction waits for the result of the one just before it.  An operand's four rows are requested again
+        // (stage st+2) when its fourth column has left the registers: every load has a whole period to arrive.
+        const int tile_x0 = (wk * 2) * 32 * T3_HP + frag, tile_x1 = (wk * 2 + 1) * 32 * T3_HP + frag;
+        for (long st = 0; st < nst; ++st) {
+            const _Float16* Gh = lds + (st & 1) * (4 * T3_PLANE);
+            const _Float16* Gl = Gh + T3_PLANE;
+            const _Float16* Xh = Gh + 2 * T3_PLANE;
+            const _Float16* Xl = Gh + 3 * T3_PLANE;
+            _Float16* nb = lds + ((st + 1) & 1) * (4 * T3_PLANE);        // stage st+1 goes here (rows past the slice: zeros)
+            float sg[4], sx[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool ok = mbeg + (st + 1) * TN_ROWS + 4 * wave + r < mend;
+                sg[r] = ok ? g_scale : 0.f;
+                sx[r] = ok ? x_scale : 0.f;
+            }
+            half8 xh0 = lds_read8(Xh + tile_x0), xl0 = lds_read8(Xl + tile_x0), xh1 = lds_read8(Xh + tile_x1), xl1 = lds_read8(Xl + tile_x1);
+            half8 gh = lds_read8(Gh + (wn * 4) * 32 * T3_HP + frag), gl = lds_read8(Gl + (wn * 4) * 32 * T3_HP + frag);
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const int i = g & 3, j = g & 3;
+                const bool is_g = g < 4;
+                const float4 (&q)[4] = is_g ? rg : rx;
+                const float (&sc)[4] = is_g ? sg : sx;
+                _Float16* hi_plane = nb + (is_g ? 0 : 2 * T3_PLANE);
+                half8 ghn = gh, gln = gl;
+                if (g < 7) {                             // next group's G fragments
+                    const int o = (wn * 4 + ((g + 1) & 3)) * 32 * T3_HP + frag + 16 * ((g + 1) >> 2);
+                    ghn = lds_read8(Gh + o); gln = lds_read8(Gl + o);
+                }
+                const bool on = FULL || live_n[i], k0 = FULL || live_k[0], k1 = FULL || live_k[1];
+                if (on && k0) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gl, xh0, acc[i][0], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                const float y0 = comp4(q[0], j) * sc[0], y1 = comp4(q[1], j) * sc[1], y2 = comp4(q[2], j) * sc[2], y3 = comp4(q[3], j) * sc[3];
+                __builtin_amdgcn_sched_barrier(0);
+                if (on && k1) acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gl, xh1, acc[i][1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                const half4 hi = half4{(_Float16)y0, (_Float16)y1, (_Float16)y2, (_Float16)y3};
+                const int off = (lane + 64 * j) * T3_HP + 4 * wave;
+                __builtin_amdgcn_sched_barrier(0);
+                if (on && k0) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, xl0, acc[i][0], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                const float d0 = y0 - (float)hi[0], d1 = y1 - (float)hi[1], d2 = y2 - (float)hi[2], d3 = y3 - (float)hi[3];
+                *reinterpret_cast<half4*>(hi_plane + off) = hi;
+                __builtin_amdgcn_sched_barrier(0);
+                if (on && k1) acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, xl1, acc[i][1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                const half4 lo = half4{(_Float16)d0, (_Float16)d1, (_Float16)d2, (_Float16)d3};
+                *reinterpret_cast<half4*>(hi_plane + T3_PLANE + off) = lo;
+                __builtin_amdgcn_sched_barrier(0);
+                if (on && k0) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, xh0, acc[i][0], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (is_g) colsum[j] += (sg[0] != 0.f ? comp4(rg[0], j) : 0.f) + (sg[1] != 0.f ? comp4(rg[1], j) : 0.f)
+                                     + (sg[2] != 0.f ? comp4(rg[2], j) : 0.f) + (sg[3] != 0.f ? comp4(rg[3], j) : 0.f);
+                __builtin_amdgcn_sched_barrier(0);
+                if (on && k1) acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, xh1, acc[i][1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (g == 3) {                            // second k step of the stage: its X fragments, and the G rows of stage st+2
+                    xh0 = lds_read8(Xh + tile_x0 + 16); xl0 = lds_read8(Xl + tile_x0 + 16);
+                    xh1 = lds_read8(Xh + tile_x1 + 16); xl1 = lds_read8(Xl + tile_x1 + 16);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        long m = mbeg + (st + 2) * TN_ROWS + 4 * wave + r;
+                        m = m < mend ? m : mend - 1;
+                        rg[r] = *reinterpret_cast<const float4*>(p.G + m * p.ldg + cg);
+                    }
+                }
+                if (g == 7) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        long m = mbeg + (st + 2) * TN_ROWS + 4 * wave + r;
+                        m = m < mend ? m : mend - 1;
+                        rx[r] = *reinterpret_cast<const float4*>(p.X + m * p.ldx + cx);
+                    }
+                }
+                gh = ghn; gl = gln;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            lds_barrier();
+        }
     }
 
     // slab in LDS-row order on both axes (un-permuted by the reduction), un-scaled
@@ -1011,14 +1102,23 @@ int gemm_tn_h3(const float* G, long ldg, int N, const float* X, long ldx, int K,
     a.bias_slab = a.slab + (size_t)MAX_SLICES * SLAB * SLAB;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_h3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T3_LDS_BYTES);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_h3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T3_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_h3_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T3_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_h3_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T3_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_h3_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T3_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_h3_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T3_LDS_BYTES);
         attr_set = true;
     }
     const bool prof = papr_prof_on();
     if (prof) papr_prof_begin(8, M, N, K, s);
-    if (N > 131 && K > 131) gemm_tn_h3_kernel<true><<<dim3(S), dim3(512), T3_LDS_BYTES, s>>>(a);      // 128 + 3 < N: all eight tiles live
-    else gemm_tn_h3_kernel<false><<<dim3(S), dim3(512), T3_LDS_BYTES, s>>>(a);
+    static const bool pipe = !getenv("PAPR_TN_NOPIPE");
+    const bool full = N > 131 && K > 131;                           // 128 + 3 < N: all eight tiles live
+    if (pipe) {
+        if (full) gemm_tn_h3_kernel<true, true><<<dim3(S), dim3(512), T3_LDS_BYTES, s>>>(a);
+        else gemm_tn_h3_kernel<false, true><<<dim3(S), dim3(512), T3_LDS_BYTES, s>>>(a);
+    } else {
+        if (full) gemm_tn_h3_kernel<true, false><<<dim3(S), dim3(512), T3_LDS_BYTES, s>>>(a);
+        else gemm_tn_h3_kernel<false, false><<<dim3(S), dim3(512), T3_LDS_BYTES, s>>>(a);
+    }
     if (prof) papr_prof_end(s);
     PAPR_CHECK_LAUNCH("gemm_tn_h3");
     slab_reduce_kernel<true><<<dim3(SLAB * SLAB / 4 / 16), dim3(256), 0, s>>>(a.slab, a.bias_slab, S, N, K, dW, ldw, db);
