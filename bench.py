@@ -192,10 +192,12 @@ def main():
         # written once and read once by the reduction
         rs = [r for r in recs if r[0] == 8]
         ms = sum(r[4] for r in rs)
-        by = sum(4.0 * M * (Nn + true_k.get(K, K)) for _, M, Nn, K, *_ in rs)
-        fl = sum(2.0 * M * Nn * true_k.get(K, K) for _, M, Nn, K, *_ in rs)
+        # (one record per launch = a batch of weight-gradients; the library sums 4 M (N + K) bytes and 2 M N K flops over its jobs)
+        by = float(sum(r[5] for r in rs))
+        fl = float(sum(r[6] for r in rs))
         ach = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        return ms, {"kernel": "gemm_tn_h3_kernel (weight gradients, one slice of the rows per CU, split-f16 MFMA)",
+        return ms, {"kernel": "gemm_tn_h3_kernel (weight gradients of a fused run in one launch, one slice of the rows per CU, split-f16 MFMA)",
+                    "jobs": int(sum(r[2] for r in rs)),
                     "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                     "traffic": traffic_db.get("gemm_tn_h3_bytes_per_launch"), "launches": len(rs),
                     "avg_launch_ms": ms / max(len(rs), 1), "algorithmic_bytes_per_launch": by / max(len(rs), 1),

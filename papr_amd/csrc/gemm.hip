@@ -734,10 +734,17 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(TNArgs p) {
 // loads, then the 16 partial sums of an element meet in LDS.  (A thread-per-element loop over all S
 // slabs is a 256-deep dependent load chain on 64 workgroups: 113 us instead of ~10.)
 // PERM: the slabs come from gemm_tn_h3 with both axes in LDS-row order (row r holds column 4 (r & 63) + (r >> 6)).
+struct ReduceJob { const float* slab; const float* bias_slab; int S, N, K; float* dW; int ldw; float* db; };
+struct ReduceBatch { ReduceJob job[8]; };
+
 template <bool PERM>
-__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bias_slab,
-                                                          int S, int N, int K, float* __restrict__ dW, int ldw,
-                                                          float* __restrict__ db) {
+__global__ __launch_bounds__(256) void slab_reduce_kernel(ReduceBatch rb) {
+    const ReduceJob& rj = rb.job[blockIdx.y];
+    const float* __restrict__ slab = rj.slab;
+    const float* __restrict__ bias_slab = rj.bias_slab;
+    const int S = rj.S, N = rj.N, K = rj.K, ldw = rj.ldw;
+    float* __restrict__ dW = rj.dW;
+    float* __restrict__ db = rj.db;
     __shared__ float4 part[16][17];
     const int el = threadIdx.x & 15, grp = threadIdx.x >> 4;
     const int e = blockIdx.x * 16 + el;              // float4 index inside the 256x256 tile
@@ -798,7 +805,9 @@ int gemm_tn(const float* G, long ldg, int N, const float* X, long ldx, int K, lo
     gemm_tn_kernel<<<dim3(S), dim3(512), 2 * TN_ROWS * SLAB * sizeof(float), s>>>(a);
     if (prof) papr_prof_end(s);
     PAPR_CHECK_LAUNCH("gemm_tn");
-    slab_reduce_kernel<false><<<dim3(SLAB * SLAB / 4 / 16), dim3(256), 0, s>>>(a.slab, a.bias_slab, S, N, K, dW, ldw, db);
+    ReduceBatch rb = {};
+    rb.job[0] = ReduceJob{a.slab, a.bias_slab, S, N, K, dW, ldw, db};
+    slab_reduce_kernel<false><<<dim3(SLAB * SLAB / 4 / 16, 1), dim3(256), 0, s>>>(rb);
     PAPR_CHECK_LAUNCH("slab_reduce");
     return 0;
 }
@@ -825,6 +834,11 @@ struct TNH3Args {
     const float* gmax; const float* xmax;      // per-row max |.| of G and of X
     float* slab; float* bias_slab;
 };
+// Several weight-gradients in one launch: a workgroup streams its slice of job 0, then of job 1, ...  The partial
+// tile of a job (256 KB per workgroup) drains to memory while the next job's first rows are already on their way,
+// and the launch ramp and tail are paid once per batch instead of once per layer.
+constexpr int TN_BATCH = 8;
+struct TNH3Batch { TNH3Args job[TN_BATCH]; int n; };
 
 constexpr int T3_HP = 36;                         // LDS row pitch in halfs
 constexpr int T3_PLANE = SLAB * T3_HP;            // halfs per plane (256 LDS rows x 32 m)
@@ -838,17 +852,19 @@ __device__ __forceinline__ half8 lds_read8(const _Float16* q) {
 // FULL: every 32-column tile holds real columns (N, K > 131): the hot loop has no tile tests
 __device__ __forceinline__ float comp4(const float4& v, int j) { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); }
 
-template <bool FULL, bool PIPE>
-__global__ __launch_bounds__(512, 2) void gemm_tn_h3_kernel(TNH3Args p) {
+template <bool FULL>
+__global__ __launch_bounds__(512, 2) void gemm_tn_h3_kernel(TNH3Batch batch) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     _Float16* lds = reinterpret_cast<_Float16*>(smem);
     __shared__ float red[2][8];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: row tests and tile skips become SALU
     const int wn = wave >> 2, wk = wave & 3;     // wave's corner in LDS-row space: n-tiles 4 wn .. +3, k-tiles 2 wk, 2 wk + 1
+  for (int jb = 0; jb < batch.n; ++jb) {
+    const TNH3Args& p = batch.job[jb];
     const long mbeg = (long)blockIdx.x * p.rows_per_slice;
     long mend = mbeg + p.rows_per_slice;
     if (mend > p.M) mend = p.M;
-    if (mbeg >= mend) return;                    // (the launch never creates such a slice)
+    if (mbeg >= mend) continue;                  // (workgroup-uniform: a job with fewer slices than the launch has workgroups)
 
     // slice scales
     float gm = 0.f, xm = 0.f;
@@ -922,60 +938,21 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_h3_kernel(TNH3Args p) {
         put_block(qx, sx, base + 2 * T3_PLANE, base + 3 * T3_PLANE);
     };
     const int frag = (lane & 31) * T3_HP + 8 * (lane >> 5);
-    auto multiply = [&](long st) {
-        const _Float16* Gh = lds + (st & 1) * (4 * T3_PLANE);
-        const _Float16* Gl = Gh + T3_PLANE;
-        const _Float16* Xh = Gh + 2 * T3_PLANE;
-        const _Float16* Xl = Gh + 3 * T3_PLANE;
-#pragma unroll
-        for (int ks = 0; ks < TN_ROWS; ks += 16) {
-            half8 xh[2], xl[2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int o = (wk * 2 + j) * 32 * T3_HP + frag + ks;
-                xh[j] = lds_read8(Xh + o);
-                xl[j] = lds_read8(Xl + o);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (!live_n[i]) continue;
-                const int o = (wn * 4 + i) * 32 * T3_HP + frag + ks;
-                const half8 gh = lds_read8(Gh + o), gl = lds_read8(Gl + o);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    if (!live_k[j]) continue;
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gl, xh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, xl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, xh[j], acc[i][j], 0, 0, 0);
-                }
-            }
-        }
-    };
-
-    // One register set: stage st+2 is requested as soon as stage st+1 has left the registers for LDS, and
-    // has the whole matrix phase of stage st+1 to arrive (a second set does not fit beside the 128
-    // accumulator registers: the compiler spilled 158 dwords with it).
+    // One register set of 32 rows in flight (a second set does not fit beside the 128 accumulator registers).
     const long nst = (mend - mbeg + TN_ROWS - 1) / TN_ROWS;
     load_stage(0, rg, rx);
     store_stage(0, rg, rx);
     load_stage(1, rg, rx);
     lds_barrier();
-    if (!PIPE) {
-        for (long st = 0; st < nst; ++st) {
-            multiply(st);
-            if (st + 1 < nst) store_stage(st + 1, rg, rx);
-            load_stage(st + 2, rg, rx);
-            lds_barrier();
-        }
-    } else {
+    {
         // The split of stage st+1 rides between the matrix instructions of stage st.  A wave issues in order and a
         // matrix instruction waits for its pipe (32 cycles each), so vector work placed behind a run of matrix
         // instructions only starts when the last of them has been issued: the two kinds of work overlap only when
         // they alternate instruction by instruction.  A stage is cut into eight pieces -- (operand, column j of the
-        // thread's 4 x 4 block) -- one per group of six matrix instructions, and each piece into six steps, one behind
-        // each instruction (sched_barrier pins the order).  The two accumulators of a group alternate, so that no
-        // instruction waits for the result of the one just before it.  An operand's four rows are requested again
-        // (stage st+2) when its fourth column has left the registers: every load has a whole period to arrive.
+        // thread's 4 x 4 block) -- one per group of six matrix instructions, each piece in two steps behind one
+        // instruction each (sched_barrier pins the order).  The two accumulators of a group
+        // alternate, so that no instruction waits for the result of the one just before it.  An operand's four rows are
+        // requested again (stage st+2) when its fourth column has left the registers.
         const int tile_x0 = (wk * 2) * 32 * T3_HP + frag, tile_x1 = (wk * 2 + 1) * 32 * T3_HP + frag;
         for (long st = 0; st < nst; ++st) {
             const _Float16* Gh = lds + (st & 1) * (4 * T3_PLANE);
@@ -983,57 +960,71 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_h3_kernel(TNH3Args p) {
             const _Float16* Xh = Gh + 2 * T3_PLANE;
             const _Float16* Xl = Gh + 3 * T3_PLANE;
             _Float16* nb = lds + ((st + 1) & 1) * (4 * T3_PLANE);        // stage st+1 goes here (rows past the slice: zeros)
-            float sg[4], sx[4];
+            float sg[4], sx[4], okf[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const bool ok = mbeg + (st + 1) * TN_ROWS + 4 * wave + r < mend;
                 sg[r] = ok ? g_scale : 0.f;
                 sx[r] = ok ? x_scale : 0.f;
+                okf[r] = ok ? 1.f : 0.f;
             }
             half8 xh0 = lds_read8(Xh + tile_x0), xl0 = lds_read8(Xl + tile_x0), xh1 = lds_read8(Xh + tile_x1), xl1 = lds_read8(Xl + tile_x1);
             half8 gh = lds_read8(Gh + (wn * 4) * 32 * T3_HP + frag), gl = lds_read8(Gl + (wn * 4) * 32 * T3_HP + frag);
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
-                const int i = g & 3, j = g & 3;
+                const int i = g & 3;
+                // piece of this group: column j of the G block (g < 4) or of the X block.  (Two pieces per group in the first
+                // half of the stage, which leaves a reloaded operand six groups instead of four to arrive, measured slower:
+                // 219 against 212 us.)
                 const bool is_g = g < 4;
+                const int j = g & 3;
                 const float4 (&q)[4] = is_g ? rg : rx;
                 const float (&sc)[4] = is_g ? sg : sx;
                 _Float16* hi_plane = nb + (is_g ? 0 : 2 * T3_PLANE);
+                const bool on = FULL || live_n[i], k0 = FULL || live_k[0], k1 = FULL || live_k[1];
                 half8 ghn = gh, gln = gl;
+                unsigned h01, h23, l01, l23;             // packed f16 pairs (rows 0,1 and 2,3 of a column)
+                // hi = f16(q * scale), two rows per register; lo = f16(q * scale - hi) in one fused instruction each (the
+                // scale is a power of two, so the product is exact and this rounds like the two-step form)
+                auto split_hi = [&](const int j) {
+                    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h01) : "v"(comp4(q[0], j)), "v"(sc[0]));
+                    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h23) : "v"(comp4(q[2], j)), "v"(sc[2]));
+                    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h01) : "v"(comp4(q[1], j)), "v"(sc[1]));
+                    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h23) : "v"(comp4(q[3], j)), "v"(sc[3]));
+                    *reinterpret_cast<uint2*>(hi_plane + (lane + 64 * j) * T3_HP + 4 * wave) = make_uint2(h01, h23);
+                };
+                auto split_lo = [&](const int j) {
+                    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l01) : "v"(comp4(q[0], j)), "v"(sc[0]), "v"(h01));
+                    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l23) : "v"(comp4(q[2], j)), "v"(sc[2]), "v"(h23));
+                    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l01) : "v"(comp4(q[1], j)), "v"(sc[1]), "v"(h01));
+                    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l23) : "v"(comp4(q[3], j)), "v"(sc[3]), "v"(h23));
+                    *reinterpret_cast<uint2*>(hi_plane + T3_PLANE + (lane + 64 * j) * T3_HP + 4 * wave) = make_uint2(l01, l23);
+                    if (is_g) colsum[j] = __builtin_fmaf(comp4(q[3], j), okf[3], __builtin_fmaf(comp4(q[2], j), okf[2],
+                                          __builtin_fmaf(comp4(q[1], j), okf[1], __builtin_fmaf(comp4(q[0], j), okf[0], colsum[j]))));
+                };
+                if (on && k0) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gl, xh0, acc[i][0], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
                 if (g < 7) {                             // next group's G fragments
                     const int o = (wn * 4 + ((g + 1) & 3)) * 32 * T3_HP + frag + 16 * ((g + 1) >> 2);
                     ghn = lds_read8(Gh + o); gln = lds_read8(Gl + o);
                 }
-                const bool on = FULL || live_n[i], k0 = FULL || live_k[0], k1 = FULL || live_k[1];
-                if (on && k0) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gl, xh0, acc[i][0], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                const float y0 = comp4(q[0], j) * sc[0], y1 = comp4(q[1], j) * sc[1], y2 = comp4(q[2], j) * sc[2], y3 = comp4(q[3], j) * sc[3];
                 __builtin_amdgcn_sched_barrier(0);
                 if (on && k1) acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gl, xh1, acc[i][1], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                const half4 hi = half4{(_Float16)y0, (_Float16)y1, (_Float16)y2, (_Float16)y3};
-                const int off = (lane + 64 * j) * T3_HP + 4 * wave;
+                split_hi(j);
                 __builtin_amdgcn_sched_barrier(0);
                 if (on && k0) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, xl0, acc[i][0], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                const float d0 = y0 - (float)hi[0], d1 = y1 - (float)hi[1], d2 = y2 - (float)hi[2], d3 = y3 - (float)hi[3];
-                *reinterpret_cast<half4*>(hi_plane + off) = hi;
-                __builtin_amdgcn_sched_barrier(0);
                 if (on && k1) acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, xl1, acc[i][1], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                const half4 lo = half4{(_Float16)d0, (_Float16)d1, (_Float16)d2, (_Float16)d3};
-                *reinterpret_cast<half4*>(hi_plane + T3_PLANE + off) = lo;
+                split_lo(j);
                 __builtin_amdgcn_sched_barrier(0);
                 if (on && k0) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, xh0, acc[i][0], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (is_g) colsum[j] += (sg[0] != 0.f ? comp4(rg[0], j) : 0.f) + (sg[1] != 0.f ? comp4(rg[1], j) : 0.f)
-                                     + (sg[2] != 0.f ? comp4(rg[2], j) : 0.f) + (sg[3] != 0.f ? comp4(rg[3], j) : 0.f);
-                __builtin_amdgcn_sched_barrier(0);
                 if (on && k1) acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, xh1, acc[i][1], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (g == 3) {                            // second k step of the stage: its X fragments, and the G rows of stage st+2
-                    xh0 = lds_read8(Xh + tile_x0 + 16); xl0 = lds_read8(Xl + tile_x0 + 16);
-                    xh1 = lds_read8(Xh + tile_x1 + 16); xl1 = lds_read8(Xl + tile_x1 + 16);
+#ifndef TN_ABL_NO_LOAD
+                if (g == 3) {                            // the G block has left the registers: its rows of stage st+2
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         long m = mbeg + (st + 2) * TN_ROWS + 4 * wave + r;
@@ -1041,13 +1032,20 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_h3_kernel(TNH3Args p) {
                         rg[r] = *reinterpret_cast<const float4*>(p.G + m * p.ldg + cg);
                     }
                 }
-                if (g == 7) {
+#endif
+                if (g == 3) {                            // second k step of the stage: its X fragments
+                    xh0 = lds_read8(Xh + tile_x0 + 16); xl0 = lds_read8(Xl + tile_x0 + 16);
+                    xh1 = lds_read8(Xh + tile_x1 + 16); xl1 = lds_read8(Xl + tile_x1 + 16);
+                }
+                if (g == 7) {                            // the X rows of stage st+2
+#ifndef TN_ABL_NO_LOAD
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         long m = mbeg + (st + 2) * TN_ROWS + 4 * wave + r;
                         m = m < mend ? m : mend - 1;
                         rx[r] = *reinterpret_cast<const float4*>(p.X + m * p.ldx + cx);
                     }
+#endif
                 }
                 gh = ghn; gl = gln;
                 __builtin_amdgcn_sched_barrier(0);
@@ -1081,50 +1079,68 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_h3_kernel(TNH3Args p) {
         for (int w = 0; w < 8; ++w) b += cs[w * SLAB + tid];
         p.bias_slab[(long)blockIdx.x * SLAB + tid] = b;
     }
+    // (the next job's first barrier comes before its first LDS write: the sums above are read by then)
+  }
 }
 
-// dW = G^T X on the split-f16 kernel; gmax / xmax: per-row max |.| of G and X (M floats each)
-int gemm_tn_h3(const float* G, long ldg, int N, const float* X, long ldx, int K, long M, const float* gmax, const float* xmax,
-               float* dW, int ldw, float* db, void* workspace, hipStream_t s) {
-    PAPR_REQUIRE(N <= SLAB && K <= SLAB, "gemm_tn_h3: N=%d, K=%d exceed %d", N, K, SLAB);
-    PAPR_REQUIRE(N % 4 == 0 && K % 4 == 0 && ldg % 4 == 0 && ldx % 4 == 0, "gemm_tn_h3: sizes must be multiples of 4");
-    if (M <= 0) return 0;
-    static int n_cu = 0;
-    if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu <= 0 || n_cu > MAX_SLICES) n_cu = MAX_SLICES; }
-    long stages = (M + TN_ROWS - 1) / TN_ROWS;
-    int S = (int)(stages < n_cu ? stages : n_cu);                   // one workgroup per CU streams one slice
-    long rows_per_slice = ((stages + S - 1) / S) * TN_ROWS;
-    S = (int)((M + rows_per_slice - 1) / rows_per_slice);
-    TNH3Args a;
-    a.G = G; a.ldg = ldg; a.N = N; a.X = X; a.ldx = ldx; a.K = K; a.M = M; a.rows_per_slice = rows_per_slice;
-    a.gmax = gmax; a.xmax = xmax;
-    a.slab = static_cast<float*>(workspace);
-    a.bias_slab = a.slab + (size_t)MAX_SLICES * SLAB * SLAB;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_h3_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T3_LDS_BYTES);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_h3_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T3_LDS_BYTES);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_h3_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T3_LDS_BYTES);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_h3_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T3_LDS_BYTES);
-        attr_set = true;
+// dW = G^T X on the split-f16 kernel; gmax / xmax: per-row max |.| of G and X (M floats each).  Jobs queue up and go out
+// TN_BATCH to a launch (flush() at the latest before anything reads a result or reuses the partial-tile workspace).
+constexpr size_t TN_JOB_FLOATS = (size_t)MAX_SLICES * (SLAB * SLAB + SLAB);
+struct TNH3Queue {
+    TNH3Batch batch;
+    ReduceBatch red;
+    bool full = false;
+    int grid = 0;
+    long long bytes = 0, flops = 0;
+    void* workspace;
+    hipStream_t s;
+    TNH3Queue(void* ws, hipStream_t st) : workspace(ws), s(st) { batch.n = 0; }
+    int push(const float* G, long ldg, int N, const float* X, long ldx, int K, long M, const float* gmax, const float* xmax,
+             float* dW, int ldw, float* db) {
+        PAPR_REQUIRE(N <= SLAB && K <= SLAB, "gemm_tn_h3: N=%d, K=%d exceed %d", N, K, SLAB);
+        PAPR_REQUIRE(N % 4 == 0 && K % 4 == 0 && ldg % 4 == 0 && ldx % 4 == 0, "gemm_tn_h3: sizes must be multiples of 4");
+        if (M <= 0) return 0;
+        const bool job_full = N > 131 && K > 131;                       // 128 + 3 < N: all eight tiles live
+        if (batch.n == TN_BATCH || (batch.n > 0 && job_full != full))
+            if (int e = flush()) return e;
+        full = job_full;
+        static int n_cu = 0;
+        if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu <= 0 || n_cu > MAX_SLICES) n_cu = MAX_SLICES; }
+        long stages = (M + TN_ROWS - 1) / TN_ROWS;
+        int S = (int)(stages < n_cu ? stages : n_cu);                   // one workgroup per CU streams one slice
+        long rows_per_slice = ((stages + S - 1) / S) * TN_ROWS;
+        S = (int)((M + rows_per_slice - 1) / rows_per_slice);
+        TNH3Args& a = batch.job[batch.n];
+        a.G = G; a.ldg = ldg; a.N = N; a.X = X; a.ldx = ldx; a.K = K; a.M = M; a.rows_per_slice = rows_per_slice;
+        a.gmax = gmax; a.xmax = xmax;
+        a.slab = static_cast<float*>(workspace) + (size_t)batch.n * TN_JOB_FLOATS;
+        a.bias_slab = a.slab + (size_t)MAX_SLICES * SLAB * SLAB;
+        red.job[batch.n] = ReduceJob{a.slab, a.bias_slab, S, N, K, dW, ldw, db};
+        grid = S > grid ? S : grid;
+        bytes += 4LL * M * (N + K); flops += 2LL * M * N * K;
+        ++batch.n;
+        return 0;
     }
-    const bool prof = papr_prof_on();
-    if (prof) papr_prof_begin(8, M, N, K, s);
-    static const bool pipe = !getenv("PAPR_TN_NOPIPE");
-    const bool full = N > 131 && K > 131;                           // 128 + 3 < N: all eight tiles live
-    if (pipe) {
-        if (full) gemm_tn_h3_kernel<true, true><<<dim3(S), dim3(512), T3_LDS_BYTES, s>>>(a);
-        else gemm_tn_h3_kernel<false, true><<<dim3(S), dim3(512), T3_LDS_BYTES, s>>>(a);
-    } else {
-        if (full) gemm_tn_h3_kernel<true, false><<<dim3(S), dim3(512), T3_LDS_BYTES, s>>>(a);
-        else gemm_tn_h3_kernel<false, false><<<dim3(S), dim3(512), T3_LDS_BYTES, s>>>(a);
+    int flush() {
+        if (batch.n == 0) return 0;
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_h3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T3_LDS_BYTES);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_h3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T3_LDS_BYTES);
+            attr_set = true;
+        }
+        const bool prof = papr_prof_on();
+        if (prof) papr_prof_begin2(8, batch.job[0].M, batch.n, 0, bytes, flops, s);
+        if (full) gemm_tn_h3_kernel<true><<<dim3(grid), dim3(512), T3_LDS_BYTES, s>>>(batch);
+        else gemm_tn_h3_kernel<false><<<dim3(grid), dim3(512), T3_LDS_BYTES, s>>>(batch);
+        if (prof) papr_prof_end(s);
+        PAPR_CHECK_LAUNCH("gemm_tn_h3");
+        slab_reduce_kernel<true><<<dim3(SLAB * SLAB / 4 / 16, batch.n), dim3(256), 0, s>>>(red);
+        PAPR_CHECK_LAUNCH("slab_reduce");
+        batch.n = 0; grid = 0; bytes = 0; flops = 0;
+        return 0;
     }
-    if (prof) papr_prof_end(s);
-    PAPR_CHECK_LAUNCH("gemm_tn_h3");
-    slab_reduce_kernel<true><<<dim3(SLAB * SLAB / 4 / 16), dim3(256), 0, s>>>(a.slab, a.bias_slab, S, N, K, dW, ldw, db);
-    PAPR_CHECK_LAUNCH("slab_reduce");
-    return 0;
-}
+};
 
 // in-place g *= act'(y)
 __global__ __launch_bounds__(256) void act_grad_kernel(float* g, long ldg, const float* __restrict__ y, long ldy, long M,
@@ -1138,7 +1154,7 @@ __global__ __launch_bounds__(256) void act_grad_kernel(float* g, long ldg, const
 
 }  // namespace
 
-constexpr size_t TN_SLAB_BYTES = (size_t)MAX_SLICES * (SLAB * SLAB + SLAB) * sizeof(float);
+constexpr size_t TN_SLAB_BYTES = (size_t)TN_BATCH * TN_JOB_FLOATS * sizeof(float);      // partial tiles of a batch of weight-gradients
 
 extern "C" size_t papr_mlp_fwd_workspace_bytes(int64_t M) { return H3Scratch::bytes(M); }
 extern "C" size_t papr_mlp_saved_floats(int32_t n_layers, int64_t M) { return (size_t)n_layers * M * (1 + CHAIN_SIGN_WORDS); }
@@ -1385,6 +1401,7 @@ extern "C" int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float*
             PAPR_CHECK_LAUNCH("act_grad");
         }
     }
+    TNH3Queue tnq(workspace, s);             // split-f16 weight-gradients collect here; the fp32 kernel shares the workspace, so flush before it
     auto wgrad = [&](int i, const float* gi, long ldgi, const float* gmax_i) -> int {
         const papr_layer& L = layers[i];
         const float* in = i == 0 ? x : outs[i - 1];
@@ -1393,10 +1410,15 @@ extern "C" int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float*
         // split-f16 when the forward pass left the row maxima of this layer's input
         const bool h3w = GEMM_H3_WGRAD && row_absmax && gmax_i && layer_rowmax_saved(layers, n_layers, i) && L.n_out <= SLAB && L.n_in <= SLAB;
         if (h3w) {
-            if (int e = gemm_tn_h3(gi, ldgi, L.n_out, in, ld_in, L.n_in, M, gmax_i, row_absmax + (size_t)i * M, d_weight[i], L.ldw, d_bias[i], workspace, s)) return e;
-        } else if (int e = gemm_tn(gi, ldgi, L.n_out, in, ld_in, L.n_in, M, d_weight[i], L.ldw, d_bias[i], workspace, s)) return e;
-        if (L.n_skip > 0)
+            if (int e = tnq.push(gi, ldgi, L.n_out, in, ld_in, L.n_in, M, gmax_i, row_absmax + (size_t)i * M, d_weight[i], L.ldw, d_bias[i])) return e;
+        } else {
+            if (int e = tnq.flush()) return e;
+            if (int e = gemm_tn(gi, ldgi, L.n_out, in, ld_in, L.n_in, M, d_weight[i], L.ldw, d_bias[i], workspace, s)) return e;
+        }
+        if (L.n_skip > 0) {
+            if (int e = tnq.flush()) return e;
             if (int e = gemm_tn(gi, ldgi, L.n_out, x, ldx, L.n_skip, M, d_weight[i] + L.skip_col, L.ldw, nullptr, workspace, s)) return e;
+        }
         return 0;
     };
     for (int i = n_layers - 1; i >= 0; --i) {
@@ -1449,6 +1471,7 @@ extern "C" int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float*
                 const float* gm = l == i ? runs.gmax[CHAIN_MAX_LAYERS] : runs.gmax[slot(l)];
                 if (int err = wgrad(l, gl, ldl, gm)) return err;
             }
+            if (int err = tnq.flush()) return err;               // (the next run reuses the gradient-row slots)
             if (b == 0 && d_x && !to_dx) {                       // d_x accumulates (a skip layer wrote into it): separate launch
                 PAPR_REQUIRE(layers[0].weight_t, "papr_mlp_bwd: layer 0 needs weight_t");
                 NTArgs a = {};
@@ -1467,6 +1490,7 @@ extern "C" int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float*
         if (h3w)
             if (int e = need_gmax(g, ldg, L.n_out)) return e;
         if (int e = wgrad(i, g, ldg, h3w ? reinterpret_cast<const float*>(gmax) : nullptr)) return e;
+        if (int e = tnq.flush()) return e;                       // (the data-gradient below overwrites the other scratch buffer)
         // data gradients
         if (L.n_skip > 0 && d_x) {
             PAPR_REQUIRE(L.weight_t, "papr_mlp_bwd: layer %d needs weight_t", i);

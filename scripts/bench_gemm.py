@@ -42,7 +42,11 @@ rep("dgrad gemm_nt", bwd, 0)
 rep("wgrad gemm_tn", bwd, 4)
 rep("fwd  gemm_nt_h3", fwd, 6)
 rep("dgrad gemm_nt_h3", bwd, 7)
-rep("wgrad gemm_tn_h3", bwd, 8)
+r8 = [x for x in bwd if x[0] == 8]
+if r8:      # one record per batch of weight-gradients: N = jobs in the launch, bytes / flops summed over them
+    ms = sum(x[4] for x in r8); jobs = sum(x[2] for x in r8)
+    print("%-28s n=%3d launches of %d jobs, avg %.1f us per job  %.0f GB/s  %.1f TFLOP/s" % ("wgrad gemm_tn_h3", len(r8), r8[0][2], ms * 1e3 / jobs,
+          sum(x[5] for x in r8) / ms / 1e6, sum(x[6] for x in r8) / ms / 1e9))
 def rep_chain(tag, recs, kid):
     r = [x for x in recs if x[0] == kid]
     if not r: return
