@@ -20,9 +20,21 @@ __device__ __forceinline__ float pow2_from_biased(int e) {       // 2^(e-127), e
     return __uint_as_float((unsigned)e << 23);
 }
 
+// hi = f16(v * s), lo = f16(v * s - hi) for four values; s is a power of two, so v * s is exact and the fused forms
+// below round exactly like the multiply / convert / convert back / subtract / convert sequence they replace:
+// v_fma_mixlo/hi_f16 write one half of a register from an fp32 fma, and take the f16 hi as an operand (8 instructions
+// instead of ~20 per four values: the row phases of the kernels are vector-instruction bound).
 __device__ __forceinline__ void split4(const float4& v, float s, half4& hi, half4& lo) {
-    float x0 = v.x * s, x1 = v.y * s, x2 = v.z * s, x3 = v.w * s;
-    hi = half4{(_Float16)x0, (_Float16)x1, (_Float16)x2, (_Float16)x3};
-    lo = half4{(_Float16)(x0 - (float)hi[0]), (_Float16)(x1 - (float)hi[1]), (_Float16)(x2 - (float)hi[2]), (_Float16)(x3 - (float)hi[3])};
+    unsigned h01, h23, l01, l23;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h01) : "v"(v.x), "v"(s));
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h23) : "v"(v.z), "v"(s));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h01) : "v"(v.y), "v"(s));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h23) : "v"(v.w), "v"(s));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l01) : "v"(v.x), "v"(s), "v"(h01));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l23) : "v"(v.z), "v"(s), "v"(h23));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l01) : "v"(v.y), "v"(s), "v"(h01));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l23) : "v"(v.w), "v"(s), "v"(h23));
+    const uint2 h = make_uint2(h01, h23), l = make_uint2(l01, l23);
+    hi = *reinterpret_cast<const half4*>(&h);
+    lo = *reinterpret_cast<const half4*>(&l);
 }
-
