@@ -433,6 +433,13 @@ __global__ __launch_bounds__(CH_THREADS, CH_WGS_PER_CU * CH_WAVES / 4) void mlp_
             const bool more = l + 1 < p.n_layers;
             const float slope = L.act == PAPR_ACT_RELU ? 0.f : (L.act == PAPR_ACT_LEAKY_RELU ? 0.2f : 1.f);     // data-gradient: derivative on the negative side
             const bool want_bits = !DGRAD && L.sign_bits != nullptr;      // forward: leave the signs for the data-gradient run
+            // Straight-line code matters here: with a test around every 16-byte store the compiler cut the phase into
+            // ~50 basic blocks, each with its own LDS wait, exec-mask juggling and a reload of the row stride (~450 scalar
+            // instructions per layer and wave).  So: compute everything first, then the sign words under ONE uniform test,
+            // then all stores of a 32-row block under ONE lane mask (row < M), with the row's base pointer computed once.
+            float* const Cbase = L.C;
+            const long ldc = L.ldc;
+            const bool cols_whole = (N & 31) == 0;              // every live 32-column tile lies wholly inside the matrix
             auto rows_phase = [&](auto act_fn) {
 #pragma unroll
                 for (int i = 0; i < NI; ++i) {
@@ -440,11 +447,10 @@ __global__ __launch_bounds__(CH_THREADS, CH_WGS_PER_CU * CH_WAVES / 4) void mlp_
                     const long row = m0 + rl;
                     const float inv = inv_tab[rl];
                     float mx = 0.f;
-                    unsigned sb = 0u;                           // forward: sign word of this lane's 32 values, first value in the top bit
                     unsigned mb = mbits[i];
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) {
-                        if (!live[j]) { sb <<= 16; mb <<= 16; continue; }
+                        if (!live[j]) { mb <<= 16; continue; }
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
                             const int col = (wn * NJ + j) * 32 + 8 * g + 4 * hh;
@@ -468,17 +474,46 @@ __global__ __launch_bounds__(CH_THREADS, CH_WGS_PER_CU * CH_WAVES / 4) void mlp_
                                 r.y = act_fn(__builtin_fmaf(acc[i][j][4 * g + 1], inv, b4.y), 0.f);
                                 r.z = act_fn(__builtin_fmaf(acc[i][j][4 * g + 2], inv, b4.z), 0.f);
                                 r.w = act_fn(__builtin_fmaf(acc[i][j][4 * g + 3], inv, b4.w), 0.f);
-                                if (want_bits)
-                                    sb = (sb << 4) | (r.x > 0.f ? 8u : 0u) | (r.y > 0.f ? 4u : 0u) | (r.z > 0.f ? 2u : 0u) | (r.w > 0.f ? 1u : 0u);
                             }
                             acc[i][j][4 * g] = r.x; acc[i][j][4 * g + 1] = r.y; acc[i][j][4 * g + 2] = r.z; acc[i][j][4 * g + 3] = r.w;
-                            // (plain stores: the 32-byte pieces of a line meet in L2; non-temporal stores double the run time)
-                            if (L.C && col < N && row < p.M) *reinterpret_cast<float4*>(L.C + row * L.ldc + col) = r;
                             mx = fmaxf(mx, fmaxf(fmaxf(fabsf(r.x), fabsf(r.y)), fmaxf(fabsf(r.z), fabsf(r.w))));
                         }
                     }
-                    if (want_bits && row < p.M) L.sign_bits[(long)(wn * 2 + hh) * p.M + row] = sb << (32 - 16 * NJ);
                     if (live[0]) atomicMax(rmax_tab + par * CH_BM + rl, __float_as_uint(mx));
+                    if (want_bits) {                            // forward: sign word of this lane's 32 values, first value in the top bit
+                        unsigned sb = 0u;
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) {
+                            if (!live[j]) { sb <<= 16; continue; }
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) sb = (sb << 1) | (acc[i][j][e] > 0.f ? 1u : 0u);
+                        }
+                        if (row < p.M) L.sign_bits[(long)(wn * 2 + hh) * p.M + row] = sb << (32 - 16 * NJ);
+                    }
+                    if (Cbase) {
+                        // (plain stores: the 32-byte pieces of a line meet in L2; non-temporal stores double the run time)
+                        float* const crow = Cbase + row * ldc + 4 * hh;
+                        if (cols_whole) {
+                            if (row < p.M) {
+#pragma unroll
+                                for (int j = 0; j < NJ; ++j) {
+                                    if (!live[j]) continue;
+#pragma unroll
+                                    for (int g = 0; g < 4; ++g)
+                                        *reinterpret_cast<float4*>(crow + (wn * NJ + j) * 32 + 8 * g) =
+                                            make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+                                }
+                            }
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                                for (int g = 0; g < 4; ++g)
+                                    if (live[j] && (wn * NJ + j) * 32 + 8 * g + 4 * hh < N && row < p.M)
+                                        *reinterpret_cast<float4*>(crow + (wn * NJ + j) * 32 + 8 * g) =
+                                            make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+                        }
+                    }
                 }
             };
 #ifndef CH_EXP_NO_PHASES

@@ -22,8 +22,9 @@ __device__ __forceinline__ float pow2_from_biased(int e) {       // 2^(e-127), e
 
 // hi = f16(v * s), lo = f16(v * s - hi) for four values; s is a power of two, so v * s is exact and the fused forms
 // below round exactly like the multiply / convert / convert back / subtract / convert sequence they replace:
-// v_fma_mixlo/hi_f16 write one half of a register from an fp32 fma, and take the f16 hi as an operand (8 instructions
-// instead of ~20 per four values: the row phases of the kernels are vector-instruction bound).
+// v_fma_mixlo/hi_f16 write one half of a register from an fp32 fma, and take the f16 hi as an operand: 8 instructions
+// instead of ~20 per four values (they issue at half rate, `scripts/probes/mfma_valu_overlap.hip`).  Worth 14 % in the
+// weight-gradient kernel, whose split sits between matrix instructions; 1-2 % in the fused-run kernel (in-box A/B).
 __device__ __forceinline__ void split4(const float4& v, float s, half4& hi, half4& lo) {
     unsigned h01, h23, l01, l23;
     asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h01) : "v"(v.x), "v"(s));
