@@ -203,12 +203,18 @@ int papr_attn_tail_fwd(const papr_tail_desc* d, const float* kp, const float* qp
 /* d_v rows are overwritten; d_kp rows are overwritten; d_qp (R, ld_qp) overwritten; d_score_bias (R) or
  * NULL overwritten.  Influence gradient: either d_pair_influ (R*k) receives one term per pair (to be
  * summed per point by papr_segment_reduce; d_influ may be NULL), or, when d_pair_influ is NULL, the terms
- * are accumulated into d_influ (P) with atomic adds (caller zeroes). */
+ * are accumulated into d_influ (P) with atomic adds (caller zeroes).
+ * kp_norm_stats (R*k, 2) or NULL: when the kp rows are the output of a row standardisation (the LayerNorm core
+ * behind the key MLP, models/attn.py:39-42; stats as papr_rownorm_fwd / papr_row_norm leave them), d_kp receives the
+ * gradient w.r.t. the rows BEFORE the standardisation, i.e. papr_rownorm_bwd is applied on the way out: a row of
+ * d_kp is a multiple of the ray's qp row, so its two row sums come from the ray's sum of qp and from the score
+ * itself and no extra pass over the (R*k, d_model) rows is needed.  score_bias (R) as in papr_attn_tail_fwd is
+ * then required if one was used (NULL = none). */
 int papr_attn_tail_bwd(const papr_tail_desc* d, const float* kp, const float* qp, const float* v,
                        const float* influ, const int32_t* idx, int64_t R, const float* scores,
                        const float* attn, const float* d_fused, const float* d_attn, float* d_kp,
                        float* d_qp, float* d_v, float* d_influ, float* d_score_bias, float* d_pair_influ,
-                       papr_stream_t stream);
+                       const float* kp_norm_stats, const float* score_bias, papr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Optional timing of the GEMM / kNN launches with HIP events recorded on the launch stream

@@ -157,7 +157,8 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(papr_tail_desc d, const f
                                                        const float* __restrict__ d_attn, float* __restrict__ d_kp,
                                                        float* __restrict__ d_qp, float* __restrict__ d_v,
                                                        float* __restrict__ d_influ, float* __restrict__ d_score_bias,
-                                                       float* __restrict__ d_pair_influ) {
+                                                       float* __restrict__ d_pair_influ, const float* __restrict__ kp_stats,
+                                                       const float* __restrict__ score_bias) {
     const int lane = threadIdx.x & 63;
     long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= R) return;
@@ -204,14 +205,43 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(papr_tail_desc d, const f
     }
     // d_qp = sum_j ddot_j kp_j ;  d_kp_j = ddot_j qp
     const float* q = qp + r * d.ld_qp;
+    // kp rows standardised (y = (x - mean) / (sigma + eps)): hand back the gradient w.r.t. x (rownorm_bwd_kernel's
+    // formula).  dy_j = ddot_j qp, so mean(dy_j) = ddot_j mean(qp) and sum_c dy_jc y_jc = ddot_j (qp . y_j), which is
+    // the score before bias, scaling and activation: where the activation's derivative is not zero it is recovered
+    // from the saved score (and where it is zero, ddot_j is).
+    //   dx_jc = ddot_j rinv_j (qp_c - mean(qp)) - y_jc ddot_j (qp . y_j) / ((n - 1) sigma_j)
+    float ca = ddot, cb = 0.f, qmean = 0.f;
+    if (kp_stats) {
+        float qs = 0.f;
+        for (int c = lane * 4; c < d.d_model; c += 256) {
+            const float4 qv = *reinterpret_cast<const float4*>(q + c);
+            qs += (qv.x + qv.y) + (qv.z + qv.w);
+        }
+        qmean = wave_sum(qs) / (float)d.d_model;
+        if (lane < k) {
+            const float pre = (d.score_act == PAPR_ACT_LEAKY_RELU && sc < 0.f) ? sc * 5.0f : sc;      // activation undone
+            const float dot = pre / inv_sqrt_d - (score_bias ? score_bias[r] : 0.f);
+            const float rinv = kp_stats[(r * k + lane) * 2], sigma = kp_stats[(r * k + lane) * 2 + 1];
+            ca = ddot * rinv;
+            cb = (sigma > 0.f && ddot != 0.f) ? ddot * dot / ((float)(d.d_model - 1) * sigma) : 0.f;
+        }
+    }
     for (int c = lane * 4; c < d.d_model; c += 256) {
         float4 qv = *reinterpret_cast<const float4*>(q + c);
+        const float4 qc = make_float4(qv.x - qmean, qv.y - qmean, qv.z - qmean, qv.w - qmean);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int j = 0; j < k; ++j) {               // (requesting the rows of a round ahead of its stores was slower: 335 vs 229 us)
             float gj = bcast(ddot, j);
             float4 kv = *reinterpret_cast<const float4*>(kp + (r * k + j) * d.ld_kp + c);
             acc.x += gj * kv.x; acc.y += gj * kv.y; acc.z += gj * kv.z; acc.w += gj * kv.w;
-            *reinterpret_cast<float4*>(d_kp + (r * k + j) * d.ld_kp + c) = make_float4(gj * qv.x, gj * qv.y, gj * qv.z, gj * qv.w);
+            float4 o;
+            if (kp_stats) {
+                const float aj = bcast(ca, j), bj = bcast(cb, j);
+                o = make_float4(aj * qc.x - bj * kv.x, aj * qc.y - bj * kv.y, aj * qc.z - bj * kv.z, aj * qc.w - bj * kv.w);
+            } else {
+                o = make_float4(gj * qv.x, gj * qv.y, gj * qv.z, gj * qv.w);
+            }
+            *reinterpret_cast<float4*>(d_kp + (r * k + j) * d.ld_kp + c) = o;
         }
         *reinterpret_cast<float4*>(d_qp + r * d.ld_qp + c) = acc;
     }
@@ -267,13 +297,14 @@ extern "C" int papr_attn_tail_bwd(const papr_tail_desc* d, const float* kp, cons
                                   const float* influ, const int32_t* idx, int64_t R, const float* scores,
                                   const float* attn, const float* d_fused, const float* d_attn, float* d_kp,
                                   float* d_qp, float* d_v, float* d_influ, float* d_score_bias, float* d_pair_influ,
-                                  papr_stream_t stream) {
+                                  const float* kp_norm_stats, const float* score_bias, papr_stream_t stream) {
     if (int e = check_tail(d, "papr_attn_tail_bwd")) return e;
     PAPR_REQUIRE(kp && qp && v && influ && idx && scores && attn && d_fused && d_kp && d_qp && d_v && (d_influ || d_pair_influ),
                  "papr_attn_tail_bwd: null pointer");
     if (R <= 0) return 0;
     tail_bwd_kernel<<<dim3((unsigned)((R + 3) / 4)), dim3(256), 0, as_stream(stream)>>>(
-        *d, kp, qp, v, influ, idx, R, scores, attn, d_fused, d_attn, d_kp, d_qp, d_v, d_influ, d_score_bias, d_pair_influ);
+        *d, kp, qp, v, influ, idx, R, scores, attn, d_fused, d_attn, d_kp, d_qp, d_v, d_influ, d_score_bias, d_pair_influ,
+        kp_norm_stats, score_bias);
     PAPR_CHECK_LAUNCH("tail_bwd");
     return 0;
 }

@@ -92,7 +92,7 @@ def lib():
     L.papr_mlp_bwd.argtypes = [C.POINTER(Layer), i32, vp, i32, i64, C.POINTER(vp), C.POINTER(C.c_int32), vp, vp, vp, vp,
                                i32, C.POINTER(vp), C.POINTER(vp), vp, vp, vp]
     L.papr_attn_tail_fwd.argtypes = [C.POINTER(TailDesc), vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp]
-    L.papr_attn_tail_bwd.argtypes = [C.POINTER(TailDesc), vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.papr_attn_tail_bwd.argtypes = [C.POINTER(TailDesc), vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.papr_profile_enable.argtypes = [i32]
     L.papr_profile_collect.argtypes = [C.POINTER(ProfileRecord), i32]
     for name in EXPORTS:

@@ -89,9 +89,12 @@ def prepare_mlp_weights(spec, weights, biases, ln_in=None):
             if extra is not None:
                 b = b + (extra * sh).sum(1)
                 extra = extra * a
-        main = F.pad(main, (0, L["n_in"] - main.shape[1]))
+        # (F.pad with nothing to pad still copies, forward and backward: 38 launches per step for the default model)
+        if L["n_in"] != main.shape[1]:
+            main = F.pad(main, (0, L["n_in"] - main.shape[1]))
         if extra is not None:
-            extra = F.pad(extra, (0, spec.ld_in - extra.shape[1]))
+            if spec.ld_in != extra.shape[1]:
+                extra = F.pad(extra, (0, spec.ld_in - extra.shape[1]))
             main = torch.cat([main, extra], dim=1)
         if L["n_out_pad"] != L["n_out"]:
             main = F.pad(main, (0, 0, 0, L["n_out_pad"] - L["n_out"]))
@@ -421,7 +424,7 @@ class _RenderFn(torch.autograd.Function):
             torch.cumsum(torch.bincount(flat, minlength=points.shape[0]), 0, out=seg[1:])
             ctx.saved = dict(rays_o=rays_o, rays_d=rays_d, idx=idx, points=points, influ=influ, key_in=key_in, qry_in=qry_in,
                              val_in=val_in, kst=kst, qst=qst, kst2=kst2, qst2=qst2, k_outs=k_outs, q_outs=q_outs,
-                             v_outs=v_outs, g=g, qp=qp, order=order, sorted_pts=sorted_pts, seg=seg, scores=scores, attn=attn, wb=wb, P=points.shape[0],
+                             v_outs=v_outs, g=g, c0=c0, qp=qp, order=order, sorted_pts=sorted_pts, seg=seg, scores=scores, attn=attn, wb=wb, P=points.shape[0],
                              feat_shape=None if pc_feats is None else pc_feats.shape)
         return fused, attn, sel
 
@@ -453,9 +456,12 @@ class _RenderFn(torch.autograd.Function):
         pair_influ = torch.empty((M,), device=dev, dtype=torch.float32)
         d_fused = d_fused.contiguous()
         d_attn = d_attn.contiguous() if d_attn is not None else None
+        # (with the LayerNorm core behind the key MLP, d_K comes back as the gradient in front of it: no papr_rownorm_bwd pass)
         hip.check(lib.papr_attn_tail_bwd(C.byref(td), hip.ptr(K), hip.ptr(s["g"]), hip.ptr(V), hip.ptr(s["influ"]), hip.ptr(idx),
                                          R, hip.ptr(s["scores"]), hip.ptr(s["attn"]), hip.ptr(d_fused), hip.ptr(d_attn), hip.ptr(d_K),
-                                         hip.ptr(d_g), hip.ptr(d_V), None, hip.ptr(d_c0), hip.ptr(pair_influ), hip.stream_ptr()), "papr_attn_tail_bwd")
+                                         hip.ptr(d_g), hip.ptr(d_V), None, hip.ptr(d_c0), hip.ptr(pair_influ),
+                                         hip.ptr(s["kst2"]) if plan.kq_norm else None, hip.ptr(s["c0"]) if plan.kq_norm else None,
+                                         hip.stream_ptr()), "papr_attn_tail_bwd")
         # backward of g = q' W_k, c0 = q'.b_k: R-row products on the library's GEMMs (rocBLAS / hipBLASLt pick 130-270 us
         # kernels for these 25,600 x 256 shapes; the same work is ~100 us here)
         qp = s["qp"]
@@ -468,8 +474,6 @@ class _RenderFn(torch.autograd.Function):
         d_wk = [d_wkT[0].t()]
         d_wkb = [(qp * d_c0[:, None]).sum(0)]
         # key branch
-        if plan.kq_norm:
-            rownorm_bwd_(d_K, K, s["kst2"], plan.key.d_out, eps)
         need_pts = ctx.needs_input_grad[6]
         d_kw, d_kb, d_key = mlp_backward(plan.key, kw, kb, s["key_in"], M, s["k_outs"], d_K, scratch, need_pts)
         if plan.kq_norm and d_key is not None:

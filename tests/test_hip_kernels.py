@@ -23,7 +23,7 @@ def dev():
 
 def test_library_loads_on_device():
     from papr_amd import hip
-    assert hip.lib().papr_abi_version() == 6
+    assert hip.lib().papr_abi_version() == 7
 
 
 # ------------------------------------------------------------------------------------------- K1
@@ -330,7 +330,7 @@ def test_attention_tail_forward_backward(R, k, d_model, Cc, act, normalize):
     gf_d, ga_d = gf.to(d), ga.to(d)
     hip.check(hip.lib().papr_attn_tail_bwd(C.byref(td), hip.ptr(kpd), hip.ptr(qpd), hip.ptr(vd), hip.ptr(infd), hip.ptr(idxd), R,
                                            hip.ptr(scores), hip.ptr(attn), hip.ptr(gf_d), hip.ptr(ga_d), hip.ptr(d_kp),
-                                           hip.ptr(d_qp), hip.ptr(d_v), hip.ptr(d_inf), hip.ptr(d_sb), None, hip.stream_ptr()), "tail_bwd")
+                                           hip.ptr(d_qp), hip.ptr(d_v), hip.ptr(d_inf), hip.ptr(d_sb), None, None, None, hip.stream_ptr()), "tail_bwd")
     torch.cuda.synchronize()
     tol = lambda ref: 3e-5 * ref.abs().max().item() + 1e-9
     np.testing.assert_allclose(d_kp.cpu().numpy(), kp.grad.reshape(R * k, -1).numpy(), rtol=0, atol=tol(kp.grad))
@@ -339,6 +339,52 @@ def test_attention_tail_forward_backward(R, k, d_model, Cc, act, normalize):
     assert torch.all(d_v.cpu()[:, Cc:] == 0)
     np.testing.assert_allclose(d_inf.cpu().numpy(), influ.grad.numpy(), rtol=0, atol=tol(influ.grad))
     np.testing.assert_allclose(d_sb.cpu().numpy(), sb.grad.numpy(), rtol=0, atol=tol(sb.grad))
+
+
+@pytest.mark.parametrize("R,k,d_model,act", [(130, 20, 256, "relu"), (33, 7, 64, "leakyrelu"), (20, 3, 128, "none")])
+def test_attention_tail_backward_through_standardised_keys(R, k, d_model, act):
+    """kp_norm_stats: the key rows are LayerNorm-core outputs (models/attn.py:39-42) and d_kp comes back as the gradient
+    w.r.t. the rows in front of the standardisation -- against autograd through the oracle's row norm."""
+    from papr_amd import hip
+    gen = torch.Generator().manual_seed(R + k)
+    P, Cc, ldv, eps, bkg = 200, 32, 32, 1e-6, 5.0
+    x = (torch.randn(R, k, d_model, generator=gen) * 1.3 + 0.2).requires_grad_(True)
+    mean = x.mean(-1, keepdim=True)
+    sigma = x.std(-1, keepdim=True)                                  # unbiased, eps on the std (attn.py:41-42)
+    kp = (x - mean) / (sigma + eps)
+    qp = (torch.randn(R, 1, d_model, generator=gen) * 0.2).requires_grad_(True)
+    v = torch.randn(R, k, Cc, generator=gen)
+    influ = torch.rand(P, 1, generator=gen) * 1.2 - 0.2
+    idx = torch.randint(0, P, (R, k), generator=gen)
+    sb = torch.randn(R, generator=gen) * 0.5
+    sc = O._act((torch.matmul(qp, kp.transpose(-2, -1)).squeeze(1) + sb[:, None]) / d_model ** 0.5, act)
+    fused_ref, attn_ref = O.attention_tail(sc, influ[idx].squeeze(-1), v, bkg, True)
+    gf = torch.randn(R, Cc, generator=gen)
+    ga = torch.randn(R, k + 1, generator=gen)
+    ((fused_ref * gf).sum() + (attn_ref * ga).sum()).backward()
+
+    d = dev()
+    td = hip.TailDesc()
+    td.k, td.d_model, td.C, td.ld_kp, td.ld_qp, td.ld_v = k, d_model, Cc, d_model, d_model, ldv
+    td.score_act, td.normalize, td.bkg_score, td.scale_dim = hip.ACT[act], 1, bkg, d_model
+    kpd = kp.detach().reshape(R * k, d_model).contiguous().to(d)
+    stats = torch.stack([1.0 / (sigma.detach().reshape(-1) + eps), sigma.detach().reshape(-1)], 1).contiguous().to(d)
+    qpd, vd, sbd = qp.detach().reshape(R, d_model).to(d), v.reshape(R * k, Cc).contiguous().to(d), sb.to(d)
+    infd, idxd = influ.to(d), idx.int().to(d)
+    scores = torch.empty((R, k), device=d); attn = torch.empty((R, k + 1), device=d); fused = torch.empty((R, Cc), device=d)
+    hip.check(hip.lib().papr_attn_tail_fwd(C.byref(td), hip.ptr(kpd), hip.ptr(qpd), hip.ptr(sbd), hip.ptr(vd), hip.ptr(infd), hip.ptr(idxd), R,
+                                           hip.ptr(scores), hip.ptr(attn), hip.ptr(fused), hip.stream_ptr()), "tail_fwd")
+    d_x = torch.empty_like(kpd); d_qp = torch.empty_like(qpd); d_v = torch.empty_like(vd)
+    d_inf = torch.zeros((P, 1), device=d)
+    gf_d, ga_d = gf.to(d), ga.to(d)                                  # (kept alive: a temporary's block would be handed to the next one)
+    hip.check(hip.lib().papr_attn_tail_bwd(C.byref(td), hip.ptr(kpd), hip.ptr(qpd), hip.ptr(vd), hip.ptr(infd), hip.ptr(idxd), R,
+                                           hip.ptr(scores), hip.ptr(attn), hip.ptr(gf_d), hip.ptr(ga_d), hip.ptr(d_x),
+                                           hip.ptr(d_qp), hip.ptr(d_v), hip.ptr(d_inf), None, None, hip.ptr(stats), hip.ptr(sbd),
+                                           hip.stream_ptr()), "tail_bwd")
+    torch.cuda.synchronize()
+    tol = lambda ref: 1e-4 * ref.abs().max().item() + 1e-9
+    np.testing.assert_allclose(d_x.cpu().numpy(), x.grad.reshape(R * k, -1).numpy(), rtol=0, atol=tol(x.grad))
+    np.testing.assert_allclose(d_qp.cpu().numpy(), qp.grad.reshape(R, -1).numpy(), rtol=0, atol=tol(qp.grad))
 
 
 @pytest.mark.parametrize("mode", ["f32", "fwd", "dgrad", "layers"])
