@@ -113,6 +113,17 @@ int papr_rownorm_fwd(const float* x, int64_t rows, int width, int ld, float eps,
 int papr_rownorm_bwd(const float* dy, const float* y, const float* stats, int64_t rows, int width, int ld,
                      float eps, float* dx, papr_stream_t stream);
 
+/* The affine part of that LayerNorm, y = a_2 * xh + b_2 (models/attn.py:42), folded into the Linear layer behind it:
+ *   W (a_2 * xh + b_2) + c  =  (W * a_2) xh + (W b_2 + c).
+ * fwd: eff_w (n_out, ld_eff) = W[:, :n_in] * a_2 with columns n_in .. ld_eff-1 zeroed, eff_b = c + W b_2.
+ * bwd: d_w = d_eff_w * a_2 + d_eff_b (x) b_2,  d_a2 = column sums of d_eff_w * W,  d_b2 = W^T d_eff_b
+ * (d_c = d_eff_b: the caller's).  Sums run in a fixed order.  n_in, ld_eff <= 1024. */
+int papr_ln_fold_fwd(const float* w, int32_t n_out, int32_t n_in, int32_t ldw, const float* c, const float* a2,
+                     const float* b2, float* eff_w, int32_t ld_eff, float* eff_b, papr_stream_t stream);
+int papr_ln_fold_bwd(const float* w, int32_t n_out, int32_t n_in, int32_t ldw, const float* a2, const float* b2,
+                     const float* d_eff_w, int32_t ld_eff, const float* d_eff_b, float* d_w, float* d_a2, float* d_b2,
+                     papr_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * K3  embedding MLP chain on MFMA      replaces MLP.forward (models/mlp.py:47-59) and its autograd.
  * Layer i computes out_i = act_i(in_i W_i^T + b_i), in_0 = x, in_i = out_{i-1}; a layer with

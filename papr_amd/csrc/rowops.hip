@@ -247,7 +247,75 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(papr_tail_desc d, const f
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// LayerNorm affine folded into the following Linear layer (see papr_hip.h).  One wave per output row.
+__global__ __launch_bounds__(256) void ln_fold_fwd_kernel(const float* __restrict__ w, int n_out, int n_in, int ldw,
+                                                          const float* __restrict__ c, const float* __restrict__ a2,
+                                                          const float* __restrict__ b2, float* __restrict__ eff_w, int ld_eff,
+                                                          float* __restrict__ eff_b) {
+    const int lane = threadIdx.x & 63;
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (o >= n_out) return;
+    float acc = 0.f;
+    for (int i = lane; i < ld_eff; i += 64) {
+        const float wv = i < n_in ? w[(long)o * ldw + i] : 0.f;
+        eff_w[(long)o * ld_eff + i] = i < n_in ? wv * a2[i] : 0.f;
+        acc += i < n_in ? wv * b2[i] : 0.f;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) eff_b[o] = (c ? c[o] : 0.f) + acc;
+}
+
+// a workgroup owns 64 columns over all rows: wave q takes the rows q, q + 4, ...; the four partial column sums meet in
+// LDS in a fixed order
+__global__ __launch_bounds__(256) void ln_fold_bwd_kernel(const float* __restrict__ w, int n_out, int n_in, int ldw,
+                                                          const float* __restrict__ a2, const float* __restrict__ b2,
+                                                          const float* __restrict__ d_eff_w, int ld_eff,
+                                                          const float* __restrict__ d_eff_b, float* __restrict__ d_w,
+                                                          float* __restrict__ d_a2, float* __restrict__ d_b2) {
+    __shared__ float part[2][4][64];
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;
+    const bool ok = i < n_in;
+    const float av = ok ? a2[i] : 0.f, bv = ok ? b2[i] : 0.f;
+    float sa = 0.f, sb = 0.f;
+    for (int o = q; o < n_out; o += 4) {
+        const float de = ok ? d_eff_w[(long)o * ld_eff + i] : 0.f;
+        const float wv = ok ? w[(long)o * ldw + i] : 0.f;
+        const float db = d_eff_b[o];
+        if (ok) d_w[(long)o * ldw + i] = de * av + db * bv;
+        sa += de * wv;
+        sb += db * wv;
+    }
+    part[0][q][lane] = sa;
+    part[1][q][lane] = sb;
+    __syncthreads();
+    if (q == 0 && ok) {
+        d_a2[i] = ((part[0][0][lane] + part[0][1][lane]) + part[0][2][lane]) + part[0][3][lane];
+        d_b2[i] = ((part[1][0][lane] + part[1][1][lane]) + part[1][2][lane]) + part[1][3][lane];
+    }
+}
+
 }  // namespace
+
+extern "C" int papr_ln_fold_fwd(const float* w, int32_t n_out, int32_t n_in, int32_t ldw, const float* c, const float* a2,
+                                const float* b2, float* eff_w, int32_t ld_eff, float* eff_b, papr_stream_t stream) {
+    PAPR_REQUIRE(w && a2 && b2 && eff_w && eff_b, "papr_ln_fold_fwd: null pointer");
+    PAPR_REQUIRE(n_out >= 1 && n_in >= 1 && ldw >= n_in && ld_eff >= n_in && ld_eff <= 1024, "papr_ln_fold_fwd: n_out %d, n_in %d, ldw %d, ld_eff %d", n_out, n_in, ldw, ld_eff);
+    ln_fold_fwd_kernel<<<dim3((unsigned)((n_out + 3) / 4)), dim3(256), 0, as_stream(stream)>>>(w, n_out, n_in, ldw, c, a2, b2, eff_w, ld_eff, eff_b);
+    PAPR_CHECK_LAUNCH("ln_fold_fwd");
+    return 0;
+}
+
+extern "C" int papr_ln_fold_bwd(const float* w, int32_t n_out, int32_t n_in, int32_t ldw, const float* a2, const float* b2,
+                                const float* d_eff_w, int32_t ld_eff, const float* d_eff_b, float* d_w, float* d_a2, float* d_b2,
+                                papr_stream_t stream) {
+    PAPR_REQUIRE(w && a2 && b2 && d_eff_w && d_eff_b && d_w && d_a2 && d_b2, "papr_ln_fold_bwd: null pointer");
+    PAPR_REQUIRE(n_out >= 1 && n_in >= 1 && ldw >= n_in && ld_eff >= n_in && ld_eff <= 1024, "papr_ln_fold_bwd: n_out %d, n_in %d, ldw %d, ld_eff %d", n_out, n_in, ldw, ld_eff);
+    ln_fold_bwd_kernel<<<dim3((unsigned)((n_in + 63) / 64)), dim3(256), 0, as_stream(stream)>>>(w, n_out, n_in, ldw, a2, b2, d_eff_w, ld_eff, d_eff_b, d_w, d_a2, d_b2);
+    PAPR_CHECK_LAUNCH("ln_fold_bwd");
+    return 0;
+}
 
 extern "C" int papr_rownorm_fwd(const float* x, int64_t rows, int width, int ld, float eps, float* y, float* stats,
                                 papr_stream_t stream) {

@@ -18,7 +18,7 @@ EXPORTS = [
     "papr_abi_version", "papr_last_error", "papr_ray_knn_workspace_bytes", "papr_ray_knn",
     "papr_feature_widths", "papr_build_features_fwd", "papr_build_features_bwd", "papr_build_features_bwd_pairs",
     "papr_segment_reduce",
-    "papr_rownorm_fwd", "papr_rownorm_bwd", "papr_mlp_fwd_workspace_bytes", "papr_mlp_bwd_workspace_bytes", "papr_mlp_saved_floats", "papr_mlp_bwd_needs_weight_t", "papr_mlp_fwd",
+    "papr_rownorm_fwd", "papr_rownorm_bwd", "papr_ln_fold_fwd", "papr_ln_fold_bwd", "papr_mlp_fwd_workspace_bytes", "papr_mlp_bwd_workspace_bytes", "papr_mlp_saved_floats", "papr_mlp_bwd_needs_weight_t", "papr_mlp_fwd",
     "papr_mlp_bwd",
     "papr_attn_tail_fwd", "papr_attn_tail_bwd", "papr_profile_enable", "papr_profile_collect",
 ]
@@ -81,6 +81,8 @@ def lib():
     L.papr_segment_reduce.argtypes = [vp, vp, vp, i64, i64, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]
     L.papr_rownorm_fwd.argtypes = [vp, i64, i32, i32, f32, vp, vp, vp]
     L.papr_rownorm_bwd.argtypes = [vp, vp, vp, i64, i32, i32, f32, vp, vp]
+    L.papr_ln_fold_fwd.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp]
+    L.papr_ln_fold_bwd.argtypes = [vp, i32, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp]
     L.papr_mlp_fwd_workspace_bytes.restype = C.c_size_t
     L.papr_mlp_fwd_workspace_bytes.argtypes = [i64]
     L.papr_mlp_bwd_workspace_bytes.restype = C.c_size_t

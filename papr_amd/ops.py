@@ -69,6 +69,34 @@ class MlpSpec:
         self.ld_out = [l["n_out_pad"] for l in self.layers]
 
 
+class _LnFoldFn(torch.autograd.Function):
+    """(W * a_2 zero-padded to ld_eff columns, c + W b_2): the LayerNorm affine in front of a Linear layer folded into it, one
+    launch each way (in torch ops: two products, a row sum and a pad forward, eight small kernels backward, two of them
+    16 us column sums)."""
+
+    @staticmethod
+    def forward(ctx, w, c, a2, b2, ld_eff):
+        w, c, a2, b2 = w.contiguous(), c.contiguous(), a2.contiguous(), b2.contiguous()
+        n_out, n_in = w.shape
+        eff_w = torch.empty((n_out, ld_eff), device=w.device, dtype=torch.float32)
+        eff_b = torch.empty((n_out,), device=w.device, dtype=torch.float32)
+        hip.check(hip.lib().papr_ln_fold_fwd(hip.ptr(w), n_out, n_in, n_in, hip.ptr(c), hip.ptr(a2), hip.ptr(b2), hip.ptr(eff_w), ld_eff,
+                                              hip.ptr(eff_b), hip.stream_ptr()), "papr_ln_fold_fwd")
+        ctx.save_for_backward(w, a2, b2)
+        ctx.ld_eff = ld_eff
+        return eff_w, eff_b
+
+    @staticmethod
+    def backward(ctx, d_eff_w, d_eff_b):
+        w, a2, b2 = ctx.saved_tensors
+        n_out, n_in = w.shape
+        d_eff_w, d_eff_b = d_eff_w.contiguous(), d_eff_b.contiguous()
+        d_w, d_a2, d_b2 = torch.empty_like(w), torch.empty_like(a2), torch.empty_like(b2)
+        hip.check(hip.lib().papr_ln_fold_bwd(hip.ptr(w), n_out, n_in, n_in, hip.ptr(a2), hip.ptr(b2), hip.ptr(d_eff_w), ctx.ld_eff,
+                                              hip.ptr(d_eff_b), hip.ptr(d_w), hip.ptr(d_a2), hip.ptr(d_b2), hip.stream_ptr()), "papr_ln_fold_bwd")
+        return d_w, d_eff_b, d_a2, d_b2, None
+
+
 def prepare_mlp_weights(spec, weights, biases, ln_in=None):
     """Reference-shaped Linear parameters -> effective, padded weights for the kernels (differentiable).
 
@@ -81,7 +109,9 @@ def prepare_mlp_weights(spec, weights, biases, ln_in=None):
         # (no slice when the layer has no skip block: its backward would zero-fill and copy a full-size gradient)
         main = w[:, :L["raw_in"]] if L["skip"] else w
         extra = w[:, L["raw_in"]:] if L["skip"] else None
-        if ln_in is not None:
+        if ln_in is not None and i == 0 and extra is None and w.is_cuda and L["n_in"] <= 1024:
+            main, b = _LnFoldFn.apply(main, b, ln_in[0], ln_in[1], L["n_in"])      # (already padded to the kernel's row length)
+        elif ln_in is not None:
             a, sh = ln_in
             if i == 0:
                 b = b + (main * sh).sum(1)      # (not `main @ sh`: rocBLAS' gemv takes 58 us for a 256 x 117 matrix)

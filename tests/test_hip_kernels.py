@@ -387,6 +387,29 @@ def test_attention_tail_backward_through_standardised_keys(R, k, d_model, act):
     np.testing.assert_allclose(d_qp.cpu().numpy(), qp.grad.reshape(R, -1).numpy(), rtol=0, atol=tol(qp.grad))
 
 
+@pytest.mark.parametrize("n_out,n_in,ld_eff", [(256, 117, 120), (256, 256, 256), (32, 39, 40), (5, 3, 8)])
+def test_layernorm_affine_fold(n_out, n_in, ld_eff):
+    """papr_ln_fold_fwd / bwd against the torch expressions they replace: W (a_2 xh + b_2) + c = (W a_2) xh + (W b_2 + c)."""
+    from papr_amd import ops
+    gen = torch.Generator().manual_seed(n_out + n_in)
+    w = torch.randn(n_out, n_in, generator=gen).requires_grad_(True)
+    c = torch.randn(n_out, generator=gen).requires_grad_(True)
+    a2 = (1 + 0.3 * torch.randn(n_in, generator=gen)).requires_grad_(True)
+    b2 = (0.3 * torch.randn(n_in, generator=gen)).requires_grad_(True)
+    gw, gb = torch.randn(n_out, ld_eff, generator=gen), torch.randn(n_out, generator=gen)
+    eff_w = torch.nn.functional.pad(w * a2, (0, ld_eff - n_in))
+    eff_b = c + (w * b2).sum(1)
+    ((eff_w * gw).sum() + (eff_b * gb).sum()).backward()
+    d = dev()
+    leaves = [t.detach().to(d).requires_grad_(True) for t in (w, c, a2, b2)]
+    ew, eb = ops._LnFoldFn.apply(*leaves, ld_eff)
+    ((ew * gw.to(d)).sum() + (eb * gb.to(d)).sum()).backward()
+    np.testing.assert_allclose(ew.detach().cpu().numpy(), eff_w.detach().numpy(), rtol=0, atol=0)
+    np.testing.assert_allclose(eb.detach().cpu().numpy(), eff_b.detach().numpy(), rtol=0, atol=2e-6 * (1 + eff_b.abs().max().item()))
+    for got, ref in zip(leaves, (w, c, a2, b2)):
+        np.testing.assert_allclose(got.grad.cpu().numpy(), ref.grad.numpy(), rtol=0, atol=3e-6 * (1 + ref.grad.abs().max().item()))
+
+
 @pytest.mark.parametrize("mode", ["f32", "fwd", "dgrad", "layers"])
 def test_other_gemm_modes_meet_the_same_mlp_parity(mode):
     """PAPR_GEMM_MODE selects which wide GEMMs use the split-f16 (hi/lo, 3 MFMA) kernels (default `h3`: forward
