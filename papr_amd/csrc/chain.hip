@@ -53,6 +53,9 @@ constexpr int CH_BM = 32 * NI;              // rows per tile
 //   NJ=1 NI=4  8 waves of 128 x 32, one workgroup per CU      1181 / 1135 / 942   (half the W traffic through L1: no gain)
 //   NJ=2 NI=4  4 waves of 128 x 64, one workgroup per CU      1354 / 1240 / 1107  (nothing overlaps the row phases)
 //   NJ=2 NI=1  4 waves of 32 x 64, three workgroups per CU    1336 / 1281 / 986   (twice the W traffic per MFMA)
+#ifndef CH_STAGE_ROWS
+#define CH_STAGE_ROWS 8                 // input rows a wave requests at once when it stages a tile (of its 64 / waves rows); 16 (one round trip instead of two) measured 2-5 % slower: 16 more spilled registers
+#endif
 #ifndef CH_NJ
 #define CH_NJ 2                         // 32-column tiles per wave: 2 = four waves of 64 x 64 (one per SIMD), 1 = eight waves of 64 x 32 (two per SIMD)
 #endif
@@ -216,7 +219,7 @@ __global__ __launch_bounds__(CH_THREADS, CH_WGS_PER_CU * CH_WAVES / 4) void mlp_
                 }
             }
         };
-        stage_rows(p.L[0].k1steps * 16, true, std::integral_constant<int, 8>());
+        stage_rows(p.L[0].k1steps * 16, true, std::integral_constant<int, CH_STAGE_ROWS>());
         for (int t = tid; t < CH_BM; t += CH_THREADS) rmax_tab[t] = 0u;
         lds_barrier();
         CH_STAMP();
