@@ -503,7 +503,11 @@ __global__ __launch_bounds__(CH_THREADS, CH_WGS_PER_CU * CH_WAVES / 4) void mlp_
                                     if (!live[j]) continue;
 #pragma unroll
                                     for (int g = 0; g < 4; ++g)
+#ifdef CH_EXP_COALESCED_STORES      // experiment (wrong layout, same bytes): what fully coalesced stores of the tile would cost
+                                        *reinterpret_cast<float4*>(Cbase + m0 * ldc + ((long)((wn * NI + i) * NJ * 4 + j * 4 + g) * 64 + lane) * 4) =
+#else
                                         *reinterpret_cast<float4*>(crow + (wn * NJ + j) * 32 + 8 * g) =
+#endif
                                             make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
                                 }
                             }
