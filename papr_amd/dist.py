@@ -49,16 +49,17 @@ def average_gradients(params):
     if not params:
         return 0
     flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
-    td.all_reduce(flat, op=td.ReduceOp.SUM)
-    flat.div_(ws)
+    if td.get_backend() == "nccl":                   # RCCL averages in the collective; gloo has no AVG
+        td.all_reduce(flat, op=td.ReduceOp.AVG)
+    else:
+        td.all_reduce(flat, op=td.ReduceOp.SUM)
+        flat.div_(ws)
+    # the averaged gradients stay where they are: every p.grad becomes a view of the bucket (67 copy-back launches per step
+    # otherwise; the optimizers' zero_grad drops the views before the next backward pass)
     off = 0
     for p in params:
         n = p.numel()
-        g = flat[off:off + n].view_as(p)
-        if p.grad is None:
-            p.grad = g.clone()
-        else:
-            p.grad.copy_(g)
+        p.grad = flat[off:off + n].view_as(p)
         off += n
     return flat.numel()
 
