@@ -121,6 +121,10 @@ def main():
         model.points_influ_scores.uniform_(0.0, 1.0, generator=torch.Generator().manual_seed(5))
     init_state = {k: v.detach().clone() for k, v in model.state_dict().items()}
     model = model.to(dev)
+    model.clear_optimizer(); model.clear_scheduler()    # optimizers over the device tensors, as `get_model(args, "cuda")` creates them
+    sys.stdout = devnull
+    model.init_optimizers(0)
+    sys.stdout = stdout
     pdist.broadcast_module_state(model)
     loss_fn = get_loss(cfg["training"]["losses"]).to(dev)
 

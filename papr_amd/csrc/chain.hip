@@ -28,9 +28,13 @@
 // with one LDS-only barrier between the stages.  The last layer of a forward run can standardise its rows
 // (LayerNorm core of the key / query embeddings) before they are stored.
 //
-// Measured (512,000 rows, 256-wide layers, MI355X): 215 us per layer in inference and 285 / 280 us per
-// forward / data-gradient layer in training, against 369 / 483 us for the per-layer kernel.  Half of the
-// remaining time is not matrix work: scripts/probes/chain_trace.py (cycle stamps), mfma_filler.hip.
+// Measured (512,000 rows, 256-wide layers, MI355X): 215 us per layer in inference and 300 / 285 us per
+// forward / data-gradient layer in training, against 369 / 483 us for the per-layer kernel.  Two thirds of
+// the time is not matrix work.  In-box ablations (scripts/probes/build_variant.sh + the CH_EXP_* switches below):
+// the weight-fragment stream costs 22 %, the wait for a tile's input rows 13 % (training), storing the layers
+// 29 % of a forward run (10 points of it the row-per-lane pattern); the instruction count of the row phases
+// hardly matters (an MFMA stream and a vector stream of two waves of a SIMD run side by side,
+// scripts/probes/mfma_vs_valu_waves.hip) -- the waves wait.
 #include "papr_common.h"
 #include "h3_common.h"
 #include "chain.h"

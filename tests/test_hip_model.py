@@ -95,12 +95,16 @@ def test_gradients_match_reference_golden(tag):
     print(tag, "worst relative gradient error", worst)
 
 
-def test_three_training_steps_follow_reference_losses():
+@pytest.mark.parametrize("fused_adam", [True, False])
+def test_three_training_steps_follow_reference_losses(fused_adam):
     from papr_amd import get_loss
     g = golden("g7_trajectory.npz")
     g5 = golden("g567_chair1k.npz")
     cfg = case_cfg("chair1k")
     m = build("chair1k", T(g5["points"]))
+    if fused_adam:                  # optimizers created over device tensors (as get_model(args, "cuda") does) are the fused ones
+        m.clear_optimizer(); m.clear_scheduler(); m.init_optimizers(0)
+        assert all(o.defaults.get("fused") for o in m.optimizers.values())
     ro, rd, c2w = cuda(*case_rays("chair1k"))
     tgt = T(g["target"]).to("cuda")
     loss_fn = get_loss(cfg["training"]["losses"])
