@@ -6,6 +6,8 @@ modulation).  It is convolutional over the whole patch rather than per ray, so i
 the hand-written per-ray kernels; it keeps the reference's module
 attribute names so that state-dict keys are interchangeable.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -38,7 +40,8 @@ class UpStage(nn.Module):
     def forward(self, low, skip):
         low = self.up(low)
         dy, dx = skip.shape[2] - low.shape[2], skip.shape[3] - low.shape[3]
-        low = F.pad(low, [dx // 2, dx - dx // 2, dy // 2, dy - dy // 2])
+        if dx or dy:                                   # (F.pad with nothing to pad still copies the map, forward and backward)
+            low = F.pad(low, [dx // 2, dx - dx // 2, dy // 2, dy - dy // 2])
         return self.conv(torch.cat([skip, low], dim=1))
 
 
@@ -61,6 +64,10 @@ class SmallUNet(nn.Module):
         self.up1 = UpStage(512, 256)
         self.up2 = UpStage(256, 128)
         self.outc = Head(128, n_classes)
+        # The feature map arrives as (N, H, W, C) rows; with channels-last weights MIOpen's NHWC kernels take both as they
+        # are (the state dict is unchanged: same keys, shapes and values, only the strides differ).
+        if os.environ.get("PAPR_UNET_CL", "1") == "1":
+            self.to(memory_format=torch.channels_last)
 
     def forward(self, x, gamma=None, beta=None):
         with torch.autocast(device_type="cuda", dtype=self.amp_dtype, enabled=self.use_amp and x.is_cuda):

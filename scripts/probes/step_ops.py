@@ -10,6 +10,7 @@ torch.manual_seed(1); np.random.seed(1)
 so = sys.stdout; sys.stdout = open(os.devnull, "w")
 m = get_model(cfg, "cpu"); sys.stdout = so
 m = m.to("cuda")
+m.clear_optimizer(); m.clear_scheduler(); sys.stdout = open(os.devnull, "w"); m.init_optimizers(0); sys.stdout = so
 loss_fn = get_loss(cfg["training"]["losses"]).to("cuda")
 data = SyntheticRayData(cfg["dataset"], n_views=4, seed=0, device="cuda")
 batch = data.patch()
@@ -27,5 +28,5 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stac
     step(3); torch.cuda.synchronize()
 rows = sorted(prof.key_averages(), key=lambda e: -e.count)
 print("%-60s %6s %10s" % ("op", "count", "cuda_us"))
-for e in rows[:45]:
+for e in rows[:70]:
     print("%-60s %6d %10.1f" % (e.key[:60], e.count, getattr(e, "device_time_total", getattr(e, "cuda_time_total", 0.0))))
