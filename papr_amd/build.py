@@ -10,7 +10,7 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libpapr_hip.so")
-SOURCES = ["error.hip", "knn.hip", "features.hip", "rowops.hip", "gemm.hip", "chain.hip"]
+SOURCES = ["error.hip", "knn.hip", "features.hip", "rowops.hip", "gemm.hip", "chain.hip", "conv.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics",
          "-Wall", "-Wno-unused-function"]
 

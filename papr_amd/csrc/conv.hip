@@ -1,0 +1,280 @@
+// K5: 3x3 convolution (stride 1, zero padding 1) over an NHWC map as an implicit GEMM on the f16 matrix pipe with split
+// fp32 operands -- the 3x3 layers of the U-Net render head (reference models/unet.py:16-33 DoubleConv with single=True,
+// applied in SmallUNet, :182-258).
+//
+//   out[p][n] = act( bias[n] + sum_{tap, c} x[p + off(tap)][c] * w[n][tap][c] )        p = pixel, zero outside the image
+//
+// is a GEMM with M = B*H*W pixels, N = C_out, K = 9*C_in whose A rows are gathered: k-slab s (32 channels of one tap)
+// of pixel row p is 128 contiguous bytes of the row of pixel p + off(tap) (NHWC keeps a pixel's channels together).
+// Arithmetic as in gemm.hip / chain.hip: a * b ~ hi_a hi_b + hi_a lo_b + lo_a hi_b with f16 halves, fp32 accumulation.
+// The nine taps of an output pixel read nine different input pixels, so the power-of-two scale that brings the
+// activations into f16 range is one per TENSOR (max |x| from papr_tensor_absmax): an element 2^-11 below the maximum
+// still keeps 22 bits, smaller ones lose absolute precision of 2^-39 of the maximum -- far below the fp32 rounding of a
+// 288..4608-term sum (the reference's own convolutions run in TF32 on its hardware: 10-bit operands).
+// The same kernel is the data-gradient: d_in = conv(d_out, w'), w'[c][tap][n] = w[n][flipped tap][c] (host: ops.py).
+//
+// Shape: 256 threads = 2 x 2 waves of 64 pixels x 64 channels over a 128 x 128 tile; both operands go through LDS (40 KB:
+// [A hi | A lo | W hi | W lo] x 128 rows x 32 k, pitch 40 halfs), single-buffered with the next slab already in
+// registers, so three workgroups share a CU and overlap each other's barriers.  Small maps (few tiles) deal the nine
+// taps to 3 or 9 workgroups per tile, whose partial sums a second kernel adds in a fixed order with bias and ReLU.  W arrives pre-split as row-major
+// f16 planes (papr_conv3x3_prepare_weight).  The MFMA takes the W fragment as its row operand: a lane owns one pixel and
+// its registers are runs of four consecutive output channels (16-byte stores, bias / ReLU in registers).
+#include "papr_common.h"
+#include "h3_common.h"
+
+namespace {
+
+constexpr int CV_BM = 128, CV_BN = 128, CV_BK = 32, CV_HP = CV_BK + 8;     // tile, k-slab, LDS row pitch in halfs
+constexpr int CV_PLANE = 128 * CV_HP;                                     // halfs per plane
+constexpr size_t CV_LDS_BYTES = (size_t)4 * CV_PLANE * sizeof(_Float16);
+
+struct ConvArgs {
+    const float* x; int B, H, W, C;
+    const _Float16* w_hi; const _Float16* w_lo; long K;       // planes [N_pad][K], K = 9 C
+    const float* bias; float* out; int N; int relu;
+    const unsigned* xmax_bits;
+    int splits; float* partial;                  // splits > 1: blockIdx.z sums 9 / splits taps into partial[z] (M, N), no bias / act
+};
+
+__global__ __launch_bounds__(256, 3) void conv3x3_h3_kernel(ConvArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    _Float16* Ah = reinterpret_cast<_Float16*>(smem);
+    _Float16* Al = Ah + CV_PLANE;
+    _Float16* Wh = Al + CV_PLANE;
+    _Float16* Wl = Wh + CV_PLANE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const long M = (long)p.B * p.H * p.W;
+    const long m0 = (long)blockIdx.x * CV_BM;
+    const int n0 = blockIdx.y * CV_BN;
+    const int slabs_per_tap = p.C / CV_BK;
+    const int s_begin = blockIdx.z * (9 / p.splits) * slabs_per_tap, s_end = s_begin + (9 / p.splits) * slabs_per_tap;
+
+    // scale of the whole input tensor: max -> [2^13, 2^14)
+    const unsigned mb = *p.xmax_bits;
+    const int ea = mb ? (int)((mb >> 23) & 0xff) : 127 + 13;
+    const float x_scale = pow2_from_biased(127 + 13 - (ea - 127)), x_inv = pow2_from_biased(127 - 13 + (ea - 127));
+
+    // A slab copy: thread t carries rows t/8 + 32 q (q < 4), floats 4 (t % 8) .. + 3 of the 32-channel slab
+    const int a_kq = (tid & 7) * 4;
+    int py[4], px[4];
+    long pbase[4];                                // element offset of the thread's pixel rows (clamped), -1: past the map
+    bool prow_ok[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        long m = m0 + (tid >> 3) + 32 * q;
+        prow_ok[q] = m < M;
+        m = prow_ok[q] ? m : M - 1;
+        const int rem = (int)(m % ((long)p.H * p.W));
+        py[q] = rem / p.W; px[q] = rem - py[q] * p.W;
+        pbase[q] = m * p.C;
+    }
+    // W slab copy: chunk c = t + 256 q (q < 2): row c / 4, halfs 8 (c % 4) .. + 7
+    struct SlabRegs { float4 a[4]; bool ok[4]; half8 wh[2], wl[2]; };
+    auto load_slab = [&](int s, SlabRegs& r) {
+        const int tap = s / slabs_per_tap, c0 = (s - tap * slabs_per_tap) * CV_BK;
+        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int yy = py[q] + dy, xx = px[q] + dx;
+            r.ok[q] = prow_ok[q] && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+            const long off = r.ok[q] ? pbase[q] + ((long)dy * p.W + dx) * p.C : pbase[q];
+            r.a[q] = *reinterpret_cast<const float4*>(p.x + off + c0 + a_kq);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int c = tid + 256 * q;
+            const long o = (long)(n0 + (c >> 2)) * p.K + (long)s * CV_BK + (c & 3) * 8;
+            r.wh[q] = *reinterpret_cast<const half8*>(p.w_hi + o);
+            r.wl[q] = *reinterpret_cast<const half8*>(p.w_lo + o);
+        }
+    };
+    auto store_slab = [&](const SlabRegs& r) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            half4 hi, lo;
+            split4(r.a[q], r.ok[q] ? x_scale : 0.f, hi, lo);
+            const int off = ((tid >> 3) + 32 * q) * CV_HP + a_kq;
+            *reinterpret_cast<half4*>(Ah + off) = hi;
+            *reinterpret_cast<half4*>(Al + off) = lo;
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int c = tid + 256 * q;
+            const int off = (c >> 2) * CV_HP + (c & 3) * 8;
+            *reinterpret_cast<half8*>(Wh + off) = r.wh[q];
+            *reinterpret_cast<half8*>(Wl + off) = r.wl[q];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int frag = (lane & 31) * CV_HP + 8 * (lane >> 5);
+    auto multiply = [&]() {
+#pragma unroll
+        for (int ks = 0; ks < CV_BK; ks += 16) {
+            half8 ah[2], al[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int o = (wm * 64 + i * 32) * CV_HP + frag + ks;
+                ah[i] = *reinterpret_cast<const half8*>(Ah + o);
+                al[i] = *reinterpret_cast<const half8*>(Al + o);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int o = (wn * 64 + j * 32) * CV_HP + frag + ks;
+                const half8 wh = *reinterpret_cast<const half8*>(Wh + o), wl = *reinterpret_cast<const half8*>(Wl + o);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, ah[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, al[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, ah[i], acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+    };
+    // One register set: slab s+1 is requested before slab s is multiplied.  (A second set -- two slabs ahead -- measured
+    // no gain on small maps and -5 % on large ones, where it costs the third workgroup of the CU its registers.)
+    SlabRegs r0;
+    load_slab(s_begin, r0);
+    store_slab(r0);
+    lds_barrier();
+    for (int s = s_begin; s < s_end; ++s) {
+        if (s + 1 < s_end) load_slab(s + 1, r0);
+        multiply();
+        lds_barrier();                               // everybody has read slab s
+        if (s + 1 < s_end) store_slab(r0);
+        lds_barrier();
+    }
+
+    // epilogue: lane = pixel, registers = runs of four channels
+    const int hh = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const long m = m0 + wm * 64 + i * 32 + (lane & 31);
+        if (m >= M) continue;
+        float* orow = p.splits > 1 ? p.partial + ((long)blockIdx.z * M + m) * p.N : p.out + m * p.N;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = n0 + wn * 64 + j * 32 + 8 * g + 4 * hh;
+                if (col >= p.N) continue;
+                float4 b4 = (p.bias && p.splits == 1) ? *reinterpret_cast<const float4*>(p.bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+                float4 r = make_float4(__builtin_fmaf(acc[i][j][4 * g], x_inv, b4.x), __builtin_fmaf(acc[i][j][4 * g + 1], x_inv, b4.y),
+                                       __builtin_fmaf(acc[i][j][4 * g + 2], x_inv, b4.z), __builtin_fmaf(acc[i][j][4 * g + 3], x_inv, b4.w));
+                if (p.relu && p.splits == 1) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
+                *reinterpret_cast<float4*>(orow + col) = r;
+            }
+    }
+}
+
+// w (N, K) fp32 row-major -> f16 planes hi / lo (N_pad, K), rows N .. N_pad-1 zero
+__global__ __launch_bounds__(256) void conv_split_weight_kernel(const float* __restrict__ w, int N, long K, long total4,
+                                                                _Float16* __restrict__ hi, _Float16* __restrict__ lo) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;       // one float4 each
+    if (e >= total4) return;
+    const long row = e * 4 / K;
+    const float4 v = row < N ? reinterpret_cast<const float4*>(w)[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+    half4 h, l;
+    split4(v, 1.0f, h, l);
+    reinterpret_cast<half4*>(hi)[e] = h;
+    reinterpret_cast<half4*>(lo)[e] = l;
+}
+
+// out = act(bias + partial[0] + partial[1] + ...): the tap groups of a split launch meet in a fixed order
+__global__ __launch_bounds__(256) void conv_reduce_kernel(const float4* __restrict__ partial, int splits, long mn4, int n4,
+                                                          const float4* __restrict__ bias, int relu, float4* __restrict__ out) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= mn4) return;
+    float4 r = bias ? bias[e % n4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int z = 0; z < splits; ++z) {
+        const float4 v = partial[(long)z * mn4 + e];
+        r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w;
+    }
+    if (relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
+    out[e] = r;
+}
+
+__global__ __launch_bounds__(256) void tensor_absmax_kernel(const float4* __restrict__ x, long n4, unsigned* __restrict__ out) {
+    float m = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float4 v = x[i];
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));       // |x| bit patterns order like unsigned ints
+}
+
+}  // namespace
+
+extern "C" size_t papr_conv3x3_weight_halfs(int32_t c_out, int32_t c_in) {
+    const long n_pad = (c_out + CV_BN - 1) / CV_BN * CV_BN;
+    return (size_t)2 * n_pad * 9 * c_in;
+}
+
+extern "C" int papr_conv3x3_prepare_weight(const float* w, int32_t c_out, int32_t c_in, void* planes, papr_stream_t stream) {
+    PAPR_REQUIRE(w && planes, "papr_conv3x3_prepare_weight: null pointer");
+    PAPR_REQUIRE(c_out >= 1 && c_in >= 32 && c_in % 32 == 0, "papr_conv3x3_prepare_weight: c_out %d, c_in %d (c_in must be a multiple of 32)", c_out, c_in);
+    const long K = 9L * c_in, n_pad = (c_out + CV_BN - 1) / CV_BN * CV_BN, total4 = n_pad * K / 4;
+    _Float16* hi = static_cast<_Float16*>(planes);
+    conv_split_weight_kernel<<<dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, as_stream(stream)>>>(w, c_out, K, total4, hi, hi + n_pad * K);
+    PAPR_CHECK_LAUNCH("conv_split_weight");
+    return 0;
+}
+
+// tap groups per launch: small maps leave most CUs without a tile, so their 9 taps are dealt to 3 or 9 workgroups
+static int conv_splits(long M, int c_in, int c_out) {
+    const long tiles = ((M + CV_BM - 1) / CV_BM) * ((c_out + CV_BN - 1) / CV_BN);
+    if (c_in < 128 || tiles >= 400) return 1;
+    return tiles * 3 >= 400 ? 3 : 9;
+}
+
+extern "C" size_t papr_conv3x3_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t c_in, int32_t c_out) {
+    const long M = (long)B * H * W;
+    const int sp = conv_splits(M, c_in, c_out);
+    return 16 + (sp > 1 ? (size_t)sp * M * c_out * sizeof(float) : 0);
+}
+
+extern "C" int papr_conv3x3_fwd(const float* x, int32_t B, int32_t H, int32_t W, int32_t c_in, const void* planes, const float* bias,
+                                int32_t c_out, int32_t relu, float* out, void* workspace, papr_stream_t stream) {
+    PAPR_REQUIRE(x && planes && out && workspace, "papr_conv3x3_fwd: null pointer");
+    PAPR_REQUIRE(B >= 1 && H >= 1 && W >= 1 && c_in >= 32 && c_in % 32 == 0 && c_out >= 4 && c_out % 4 == 0,
+                 "papr_conv3x3_fwd: B %d, H %d, W %d, c_in %d (multiple of 32), c_out %d (multiple of 4)", B, H, W, c_in, c_out);
+    hipStream_t s = as_stream(stream);
+    const long M = (long)B * H * W, K = 9L * c_in, n_pad = (c_out + CV_BN - 1) / CV_BN * CV_BN;
+    unsigned* xmax = static_cast<unsigned*>(workspace);
+    PAPR_REQUIRE(hipMemsetAsync(xmax, 0, sizeof(unsigned), s) == hipSuccess, "papr_conv3x3_fwd: memset failed");
+    const long n4 = M * c_in / 4;
+    tensor_absmax_kernel<<<dim3((unsigned)(n4 / 256 / 8 + 1 < 2048 ? n4 / 256 / 8 + 1 : 2048)), dim3(256), 0, s>>>(reinterpret_cast<const float4*>(x), n4, xmax);
+    PAPR_CHECK_LAUNCH("tensor_absmax");
+    ConvArgs a;
+    a.x = x; a.B = B; a.H = H; a.W = W; a.C = c_in;
+    a.w_hi = static_cast<const _Float16*>(planes); a.w_lo = a.w_hi + n_pad * K; a.K = K;
+    a.bias = bias; a.out = out; a.N = c_out; a.relu = relu; a.xmax_bits = xmax;
+    a.splits = conv_splits(M, c_in, c_out);
+    a.partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + 16);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_h3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CV_LDS_BYTES);
+        attr_set = true;
+    }
+    const bool prof = papr_prof_on();
+    if (prof) papr_prof_begin2(11, M, c_out, (int)K, 4LL * M * (c_in + c_out), 2LL * M * c_out * K, s);
+    conv3x3_h3_kernel<<<dim3((unsigned)((M + CV_BM - 1) / CV_BM), (unsigned)(n_pad / CV_BN), (unsigned)a.splits), dim3(256), CV_LDS_BYTES, s>>>(a);
+    PAPR_CHECK_LAUNCH("conv3x3_h3");
+    if (a.splits > 1) {
+        const long mn4 = M * c_out / 4;
+        conv_reduce_kernel<<<dim3((unsigned)((mn4 + 255) / 256)), dim3(256), 0, s>>>(reinterpret_cast<const float4*>(a.partial), a.splits, mn4, c_out / 4,
+                                                                                     reinterpret_cast<const float4*>(bias), relu, reinterpret_cast<float4*>(out));
+        PAPR_CHECK_LAUNCH("conv_reduce");
+    }
+    if (prof) papr_prof_end(s);
+    return 0;
+}

@@ -69,6 +69,56 @@ class MlpSpec:
         self.ld_out = [l["n_out_pad"] for l in self.layers]
 
 
+def conv3x3_rows(x, w_taps, bias, relu):
+    """x (B, H, W, C_in) fp32 contiguous, w_taps (C_out, 3, 3, C_in) -> (B, H, W, C_out): 3x3 convolution, stride 1, zero
+    padding 1, on the split-f16 implicit-GEMM kernel (papr_conv3x3_fwd).  No autograd (see _Conv3x3Fn)."""
+    if not x.is_cuda:
+        raise RuntimeError("papr_amd: the convolution kernel runs only on a ROCm device (HIP); there is no CPU fallback")
+    B, H, W, c_in = x.shape
+    c_out = w_taps.shape[0]
+    lib = hip.lib()
+    planes = torch.empty(lib.papr_conv3x3_weight_halfs(c_out, c_in), device=x.device, dtype=torch.float16)
+    hip.check(lib.papr_conv3x3_prepare_weight(hip.ptr(w_taps), c_out, c_in, C.c_void_p(planes.data_ptr()), hip.stream_ptr()), "papr_conv3x3_prepare_weight")
+    out = torch.empty((B, H, W, c_out), device=x.device, dtype=torch.float32)
+    ws = torch.empty((lib.papr_conv3x3_workspace_bytes(B, H, W, c_in, c_out) + 3) // 4, device=x.device, dtype=torch.float32)
+    hip.check(lib.papr_conv3x3_fwd(hip.ptr(x), B, H, W, c_in, C.c_void_p(planes.data_ptr()), hip.ptr(bias), c_out, 1 if relu else 0,
+                                   hip.ptr(out), hip.ptr(ws), hip.stream_ptr()), "papr_conv3x3_fwd")
+    return out
+
+
+class _Conv3x3Fn(torch.autograd.Function):
+    """relu(conv3x3(x) + b) over an NHWC map with the reference's (C_out, C_in, 3, 3) weight.  Forward and data-gradient on
+    papr_conv3x3_fwd (the data-gradient is the convolution of d_out with the tap-flipped, transposed weight); the weight
+    and bias gradients come from MIOpen (aten.convolution_backward)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        w_taps = weight.permute(0, 2, 3, 1).contiguous()
+        y = conv3x3_rows(x, w_taps, bias, relu)
+        ctx.save_for_backward(x, weight, y if relu else None)
+        ctx.relu = relu
+        return y
+
+    @staticmethod
+    def backward(ctx, d_y):
+        x, weight, y = ctx.saved_tensors
+        d_y = d_y.contiguous()
+        if ctx.relu:
+            d_y = d_y * (y > 0)
+        d_x = d_w = d_b = None
+        own_dx = ctx.needs_input_grad[0] and weight.shape[0] % 32 == 0          # (the kernel's K slabs are 32 channels)
+        if own_dx:
+            w_back = weight.flip(2, 3).permute(1, 2, 3, 0).contiguous()         # (C_in, 3, 3, C_out), taps flipped
+            d_x = conv3x3_rows(d_y, w_back, None, False)
+        lib_dx = ctx.needs_input_grad[0] and not own_dx
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2] or lib_dx:
+            g_x, d_w, d_b = torch.ops.aten.convolution_backward(d_y.permute(0, 3, 1, 2), x.permute(0, 3, 1, 2), weight, [weight.shape[0]],
+                                                                [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [lib_dx, True, True])
+            if lib_dx:
+                d_x = g_x.permute(0, 2, 3, 1)
+        return d_x, d_w, d_b, None
+
+
 class _LnFoldFn(torch.autograd.Function):
     """(W * a_2 zero-padded to ld_eff columns, c + W b_2): the LayerNorm affine in front of a Linear layer folded into it, one
     launch each way (in torch ops: two products, a row sum and a pad forward, eight small kernels backward, two of them

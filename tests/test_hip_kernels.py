@@ -410,6 +410,32 @@ def test_layernorm_affine_fold(n_out, n_in, ld_eff):
         np.testing.assert_allclose(got.grad.cpu().numpy(), ref.grad.numpy(), rtol=0, atol=3e-6 * (1 + ref.grad.abs().max().item()))
 
 
+@pytest.mark.parametrize("B,H,W,c_in,c_out,relu", [(1, 20, 24, 32, 128, True), (2, 9, 7, 64, 36, False), (1, 40, 40, 256, 512, True),
+                                                     (1, 13, 130, 128, 128, True)])
+def test_conv3x3_forward_and_gradients_match_torch(B, H, W, c_in, c_out, relu):
+    """papr_conv3x3_fwd (forward and, through the flipped weight, data-gradient) against torch.nn.functional.conv2d in fp32
+    on the CPU -- the 3x3 layers of the reference's SmallUNet (models/unet.py:16-33)."""
+    from papr_amd import ops
+    gen = torch.Generator().manual_seed(B * H + c_out)
+    x = torch.randn(B, c_in, H, W, generator=gen).requires_grad_(True)
+    w = (torch.randn(c_out, c_in, 3, 3, generator=gen) * (2.0 / (9 * c_in)) ** 0.5).requires_grad_(True)
+    b = (torch.randn(c_out, generator=gen) * 0.1).requires_grad_(True)
+    y = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1)
+    y = torch.relu(y) if relu else y
+    gy = torch.randn(B, c_out, H, W, generator=gen)
+    (y * gy.double()).sum().backward()
+    d = dev()
+    xd = x.detach().permute(0, 2, 3, 1).contiguous().to(d).requires_grad_(True)
+    wd, bd = w.detach().to(d).requires_grad_(True), b.detach().to(d).requires_grad_(True)
+    yd = ops._Conv3x3Fn.apply(xd, wd, bd, relu)
+    (yd * gy.permute(0, 2, 3, 1).contiguous().to(d)).sum().backward()
+    tol = lambda ref: 2e-6 * ref.abs().max().item()
+    np.testing.assert_allclose(yd.detach().cpu().permute(0, 3, 1, 2).numpy(), y.detach().float().numpy(), rtol=0, atol=tol(y))
+    np.testing.assert_allclose(xd.grad.cpu().permute(0, 3, 1, 2).numpy(), x.grad.numpy(), rtol=0, atol=3e-6 * x.grad.abs().max().item())
+    np.testing.assert_allclose(wd.grad.cpu().numpy(), w.grad.numpy(), rtol=0, atol=2e-5 * w.grad.abs().max().item())
+    np.testing.assert_allclose(bd.grad.cpu().numpy(), b.grad.numpy(), rtol=0, atol=2e-5 * b.grad.abs().max().item())
+
+
 @pytest.mark.parametrize("mode", ["f32", "fwd", "dgrad", "layers"])
 def test_other_gemm_modes_meet_the_same_mlp_parity(mode):
     """PAPR_GEMM_MODE selects which wide GEMMs use the split-f16 (hi/lo, 3 MFMA) kernels (default `h3`: forward
