@@ -231,14 +231,15 @@ int papr_attn_tail_bwd(const papr_tail_desc* d, const float* kp, const float* qp
  * K5  3x3 convolution (stride 1, zero padding 1) over an NHWC map, split-f16 MFMA implicit GEMM: the 3x3 layers of the
  * U-Net render head (reference models/unet.py:16-33 inside SmallUNet, :182-258; torch.nn.Conv2d(k=3, padding=1) + ReLU).
  *   out (B*H*W, c_out) = act(bias + conv(x (B*H*W, c_in), w))        c_in % 32 == 0, c_out % 4 == 0
- * The weight goes in as (c_out, 3, 3, c_in) fp32 (the reference's (c_out, c_in, 3, 3) permuted (0, 2, 3, 1)) and is
- * split once into f16 planes: papr_conv3x3_weight_halfs() halfs at `planes`.  The data-gradient of the layer is the same
- * call on d_out with the weight (c_in, 3, 3, c_out) whose taps are flipped.  workspace: papr_conv3x3_workspace_bytes().
+ * The weight is read where it lies: element (n, ky, kx, c) at w[n*w_stride_n + c*w_stride_c + ky*w_stride_ky +
+ * kx*w_stride_kx] (the strides of the reference's (c_out, c_in, 3, 3) parameter in any memory format).  The data-gradient
+ * of a layer is the same call on d_out with c_in / c_out and the n / c strides exchanged and flip_taps = 1.
+ * workspace: papr_conv3x3_workspace_bytes() (the weight's f16 planes, the partial sums of small maps, the input's max).
  */
 size_t papr_conv3x3_weight_halfs(int32_t c_out, int32_t c_in);
 size_t papr_conv3x3_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t c_in, int32_t c_out);
-int papr_conv3x3_prepare_weight(const float* w, int32_t c_out, int32_t c_in, void* planes, papr_stream_t stream);
-int papr_conv3x3_fwd(const float* x, int32_t B, int32_t H, int32_t W, int32_t c_in, const void* planes, const float* bias,
+int papr_conv3x3_fwd(const float* x, int32_t B, int32_t H, int32_t W, int32_t c_in, const float* w, int64_t w_stride_n,
+                     int64_t w_stride_c, int64_t w_stride_ky, int64_t w_stride_kx, int32_t flip_taps, const float* bias,
                      int32_t c_out, int32_t relu, float* out, void* workspace, papr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------

@@ -175,13 +175,22 @@ __global__ __launch_bounds__(256, 3) void conv3x3_h3_kernel(ConvArgs p) {
     }
 }
 
-// w (N, K) fp32 row-major -> f16 planes hi / lo (N_pad, K), rows N .. N_pad-1 zero
-__global__ __launch_bounds__(256) void conv_split_weight_kernel(const float* __restrict__ w, int N, long K, long total4,
-                                                                _Float16* __restrict__ hi, _Float16* __restrict__ lo) {
-    const long e = (long)blockIdx.x * 256 + threadIdx.x;       // one float4 each
+// planes hi / lo (N_pad, 9 C) <- weight element (n, ky, kx, c) at w[n sn + c sc + ky sky + kx skx]; flip: taps mirrored
+// (the data-gradient's weight); rows N .. N_pad-1 zero.  One thread per four consecutive c.
+__global__ __launch_bounds__(256) void conv_split_weight_kernel(const float* __restrict__ w, int N, int C, long sn, long sc, long sky, long skx,
+                                                                int flip, long total4, _Float16* __restrict__ hi, _Float16* __restrict__ lo) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
     if (e >= total4) return;
-    const long row = e * 4 / K;
-    const float4 v = row < N ? reinterpret_cast<const float4*>(w)[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const long K = 9L * C;
+    const long n = e * 4 / K;
+    const int k = (int)(e * 4 - n * K), tap = k / C, c = k - tap * C;
+    int ky = tap / 3, kx = tap - ky * 3;
+    if (flip) { ky = 2 - ky; kx = 2 - kx; }
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n < N) {
+        const float* q = w + n * sn + ky * sky + kx * skx + c * sc;
+        v = sc == 1 ? *reinterpret_cast<const float4*>(q) : make_float4(q[0], q[sc], q[2 * sc], q[3 * sc]);
+    }
     half4 h, l;
     split4(v, 1.0f, h, l);
     reinterpret_cast<half4*>(hi)[e] = h;
@@ -203,13 +212,17 @@ __global__ __launch_bounds__(256) void conv_reduce_kernel(const float4* __restri
 }
 
 __global__ __launch_bounds__(256) void tensor_absmax_kernel(const float4* __restrict__ x, long n4, unsigned* __restrict__ out) {
+    __shared__ float part[4];
     float m = 0.f;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         const float4 v = x[i];
         m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
     }
     m = wave_max(m);
-    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));       // |x| bit patterns order like unsigned ints
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0)                                   // |x| bit patterns order like unsigned ints
+        atomicMax(out, __float_as_uint(fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]))));
 }
 
 }  // namespace
@@ -217,16 +230,6 @@ __global__ __launch_bounds__(256) void tensor_absmax_kernel(const float4* __rest
 extern "C" size_t papr_conv3x3_weight_halfs(int32_t c_out, int32_t c_in) {
     const long n_pad = (c_out + CV_BN - 1) / CV_BN * CV_BN;
     return (size_t)2 * n_pad * 9 * c_in;
-}
-
-extern "C" int papr_conv3x3_prepare_weight(const float* w, int32_t c_out, int32_t c_in, void* planes, papr_stream_t stream) {
-    PAPR_REQUIRE(w && planes, "papr_conv3x3_prepare_weight: null pointer");
-    PAPR_REQUIRE(c_out >= 1 && c_in >= 32 && c_in % 32 == 0, "papr_conv3x3_prepare_weight: c_out %d, c_in %d (c_in must be a multiple of 32)", c_out, c_in);
-    const long K = 9L * c_in, n_pad = (c_out + CV_BN - 1) / CV_BN * CV_BN, total4 = n_pad * K / 4;
-    _Float16* hi = static_cast<_Float16*>(planes);
-    conv_split_weight_kernel<<<dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, as_stream(stream)>>>(w, c_out, K, total4, hi, hi + n_pad * K);
-    PAPR_CHECK_LAUNCH("conv_split_weight");
-    return 0;
 }
 
 // tap groups per launch: small maps leave most CUs without a tile, so their 9 taps are dealt to 3 or 9 workgroups
@@ -239,27 +242,34 @@ static int conv_splits(long M, int c_in, int c_out) {
 extern "C" size_t papr_conv3x3_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t c_in, int32_t c_out) {
     const long M = (long)B * H * W;
     const int sp = conv_splits(M, c_in, c_out);
-    return 16 + (sp > 1 ? (size_t)sp * M * c_out * sizeof(float) : 0);
+    return 256 + papr_conv3x3_weight_halfs(c_out, c_in) * sizeof(_Float16) + (sp > 1 ? (size_t)sp * M * c_out * sizeof(float) : 0);
 }
 
-extern "C" int papr_conv3x3_fwd(const float* x, int32_t B, int32_t H, int32_t W, int32_t c_in, const void* planes, const float* bias,
+extern "C" int papr_conv3x3_fwd(const float* x, int32_t B, int32_t H, int32_t W, int32_t c_in, const float* w, int64_t w_stride_n,
+                                int64_t w_stride_c, int64_t w_stride_ky, int64_t w_stride_kx, int32_t flip_taps, const float* bias,
                                 int32_t c_out, int32_t relu, float* out, void* workspace, papr_stream_t stream) {
-    PAPR_REQUIRE(x && planes && out && workspace, "papr_conv3x3_fwd: null pointer");
+    PAPR_REQUIRE(x && w && out && workspace, "papr_conv3x3_fwd: null pointer");
     PAPR_REQUIRE(B >= 1 && H >= 1 && W >= 1 && c_in >= 32 && c_in % 32 == 0 && c_out >= 4 && c_out % 4 == 0,
                  "papr_conv3x3_fwd: B %d, H %d, W %d, c_in %d (multiple of 32), c_out %d (multiple of 4)", B, H, W, c_in, c_out);
     hipStream_t s = as_stream(stream);
     const long M = (long)B * H * W, K = 9L * c_in, n_pad = (c_out + CV_BN - 1) / CV_BN * CV_BN;
     unsigned* xmax = static_cast<unsigned*>(workspace);
+    _Float16* planes = reinterpret_cast<_Float16*>(static_cast<char*>(workspace) + 256);
     PAPR_REQUIRE(hipMemsetAsync(xmax, 0, sizeof(unsigned), s) == hipSuccess, "papr_conv3x3_fwd: memset failed");
     const long n4 = M * c_in / 4;
-    tensor_absmax_kernel<<<dim3((unsigned)(n4 / 256 / 8 + 1 < 2048 ? n4 / 256 / 8 + 1 : 2048)), dim3(256), 0, s>>>(reinterpret_cast<const float4*>(x), n4, xmax);
+    const long want = (n4 + 256 * 16 - 1) / (256 * 16);
+    tensor_absmax_kernel<<<dim3((unsigned)(want < 256 ? want : 256)), dim3(256), 0, s>>>(reinterpret_cast<const float4*>(x), n4, xmax);
     PAPR_CHECK_LAUNCH("tensor_absmax");
+    const long total4 = n_pad * K / 4;
+    conv_split_weight_kernel<<<dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s>>>(w, c_out, c_in, w_stride_n, w_stride_c, w_stride_ky, w_stride_kx,
+                                                                                         flip_taps, total4, planes, planes + n_pad * K);
+    PAPR_CHECK_LAUNCH("conv_split_weight");
     ConvArgs a;
     a.x = x; a.B = B; a.H = H; a.W = W; a.C = c_in;
-    a.w_hi = static_cast<const _Float16*>(planes); a.w_lo = a.w_hi + n_pad * K; a.K = K;
+    a.w_hi = planes; a.w_lo = planes + n_pad * K; a.K = K;
     a.bias = bias; a.out = out; a.N = c_out; a.relu = relu; a.xmax_bits = xmax;
     a.splits = conv_splits(M, c_in, c_out);
-    a.partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + 16);
+    a.partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + 256 + papr_conv3x3_weight_halfs(c_out, c_in) * sizeof(_Float16));
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_h3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CV_LDS_BYTES);

@@ -69,32 +69,38 @@ class MlpSpec:
         self.ld_out = [l["n_out_pad"] for l in self.layers]
 
 
-def conv3x3_rows(x, w_taps, bias, relu):
-    """x (B, H, W, C_in) fp32 contiguous, w_taps (C_out, 3, 3, C_in) -> (B, H, W, C_out): 3x3 convolution, stride 1, zero
-    padding 1, on the split-f16 implicit-GEMM kernel (papr_conv3x3_fwd).  No autograd (see _Conv3x3Fn)."""
+def conv3x3_rows(x, weight, bias, relu, transposed=False):
+    """x (B, H, W, C_in) fp32 contiguous, weight = the reference's (C_out, C_in, 3, 3) Conv2d parameter in any memory format
+    -> (B, H, W, C_out): 3x3 convolution, stride 1, zero padding 1, on the split-f16 implicit-GEMM kernel.  transposed:
+    the layer's data-gradient (x = d_out: channels and taps of the weight exchanged / mirrored inside the kernel's weight
+    split).  No autograd here (see _Conv3x3Fn)."""
     if not x.is_cuda:
         raise RuntimeError("papr_amd: the convolution kernel runs only on a ROCm device (HIP); there is no CPU fallback")
     B, H, W, c_in = x.shape
-    c_out = w_taps.shape[0]
+    sn, sc, sky, skx = weight.stride()
+    c_out = weight.shape[0]
+    if transposed:
+        c_out, sn, sc = weight.shape[1], sc, sn
+    assert weight.shape[1 if not transposed else 0] == c_in and x.is_contiguous()
     lib = hip.lib()
-    planes = torch.empty(lib.papr_conv3x3_weight_halfs(c_out, c_in), device=x.device, dtype=torch.float16)
-    hip.check(lib.papr_conv3x3_prepare_weight(hip.ptr(w_taps), c_out, c_in, C.c_void_p(planes.data_ptr()), hip.stream_ptr()), "papr_conv3x3_prepare_weight")
     out = torch.empty((B, H, W, c_out), device=x.device, dtype=torch.float32)
-    ws = torch.empty((lib.papr_conv3x3_workspace_bytes(B, H, W, c_in, c_out) + 3) // 4, device=x.device, dtype=torch.float32)
-    hip.check(lib.papr_conv3x3_fwd(hip.ptr(x), B, H, W, c_in, C.c_void_p(planes.data_ptr()), hip.ptr(bias), c_out, 1 if relu else 0,
-                                   hip.ptr(out), hip.ptr(ws), hip.stream_ptr()), "papr_conv3x3_fwd")
+    size = lib.papr_conv3x3_workspace_bytes(B, H, W, c_in, c_out)
+    key = (x.device.type, x.device.index, "conv")
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() * 4 < size:
+        ws = _ws_cache[key] = torch.empty((size + 3) // 4, device=x.device, dtype=torch.float32)
+    hip.check(lib.papr_conv3x3_fwd(hip.ptr(x), B, H, W, c_in, C.c_void_p(weight.data_ptr()), sn, sc, sky, skx, 1 if transposed else 0,
+                                   hip.ptr(bias), c_out, 1 if relu else 0, hip.ptr(out), hip.ptr(ws), hip.stream_ptr()), "papr_conv3x3_fwd")
     return out
 
 
 class _Conv3x3Fn(torch.autograd.Function):
     """relu(conv3x3(x) + b) over an NHWC map with the reference's (C_out, C_in, 3, 3) weight.  Forward and data-gradient on
-    papr_conv3x3_fwd (the data-gradient is the convolution of d_out with the tap-flipped, transposed weight); the weight
-    and bias gradients come from MIOpen (aten.convolution_backward)."""
+    papr_conv3x3_fwd; the weight and bias gradients come from MIOpen (aten.convolution_backward)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, relu):
-        w_taps = weight.permute(0, 2, 3, 1).contiguous()
-        y = conv3x3_rows(x, w_taps, bias, relu)
+        y = conv3x3_rows(x, weight.detach(), bias.detach() if bias is not None else None, relu)
         ctx.save_for_backward(x, weight, y if relu else None)
         ctx.relu = relu
         return y
@@ -104,12 +110,11 @@ class _Conv3x3Fn(torch.autograd.Function):
         x, weight, y = ctx.saved_tensors
         d_y = d_y.contiguous()
         if ctx.relu:
-            d_y = d_y * (y > 0)
+            d_y = torch.ops.aten.threshold_backward(d_y, y, 0)
         d_x = d_w = d_b = None
         own_dx = ctx.needs_input_grad[0] and weight.shape[0] % 32 == 0          # (the kernel's K slabs are 32 channels)
         if own_dx:
-            w_back = weight.flip(2, 3).permute(1, 2, 3, 0).contiguous()         # (C_in, 3, 3, C_out), taps flipped
-            d_x = conv3x3_rows(d_y, w_back, None, False)
+            d_x = conv3x3_rows(d_y, weight, None, False, transposed=True)
         lib_dx = ctx.needs_input_grad[0] and not own_dx
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2] or lib_dx:
             g_x, d_w, d_b = torch.ops.aten.convolution_backward(d_y.permute(0, 3, 1, 2), x.permute(0, 3, 1, 2), weight, [weight.shape[0]],

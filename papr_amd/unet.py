@@ -12,13 +12,26 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+_OWN_CONV = os.environ.get("PAPR_UNET_CONV", "1") == "1"
+
 
 class ConvStage(nn.Module):
+    """Conv2d(3x3, padding 1) + ReLU (the reference's DoubleConv with single=True, models/unet.py:16-33).  On the device, in
+    fp32 and with a channels-last map it runs on the split-f16 implicit-GEMM kernel (papr_conv3x3_fwd: forward and
+    data-gradient; the weight gradient stays with MIOpen); otherwise on torch's convolution.  PAPR_UNET_CONV=0 forces the
+    latter (A/B)."""
+
     def __init__(self, c_in, c_out):
         super().__init__()
         self.double_conv = nn.Sequential(nn.Conv2d(c_in, c_out, kernel_size=3, padding=1), nn.ReLU(inplace=True))
 
     def forward(self, x):
+        conv = self.double_conv[0]
+        if (_OWN_CONV and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled() and conv.in_channels % 32 == 0
+                and conv.out_channels % 4 == 0):
+            from .ops import _Conv3x3Fn
+            rows = x.permute(0, 2, 3, 1).contiguous()             # (no copy when the map is channels-last already)
+            return _Conv3x3Fn.apply(rows, conv.weight, conv.bias, True).permute(0, 3, 1, 2)
         return self.double_conv(x)
 
 

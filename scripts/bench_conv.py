@@ -16,10 +16,9 @@ for S in (160, 800):
         x = torch.randn(1, hw, hw, ci, device=d)
         w = torch.randn(co, ci, 3, 3, device=d) * 0.05
         b = torch.zeros(co, device=d)
-        wt = w.permute(0, 2, 3, 1).contiguous()
         xc = x.permute(0, 3, 1, 2)                                   # NCHW view with channels-last strides
         wc = w.contiguous(memory_format=torch.channels_last)
         us_m = t(lambda: torch.relu_(torch.nn.functional.conv2d(xc, wc, b, padding=1)))
-        us_h = t(lambda: ops.conv3x3_rows(x, wt, b, True))
+        us_h = t(lambda: ops.conv3x3_rows(x, wc, b, True))
         fl = 2.0 * hw * hw * co * 9 * ci
         print("%4d^2 %-9s %4d->%4d  MIOpen %7.1f us (%5.1f TF)   split-f16 %7.1f us (%5.1f TF)  x%.2f" % (S, name, ci, co, us_m, fl / us_m / 1e6, us_h, fl / us_h / 1e6, us_m / us_h))
