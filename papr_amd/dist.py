@@ -56,10 +56,13 @@ def average_gradients(params):
         flat.div_(ws)
     # the averaged gradients stay where they are: every p.grad becomes a view of the bucket (67 copy-back launches per step
     # otherwise; the optimizers' zero_grad drops the views before the next backward pass)
+    # (a parameter in another memory format -- the U-Net's channels-last weights -- gets a gradient with ITS strides, as
+    # autograd's layout contract has it: the fused / foreach optimizers walk parameter and gradient memory side by side)
     off = 0
     for p in params:
         n = p.numel()
-        p.grad = flat[off:off + n].view_as(p)
+        g = flat[off:off + n].view_as(p)
+        p.grad = g if g.stride() == p.stride() else torch.empty_like(p).copy_(g)
         off += n
     return flat.numel()
 

@@ -60,11 +60,15 @@ def w_step_averages(rank, world):
     grads = {n: (p.grad.clone() if p.grad is not None else torch.zeros_like(p)) for n, p in m.named_parameters() if p.requires_grad}
     m.step(0)
     return {"grads": grads, "after": {n: p.detach().clone() for n, p in m.named_parameters()},
-            "avg": {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}}
+            "avg": {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None},
+            # the averaged gradient keeps its parameter's memory format (the fused optimizers refuse anything else)
+            "layout_kept": all(p.grad.stride() == p.stride() for p in m.parameters() if p.grad is not None),
+            "channels_last_weights": sum(1 for p in m.parameters() if p.dim() == 4 and not p.is_contiguous())}
 
 
 def test_step_allreduces_mean_gradient_and_keeps_replicas_identical(tmp_path):
     r0, r1 = run2("w_step_averages", tmp_path)
+    assert r0["layout_kept"] and r1["layout_kept"] and r0["channels_last_weights"] >= 5
     for n in r0["grads"]:
         mean = 0.5 * (r0["grads"][n] + r1["grads"][n])
         assert torch.allclose(r0["avg"][n], mean, atol=1e-7), n
