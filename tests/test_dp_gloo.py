@@ -50,7 +50,9 @@ def _model(seed=1):
 
 # ---------------------------------------------------------------------------------------------
 def w_step_averages(rank, world):
-    m = _model()
+    from papr_amd import dist as pdist
+    m = _model(seed=1 + rank)                     # replicas start different ...
+    pdist.broadcast_module_state(m)               # ... and take rank 0's state, channels-last U-Net weights included
     g = torch.Generator().manual_seed(100 + rank)
     for p in m.parameters():
         if p.requires_grad:
