@@ -234,13 +234,16 @@ int papr_attn_tail_bwd(const papr_tail_desc* d, const float* kp, const float* qp
  * The weight is read where it lies: element (n, ky, kx, c) at w[n*w_stride_n + c*w_stride_c + ky*w_stride_ky +
  * kx*w_stride_kx] (the strides of the reference's (c_out, c_in, 3, 3) parameter in any memory format).  The data-gradient
  * of a layer is the same call on d_out with c_in / c_out and the n / c strides exchanged and flip_taps = 1.
- * workspace: papr_conv3x3_workspace_bytes() (the weight's f16 planes, the partial sums of small maps, the input's max).
+ * workspace: papr_conv3x3_workspace_bytes() (the weight's f16 planes, the partial sums of small maps, and in its first
+ * 256 bytes 64 slots for the input's maximum).  The caller zeroes those 256 bytes once, when it allocates the buffer, and
+ * passes slot = (number of calls made with this buffer) mod 64: a call leaves its maximum in its slot and clears the one 32
+ * calls behind, which spares a memset launch per call.
  */
 size_t papr_conv3x3_weight_halfs(int32_t c_out, int32_t c_in);
 size_t papr_conv3x3_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t c_in, int32_t c_out);
 int papr_conv3x3_fwd(const float* x, int32_t B, int32_t H, int32_t W, int32_t c_in, const float* w, int64_t w_stride_n,
                      int64_t w_stride_c, int64_t w_stride_ky, int64_t w_stride_kx, int32_t flip_taps, const float* bias,
-                     int32_t c_out, int32_t relu, float* out, void* workspace, papr_stream_t stream);
+                     int32_t c_out, int32_t relu, float* out, void* workspace, int32_t slot, papr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Optional timing of the GEMM / kNN launches with HIP events recorded on the launch stream

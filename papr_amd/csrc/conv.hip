@@ -211,8 +211,10 @@ __global__ __launch_bounds__(256) void conv_reduce_kernel(const float4* __restri
     out[e] = r;
 }
 
-__global__ __launch_bounds__(256) void tensor_absmax_kernel(const float4* __restrict__ x, long n4, unsigned* __restrict__ out) {
+__global__ __launch_bounds__(256) void tensor_absmax_kernel(const float4* __restrict__ x, long n4, unsigned* __restrict__ out,
+                                                            unsigned* __restrict__ stale) {
     __shared__ float part[4];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *stale = 0u;       // the slot of 32 calls ago, for its next turn (no memset launch)
     float m = 0.f;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         const float4 v = x[i];
@@ -247,18 +249,19 @@ extern "C" size_t papr_conv3x3_workspace_bytes(int32_t B, int32_t H, int32_t W, 
 
 extern "C" int papr_conv3x3_fwd(const float* x, int32_t B, int32_t H, int32_t W, int32_t c_in, const float* w, int64_t w_stride_n,
                                 int64_t w_stride_c, int64_t w_stride_ky, int64_t w_stride_kx, int32_t flip_taps, const float* bias,
-                                int32_t c_out, int32_t relu, float* out, void* workspace, papr_stream_t stream) {
+                                int32_t c_out, int32_t relu, float* out, void* workspace, int32_t slot, papr_stream_t stream) {
     PAPR_REQUIRE(x && w && out && workspace, "papr_conv3x3_fwd: null pointer");
+    PAPR_REQUIRE(slot >= 0 && slot < 64, "papr_conv3x3_fwd: slot %d outside 0 .. 63", slot);
     PAPR_REQUIRE(B >= 1 && H >= 1 && W >= 1 && c_in >= 32 && c_in % 32 == 0 && c_out >= 4 && c_out % 4 == 0,
                  "papr_conv3x3_fwd: B %d, H %d, W %d, c_in %d (multiple of 32), c_out %d (multiple of 4)", B, H, W, c_in, c_out);
     hipStream_t s = as_stream(stream);
     const long M = (long)B * H * W, K = 9L * c_in, n_pad = (c_out + CV_BN - 1) / CV_BN * CV_BN;
-    unsigned* xmax = static_cast<unsigned*>(workspace);
+    unsigned* xmax = static_cast<unsigned*>(workspace) + slot;
+    unsigned* stale = static_cast<unsigned*>(workspace) + ((slot + 32) & 63);
     _Float16* planes = reinterpret_cast<_Float16*>(static_cast<char*>(workspace) + 256);
-    PAPR_REQUIRE(hipMemsetAsync(xmax, 0, sizeof(unsigned), s) == hipSuccess, "papr_conv3x3_fwd: memset failed");
     const long n4 = M * c_in / 4;
     const long want = (n4 + 256 * 16 - 1) / (256 * 16);
-    tensor_absmax_kernel<<<dim3((unsigned)(want < 256 ? want : 256)), dim3(256), 0, s>>>(reinterpret_cast<const float4*>(x), n4, xmax);
+    tensor_absmax_kernel<<<dim3((unsigned)(want < 256 ? want : 256)), dim3(256), 0, s>>>(reinterpret_cast<const float4*>(x), n4, xmax, stale);
     PAPR_CHECK_LAUNCH("tensor_absmax");
     const long total4 = n_pad * K / 4;
     conv_split_weight_kernel<<<dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s>>>(w, c_out, c_in, w_stride_n, w_stride_c, w_stride_ky, w_stride_kx,

@@ -86,11 +86,13 @@ def conv3x3_rows(x, weight, bias, relu, transposed=False):
     out = torch.empty((B, H, W, c_out), device=x.device, dtype=torch.float32)
     size = lib.papr_conv3x3_workspace_bytes(B, H, W, c_in, c_out)
     key = (x.device.type, x.device.index, "conv")
-    ws = _ws_cache.get(key)
+    ws, calls = _ws_cache.get(key, (None, 0))
     if ws is None or ws.numel() * 4 < size:
-        ws = _ws_cache[key] = torch.empty((size + 3) // 4, device=x.device, dtype=torch.float32)
+        ws, calls = torch.empty((size + 3) // 4, device=x.device, dtype=torch.float32), 0
+        ws[:64].zero_()                                      # the 64 maximum slots (include/papr_hip.h)
+    _ws_cache[key] = (ws, calls + 1)
     hip.check(lib.papr_conv3x3_fwd(hip.ptr(x), B, H, W, c_in, C.c_void_p(weight.data_ptr()), sn, sc, sky, skx, 1 if transposed else 0,
-                                   hip.ptr(bias), c_out, 1 if relu else 0, hip.ptr(out), hip.ptr(ws), hip.stream_ptr()), "papr_conv3x3_fwd")
+                                   hip.ptr(bias), c_out, 1 if relu else 0, hip.ptr(out), hip.ptr(ws), calls % 64, hip.stream_ptr()), "papr_conv3x3_fwd")
     return out
 
 
