@@ -244,6 +244,13 @@ size_t papr_conv3x3_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t c_i
 int papr_conv3x3_fwd(const float* x, int32_t B, int32_t H, int32_t W, int32_t c_in, const float* w, int64_t w_stride_n,
                      int64_t w_stride_c, int64_t w_stride_ky, int64_t w_stride_kx, int32_t flip_taps, const float* bias,
                      int32_t c_out, int32_t relu, float* out, void* workspace, int32_t slot, papr_stream_t stream);
+/* Weight gradient of the layer: d_w (c_out, 3, 3, c_in) contiguous (= the reference's (c_out, c_in, 3, 3) gradient in
+ * channels-last memory format) from d_out (B*H*W, c_out) -- already multiplied by the activation's derivative -- and the
+ * layer's input x (B*H*W, c_in).  Channels multiples of 4.  workspace: papr_conv3x3_wgrad_workspace_bytes(), first 256
+ * bytes zeroed by the caller at allocation; slot = (calls made with this buffer) mod 32. */
+size_t papr_conv3x3_wgrad_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t c_in, int32_t c_out);
+int papr_conv3x3_wgrad(const float* d_out, const float* x, int32_t B, int32_t H, int32_t W, int32_t c_in, int32_t c_out,
+                       float* d_w, void* workspace, int32_t slot, papr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Optional timing of the GEMM / kNN launches with HIP events recorded on the launch stream

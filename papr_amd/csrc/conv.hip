@@ -21,8 +21,11 @@
 // its registers are runs of four consecutive output channels (16-byte stores, bias / ReLU in registers).
 #include "papr_common.h"
 #include "h3_common.h"
+#include <stdlib.h>
 
 namespace {
+
+__device__ __forceinline__ float comp4c(const float4& v, int j) { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); }
 
 constexpr int CV_BM = 128, CV_BN = 128, CV_BK = 32, CV_HP = CV_BK + 8;     // tile, k-slab, LDS row pitch in halfs
 constexpr int CV_PLANE = 128 * CV_HP;                                     // halfs per plane
@@ -197,6 +200,164 @@ __global__ __launch_bounds__(256) void conv_split_weight_kernel(const float* __r
     reinterpret_cast<half4*>(lo)[e] = l;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight gradient of the same layer: dW[n][tap][c] = sum over pixels p of dY[p][n] * X[p + off(tap)][c].
+// The reduction runs over pixels, so both operands go into LDS TRANSPOSED (rows = channels, k = pixels): a thread loads
+// a 4-pixel x 4-channel block (four float4, one per pixel) and writes its columns as 4-pixel runs (the trick of
+// gemm_tn_h3).  Channel 4 q + j of the 128-channel block lives in LDS row q + 32 j, so the lanes of a write hit
+// consecutive rows; the epilogue undoes the permutation.  One workgroup = one tap, one 128 x 128 (n, c) tile and one
+// CHUNK of the pixels (few output tiles exist: 9 ... 72 per layer); the chunks' partial tiles meet in a fixed order in
+// conv_wgrad_reduce_kernel.  Scales: one power of two per tensor for dY and for X.
+struct ConvWArgs {
+    const float* dy; const float* x; int B, H, W, N, C;
+    const unsigned* dymax_bits; const unsigned* xmax_bits;
+    float* partial;                              // [chunk][N][9][C]
+    long px_per_chunk;                           // multiple of 32
+};
+
+__global__ __launch_bounds__(256, 3) void conv3x3_wgrad_h3_kernel(ConvWArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    _Float16* Gh = reinterpret_cast<_Float16*>(smem);
+    _Float16* Gl = Gh + CV_PLANE;
+    _Float16* Xh = Gl + CV_PLANE;
+    _Float16* Xl = Xh + CV_PLANE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const long M = (long)p.B * p.H * p.W;
+    const int cb = (p.C + 127) / 128;
+    const int n0 = (blockIdx.y / cb) * 128, c0 = (blockIdx.y % cb) * 128;
+    const int tap = blockIdx.z, dy_ = tap / 3 - 1, dx_ = tap - (tap / 3) * 3 - 1;
+    const long pbeg = (long)blockIdx.x * p.px_per_chunk;
+    long pend = pbeg + p.px_per_chunk;
+    if (pend > M) pend = M;
+
+    auto scale_of = [](unsigned mb, float& inv) {
+        const int ea = mb ? (int)((mb >> 23) & 0xff) : 127 + 13;
+        inv = pow2_from_biased(127 - 13 + (ea - 127));
+        return pow2_from_biased(127 + 13 - (ea - 127));
+    };
+    float g_inv, x_inv;
+    const float g_scale = scale_of(*p.dymax_bits, g_inv), x_scale = scale_of(*p.xmax_bits, x_inv);
+
+    // block of the thread: channels 4 q .. 4 q + 3 (q = tid % 32), pixels 4 r .. 4 r + 3 of the 32-pixel slab (r = tid / 32)
+    const int q = tid & 31, r = tid >> 5;
+    const bool n_ok = n0 + 4 * q < p.N, c_ok = c0 + 4 * q < p.C;
+    const int ncol = n_ok ? n0 + 4 * q : 0, ccol = c_ok ? c0 + 4 * q : 0;
+    float4 rg[4], rx[4];
+    bool okg[4], okx[4];
+    // (y, x) of the thread's four pixels of the current slab, kept up to date by steps of 32 pixels (no division per slab)
+    int py[4], px[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        long pix = pbeg + 4 * r + j;
+        pix = pix < M ? pix : M - 1;
+        const int rem = (int)(pix % ((long)p.H * p.W));
+        py[j] = rem / p.W; px[j] = rem - py[j] * p.W;
+    }
+    auto load_slab = [&](long ps) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long pix = ps + 4 * r + j;
+            okg[j] = n_ok && pix < pend;
+            const long pc = pix < M ? pix : M - 1;
+            rg[j] = *reinterpret_cast<const float4*>(p.dy + pc * p.N + ncol);
+            const int yy = py[j] + dy_, xx = px[j] + dx_;
+            okx[j] = c_ok && pix < pend && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+            const long src = okx[j] ? pc + (long)dy_ * p.W + dx_ : pc;
+            rx[j] = *reinterpret_cast<const float4*>(p.x + src * p.C + ccol);
+            px[j] += 32;                                  // the same thread's pixel of the next slab
+            while (px[j] >= p.W) { px[j] -= p.W; if (++py[j] == p.H) py[j] = 0; }
+        }
+    };
+    auto put = [&](const float4 (&v)[4], const bool (&ok)[4], float sc, _Float16* hi_plane, _Float16* lo_plane) {
+        const float s0 = ok[0] ? sc : 0.f, s1 = ok[1] ? sc : 0.f, s2 = ok[2] ? sc : 0.f, s3 = ok[3] ? sc : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                    // channel 4 q + j: its four pixels
+            const float4 col = make_float4(comp4c(v[0], j) * s0, comp4c(v[1], j) * s1, comp4c(v[2], j) * s2, comp4c(v[3], j) * s3);
+            half4 hi, lo;
+            split4(col, 1.0f, hi, lo);
+            const int off = (q + 32 * j) * CV_HP + 4 * r;
+            *reinterpret_cast<half4*>(hi_plane + off) = hi;
+            *reinterpret_cast<half4*>(lo_plane + off) = lo;
+        }
+    };
+    auto store_slab = [&]() {
+        put(rg, okg, g_scale, Gh, Gl);
+        put(rx, okx, x_scale, Xh, Xl);
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const int frag = (lane & 31) * CV_HP + 8 * (lane >> 5);
+    if (pbeg < pend) {
+        load_slab(pbeg);
+        store_slab();
+        lds_barrier();
+        for (long ps = pbeg; ps < pend; ps += 32) {
+            if (ps + 32 < pend) load_slab(ps + 32);
+#pragma unroll
+            for (int ks = 0; ks < CV_BK; ks += 16) {
+                half8 xh[2], xl[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int o = (wn * 64 + j * 32) * CV_HP + frag + ks;
+                    xh[j] = *reinterpret_cast<const half8*>(Xh + o);
+                    xl[j] = *reinterpret_cast<const half8*>(Xl + o);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int o = (wm * 64 + i * 32) * CV_HP + frag + ks;
+                    const half8 gh = *reinterpret_cast<const half8*>(Gh + o), gl = *reinterpret_cast<const half8*>(Gl + o);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gl, xh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, xl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, xh[j], acc[i][j], 0, 0, 0);
+                    }
+                }
+            }
+            lds_barrier();
+            if (ps + 32 < pend) store_slab();
+            lds_barrier();
+        }
+    }
+    // acc[i][j][e]: LDS rows (n) 64 wm + 32 i + (e & 3) + 8 (e >> 2) + 4 (lane >> 5), LDS row (c) 64 wn + 32 j + (lane & 31);
+    // LDS row R holds channel 4 (R % 32) + R / 32 of the block
+    float* out = p.partial + (long)blockIdx.x * p.N * 9 * p.C;
+    const float inv = g_inv * x_inv;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int rc = 64 * wn + 32 * j + (lane & 31);
+        const int c = c0 + 4 * (rc & 31) + (rc >> 5);
+        if (c >= p.C) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int rn = 64 * wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                const int n = n0 + 4 * (rn & 31) + (rn >> 5);
+                if (n < p.N) out[((long)n * 9 + tap) * p.C + c] = acc[i][j][e] * inv;
+            }
+    }
+}
+
+// d_w (N, 3, 3, C) contiguous = sum of the chunks' partial tiles, in chunk order
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float4* __restrict__ partial, int chunks, long n4, float4* __restrict__ out) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n4) return;
+    float4 r = partial[e];
+    for (int z = 1; z < chunks; ++z) {
+        const float4 v = partial[(long)z * n4 + e];
+        r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w;
+    }
+    out[e] = r;
+}
+
 // out = act(bias + partial[0] + partial[1] + ...): the tap groups of a split launch meet in a fixed order
 __global__ __launch_bounds__(256) void conv_reduce_kernel(const float4* __restrict__ partial, int splits, long mn4, int n4,
                                                           const float4* __restrict__ bias, int relu, float4* __restrict__ out) {
@@ -288,6 +449,62 @@ extern "C" int papr_conv3x3_fwd(const float* x, int32_t B, int32_t H, int32_t W,
                                                                                      reinterpret_cast<const float4*>(bias), relu, reinterpret_cast<float4*>(out));
         PAPR_CHECK_LAUNCH("conv_reduce");
     }
+    if (prof) papr_prof_end(s);
+    return 0;
+}
+
+// pixels per workgroup of the weight-gradient launch: enough chunks for ~600 workgroups, at least 8 slabs each
+static long wgrad_px_per_chunk(long M, int c_in, int c_out) {
+    const long tiles = (long)((c_out + 127) / 128) * ((c_in + 127) / 128) * 9;
+    static const long target = getenv("PAPR_WGRAD_WGS") ? atol(getenv("PAPR_WGRAD_WGS")) : 600;
+    long chunks = (target + tiles - 1) / tiles;
+    long px = (M + chunks - 1) / chunks;
+    px = (px + 31) / 32 * 32;
+    return px < 256 ? 256 : px;
+}
+
+extern "C" size_t papr_conv3x3_wgrad_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t c_in, int32_t c_out) {
+    const long M = (long)B * H * W, px = wgrad_px_per_chunk(M, c_in, c_out), chunks = (M + px - 1) / px;
+    return 256 + (size_t)chunks * c_out * 9 * c_in * sizeof(float);
+}
+
+extern "C" int papr_conv3x3_wgrad(const float* d_out, const float* x, int32_t B, int32_t H, int32_t W, int32_t c_in, int32_t c_out,
+                                  float* d_w, void* workspace, int32_t slot, papr_stream_t stream) {
+    PAPR_REQUIRE(d_out && x && d_w && workspace, "papr_conv3x3_wgrad: null pointer");
+    PAPR_REQUIRE(B >= 1 && H >= 1 && W >= 1 && c_in >= 4 && c_in % 4 == 0 && c_out >= 4 && c_out % 4 == 0,
+                 "papr_conv3x3_wgrad: B %d, H %d, W %d, c_in %d, c_out %d (channels must be multiples of 4)", B, H, W, c_in, c_out);
+    PAPR_REQUIRE(slot >= 0 && slot < 32, "papr_conv3x3_wgrad: slot %d outside 0 .. 31", slot);
+    hipStream_t s = as_stream(stream);
+    const long M = (long)B * H * W, px = wgrad_px_per_chunk(M, c_in, c_out), chunks = (M + px - 1) / px;
+    unsigned* head = static_cast<unsigned*>(workspace);       // 64 slots: two per call (d_out, x), cleared 16 calls later
+    unsigned* gmax = head + 2 * slot;
+    unsigned* xmax = gmax + 1;
+    unsigned* stale = head + ((2 * slot + 32) & 63);
+    auto absmax = [&](const float* t, long n4, unsigned* dst, unsigned* st) {
+        const long want = (n4 + 256 * 16 - 1) / (256 * 16);
+        tensor_absmax_kernel<<<dim3((unsigned)(want < 256 ? want : 256)), dim3(256), 0, s>>>(reinterpret_cast<const float4*>(t), n4, dst, st);
+    };
+    absmax(d_out, M * c_out / 4, gmax, stale);
+    absmax(x, M * c_in / 4, xmax, stale + 1);
+    PAPR_CHECK_LAUNCH("tensor_absmax");
+    ConvWArgs a;
+    a.dy = d_out; a.x = x; a.B = B; a.H = H; a.W = W; a.N = c_out; a.C = c_in;
+    a.dymax_bits = gmax; a.xmax_bits = xmax;
+    a.partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + 256);
+    a.px_per_chunk = px;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_h3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CV_LDS_BYTES);
+        attr_set = true;
+    }
+    const int tiles = ((c_out + 127) / 128) * ((c_in + 127) / 128);
+    const bool prof = papr_prof_on();
+    if (prof) papr_prof_begin2(12, M, c_out, 9 * c_in, 4LL * M * (c_in + c_out), 2LL * M * c_out * 9 * c_in, s);
+    conv3x3_wgrad_h3_kernel<<<dim3((unsigned)chunks, (unsigned)tiles, 9), dim3(256), CV_LDS_BYTES, s>>>(a);
+    PAPR_CHECK_LAUNCH("conv3x3_wgrad_h3");
+    const long n4 = (long)c_out * 9 * c_in / 4;
+    conv_wgrad_reduce_kernel<<<dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s>>>(reinterpret_cast<const float4*>(a.partial), (int)chunks, n4, reinterpret_cast<float4*>(d_w));
+    PAPR_CHECK_LAUNCH("conv_wgrad_reduce");
     if (prof) papr_prof_end(s);
     return 0;
 }

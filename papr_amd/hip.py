@@ -20,7 +20,7 @@ EXPORTS = [
     "papr_segment_reduce",
     "papr_rownorm_fwd", "papr_rownorm_bwd", "papr_ln_fold_fwd", "papr_ln_fold_bwd", "papr_mlp_fwd_workspace_bytes", "papr_mlp_bwd_workspace_bytes", "papr_mlp_saved_floats", "papr_mlp_bwd_needs_weight_t", "papr_mlp_fwd",
     "papr_mlp_bwd",
-    "papr_attn_tail_fwd", "papr_attn_tail_bwd", "papr_conv3x3_weight_halfs", "papr_conv3x3_workspace_bytes", "papr_conv3x3_fwd", "papr_profile_enable", "papr_profile_collect",
+    "papr_attn_tail_fwd", "papr_attn_tail_bwd", "papr_conv3x3_weight_halfs", "papr_conv3x3_workspace_bytes", "papr_conv3x3_fwd", "papr_conv3x3_wgrad_workspace_bytes", "papr_conv3x3_wgrad", "papr_profile_enable", "papr_profile_collect",
 ]
 
 
@@ -86,6 +86,9 @@ def lib():
     L.papr_conv3x3_workspace_bytes.restype = C.c_size_t
     L.papr_conv3x3_workspace_bytes.argtypes = [i32, i32, i32, i32, i32]
     L.papr_conv3x3_fwd.argtypes = [vp, i32, i32, i32, i32, vp, i64, i64, i64, i64, i32, vp, i32, i32, vp, vp, i32, vp]
+    L.papr_conv3x3_wgrad_workspace_bytes.restype = C.c_size_t
+    L.papr_conv3x3_wgrad_workspace_bytes.argtypes = [i32, i32, i32, i32, i32]
+    L.papr_conv3x3_wgrad.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp]
     L.papr_ln_fold_fwd.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp]
     L.papr_ln_fold_bwd.argtypes = [vp, i32, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp]
     L.papr_mlp_fwd_workspace_bytes.restype = C.c_size_t

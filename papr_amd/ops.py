@@ -96,9 +96,32 @@ def conv3x3_rows(x, weight, bias, relu, transposed=False):
     return out
 
 
+def conv3x3_wgrad_rows(d_y, x):
+    """d_y (B, H, W, C_out), x (B, H, W, C_in) fp32 contiguous -> weight gradient (C_out, C_in, 3, 3) in channels-last memory
+    format (papr_conv3x3_wgrad: pixels reduced chunk by chunk, chunks added in a fixed order)."""
+    B, H, W, c_out = d_y.shape
+    c_in = x.shape[3]
+    lib = hip.lib()
+    size = lib.papr_conv3x3_wgrad_workspace_bytes(B, H, W, c_in, c_out)
+    key = (x.device.type, x.device.index, "conv_wgrad")
+    ws, calls = _ws_cache.get(key, (None, 0))
+    if ws is None or ws.numel() * 4 < size:
+        ws, calls = torch.empty((size + 3) // 4, device=x.device, dtype=torch.float32), 0
+        ws[:64].zero_()
+    _ws_cache[key] = (ws, calls + 1)
+    d_w = torch.empty((c_out, 3, 3, c_in), device=x.device, dtype=torch.float32)
+    hip.check(lib.papr_conv3x3_wgrad(hip.ptr(d_y), hip.ptr(x), B, H, W, c_in, c_out, hip.ptr(d_w), hip.ptr(ws), calls % 32, hip.stream_ptr()),
+              "papr_conv3x3_wgrad")
+    return d_w.permute(0, 3, 1, 2)
+
+
+_OWN_CONV_WGRAD = os.environ.get("PAPR_UNET_WGRAD", "1") == "1"
+
+
 class _Conv3x3Fn(torch.autograd.Function):
     """relu(conv3x3(x) + b) over an NHWC map with the reference's (C_out, C_in, 3, 3) weight.  Forward and data-gradient on
-    papr_conv3x3_fwd; the weight and bias gradients come from MIOpen (aten.convolution_backward)."""
+    papr_conv3x3_fwd, weight gradient on papr_conv3x3_wgrad (PAPR_UNET_WGRAD=0, or channel counts that are not multiples of
+    4: MIOpen through aten.convolution_backward)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, relu):
@@ -118,9 +141,18 @@ class _Conv3x3Fn(torch.autograd.Function):
         if own_dx:
             d_x = conv3x3_rows(d_y, weight, None, False, transposed=True)
         lib_dx = ctx.needs_input_grad[0] and not own_dx
-        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2] or lib_dx:
-            g_x, d_w, d_b = torch.ops.aten.convolution_backward(d_y.permute(0, 3, 1, 2), x.permute(0, 3, 1, 2), weight, [weight.shape[0]],
-                                                                [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [lib_dx, True, True])
+        # (a 128 x 128 tile of (c_out, c_in): the 32-channel first layer would waste three quarters of it -- MIOpen is faster there)
+        own_dw = _OWN_CONV_WGRAD and weight.shape[0] % 4 == 0 and weight.shape[1] % 4 == 0 and weight.shape[1] >= 64
+        if own_dw:
+            if ctx.needs_input_grad[1]:
+                d_w = conv3x3_wgrad_rows(d_y, x)
+            if ctx.needs_input_grad[2]:
+                d_b = d_y.sum((0, 1, 2))
+        if ((ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) and not own_dw) or lib_dx:
+            g_x, g_w, g_b = torch.ops.aten.convolution_backward(d_y.permute(0, 3, 1, 2), x.permute(0, 3, 1, 2), weight, [weight.shape[0]],
+                                                                [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [lib_dx, not own_dw, not own_dw])
+            if not own_dw:
+                d_w, d_b = g_w, g_b
             if lib_dx:
                 d_x = g_x.permute(0, 2, 3, 1)
         return d_x, d_w, d_b, None
