@@ -250,7 +250,8 @@ int papr_conv3x3_fwd(const float* x, int32_t B, int32_t H, int32_t W, int32_t c_
  * bytes zeroed by the caller at allocation; slot = (calls made with this buffer) mod 32. */
 size_t papr_conv3x3_wgrad_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t c_in, int32_t c_out);
 int papr_conv3x3_wgrad(const float* d_out, const float* x, int32_t B, int32_t H, int32_t W, int32_t c_in, int32_t c_out,
-                       float* d_w, void* workspace, int32_t slot, papr_stream_t stream);
+                       float* d_w, float* d_bias /* (c_out) column sums of d_out, or NULL */, void* workspace, int32_t slot,
+                       papr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Optional timing of the GEMM / kNN launches with HIP events recorded on the launch stream

@@ -212,6 +212,7 @@ struct ConvWArgs {
     const float* dy; const float* x; int B, H, W, N, C;
     const unsigned* dymax_bits; const unsigned* xmax_bits;
     float* partial;                              // [chunk][N][9][C]
+    float* partial_b;                            // [chunk][N] column sums of dY (bias gradient), or null
     long px_per_chunk;                           // multiple of 32
 };
 
@@ -281,7 +282,15 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wgrad_h3_kernel(ConvWArgs p) {
             *reinterpret_cast<half4*>(lo_plane + off) = lo;
         }
     };
+    // bias gradient = column sums of dY: the workgroups of the centre tap and the first c tile add up their pixels
+    const bool do_bias = p.partial_b != nullptr && tap == 4 && c0 == 0;
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
     auto store_slab = [&]() {
+        if (do_bias) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (okg[j]) { bsum.x += rg[j].x; bsum.y += rg[j].y; bsum.z += rg[j].z; bsum.w += rg[j].w; }
+        }
         put(rg, okg, g_scale, Gh, Gl);
         put(rx, okx, x_scale, Xh, Xl);
     };
@@ -326,6 +335,17 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wgrad_h3_kernel(ConvWArgs p) {
             lds_barrier();
         }
     }
+    if (do_bias) {                                   // (the slab buffers are idle: the loop ended with a barrier)
+        float4* bs = reinterpret_cast<float4*>(smem);
+        bs[r * 32 + q] = bsum;
+        __syncthreads();
+        if (r == 0 && n_ok) {
+            float4 t = bs[q];
+#pragma unroll
+            for (int g = 1; g < 8; ++g) { const float4 v = bs[g * 32 + q]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+            *reinterpret_cast<float4*>(p.partial_b + (long)blockIdx.x * p.N + n0 + 4 * q) = t;
+        }
+    }
     // acc[i][j][e]: LDS rows (n) 64 wm + 32 i + (e & 3) + 8 (e >> 2) + 4 (lane >> 5), LDS row (c) 64 wn + 32 j + (lane & 31);
     // LDS row R holds channel 4 (R % 32) + R / 32 of the block
     float* out = p.partial + (long)blockIdx.x * p.N * 9 * p.C;
@@ -347,8 +367,14 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wgrad_h3_kernel(ConvWArgs p) {
 }
 
 // d_w (N, 3, 3, C) contiguous = sum of the chunks' partial tiles, in chunk order
-__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float4* __restrict__ partial, int chunks, long n4, float4* __restrict__ out) {
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float4* __restrict__ partial, int chunks, long n4, float4* __restrict__ out,
+                                                                const float4* __restrict__ partial_b, int nb4, float4* __restrict__ out_b) {
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (out_b && e < nb4) {                          // bias gradient: the chunks' column sums
+        float4 r = partial_b[e];
+        for (int z = 1; z < chunks; ++z) { const float4 v = partial_b[(long)z * nb4 + e]; r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w; }
+        out_b[e] = r;
+    }
     if (e >= n4) return;
     float4 r = partial[e];
     for (int z = 1; z < chunks; ++z) {
@@ -465,11 +491,11 @@ static long wgrad_px_per_chunk(long M, int c_in, int c_out) {
 
 extern "C" size_t papr_conv3x3_wgrad_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t c_in, int32_t c_out) {
     const long M = (long)B * H * W, px = wgrad_px_per_chunk(M, c_in, c_out), chunks = (M + px - 1) / px;
-    return 256 + (size_t)chunks * c_out * 9 * c_in * sizeof(float);
+    return 256 + (size_t)chunks * c_out * (9 * c_in + 1) * sizeof(float);
 }
 
 extern "C" int papr_conv3x3_wgrad(const float* d_out, const float* x, int32_t B, int32_t H, int32_t W, int32_t c_in, int32_t c_out,
-                                  float* d_w, void* workspace, int32_t slot, papr_stream_t stream) {
+                                  float* d_w, float* d_bias, void* workspace, int32_t slot, papr_stream_t stream) {
     PAPR_REQUIRE(d_out && x && d_w && workspace, "papr_conv3x3_wgrad: null pointer");
     PAPR_REQUIRE(B >= 1 && H >= 1 && W >= 1 && c_in >= 4 && c_in % 4 == 0 && c_out >= 4 && c_out % 4 == 0,
                  "papr_conv3x3_wgrad: B %d, H %d, W %d, c_in %d, c_out %d (channels must be multiples of 4)", B, H, W, c_in, c_out);
@@ -491,6 +517,7 @@ extern "C" int papr_conv3x3_wgrad(const float* d_out, const float* x, int32_t B,
     a.dy = d_out; a.x = x; a.B = B; a.H = H; a.W = W; a.N = c_out; a.C = c_in;
     a.dymax_bits = gmax; a.xmax_bits = xmax;
     a.partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + 256);
+    a.partial_b = d_bias ? a.partial + (size_t)chunks * c_out * 9 * c_in : nullptr;
     a.px_per_chunk = px;
     static bool attr_set = false;
     if (!attr_set) {
@@ -503,7 +530,8 @@ extern "C" int papr_conv3x3_wgrad(const float* d_out, const float* x, int32_t B,
     conv3x3_wgrad_h3_kernel<<<dim3((unsigned)chunks, (unsigned)tiles, 9), dim3(256), CV_LDS_BYTES, s>>>(a);
     PAPR_CHECK_LAUNCH("conv3x3_wgrad_h3");
     const long n4 = (long)c_out * 9 * c_in / 4;
-    conv_wgrad_reduce_kernel<<<dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s>>>(reinterpret_cast<const float4*>(a.partial), (int)chunks, n4, reinterpret_cast<float4*>(d_w));
+    conv_wgrad_reduce_kernel<<<dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s>>>(reinterpret_cast<const float4*>(a.partial), (int)chunks, n4, reinterpret_cast<float4*>(d_w),
+                                                                                      reinterpret_cast<const float4*>(a.partial_b), c_out / 4, reinterpret_cast<float4*>(d_bias));
     PAPR_CHECK_LAUNCH("conv_wgrad_reduce");
     if (prof) papr_prof_end(s);
     return 0;

@@ -96,9 +96,9 @@ def conv3x3_rows(x, weight, bias, relu, transposed=False):
     return out
 
 
-def conv3x3_wgrad_rows(d_y, x):
-    """d_y (B, H, W, C_out), x (B, H, W, C_in) fp32 contiguous -> weight gradient (C_out, C_in, 3, 3) in channels-last memory
-    format (papr_conv3x3_wgrad: pixels reduced chunk by chunk, chunks added in a fixed order)."""
+def conv3x3_wgrad_rows(d_y, x, want_bias=True):
+    """d_y (B, H, W, C_out), x (B, H, W, C_in) fp32 contiguous -> (weight gradient (C_out, C_in, 3, 3) in channels-last memory
+    format, bias gradient (C_out,) or None)  (papr_conv3x3_wgrad: pixels reduced chunk by chunk, chunks added in a fixed order)."""
     B, H, W, c_out = d_y.shape
     c_in = x.shape[3]
     lib = hip.lib()
@@ -110,9 +110,10 @@ def conv3x3_wgrad_rows(d_y, x):
         ws[:64].zero_()
     _ws_cache[key] = (ws, calls + 1)
     d_w = torch.empty((c_out, 3, 3, c_in), device=x.device, dtype=torch.float32)
-    hip.check(lib.papr_conv3x3_wgrad(hip.ptr(d_y), hip.ptr(x), B, H, W, c_in, c_out, hip.ptr(d_w), hip.ptr(ws), calls % 32, hip.stream_ptr()),
-              "papr_conv3x3_wgrad")
-    return d_w.permute(0, 3, 1, 2)
+    d_b = torch.empty((c_out,), device=x.device, dtype=torch.float32) if want_bias else None
+    hip.check(lib.papr_conv3x3_wgrad(hip.ptr(d_y), hip.ptr(x), B, H, W, c_in, c_out, hip.ptr(d_w), hip.ptr(d_b), hip.ptr(ws), calls % 32,
+                                     hip.stream_ptr()), "papr_conv3x3_wgrad")
+    return d_w.permute(0, 3, 1, 2), d_b
 
 
 _OWN_CONV_WGRAD = os.environ.get("PAPR_UNET_WGRAD", "1") == "1"
@@ -144,10 +145,7 @@ class _Conv3x3Fn(torch.autograd.Function):
         # (a 128 x 128 tile of (c_out, c_in): the 32-channel first layer would waste three quarters of it -- MIOpen is faster there)
         own_dw = _OWN_CONV_WGRAD and weight.shape[0] % 4 == 0 and weight.shape[1] % 4 == 0 and weight.shape[1] >= 64
         if own_dw:
-            if ctx.needs_input_grad[1]:
-                d_w = conv3x3_wgrad_rows(d_y, x)
-            if ctx.needs_input_grad[2]:
-                d_b = d_y.sum((0, 1, 2))
+            d_w, d_b = conv3x3_wgrad_rows(d_y, x, ctx.needs_input_grad[2])
         if ((ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) and not own_dw) or lib_dx:
             g_x, g_w, g_b = torch.ops.aten.convolution_backward(d_y.permute(0, 3, 1, 2), x.permute(0, 3, 1, 2), weight, [weight.shape[0]],
                                                                 [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [lib_dx, not own_dw, not own_dw])

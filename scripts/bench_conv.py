@@ -29,6 +29,6 @@ for S in (160,):
         gy = torch.randn(1, hw, hw, co, device=d)
         w = (torch.randn(co, ci, 3, 3, device=d) * 0.05).contiguous(memory_format=torch.channels_last)
         us_m = t(lambda: torch.ops.aten.convolution_backward(gy.permute(0, 3, 1, 2), x.permute(0, 3, 1, 2), w, [co], [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False]))
-        us_h = t(lambda: ops.conv3x3_wgrad_rows(gy, x))
+        us_h = t(lambda: ops.conv3x3_wgrad_rows(gy, x, True))
         fl = 2.0 * hw * hw * co * 9 * ci
         print("%4d^2 %-9s %4d->%4d  MIOpen %7.1f us (%5.1f TF)   split-f16 %7.1f us (%5.1f TF)  x%.2f" % (S, name, ci, co, us_m, fl / us_m / 1e6, us_h, fl / us_h / 1e6, us_m / us_h))
