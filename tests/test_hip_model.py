@@ -104,7 +104,8 @@ def test_three_training_steps_follow_reference_losses(fused_adam):
     m = build("chair1k", T(g5["points"]))
     if fused_adam:                  # optimizers created over device tensors (as get_model(args, "cuda") does) are the fused ones
         m.clear_optimizer(); m.clear_scheduler(); m.init_optimizers(0)
-        assert all(o.defaults.get("fused") for o in m.optimizers.values())
+        import os
+        assert os.environ.get("PAPR_FUSED_ADAM", "1") != "1" or all(o.defaults.get("fused") for o in m.optimizers.values())
     ro, rd, c2w = cuda(*case_rays("chair1k"))
     tgt = T(g["target"]).to("cuda")
     loss_fn = get_loss(cfg["training"]["losses"])
