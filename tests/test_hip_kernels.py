@@ -23,7 +23,7 @@ def dev():
 
 def test_library_loads_on_device():
     from papr_amd import hip
-    assert hip.lib().papr_abi_version() == 7
+    assert hip.lib().papr_abi_version() == 8
 
 
 # ------------------------------------------------------------------------------------------- K1
