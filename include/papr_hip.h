@@ -250,8 +250,10 @@ int papr_conv3x3_fwd(const float* x, int32_t B, int32_t H, int32_t W, int32_t c_
  * bytes zeroed by the caller at allocation; slot = (calls made with this buffer) mod 32. */
 size_t papr_conv3x3_wgrad_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t c_in, int32_t c_out);
 int papr_conv3x3_wgrad(const float* d_out, const float* x, int32_t B, int32_t H, int32_t W, int32_t c_in, int32_t c_out,
-                       float* d_w, float* d_bias /* (c_out) column sums of d_out, or NULL */, void* workspace, int32_t slot,
-                       papr_stream_t stream);
+                       float* d_w, float* d_bias /* (c_out) column sums of d_out, or NULL */,
+                       const uint32_t* d_out_max_bits, const uint32_t* x_max_bits /* bit pattern of max |.| of the tensor if the
+                       caller has it (the slot a papr_conv3x3_fwd call on that tensor used: workspace + 4 * slot), else NULL */,
+                       void* workspace, int32_t slot, papr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Optional timing of the GEMM / kNN launches with HIP events recorded on the launch stream

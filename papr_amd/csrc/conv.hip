@@ -495,7 +495,8 @@ extern "C" size_t papr_conv3x3_wgrad_workspace_bytes(int32_t B, int32_t H, int32
 }
 
 extern "C" int papr_conv3x3_wgrad(const float* d_out, const float* x, int32_t B, int32_t H, int32_t W, int32_t c_in, int32_t c_out,
-                                  float* d_w, float* d_bias, void* workspace, int32_t slot, papr_stream_t stream) {
+                                  float* d_w, float* d_bias, const uint32_t* d_out_max_bits, const uint32_t* x_max_bits, void* workspace,
+                                  int32_t slot, papr_stream_t stream) {
     PAPR_REQUIRE(d_out && x && d_w && workspace, "papr_conv3x3_wgrad: null pointer");
     PAPR_REQUIRE(B >= 1 && H >= 1 && W >= 1 && c_in >= 4 && c_in % 4 == 0 && c_out >= 4 && c_out % 4 == 0,
                  "papr_conv3x3_wgrad: B %d, H %d, W %d, c_in %d, c_out %d (channels must be multiples of 4)", B, H, W, c_in, c_out);
@@ -510,12 +511,13 @@ extern "C" int papr_conv3x3_wgrad(const float* d_out, const float* x, int32_t B,
         const long want = (n4 + 256 * 16 - 1) / (256 * 16);
         tensor_absmax_kernel<<<dim3((unsigned)(want < 256 ? want : 256)), dim3(256), 0, s>>>(reinterpret_cast<const float4*>(t), n4, dst, st);
     };
-    absmax(d_out, M * c_out / 4, gmax, stale);
-    absmax(x, M * c_in / 4, xmax, stale + 1);
+    // (a maximum the caller already has -- the slot a papr_conv3x3_fwd call on the same tensor left behind -- spares its launch)
+    if (!d_out_max_bits) absmax(d_out, M * c_out / 4, gmax, stale);
+    if (!x_max_bits) absmax(x, M * c_in / 4, xmax, d_out_max_bits ? stale : stale + 1);
     PAPR_CHECK_LAUNCH("tensor_absmax");
     ConvWArgs a;
     a.dy = d_out; a.x = x; a.B = B; a.H = H; a.W = W; a.N = c_out; a.C = c_in;
-    a.dymax_bits = gmax; a.xmax_bits = xmax;
+    a.dymax_bits = d_out_max_bits ? d_out_max_bits : gmax; a.xmax_bits = x_max_bits ? x_max_bits : xmax;
     a.partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + 256);
     a.partial_b = d_bias ? a.partial + (size_t)chunks * c_out * 9 * c_in : nullptr;
     a.px_per_chunk = px;

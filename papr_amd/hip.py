@@ -88,7 +88,7 @@ def lib():
     L.papr_conv3x3_fwd.argtypes = [vp, i32, i32, i32, i32, vp, i64, i64, i64, i64, i32, vp, i32, i32, vp, vp, i32, vp]
     L.papr_conv3x3_wgrad_workspace_bytes.restype = C.c_size_t
     L.papr_conv3x3_wgrad_workspace_bytes.argtypes = [i32, i32, i32, i32, i32]
-    L.papr_conv3x3_wgrad.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp]
+    L.papr_conv3x3_wgrad.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp]
     L.papr_ln_fold_fwd.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp]
     L.papr_ln_fold_bwd.argtypes = [vp, i32, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp]
     L.papr_mlp_fwd_workspace_bytes.restype = C.c_size_t

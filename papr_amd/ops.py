@@ -69,7 +69,7 @@ class MlpSpec:
         self.ld_out = [l["n_out_pad"] for l in self.layers]
 
 
-def conv3x3_rows(x, weight, bias, relu, transposed=False):
+def conv3x3_rows(x, weight, bias, relu, transposed=False, want_max=False):
     """x (B, H, W, C_in) fp32 contiguous, weight = the reference's (C_out, C_in, 3, 3) Conv2d parameter in any memory format
     -> (B, H, W, C_out): 3x3 convolution, stride 1, zero padding 1, on the split-f16 implicit-GEMM kernel.  transposed:
     the layer's data-gradient (x = d_out: channels and taps of the weight exchanged / mirrored inside the kernel's weight
@@ -93,10 +93,21 @@ def conv3x3_rows(x, weight, bias, relu, transposed=False):
     _ws_cache[key] = (ws, calls + 1)
     hip.check(lib.papr_conv3x3_fwd(hip.ptr(x), B, H, W, c_in, C.c_void_p(weight.data_ptr()), sn, sc, sky, skx, 1 if transposed else 0,
                                    hip.ptr(bias), c_out, 1 if relu else 0, hip.ptr(out), hip.ptr(ws), calls % 64, hip.stream_ptr()), "papr_conv3x3_fwd")
+    if want_max:                                             # where this call left max |x| (valid for the next 31 calls on this workspace)
+        return out, (ws, calls)
     return out
 
 
-def conv3x3_wgrad_rows(d_y, x, want_bias=True):
+def _conv_max_ptr(token, dev):
+    """Device address of the maximum a conv3x3_rows call left, or None once its slot has been given out again."""
+    ws, calls = token
+    cur_ws, cur_calls = _ws_cache.get((dev.type, dev.index, "conv"), (None, 0))
+    if cur_ws is not ws or cur_calls - calls >= 32:
+        return None
+    return C.c_void_p(ws.data_ptr() + 4 * (calls % 64))
+
+
+def conv3x3_wgrad_rows(d_y, x, want_bias=True, d_y_max=None, x_max=None):
     """d_y (B, H, W, C_out), x (B, H, W, C_in) fp32 contiguous -> (weight gradient (C_out, C_in, 3, 3) in channels-last memory
     format, bias gradient (C_out,) or None)  (papr_conv3x3_wgrad: pixels reduced chunk by chunk, chunks added in a fixed order)."""
     B, H, W, c_out = d_y.shape
@@ -111,8 +122,8 @@ def conv3x3_wgrad_rows(d_y, x, want_bias=True):
     _ws_cache[key] = (ws, calls + 1)
     d_w = torch.empty((c_out, 3, 3, c_in), device=x.device, dtype=torch.float32)
     d_b = torch.empty((c_out,), device=x.device, dtype=torch.float32) if want_bias else None
-    hip.check(lib.papr_conv3x3_wgrad(hip.ptr(d_y), hip.ptr(x), B, H, W, c_in, c_out, hip.ptr(d_w), hip.ptr(d_b), hip.ptr(ws), calls % 32,
-                                     hip.stream_ptr()), "papr_conv3x3_wgrad")
+    hip.check(lib.papr_conv3x3_wgrad(hip.ptr(d_y), hip.ptr(x), B, H, W, c_in, c_out, hip.ptr(d_w), hip.ptr(d_b), d_y_max, x_max, hip.ptr(ws),
+                                     calls % 32, hip.stream_ptr()), "papr_conv3x3_wgrad")
     return d_w.permute(0, 3, 1, 2), d_b
 
 
@@ -126,7 +137,7 @@ class _Conv3x3Fn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, relu):
-        y = conv3x3_rows(x, weight.detach(), bias.detach() if bias is not None else None, relu)
+        y, ctx.x_max = conv3x3_rows(x, weight.detach(), bias.detach() if bias is not None else None, relu, want_max=True)
         ctx.save_for_backward(x, weight, y if relu else None)
         ctx.relu = relu
         return y
@@ -139,13 +150,15 @@ class _Conv3x3Fn(torch.autograd.Function):
             d_y = torch.ops.aten.threshold_backward(d_y, y, 0)
         d_x = d_w = d_b = None
         own_dx = ctx.needs_input_grad[0] and weight.shape[0] % 32 == 0          # (the kernel's K slabs are 32 channels)
+        dy_max = None
         if own_dx:
-            d_x = conv3x3_rows(d_y, weight, None, False, transposed=True)
+            d_x, dy_max = conv3x3_rows(d_y, weight, None, False, transposed=True, want_max=True)
         lib_dx = ctx.needs_input_grad[0] and not own_dx
         # (a 128 x 128 tile of (c_out, c_in): the 32-channel first layer would waste three quarters of it -- MIOpen is faster there)
         own_dw = _OWN_CONV_WGRAD and weight.shape[0] % 4 == 0 and weight.shape[1] % 4 == 0 and weight.shape[1] >= 64
         if own_dw:
-            d_w, d_b = conv3x3_wgrad_rows(d_y, x, ctx.needs_input_grad[2])
+            d_w, d_b = conv3x3_wgrad_rows(d_y, x, ctx.needs_input_grad[2], _conv_max_ptr(dy_max, x.device) if dy_max else None,
+                                          _conv_max_ptr(ctx.x_max, x.device))
         if ((ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) and not own_dw) or lib_dx:
             g_x, g_w, g_b = torch.ops.aten.convolution_backward(d_y.permute(0, 3, 1, 2), x.permute(0, 3, 1, 2), weight, [weight.shape[0]],
                                                                 [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [lib_dx, not own_dw, not own_dw])
