@@ -225,6 +225,19 @@ def main():
                     "hbm_gbs": by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0, "hbm_frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else 0.0,
                     "share_of_step_time": ms / (dt * 1e3)}
 
+    def conv_line():
+        # 3x3 layers of the U-Net head (conv.hip): forward / data-gradient (11) and weight-gradient (12) launches incl. their
+        # tensor-maximum, weight-split and reduction kernels; three f16 MFMA products per fp32 product
+        rs = [r for r in recs if r[0] in (11, 12)]
+        ms = sum(r[4] for r in rs)
+        if ms <= 0:
+            return None
+        fl = float(sum(r[6] for r in rs))
+        return {"kernel": "conv3x3_h3_kernel + conv3x3_wgrad_h3_kernel (U-Net 3x3 layers, split-f16 implicit GEMM)", "bound": "mfma",
+                "achieved": 3.0 * fl / (ms * 1e-3) / 1e12, "peak": F16_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                "frac": 3.0 * fl / (ms * 1e-3) / 1e12 / F16_MFMA_PEAK_TF, "traffic": None, "launches": len(rs),
+                "avg_launch_ms": ms / len(rs), "fp32_equivalent_tflops": fl / (ms * 1e-3) / 1e12, "share_of_step_time": ms / (dt * 1e3)}
+
     nt_ms, nt_line = mfma_line("gemm_nt_kernel<128,256,2,2> (embedding-MLP forward + data-gradient GEMMs, fp32 MFMA)", (0,),
                                "gemm_nt_128x256_bytes_per_launch")
     tn_ms, tn_line = mfma_line("gemm_tn_kernel (weight gradients, split over M, fp32 MFMA)", (4,), "gemm_tn_bytes_per_launch")
@@ -251,6 +264,7 @@ def main():
         "roofline_wgrad": tn_line if tn_ms > 0 and dominant is not tn_line else None,
         "roofline_wgrad_h3": wg if wg_ms > 0 and dominant is not wg else None,
         "roofline_mlp_chain": ch if ch_ms > 0 and dominant is not ch else None,
+        "roofline_conv3x3": conv_line(),
         "roofline_knn": {"kernel": "ray_knn_kernel<8,4>", "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
                          "achieved": knn_bytes / (knn_ms * 1e-3) / 1e9 if knn_ms > 0 else 0.0,
                          "frac": knn_bytes / (knn_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if knn_ms > 0 else 0.0,

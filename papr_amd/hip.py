@@ -131,10 +131,10 @@ def profile_enable(on):
 
 def profile_collect(cap=65536):
     """[(kernel, M, N, K, ms), ...] of the launches timed since the last call (fused-run launches, kernels 9 and 10:
-    (kernel, M, n_layers, K0, ms, bytes, flops); batched weight-gradient launches, kernel 8: (kernel, M, n_jobs, 0, ms, bytes, flops))."""
+    (kernel, M, n_layers, K0, ms, bytes, flops); batched weight-gradient launches, kernel 8: (kernel, M, n_jobs, 0, ms, bytes, flops); 3x3 convolution 11 and its weight gradient 12: (kernel, pixels, c_out, 9 c_in, ms, bytes, flops))."""
     buf = (ProfileRecord * cap)()
     n = lib().papr_profile_collect(buf, cap)
-    return [(r.kernel, r.M, r.N, r.K, r.ms) + ((r.bytes, r.flops) if r.kernel in (8, 9, 10) else ()) for r in buf[:min(n, cap)]]
+    return [(r.kernel, r.M, r.N, r.K, r.ms) + ((r.bytes, r.flops) if r.kernel in (8, 9, 10, 11, 12) else ()) for r in buf[:min(n, cap)]]
 
 
 def check(code, what):
