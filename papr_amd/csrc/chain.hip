@@ -147,7 +147,11 @@ __global__ __launch_bounds__(CH_THREADS, CH_WGS_PER_CU * CH_WAVES / 4) void mlp_
             const int t = 32 * (wn * NJ + j) < L.N ? wn * NJ + j : 0;
             const long o = ((long)(t * L.ksteps + ks) * 64 + lane) * 8;
             qh[j] = *reinterpret_cast<const half8*>(L.w_hi + o);
+#ifdef CH_EXP_HALF_W                    // experiment (wrong numbers): only the hi plane crosses L1 -- half the weight bytes, same matrix work
+            ql[j] = qh[j];
+#else
             ql[j] = *reinterpret_cast<const half8*>(L.w_lo + o);
+#endif
         }
     };
 #pragma unroll
