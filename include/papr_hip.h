@@ -97,11 +97,13 @@ int papr_build_features_bwd_pairs(const papr_feature_desc* d, const float* point
 /* order (M = R*k) int64: pair ids grouped by selected point (a stable sort of idx); sorted_pts (M) int32:
  * the point of each entry; seg (P+1) int64: group bounds.  d_points[p] += sum of pair_points rows,
  * d_influ[p] += sum of pair_influ, d_feats[p][c] += sum of rows[pair][col0 + c] (c < ncols <= 128) over
- * point p's group.  Any of the three inputs may be NULL.  Outputs must be zeroed by the caller: groups
- * that straddle the kernel's fixed-size chunks are completed with atomic adds. */
+ * point p's group.  Any of the three inputs may be NULL.  accumulate = 0: the outputs must be zeroed by the
+ * caller (groups that straddle the kernel's fixed-size chunks are completed with atomic adds; the other rows
+ * are overwritten); accumulate = 1: every sum is ADDED to what the outputs hold (a second pass: point features
+ * that feed both the key and the value branch, use_ink + use_inv). */
 int papr_segment_reduce(const int64_t* order, const int32_t* sorted_pts, const int64_t* seg, int64_t M, int64_t P,
                         const float* pair_points, const float* pair_influ, const float* rows, int ld, int col0,
-                        int ncols, float* d_points, float* d_influ, float* d_feats, papr_stream_t stream);
+                        int ncols, float* d_points, float* d_influ, float* d_feats, int accumulate, papr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Row standardisation  y = (x - mean) / (std_unbiased + eps)      (the non-affine core of the

@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void segment_reduce_kernel(const long* __restr
                                                              const float* __restrict__ pair_points, const float* __restrict__ pair_influ,
                                                              const float* __restrict__ rows, int ld, int col0, int ncols,
                                                              float* __restrict__ d_points, float* __restrict__ d_influ,
-                                                             float* __restrict__ d_feats) {
+                                                             float* __restrict__ d_feats, int accumulate) {
     const int lane = threadIdx.x & 63;
     const long e0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * SEG_CH;
     if (e0 >= M) return;
@@ -288,7 +288,13 @@ __global__ __launch_bounds__(256) void segment_reduce_kernel(const long* __restr
 
     auto flush = [&](int p) {
         const bool interior = seg[p] >= e0 && seg[p + 1] <= e0 + n;
-        if (interior) {
+        if (interior) {               // the group lies wholly in this chunk: this wave alone writes the point's row
+            if (accumulate) {         // (a second pass over the same outputs: features that feed both the key and the value branch)
+                if (pair_points && lane < 3) small += d_points[p * 3 + lane];
+                if (pair_influ && lane == 3) small += d_influ[p];
+                if (c0_ok) acc0 += d_feats[(long)p * ncols + lane];
+                if (c1_ok) acc1 += d_feats[(long)p * ncols + lane + 64];
+            }
             if (pair_points && lane < 3) d_points[p * 3 + lane] = small;
             if (pair_influ && lane == 3) d_influ[p] = small;
             if (c0_ok) d_feats[(long)p * ncols + lane] = acc0;
@@ -442,7 +448,7 @@ extern "C" int papr_build_features_bwd_pairs(const papr_feature_desc* d, const f
 
 extern "C" int papr_segment_reduce(const int64_t* order, const int32_t* sorted_pts, const int64_t* seg, int64_t M, int64_t P,
                                    const float* pair_points, const float* pair_influ, const float* rows, int ld, int col0,
-                                   int ncols, float* d_points, float* d_influ, float* d_feats, papr_stream_t stream) {
+                                   int ncols, float* d_points, float* d_influ, float* d_feats, int accumulate, papr_stream_t stream) {
     PAPR_REQUIRE(order && sorted_pts && seg, "papr_segment_reduce: null index arrays");
     PAPR_REQUIRE(M < ((int64_t)1 << 31), "papr_segment_reduce: more than 2^31 pairs");
     PAPR_REQUIRE(!rows || (d_feats && ncols >= 1 && ncols <= 128), "papr_segment_reduce: 1 <= ncols <= 128 and d_feats required");
@@ -452,7 +458,7 @@ extern "C" int papr_segment_reduce(const int64_t* order, const int32_t* sorted_p
     const long chunks = (M + SEG_CH - 1) / SEG_CH;
     segment_reduce_kernel<<<dim3((unsigned)((chunks + 3) / 4)), dim3(256), 0, as_stream(stream)>>>(
         reinterpret_cast<const long*>(order), sorted_pts, reinterpret_cast<const long*>(seg), M, pair_points, pair_influ, rows, ld,
-        col0, ncols, d_points, d_influ, d_feats);
+        col0, ncols, d_points, d_influ, d_feats, accumulate);
     PAPR_CHECK_LAUNCH("segment_reduce");
     return 0;
 }

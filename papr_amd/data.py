@@ -43,17 +43,38 @@ def make_cameras(n, seed, coord_scale=10.0, upper_only=True):
     return scale @ c2w          # the reference scales rotation and translation alike (dataset.py:20-26)
 
 
+_AXIS_CACHE = {}
+
+
+def _pixel_axes(H, W, focal_x, focal_y):
+    """Camera-space x (W,) and y (H,) of the pixel centres, computed exactly as the reference does
+    (dataset/utils.py:83-91: linspace over the image plane, minus half the extent, plus half a pixel) -- on the CPU, so
+    that the values do not depend on the device's linspace kernel; (H + W) floats, cached per camera."""
+    key = (int(H), int(W), float(focal_x), float(focal_y))
+    if key not in _AXIS_CACHE:
+        width = torch.linspace(0, W / focal_x, steps=int(W) + 1, dtype=torch.float32)
+        height = torch.linspace(0, H / focal_y, steps=int(H) + 1, dtype=torch.float32)
+        px, py = width[1] - width[0], height[1] - height[0]
+        _AXIS_CACHE[key] = ((width - W / focal_x / 2 + px / 2)[:-1].contiguous(), (-(height - H / focal_y / 2 + py / 2))[:-1].contiguous())
+    return _AXIS_CACHE[key]
+
+
 def get_rays(H, W, focal_x, focal_y, c2w, h0=0, w0=0, h=None, w=None):
-    """rays_o (N,3), rays_d (N,h,w,3) for the crop [h0:h0+h, w0:w0+w] of an HxW view; any device."""
+    """rays_o (N,3), rays_d (N,h,w,3) for the crop [h0:h0+h, w0:w0+w] of an HxW view; any device.
+
+    Counterpart of the reference's get_rays (dataset/utils.py:81-96) fused with the crop of extract_patches
+    (:99-118): directions (x, y, -1) through the pixel centres, rotated by c2w (cam_to_world with a zero homogeneous
+    coordinate: sum_j dir_j * c2w[i, j] in the reference's order), normalised; origin = the translation column."""
     h = H if h is None else h
     w = W if w is None else w
     dev = c2w.device
-    xs = (torch.arange(w0, w0 + w, device=dev, dtype=torch.float32) + 0.5 - W / 2) / focal_x
-    ys = -(torch.arange(h0, h0 + h, device=dev, dtype=torch.float32) + 0.5 - H / 2) / focal_y
+    xs, ys = _pixel_axes(H, W, focal_x, focal_y)
+    xs, ys = xs[w0:w0 + w].to(dev), ys[h0:h0 + h].to(dev)
     yy, xx = torch.meshgrid(ys, xs, indexing="ij")
-    dirs = torch.stack([xx, yy, -torch.ones_like(xx)], -1)                      # (h,w,3)
-    rays_d = torch.einsum("nij,hwj->nhwi", c2w[:, :3, :3], dirs)
-    rays_d = rays_d / rays_d.norm(dim=-1, keepdim=True)
+    r = c2w[:, :3, :3].reshape(-1, 1, 1, 3, 3)
+    # ((x r_i0 + y r_i1) + (-1) r_i2) + 0 r_i3: the four-term sum of cam_to_world, written out so that every device adds in one order
+    rays_d = (xx[None, :, :, None] * r[..., 0] + yy[None, :, :, None] * r[..., 1]) + (-1.0) * r[..., 2]
+    rays_d = rays_d / torch.norm(rays_d, dim=-1, keepdim=True)
     return c2w[:, :3, 3].contiguous(), rays_d.contiguous()
 
 

@@ -1,10 +1,11 @@
 """Training / evaluation data for the drivers (counterpart of the reference's dataset/ package).
 
-Two sources with one interface:
+Three sources with one interface:
   * BlenderScene  -- a nerf_synthetic-format directory (transforms_{split}.json + PNGs), read with
                      PIL (imageio is not available here); semantics of dataset/load_nerfsyn.py and
                      dataset/dataset.py:10-121 (white background compositing, coord_scale applied to
                      the whole c2w, pixel-centre rays);
+  * TanksTemplesScene -- a Tanks&Temples directory (dataset/load_t2.py);
   * SyntheticRayData (papr_amd/data.py) -- the procedural scene, used when the directory is absent.
 Rays are generated on the device (papr_amd.data.get_rays); images stay resident on the device.
 """
@@ -18,32 +19,27 @@ import torch
 from .data import SyntheticRayData, get_rays
 
 
-class BlenderScene:
-    def __init__(self, dcfg, mode="train", device="cuda"):
-        from PIL import Image
-        base = dcfg["path"]
-        with open(os.path.join(base, "transforms_%s.json" % mode)) as f:
-            meta = json.load(f)
-        imgs, poses = [], []
-        for fr in meta["frames"]:
-            im = Image.open(os.path.join(base, fr["file_path"] + ".png"))
-            if dcfg["factor"] > 1:
-                im = im.resize((im.width // dcfg["factor"], im.height // dcfg["factor"]))
-            a = np.asarray(im, dtype=np.float32) / 255.0
-            if dcfg["white_bg"] and a.shape[-1] == 4:
-                a = a[..., :3] * a[..., 3:] + (1.0 - a[..., 3:])
-            else:
-                a = a[..., :3]
-            imgs.append(a)
-            poses.append(np.array(fr["transform_matrix"], dtype=np.float32))
-        self.images = torch.from_numpy(np.stack(imgs)).to(device)
-        c2w = torch.from_numpy(np.stack(poses))
+class _ImageScene:
+    """Images + poses resident on the device; patches as the reference's extract_patches draws them
+    (dataset/utils.py:99-118: start row, then start column, uniform over [0, H - h) x [0, W - w)).
+
+    seed: this object's OWN numpy stream (legacy RandomState: the same draws as the reference's global `np.random` under
+    the same seed).  Under data parallelism train.py passes `args.seed + rank`, so every rank samples different images
+    and crops while the GLOBAL numpy stream -- which `add_points` consumes -- stays identical on all ranks."""
+
+    def _finish(self, images, c2w, focal_x, focal_y, dcfg, device, seed):
+        self.images = torch.from_numpy(np.ascontiguousarray(images)).float().to(device)
         s = dcfg["coord_scale"]
-        self.c2w = (torch.diag(torch.tensor([s, s, s, 1.0])) @ c2w).to(device)
+        c2w = torch.from_numpy(np.ascontiguousarray(c2w)).float()
+        if s != 1:                                   # the whole matrix is scaled: rotation and translation (dataset.py:19-26)
+            c2w = torch.matmul(torch.diag(torch.tensor([s, s, s, 1.0])), c2w)
+        self.c2w = c2w.to(device)
         self.H, self.W = self.images.shape[1:3]
-        self.focal = 0.5 * self.W / math.tan(0.5 * float(meta["camera_angle_x"]))
+        self.focal_x, self.focal_y = float(focal_x), float(focal_y)
+        self.focal = self.focal_x
         self.ph, self.pw = dcfg["patches"]["height"], dcfg["patches"]["width"]
         self.device = device
+        self.rng = np.random.RandomState(seed)
 
     def __len__(self):
         return self.c2w.shape[0]
@@ -53,18 +49,95 @@ class BlenderScene:
 
     def patch(self, img_idx=None):
         if img_idx is None:
-            img_idx = np.random.randint(0, len(self))
-        h0 = np.random.randint(0, self.H - self.ph)      # same draws as the reference's extract_patches
-        w0 = np.random.randint(0, self.W - self.pw)
+            img_idx = int(self.rng.randint(0, len(self)))
+        h0 = int(self.rng.randint(0, self.H - self.ph))
+        w0 = int(self.rng.randint(0, self.W - self.pw))
         c2w = self.c2w[img_idx:img_idx + 1]
-        rayo, rayd = get_rays(self.H, self.W, self.focal, self.focal, c2w, h0, w0, self.ph, self.pw)
+        rayo, rayd = get_rays(self.H, self.W, self.focal_x, self.focal_y, c2w, h0, w0, self.ph, self.pw)
         tgt = self.images[img_idx:img_idx + 1, h0:h0 + self.ph, w0:w0 + self.pw]
         return tgt, rayd, rayo, c2w
 
     def full_view(self, img_idx, H=None, W=None):
         c2w = self.c2w[img_idx:img_idx + 1]
-        rayo, rayd = get_rays(self.H, self.W, self.focal, self.focal, c2w)
+        rayo, rayd = get_rays(self.H, self.W, self.focal_x, self.focal_y, c2w)
         return self.images[img_idx:img_idx + 1], rayd, rayo, c2w
+
+
+class BlenderScene(_ImageScene):
+    """nerf_synthetic directory: transforms_{split}.json + PNGs (reference dataset/load_nerfsyn.py:8-42,
+    dataset/utils.py:133-147: white-background compositing of RGBA)."""
+
+    def __init__(self, dcfg, mode="train", device="cuda", seed=0):
+        from PIL import Image
+        base = dcfg["path"]
+        with open(os.path.join(base, "transforms_%s.json" % mode)) as f:
+            meta = json.load(f)
+        imgs, poses = [], []
+        for fr in meta["frames"]:
+            im = Image.open(os.path.join(base, fr["file_path"] + ".png"))
+            if dcfg["factor"] > 1:
+                im = im.resize((im.width // dcfg["factor"], im.height // dcfg["factor"]))
+            a = (np.array(im) / 255.).astype(np.float32)
+            if dcfg["white_bg"] and a.shape[-1] == 4:
+                a = a[..., :3] * a[..., 3:] + (1.0 - a[..., 3:])
+            else:
+                a = a[..., :3]
+            imgs.append(a)
+            poses.append(np.array(fr["transform_matrix"], dtype=np.float32))
+        W = imgs[0].shape[1]
+        focal = .5 * W / np.tan(.5 * float(meta["camera_angle_x"]))
+        self._finish(np.stack(imgs), np.stack(poses), focal, focal, dcfg, device, seed)
+
+
+_BLENDER2OPENCV = np.array([[1, 0, 0, 0], [0, -1, 0, 0], [0, 0, -1, 0], [0, 0, 0, 1]])
+
+
+def _t2_intrinsic(path):
+    """3x3 intrinsics: a matrix file, or one line `f cx cy _` (reference dataset/load_t2.py:10-27)."""
+    try:
+        return np.loadtxt(path).astype(np.float32)[:3, :3]
+    except ValueError:
+        pass
+    with open(path) as f:
+        foc, cx, cy, _ = map(float, f.readline().split())
+    return np.array([[foc, 0., cx], [0., foc, cy], [0., 0., 1.]])
+
+
+class TanksTemplesScene(_ImageScene):
+    """Tanks&Temples directory as the reference reads it (dataset/load_t2.py:29-86, dataset/utils.py:149-161):
+    rgb/0_*.png train and rgb/1_*.png test views ordered by their trailing number, pose/<name>.txt OpenCV camera-to-world
+    (flipped to the Blender convention), intrinsics.txt; with factor != 1 the images are resized to
+    (2176 // factor) x (1280 // factor) and the focal lengths follow; without white_bg pure-white pixels become black."""
+
+    def __init__(self, dcfg, mode="train", device="cuda", seed=0, tgtH=1280, tgtW=2176):
+        from PIL import Image
+        base = dcfg["path"]
+        colordir, posedir = os.path.join(base, "rgb"), os.path.join(base, "pose")
+        lead = {"train": "0", "test": "1"}.get(mode)
+        if lead is None:
+            raise ValueError("Unknown split: {}".format(mode))
+        names = [f for f in os.listdir(colordir) if os.path.isfile(os.path.join(colordir, f)) and f.startswith(lead)]
+        names = sorted(names, key=lambda x: int(x.split(".")[0].split("_")[-1]))
+        K = _t2_intrinsic(os.path.join(base, "intrinsics.txt"))
+        fx, fy = K[0][0], K[1][1]
+        imgs, poses = [], []
+        for name in names:
+            im = Image.open(os.path.join(colordir, name))
+            W0, H0 = im.width, im.height
+            if dcfg["factor"] != 1:
+                im = im.resize((tgtW // dcfg["factor"], tgtH // dcfg["factor"]))
+            imgs.append((np.array(im) / 255.).astype(np.float32))
+            pose = np.loadtxt(os.path.join(posedir, name.replace(".png", ".txt"))).astype(np.float32)
+            poses.append(pose @ _BLENDER2OPENCV)
+        images = np.stack(imgs, 0)
+        realH, realW = images.shape[1:3]
+        fx, fy = fx * (realW / W0), fy * (realH / H0)
+        if dcfg["white_bg"] and images.shape[-1] == 4:
+            images = images[..., :3] * images[..., -1:] + (1. - images[..., -1:])
+        elif not dcfg["white_bg"]:
+            images = images[..., :3]
+            images[images.sum(-1) == 3.0] = 0.
+        self._finish(images, np.stack(poses, 0), fx, fy, dcfg, device, seed)
 
 
 class _Procedural(SyntheticRayData):
@@ -75,10 +148,12 @@ class _Procedural(SyntheticRayData):
 def get_dataset(dcfg, mode="train", device="cuda", seed=0, views=None):
     meta = os.path.join(dcfg["path"], "transforms_%s.json" % mode)
     if dcfg["type"] == "synthetic" and os.path.exists(meta):
-        return BlenderScene(dcfg, mode, device)
-    if dcfg["type"] == "t2":
-        raise NotImplementedError("papr_amd: the Tanks&Temples loader is not built; use a nerf_synthetic-format directory")
-    print("[papr_amd] %s not found -> procedural scene (papr_amd/data.py)" % meta)
+        return BlenderScene(dcfg, mode, device, seed=seed)
+    if dcfg["type"] == "t2" and os.path.isdir(os.path.join(dcfg["path"], "rgb")):
+        return TanksTemplesScene(dcfg, mode, device, seed=seed)
+    if dcfg["type"] not in ("synthetic", "t2"):
+        raise ValueError("Unknown dataset type: {}".format(dcfg["type"]))
+    print("[papr_amd] %s not found -> procedural scene (papr_amd/data.py)" % dcfg["path"])
     n = views or (100 if mode == "train" else 200)
     return _Procedural(dcfg, n_views=n, seed=seed + (0 if mode == "train" else 1000), device=device)
 

@@ -20,12 +20,16 @@ def init_from_env(device=None):
     if world <= 1 or td.is_initialized():
         return world
     use_gpu = torch.cuda.is_available() and (device is None or torch.device(device).type == "cuda")
+    # PAPR_DIST_BACKEND=gloo: several ranks on ONE device (tests on a 1-GPU box: RCCL refuses two ranks per GPU); the
+    # collectives then bounce device tensors through the host (_all_reduce_sum / _broadcast below)
+    backend = os.environ.get("PAPR_DIST_BACKEND", "nccl" if use_gpu else "gloo")
     if use_gpu:
-        local = int(os.environ.get("LOCAL_RANK", "0"))
+        local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local)
+    if backend == "nccl":
         td.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
     else:
-        td.init_process_group(backend="gloo")
+        td.init_process_group(backend=backend)
     return world
 
 
@@ -35,6 +39,28 @@ def world_size():
 
 def rank():
     return td.get_rank() if td.is_available() and td.is_initialized() else 0
+
+
+def _host_bounce(t):
+    return t.is_cuda and td.get_backend() != "nccl"
+
+
+def _all_reduce_sum(t):
+    if _host_bounce(t):
+        h = t.cpu()
+        td.all_reduce(h, op=td.ReduceOp.SUM)
+        t.copy_(h)
+    else:
+        td.all_reduce(t, op=td.ReduceOp.SUM)
+
+
+def _broadcast(t, src):
+    if _host_bounce(t):
+        h = t.cpu()
+        td.broadcast(h, src=src)
+        t.copy_(h)
+    else:
+        td.broadcast(t, src=src)
 
 
 def average_gradients(params):
@@ -52,7 +78,7 @@ def average_gradients(params):
     if td.get_backend() == "nccl":                   # RCCL averages in the collective; gloo has no AVG
         td.all_reduce(flat, op=td.ReduceOp.AVG)
     else:
-        td.all_reduce(flat, op=td.ReduceOp.SUM)
+        _all_reduce_sum(flat)
         flat.div_(ws)
     # the averaged gradients stay where they are: every p.grad becomes a view of the bucket (67 copy-back launches per step
     # otherwise; the optimizers' zero_grad drops the views before the next backward pass)
@@ -75,12 +101,12 @@ def broadcast_point_cloud(tensors, src=0):
         return tensors
     dev = tensors[0].device
     n = torch.tensor([tensors[0].shape[0]], device=dev, dtype=torch.int64)
-    td.broadcast(n, src=src)
+    _broadcast(n, src)
     out = []
     for t in tensors:
         buf = t.detach().clone() if (rank() == src and t.shape[0] == int(n)) else \
             torch.empty((int(n),) + tuple(t.shape[1:]), device=dev, dtype=t.dtype)
-        td.broadcast(buf, src=src)
+        _broadcast(buf, src)
         out.append(buf)
     return out
 
@@ -89,4 +115,4 @@ def broadcast_module_state(module, src=0):
     if world_size() == 1:
         return
     for t in list(module.parameters()) + list(module.buffers()):
-        td.broadcast(t.data, src=src)
+        _broadcast(t.data, src)

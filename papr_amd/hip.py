@@ -13,6 +13,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PAPR_HIP_LIB", os.path.join(_PKG, "libpapr_hip.so"))   # override: instrumented builds (scripts/probes)
 
 ACT = {"none": 0, "relu": 1, "leakyrelu": 2}
+EXPECTED_ABI = 9          # papr_abi_version() of the library these argtypes were written for
 
 EXPORTS = [
     "papr_abi_version", "papr_last_error", "papr_ray_knn_workspace_bytes", "papr_ray_knn",
@@ -70,6 +71,9 @@ def lib():
     L = C.CDLL(LIB_PATH)
     vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
     L.papr_abi_version.restype = C.c_int
+    if L.papr_abi_version() != EXPECTED_ABI:         # a stale or variant build would be called with shifted arguments
+        raise RuntimeError("papr_amd: %s has ABI version %d, this package binds version %d -- rebuild it "
+                           "(`python -m papr_amd.build --force`)" % (LIB_PATH, L.papr_abi_version(), EXPECTED_ABI))
     L.papr_last_error.restype = C.c_char_p
     L.papr_ray_knn_workspace_bytes.restype = C.c_size_t
     L.papr_ray_knn_workspace_bytes.argtypes = [i64, i64]
@@ -78,7 +82,7 @@ def lib():
     L.papr_build_features_fwd.argtypes = [C.POINTER(FeatureDesc), vp, vp, vp, vp, i64, i64, vp, vp, vp, vp, vp, vp]
     L.papr_build_features_bwd.argtypes = [C.POINTER(FeatureDesc), vp, vp, vp, i64, i64, vp, vp, vp, vp, vp, vp]
     L.papr_build_features_bwd_pairs.argtypes = [C.POINTER(FeatureDesc), vp, vp, vp, i64, i64, vp, vp, vp, vp, vp]
-    L.papr_segment_reduce.argtypes = [vp, vp, vp, i64, i64, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]
+    L.papr_segment_reduce.argtypes = [vp, vp, vp, i64, i64, vp, vp, vp, i32, i32, i32, vp, vp, vp, i32, vp]
     L.papr_rownorm_fwd.argtypes = [vp, i64, i32, i32, f32, vp, vp, vp]
     L.papr_rownorm_bwd.argtypes = [vp, vp, vp, i64, i32, i32, f32, vp, vp]
     L.papr_conv3x3_weight_halfs.restype = C.c_size_t

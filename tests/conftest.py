@@ -38,10 +38,16 @@ TINY = {"geoms": {"points": {"init_num": 1000, "select_k": 12}},
             "value": {"d_ff": 64, "d_ff_out": 3, "n_ff_layer": 4}}}}}
 PARITY = {"use_amp": False, "training": {"losses": {"mse": 1.0, "lpips": 0.0, "lpips_alex": 0.0}}}
 
+VARIANTS = {"geoms": {"points": {"init_num": 1000}, "point_feats": {"use_ink": True, "use_inv": True}},
+            "models": {"normalize_topk_attn": False, "attn": {"embed": {"embed_type": 2}}}}
+
 CASES = {
     "chair1k": ("nerfsyn/chair.yml", SMALL, dict(n_img=1, hw=16, seed=0)),
     "lego1k": ("nerfsyn/lego.yml", SMALL, dict(n_img=1, hw=16, seed=0)),
     "tiny_norender": ("nerfsyn/chair.yml", TINY, dict(n_img=2, hw=8, seed=4)),
+    # feature variants no shipped scene file uses: point features in the key as well (use_ink), posenc without the raw
+    # coordinate (embed_type 2), un-normalised top-k attention
+    "variants1k": ("nerfsyn/chair.yml", VARIANTS, dict(n_img=1, hw=16, seed=0)),
 }
 
 

@@ -76,3 +76,24 @@ def synth_rays(n_img, H, W, seed=0, radius=40.0, spread=0.05):
         rays_o.append(rot @ torch.tensor([0.0, 0.0, radius]))
     c2w = torch.eye(4).repeat(n_img, 1, 1)
     return torch.stack(rays_o), torch.stack(rays_d), c2w
+
+
+def write_t2_fixture(base, H=40, W=64, n_train=3, n_test=2, seed=3):
+    """A Tanks&Temples-format scene (dataset/load_t2.py): rgb/{0,1}_*.png, pose/*.txt (OpenCV c2w), intrinsics.txt."""
+    import os
+    import numpy as np
+    from PIL import Image
+    from papr_amd.data import make_cameras
+    os.makedirs(os.path.join(base, "rgb"), exist_ok=True)
+    os.makedirs(os.path.join(base, "pose"), exist_ok=True)
+    rs = np.random.RandomState(seed)
+    K = np.array([[55.5, 0, W / 2.0, 0], [0, 56.25, H / 2.0, 0], [0, 0, 1, 0], [0, 0, 0, 1]])
+    np.savetxt(os.path.join(base, "intrinsics.txt"), K)
+    cams = make_cameras(n_train + n_test, seed=seed, coord_scale=1.0).numpy().astype(np.float64)
+    flip = np.diag([1.0, -1.0, -1.0, 1.0])
+    for i in range(n_train + n_test):
+        name = "%d_%04d_%08d" % (0 if i < n_train else 1, i, i)
+        img = rs.randint(0, 256, (H, W, 3)).astype(np.uint8)
+        img[:4, :5] = 255                                                   # pure white pixels: zeroed when white_bg is false
+        Image.fromarray(img).save(os.path.join(base, "rgb", name + ".png"))
+        np.savetxt(os.path.join(base, "pose", name + ".txt"), cams[i] @ flip)   # stored in OpenCV convention

@@ -25,6 +25,8 @@ sys.path.insert(0, REF)
 for name in ["lpips", "torchvision", "torchvision.models", "imageio"]:
     sys.modules[name] = types.ModuleType(name)
 sys.modules["torchvision"].models = sys.modules["torchvision.models"]
+from PIL import Image as _PILImage  # noqa: E402
+sys.modules["imageio"].imread = lambda path: np.array(_PILImage.open(path))      # (the reference only calls imageio.imread)
 import torch.optim.lr_scheduler as ls  # noqa: E402
 
 for n in ["LinearLR", "CosineAnnealingLR", "ExponentialLR", "StepLR", "SequentialLR"]:
@@ -38,7 +40,7 @@ from models.utils import posenc as ref_posenc  # noqa: E402
 from models.attn import LayerNorm as RefLayerNorm  # noqa: E402
 import train as ref_train  # noqa: E402
 
-from formula import formula_fill, synth_rays, uniform_points  # noqa: E402
+from formula import formula_fill, synth_rays, uniform_points, write_t2_fixture  # noqa: E402
 
 torch.set_num_threads(8)
 
@@ -253,8 +255,76 @@ def g9_dp(cfg):
     save("g9_dp.npz", **out)
 
 
+VARIANTS = {"geoms": {"points": {"init_num": 1000}, "point_feats": {"use_ink": True, "use_inv": True}},
+            "models": {"normalize_topk_attn": False, "attn": {"embed": {"embed_type": 2}}}}
+
+
+def ray_samples(rd):
+    """A compact witness of a full (N,H,W,3) ray map: border rows / columns, a centre block, float64 sums."""
+    N, H, W, _ = rd.shape
+    return dict(rows=npf(rd[:, [0, 1, H // 2, H - 1]]), cols=npf(rd[:, :, [0, 1, W // 2, W - 1]]),
+                block=npf(rd[:, H // 2 - 16:H // 2 + 16, W // 3:W // 3 + 32]), sums=np.stack([stats(rd[n]) for n in range(N)]))
+
+
+def g10_rays():
+    """Reference get_rays (dataset/utils.py:81-96) and extract_patches (:99-118) for the Blender 800 x 800 camera and a
+    Tanks&Temples-style 1088 x 640 camera with fx != fy (dataset/load_t2.py:63-76 after factor 2)."""
+    import math
+    from dataset.utils import get_rays as ref_get_rays, extract_patches as ref_extract
+    from papr_amd.data import make_cameras
+    out = {}
+    cams = {"blender": (800, 800, 0.5 * 800 / math.tan(0.5 * 0.6911112070083618), 0.5 * 800 / math.tan(0.5 * 0.6911112070083618), 10.0),
+            "t2": (640, 1088, 581.7877, 583.2061, 30.0)}
+    for tag, (H, W, fx, fy, scale) in cams.items():
+        c2w = make_cameras(2, seed=4 if tag == "blender" else 9, coord_scale=scale)
+        ro, rd = ref_get_rays(H, W, fx, fy, c2w)
+        out[tag + "/cam"] = np.array([H, W, fx, fy, scale], dtype=np.float64)
+        out[tag + "/c2w"] = npf(c2w)
+        out[tag + "/rays_o"] = npf(ro)
+        for k, v in ray_samples(rd).items():
+            out[tag + "/" + k] = v
+        # extract_patches under np.random.seed(7): the crop offsets come from the global numpy stream
+        ph, pw = (160, 160) if tag == "blender" else (180, 180)
+        args = DictAsMember({"patches": {"height": ph, "width": pw, "max_patches": 2}})
+        imgs = torch.arange(2 * H * W, dtype=torch.float32).reshape(2, H, W, 1)         # pixel id as "image": reveals the offsets
+        np.random.seed(7)
+        img_p, rayd_p, rayo_p, n = ref_extract(imgs, ro, rd, args)
+        off = img_p[:, :, 0, 0, 0].astype(np.int64) % (H * W)
+        out[tag + "/patch_hw"] = np.stack([off // W, off % W], -1)                       # (N, n_patches, 2)
+        out[tag + "/patch_rayd_sums"] = np.stack([[stats(torch.from_numpy(rayd_p[i, j])) for j in range(n)] for i in range(2)])
+        out[tag + "/patch_rayd_corner"] = rayd_p[:, :, :4, :4]
+    save("g10_rays.npz", **out)
+
+
+def g11_t2():
+    """Reference load_meta_data / RINDataset on a generated Tanks&Temples-format scene."""
+    import tempfile
+    from dataset.utils import load_meta_data
+    from dataset.dataset import RINDataset
+    with tempfile.TemporaryDirectory() as base:
+        write_t2_fixture(base)
+        out = {}
+        for mode in ("train", "test"):
+            args = DictAsMember({"type": "t2", "path": base, "factor": 1, "read_offline": True, "white_bg": False, "coord_scale": 30.0,
+                                 "extract_patch": False, "extract_online": False, "patches": {"height": 8, "width": 8, "max_patches": 1}})
+            ds = RINDataset(args, mode=mode)
+            out[mode + "/hwf"] = np.array([ds.H, ds.W, ds.focal_x, ds.focal_y], dtype=np.float64)
+            out[mode + "/c2w"] = npf(ds.c2w)
+            out[mode + "/images_sums"] = np.stack([stats(ds.images[i]) for i in range(ds.images.shape[0])])
+            out[mode + "/image0_head"] = npf(ds.images[0, :6, :8])
+            out[mode + "/rayd0"] = npf(ds.rayd[0])
+            out[mode + "/rayo"] = npf(ds.rayo)
+        save("g11_t2.npz", **out)
+
+
 if __name__ == "__main__":
     small = {"geoms": {"points": {"init_num": 1000}}}
+    if "--round2" in sys.argv:                       # fixtures added in round 2 (the round-1 files are left untouched)
+        sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+        model_case("variants1k", load_cfg("nerfsyn/chair.yml", **VARIANTS))
+        g10_rays()
+        g11_t2()
+        sys.exit(0)
     cfg1 = load_cfg("nerfsyn/chair.yml", **small)
     if "--init-only" in sys.argv:
         g8_init(cfg1, "g8_init_chair1k.npz")

@@ -23,7 +23,7 @@ def dev():
 
 def test_library_loads_on_device():
     from papr_amd import hip
-    assert hip.lib().papr_abi_version() == 8
+    assert hip.lib().papr_abi_version() == hip.EXPECTED_ABI
 
 
 # ------------------------------------------------------------------------------------------- K1
@@ -183,6 +183,93 @@ def test_features_backward_matches_autograd():
     ref = st["points"].grad
     np.testing.assert_allclose(d_pts.cpu().numpy(), ref.numpy(), rtol=0, atol=2e-4 * ref.abs().max().item())
     fref = st["pc_feats"].grad          # sums of up to a few hundred N(0,1) terms, atomics add in any order
+    np.testing.assert_allclose(d_f.cpu().numpy(), fref.numpy(), rtol=0, atol=3e-6 * fref.abs().max().item())
+
+
+def _segment_inputs(flat, P):
+    """What ops._RenderFn hands papr_segment_reduce: pairs grouped by point (stable), group bounds."""
+    sorted_pts, order = torch.sort(flat, stable=True)
+    seg = torch.zeros(P + 1, device=flat.device, dtype=torch.int64)
+    torch.cumsum(torch.bincount(flat, minlength=P), 0, out=seg[1:])
+    return order, sorted_pts, seg
+
+
+@pytest.mark.parametrize("P,M,hot", [(30000, 200000, 0), (1000, 50000, 3000), (257, 1283, 0), (5, 128, 0), (3, 700, 650)])
+def test_segment_reduce_matches_index_put_accumulate(P, M, hot):
+    """The product path of the three gather backwards (ops.py: papr_segment_reduce) against torch CPU
+    index_put_(accumulate=True) -- the reference's semantics (models/model.py:330, 431-435, 509).  Cases: the end-of-training
+    cloud with many never-selected points (rows stay zero), one point owning thousands of pairs (its group spans dozens of
+    128-entry chunks: atomics), sizes that are not multiples of the chunk, fewer points than lanes."""
+    from papr_amd import hip
+    gen = torch.Generator().manual_seed(P + M)
+    live = torch.randperm(P, generator=gen)[: max(1, (2 * P) // 3)]          # a third of the points is never selected
+    flat = live[torch.randint(0, live.numel(), (M,), generator=gen)].int()
+    if hot:
+        flat[torch.randperm(M, generator=gen)[:hot]] = int(live[0])
+    pair_pts = torch.randn(M, 4, generator=gen)
+    pair_influ = torch.randn(M, generator=gen)
+    ld, col0, nc = 144, 78, 64
+    rows = torch.randn(M, ld, generator=gen)
+    want_p = torch.zeros(P, 3, dtype=torch.float64).index_put_((flat.long(),), pair_pts[:, :3].double(), accumulate=True)
+    want_i = torch.zeros(P, dtype=torch.float64).index_put_((flat.long(),), pair_influ.double(), accumulate=True)
+    want_f = torch.zeros(P, nc, dtype=torch.float64).index_put_((flat.long(),), rows[:, col0:col0 + nc].double(), accumulate=True)
+    d = dev()
+    flat_d = flat.to(d)
+    order, sorted_pts, seg = _segment_inputs(flat_d, P)
+    d_p, d_i, d_f = torch.zeros(P, 3, device=d), torch.zeros(P, 1, device=d), torch.zeros(P, nc, device=d)
+    a = [hip.ptr(order), hip.ptr(sorted_pts), hip.ptr(seg), M, P]
+    hip.check(hip.lib().papr_segment_reduce(*a, hip.ptr(pair_pts.to(d)), hip.ptr(pair_influ.to(d)), hip.ptr(rows.to(d)), ld, col0, nc,
+                                            hip.ptr(d_p), hip.ptr(d_i), hip.ptr(d_f), 0, hip.stream_ptr()), "papr_segment_reduce")
+    torch.cuda.synchronize()
+    big = lambda w: 4e-6 * w.abs().max().item() + 1e-7          # fp32 sums of up to `hot` terms in another order
+    np.testing.assert_allclose(d_p.cpu().double().numpy(), want_p.numpy(), rtol=0, atol=big(want_p))
+    np.testing.assert_allclose(d_i.cpu()[:, 0].double().numpy(), want_i.numpy(), rtol=0, atol=big(want_i))
+    np.testing.assert_allclose(d_f.cpu().double().numpy(), want_f.numpy(), rtol=0, atol=big(want_f))
+    never = torch.ones(P, dtype=torch.bool); never[flat.long()] = False
+    assert torch.all(d_f.cpu()[never] == 0) and torch.all(d_p.cpu()[never] == 0)
+    # second pass onto the same outputs (use_ink + use_inv: features feed the key and the value branch): sums ADD
+    rows2 = torch.randn(M, 120, generator=gen)
+    want_f2 = want_f + torch.zeros(P, nc, dtype=torch.float64).index_put_((flat.long(),), rows2[:, 56:56 + nc].double(), accumulate=True)
+    hip.check(hip.lib().papr_segment_reduce(*a, None, None, hip.ptr(rows2.to(d)), 120, 56, nc, None, None, hip.ptr(d_f), 1,
+                                            hip.stream_ptr()), "papr_segment_reduce")
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(d_f.cpu().double().numpy(), want_f2.numpy(), rtol=0, atol=big(want_f2))
+
+
+def test_features_backward_pairs_plus_segment_reduce_is_the_product_path():
+    """papr_build_features_bwd_pairs + papr_segment_reduce (what ops._RenderFn.backward calls) against autograd through the
+    oracle's feature construction -- same case as the atomic variant above."""
+    from papr_amd import hip
+    tag = "chair1k"
+    g = golden("g567_%s.npz" % tag)
+    cfg, plan = _plan(tag)
+    from conftest import case_rays
+    ro, rd, _ = case_rays(tag)
+    idx = T(g["idx_raw"]).long()
+    P = g["points"].shape[0]
+    gen = torch.Generator().manual_seed(5)
+    st = {"points": T(g["points"]).clone().requires_grad_(True), "pc_feats": torch.randn(P, 64, generator=gen).requires_grad_(True)}
+    key_o, _, val_o, _, _, _ = O.build_inputs(st, cfg, ro, rd, idx)
+    gk, gv = torch.randn(key_o.shape, generator=gen), torch.randn(val_o.shape, generator=gen)
+    (key_o * gk).sum().add((val_o * gv).sum()).backward()
+    R, k = idx.reshape(-1, idx.shape[-1]).shape
+    M = R * k
+    d = dev()
+    fd = plan.feature_desc(k)
+    gk_p = torch.zeros((M, plan.key.ld_in)); gk_p[:, :plan.key_w] = gk.reshape(M, -1)
+    gv_p = torch.zeros((M, plan.val.ld_in)); gv_p[:, :plan.val_w] = gv.reshape(M, -1)
+    pts_d, ro_d, rd_d = st["points"].detach().to(d), ro.to(d), rd.reshape(-1, 3).contiguous().to(d)
+    idx_d, gk_d, gv_d = idx.reshape(R, k).int().to(d), gk_p.to(d), gv_p.to(d)
+    pair_pts = torch.empty((M, 4), device=d)
+    hip.check(hip.lib().papr_build_features_bwd_pairs(C.byref(fd), hip.ptr(pts_d), hip.ptr(ro_d), hip.ptr(rd_d), R, rd.shape[1] * rd.shape[2],
+                                                      hip.ptr(idx_d), hip.ptr(gk_d), hip.ptr(gv_d), hip.ptr(pair_pts), hip.stream_ptr()), "bwd_pairs")
+    order, sorted_pts, seg = _segment_inputs(idx_d.view(-1), P)
+    d_pts, d_f = torch.zeros((P, 3), device=d), torch.zeros((P, 64), device=d)
+    hip.check(hip.lib().papr_segment_reduce(hip.ptr(order), hip.ptr(sorted_pts), hip.ptr(seg), M, P, hip.ptr(pair_pts), None, hip.ptr(gv_d),
+                                            gv_d.shape[1], plan.val_w - 64, 64, hip.ptr(d_pts), None, hip.ptr(d_f), 0, hip.stream_ptr()), "segment_reduce")
+    torch.cuda.synchronize()
+    ref, fref = st["points"].grad, st["pc_feats"].grad
+    np.testing.assert_allclose(d_pts.cpu().numpy(), ref.numpy(), rtol=0, atol=2e-4 * ref.abs().max().item())
     np.testing.assert_allclose(d_f.cpu().numpy(), fref.numpy(), rtol=0, atol=3e-6 * fref.abs().max().item())
 
 

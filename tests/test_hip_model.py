@@ -340,3 +340,81 @@ def test_full_size_chair_step_properties():
         else:
             assert torch.equal(g1[n], g2[n]), n
             assert torch.equal(g3[n], 2.0 * g1[n]), n
+
+
+def test_use_amp_true_as_shipped_three_steps_and_scaler_behaviour():
+    """The reference's SHIPPED default is `use_amp: true` (configs/default.yml:6-7): GradScaler live (models/model.py:24-26,
+    train.py:174-177), the U-Net under fp16 autocast (models/unet.py:212), the attention block under autocast
+    (models/attn.py:248).  Three train steps of the G7 case with the flag left on: finite, the loss trajectory within 1e-3 of
+    the reference's fp32 trajectory (fp16 rounding of the render head; the reference's own AMP run differs from its fp32 run
+    by the same order), the scale stays at its initial 65536 while gradients are finite, and a step whose gradients overflow
+    is skipped (parameters untouched, scale halved) exactly as torch's GradScaler prescribes."""
+    from papr_amd import get_loss, get_model
+    from papr_amd.config import deep_merge
+    g = golden("g7_trajectory.npz")
+    g5 = golden("g567_chair1k.npz")
+    cfg = deep_merge(case_cfg("chair1k"), {"use_amp": True})
+    torch.manual_seed(1); np.random.seed(1)
+    m = get_model(cfg, device="cpu")
+    formula_fill(m.state_dict())
+    with torch.no_grad():
+        m.points.copy_(T(g5["points"]))
+    m = m.to("cuda")
+    m.clear_optimizer(); m.clear_scheduler(); m.init_optimizers(0)
+    assert m.use_amp and m.scaler.is_enabled() and m.scaler.get_scale() == 65536.0
+    ro, rd, c2w = cuda(*case_rays("chair1k"))
+    tgt = T(g["target"]).to("cuda")
+    loss_fn = get_loss(cfg["training"]["losses"])
+    losses = []
+    for step in range(3):
+        m.clear_grad()
+        out = m.last_act(m(ro, rd, c2w, step + 1))
+        assert out.dtype == torch.float32
+        loss = loss_fn(out, tgt)
+        m.scaler.scale(loss).backward()
+        m.step(step + 1)
+        m.scaler.update()
+        losses.append(loss.item())
+    print("amp losses", losses, "fp32 reference", g["losses"])
+    assert all(np.isfinite(losses)) and m.scaler.get_scale() == 65536.0
+    np.testing.assert_allclose(losses, g["losses"], rtol=0, atol=1e-3)
+    assert all(torch.isfinite(p).all() for p in m.parameters())
+    np.testing.assert_allclose(m.points.detach().cpu().numpy(), g["points_after"], rtol=0, atol=5e-3)   # three Adam steps of lr ~2e-3 / warm-up
+    # an overflowing step: skipped, scale halves
+    before = {n: p.detach().clone() for n, p in m.named_parameters()}
+    m.clear_grad()
+    loss = loss_fn(m.last_act(m(ro, rd, c2w, 4)), tgt) * 1e38
+    m.scaler.scale(loss).backward()
+    m.step(4)
+    m.scaler.update()
+    assert m.scaler.get_scale() == 32768.0
+    for n, p in m.named_parameters():
+        assert torch.equal(p.detach(), before[n]), n
+
+
+def test_chair_yml_verbatim_full_size_amp_step():
+    """configs/nerfsyn/chair.yml as shipped (use_amp: true, P = 10,000, 160 x 160 patch; only the LPIPS weight is zeroed --
+    its VGG weights cannot exist offline): two train steps run, stay finite and move every parameter group."""
+    from papr_amd import get_loss, get_model, load_config
+    from papr_amd.data import SyntheticRayData
+    cfg = load_config("nerfsyn/chair.yml", overrides={"training": {"losses": {"mse": 1.0, "lpips": 0.0, "lpips_alex": 0.0}}})
+    assert cfg["use_amp"] is True
+    torch.manual_seed(1); np.random.seed(1)
+    m = get_model(cfg, device="cuda").to("cuda")
+    with torch.no_grad():
+        m.points_influ_scores.uniform_(0.0, 1.0)
+    data = SyntheticRayData(cfg["dataset"], n_views=4, seed=3, device="cuda")
+    loss_fn = get_loss(cfg["training"]["losses"]).to("cuda")
+    before = {n: p.detach().clone() for n, p in m.named_parameters()}
+    for step in range(2):
+        tgt, rayd, rayo, c2w = data.patch()
+        m.clear_grad()
+        loss = loss_fn(m.last_act(m(rayo, rayd, c2w, step)), tgt)
+        m.scaler.scale(loss).backward()
+        m.step(step)
+        m.scaler.update()
+        assert np.isfinite(loss.item())
+    assert m.scaler.get_scale() == 65536.0
+    for name in ("points", "pc_feats", "points_influ_scores", "renderer.inc.double_conv.0.weight", "proximity_attn.embed.embed_k.mlp.model.1.weight"):
+        p = dict(m.named_parameters())[name]
+        assert torch.isfinite(p).all() and not torch.equal(p.detach(), before[name]), name

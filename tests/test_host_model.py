@@ -223,7 +223,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     lib.papr_abi_version.restype = ctypes.c_int
-    assert lib.papr_abi_version() == 8
+    assert lib.papr_abi_version() == hip.EXPECTED_ABI
     lib.papr_mlp_bwd_workspace_bytes.restype = ctypes.c_size_t
     lib.papr_mlp_bwd_workspace_bytes.argtypes = [ctypes.c_int64]
     lib.papr_mlp_fwd_workspace_bytes.restype = ctypes.c_size_t
