@@ -11,8 +11,9 @@ see papr_amd/data.py).  With N > 1 every rank renders its own patch (weak scalin
 averaged with one RCCL all-reduce inside PAPR.step().
 
 The JSON line also carries
-  roofline      the dominant kernel (gemm_nt<128x256 tile>: embedding-MLP forward layers and data
-                gradients), timed live with HIP events on the launch stream during the timed steps
+  roofline      the dominant kernel (default mode: mlp_chain_kernel, the fused embedding-MLP runs, forward and
+                data-gradient), timed live with HIP events on the launch stream during the timed steps; `frac` counts the
+                three f16 MFMA products of every fp32 product as work, `frac_algorithmic` only the fp32 flops
   roofline_knn  the ray -> k-nearest-points kernel against its logical HBM byte count (north_star)
   cpu_baseline  the CPU oracle's train step (torch fp32, same math) on this host's cores, on a
                 bounded sample (1,024 rays against the same 10,000-point cloud)
@@ -89,7 +90,7 @@ def cpu_baseline(cfg, state, edge, steps):
         O.train_step(st, opts, cfg, rayo, rayd, tgt)
     dt = time.perf_counter() - t0
     R = edge * edge
-    return {"value": R * steps / dt, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+    return {"value": R * steps / dt, "unit": "rays/s", "cores": torch.get_num_threads(), "host_cores": os.cpu_count(), "kind": "port",
             "sample": "%d train steps of %dx%d=%d rays vs P=%d (oracle/papr_oracle.py, torch %s fp32 CPU, Adam, MSE)"
                       % (steps, edge, edge, R, state["points"].shape[0], torch.__version__)}
 
@@ -219,7 +220,9 @@ def main():
                     "bound": "mfma", "achieved": ach, "peak": F16_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / F16_MFMA_PEAK_TF,
                     "traffic": traffic_db.get("mlp_chain_bytes_per_launch"), "launches": len(rs),
                     "avg_launch_ms": ms / max(len(rs), 1), "algorithmic_gflop_per_launch": 3.0 * fl / max(len(rs), 1) / 1e9,
-                    "note": "flops = 3 f16 MFMA products per fp32 product (hi.hi + hi.lo + lo.hi), padded input widths",
+                    "note": "achieved / frac count 3 f16 MFMA products per fp32 product (hi.hi + hi.lo + lo.hi) as work, padded input widths; "
+                            "frac_algorithmic = fp32-equivalent flops / f16 dense peak",
+                    "frac_algorithmic": fl / (ms * 1e-3) / 1e12 / F16_MFMA_PEAK_TF if ms > 0 else 0.0,
                     "fp32_equivalent_tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
                     "algorithmic_bytes_per_launch": by / max(len(rs), 1),
                     "hbm_gbs": by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0, "hbm_frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else 0.0,

@@ -70,3 +70,16 @@ def eval_config(train_cfg):
 
 def as_node(cfg):
     return cfg if isinstance(cfg, ConfigNode) else ConfigNode(cfg)
+
+
+def parse_overrides(pairs):
+    """`a.b.c=value` strings (the drivers' --set option) -> nested override dict; values are read as YAML."""
+    over = {}
+    for kv in pairs or []:
+        key, val = kv.split("=", 1)
+        node = over
+        parts = key.split(".")
+        for p in parts[:-1]:
+            node = node.setdefault(p, {})
+        node[parts[-1]] = yaml.safe_load(val)
+    return over

@@ -368,8 +368,13 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wgrad_h3_kernel(ConvWArgs p) {
 
 // d_w (N, 3, 3, C) contiguous = sum of the chunks' partial tiles, in chunk order
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float4* __restrict__ partial, int chunks, long n4, float4* __restrict__ out,
-                                                                const float4* __restrict__ partial_b, int nb4, float4* __restrict__ out_b) {
+                                                                const float4* __restrict__ partial_b, int nb4, float4* __restrict__ out_b,
+                                                                unsigned* __restrict__ stale2) {
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    // The two maximum slots this call's successors (16 calls on) will atomicMax into are cleared HERE, whatever maxima the
+    // caller supplied: clearing only as a side effect of the absmax launches left a slot uncleared whenever a supplied
+    // maximum spared its launch, and the scale of a later call would become a running maximum over history.
+    if (blockIdx.x == 0 && threadIdx.x == 0) { stale2[0] = 0u; stale2[1] = 0u; }
     if (out_b && e < nb4) {                          // bias gradient: the chunks' column sums
         float4 r = partial_b[e];
         for (int z = 1; z < chunks; ++z) { const float4 v = partial_b[(long)z * nb4 + e]; r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w; }
@@ -533,7 +538,7 @@ extern "C" int papr_conv3x3_wgrad(const float* d_out, const float* x, int32_t B,
     PAPR_CHECK_LAUNCH("conv3x3_wgrad_h3");
     const long n4 = (long)c_out * 9 * c_in / 4;
     conv_wgrad_reduce_kernel<<<dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s>>>(reinterpret_cast<const float4*>(a.partial), (int)chunks, n4, reinterpret_cast<float4*>(d_w),
-                                                                                      reinterpret_cast<const float4*>(a.partial_b), c_out / 4, reinterpret_cast<float4*>(d_bias));
+                                                                                      reinterpret_cast<const float4*>(a.partial_b), c_out / 4, reinterpret_cast<float4*>(d_bias), stale);
     PAPR_CHECK_LAUNCH("conv_wgrad_reduce");
     if (prof) papr_prof_end(s);
     return 0;

@@ -17,9 +17,9 @@ _OWN_CONV = os.environ.get("PAPR_UNET_CONV", "1") == "1"
 
 class ConvStage(nn.Module):
     """Conv2d(3x3, padding 1) + ReLU (the reference's DoubleConv with single=True, models/unet.py:16-33).  On the device, in
-    fp32 and with a channels-last map it runs on the split-f16 implicit-GEMM kernel (papr_conv3x3_fwd: forward and
-    data-gradient; the weight gradient stays with MIOpen); otherwise on torch's convolution.  PAPR_UNET_CONV=0 forces the
-    latter (A/B)."""
+    fp32 and with a channels-last map it runs on the split-f16 implicit-GEMM kernels (papr_conv3x3_fwd: forward and
+    data-gradient; papr_conv3x3_wgrad: weight gradient for c_in >= 64); otherwise on torch's convolution.  PAPR_UNET_CONV=0
+    forces the latter (A/B)."""
 
     def __init__(self, c_in, c_out):
         super().__init__()

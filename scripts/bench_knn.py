@@ -17,7 +17,7 @@ def lattice(P):
     g = torch.stack(torch.meshgrid(ax, ax, ax, indexing="ij"), -1).reshape(-1, 3)
     rest = (torch.rand(P - g.shape[0], 3) * 2 - 1) * 12
     return torch.cat([g, rest])
-for P in (10000, 30000):
+for P in ([int(a) for a in sys.argv[1:]] or [10000, 30000]):
     pts = lattice(P)
     for tag, p in (("lattice order", pts), ("shuffled", pts[torch.randperm(P)])):
         pd = p.to(d).contiguous()

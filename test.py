@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from papr_amd import get_model, load_config
-from papr_amd.config import as_node
+from papr_amd.config import as_node, parse_overrides
 from papr_amd.dataset import get_dataset
 from papr_amd.metrics import ssim
 from train import psnr, render_full
@@ -21,8 +21,9 @@ def main():
     ap.add_argument("--opt", type=str, default="")
     ap.add_argument("--max-views", type=int, default=-1)
     ap.add_argument("--save", action="store_true")
+    ap.add_argument("--set", nargs="*", default=[], help="extra overrides, e.g. use_amp=false test.max_height=200")
     cli = ap.parse_args()
-    cfg = load_config(cli.opt)
+    cfg = load_config(cli.opt, overrides=parse_overrides(cli.set))
     args = as_node(cfg)
     dev = torch.device("cuda")
     log_dir = os.path.join(args.save_dir, args.index)

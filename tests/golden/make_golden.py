@@ -317,13 +317,56 @@ def g11_t2():
         save("g11_t2.npz", **out)
 
 
+def g12_lpips():
+    """Reference LPNet (models/lpips.py:86-125) with a formula-filled backbone and heads (the ImageNet weights cannot be
+    fetched; the ARITHMETIC is what is pinned): loss value and its gradient for a seeded image pair."""
+    from papr_amd.lpips import vgg16_features
+    import models.lpips as ref_lpips
+    tv = sys.modules["torchvision.models"]
+
+    class _Holder:
+        def __init__(self):
+            self.features = vgg16_features()
+    tv.vgg16 = lambda weights=None: _Holder()
+    tv.VGG16_Weights = types.SimpleNamespace(IMAGENET1K_V1=None)
+    ref_lpips.tv = tv
+    cwd = os.getcwd()
+    os.chdir(REF)                                    # the reference loads ./vgg.pth (its own data file) -- overwritten just below
+    try:
+        net = ref_lpips.LPNet()
+    finally:
+        os.chdir(cwd)
+    sd = {}
+    for sl in (net.net.slice1, net.net.slice2, net.net.slice3, net.net.slice4, net.net.slice5):
+        for idx, layer in sl.named_children():
+            for k, v in layer.state_dict().items():
+                sd["features.%s.%s" % (idx, k)] = v
+    formula_fill(sd, salt=3)
+    with torch.no_grad():
+        for i, lin in enumerate(net.lins):
+            lin.weight.copy_(torch.rand(lin.weight.shape, generator=torch.Generator().manual_seed(40 + i)))
+    g = torch.Generator().manual_seed(31)
+    a = torch.rand((2, 40, 48, 3), generator=g).requires_grad_(True)
+    b = torch.rand((2, 40, 48, 3), generator=g)
+    val = net(a, b)
+    val.backward()
+    one = net(a[:1].detach(), b[:1])
+    save("g12_lpips.npz", a=npf(a), b=npf(b), value=np.array(val.item()), value_first=np.array(one.item()), grad_a=npf(a.grad),
+         lin_sums=np.array([float(l.weight.sum()) for l in net.lins]))
+
+
 if __name__ == "__main__":
     small = {"geoms": {"points": {"init_num": 1000}}}
+    if "--lpips" in sys.argv:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+        g12_lpips()
+        sys.exit(0)
     if "--round2" in sys.argv:                       # fixtures added in round 2 (the round-1 files are left untouched)
         sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
         model_case("variants1k", load_cfg("nerfsyn/chair.yml", **VARIANTS))
         g10_rays()
         g11_t2()
+        g12_lpips()
         sys.exit(0)
     cfg1 = load_cfg("nerfsyn/chair.yml", **small)
     if "--init-only" in sys.argv:

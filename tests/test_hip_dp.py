@@ -64,7 +64,7 @@ def test_two_ranks_on_one_gpu_match_the_reference_two_image_batch(tmp_path):
     for i, n in enumerate(names):                      # gradient norms of every parameter of the reference's batch-2 step
         ref_norm = g9["both/stats"][i][2]
         if n in r0["avg"]:
-            assert abs(r0["avg"][n].double().norm().item() - ref_norm) <= 2e-3 * ref_norm + 1e-10, n
+            assert abs(r0["avg"][n].double().norm().item() - ref_norm) <= 1e-3 * ref_norm + 1e-10, n
     # replicas stay bit-identical through the optimizer step, the prune / add round and the step after it
     for n in r0["after"]:
         assert torch.equal(r0["after"][n], r1["after"][n]), n

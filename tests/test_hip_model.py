@@ -3,7 +3,7 @@ outputs and against the CPU oracle on the same seeded inputs.
 
 Floating-point bar (north_star): rendered RGB within 1e-4 L-inf of the reference in fp32 mode; the
 same bound is applied to the fused features and attention weights, and neighbour index sets must be
-identical.  Gradients are compared at 2e-3 of each tensor's max magnitude (fp32 accumulation over
+identical.  Gradients are compared at 1e-3 of each tensor's max magnitude (fp32 accumulation over
 5,120 rows in a different order; atomics).
 """
 import numpy as np
@@ -79,7 +79,7 @@ def test_gradients_match_reference_golden(tag):
         got = named[n].grad
         assert got is not None, n
         got_norm = got.double().norm().item()
-        assert abs(got_norm - ref_norm) <= 2e-3 * ref_norm + 1e-10, (n, got_norm, ref_norm)
+        assert abs(got_norm - ref_norm) <= 1e-3 * ref_norm + 1e-10, (n, got_norm, ref_norm)
     for key in g.files:
         if not key.startswith("grad/"):
             continue
@@ -91,7 +91,7 @@ def test_gradients_match_reference_golden(tag):
         scale = max(np.abs(ref).max(), 1e-12)
         e = np.abs(named[n].grad.cpu().numpy() - ref).max() / scale
         worst = max(worst, e)
-        assert e <= 2e-3, (n, e)
+        assert e <= 1e-3, (n, e)
     print(tag, "worst relative gradient error", worst)
 
 
@@ -144,7 +144,7 @@ def test_two_image_batch_gradients_match_reference_dp_golden():
                           ("proximity_attn.attention_layer.w_q.bias", "wq_bias"), ("renderer.outc.conv.bias", "outc_bias")):
             ref = g[tag + "/" + key]
             got = dict(m.named_parameters())[name].grad.cpu().numpy()
-            assert np.abs(got - ref).max() <= 2e-3 * np.abs(ref).max(), (tag, name)
+            assert np.abs(got - ref).max() <= 1e-3 * np.abs(ref).max(), (tag, name)
 
 
 def test_chunked_evaluate_is_chunk_invariant_and_matches_oracle_at_10k_points():
@@ -231,7 +231,7 @@ def test_full_scene_configs_match_oracle(scene, P, patch):
                  "proximity_attn.attention_layer.w_k.weight", "proximity_attn.embed.embed_k.innorm.a_2"):
         ref_g = so[name].grad
         got = dict(m.named_parameters())[name].grad.cpu()
-        assert (got - ref_g).abs().max().item() <= 2e-3 * ref_g.abs().max().item() + 1e-12, name
+        assert (got - ref_g).abs().max().item() <= 1e-3 * ref_g.abs().max().item() + 1e-12, name
 
 
 def test_mlp_generator_head_in_the_model():

@@ -208,9 +208,48 @@ def test_unsupported_options_fail_at_construction():
             get_model(cfg, device="cpu")
     with pytest.raises(KeyError, match="generator.mlp"):          # `type: mlp` needs its option block (default.yml ships none)
         get_model(deep_merge(case_cfg("chair1k"), {"models": {"renderer": {"generator": {"type": "mlp"}}}}), device="cpu")
+    from papr_amd import get_loss
     with pytest.raises(NotImplementedError):
-        from papr_amd import get_loss
-        get_loss({"mse": 1.0, "lpips": 0.01})
+        get_loss({"mse": 1.0, "lpips_alex": 0.01})
+    with pytest.raises(FileNotFoundError, match="vgg.pth"):          # LPIPS without its weight files: loud, with instructions
+        cwd = os.getcwd()
+        os.chdir(os.path.join(ROOT, "tests"))
+        try:
+            get_loss({"mse": 1.0, "lpips": 0.01})
+        finally:
+            os.chdir(cwd)
+
+
+def test_lpips_loss_matches_reference_lpnet(tmp_path):
+    """papr_amd.lpips.LPNet against the reference's LPNet (models/lpips.py:86-125) on a seeded image pair, backbone and heads
+    formula-filled on both sides (golden G12); also through get_loss with weight files supplied the way a user would."""
+    from formula import formula_fill
+    from papr_amd import get_loss
+    from papr_amd.lpips import LPNet
+    g = golden("g12_lpips.npz")
+    net = LPNet(load=False)
+    formula_fill({"features." + k: v for k, v in net.features.state_dict().items()}, salt=3)
+    with torch.no_grad():
+        for i, p in enumerate(net.lins):
+            p.copy_(torch.rand(p.shape, generator=torch.Generator().manual_seed(40 + i)))
+    np.testing.assert_allclose([float(p.sum()) for p in net.lins], g["lin_sums"], rtol=1e-6)
+    a = torch.from_numpy(g["a"]).requires_grad_(True)
+    b = torch.from_numpy(g["b"])
+    val = net(a, b)
+    val.backward()
+    assert abs(val.item() - float(g["value"])) <= 1e-6 * abs(float(g["value"]))
+    assert abs(net(a[:1].detach(), b[:1]).item() - float(g["value_first"])) <= 1e-6 * abs(float(g["value_first"]))
+    np.testing.assert_allclose(a.grad.numpy(), g["grad_a"], rtol=0, atol=1e-6 * np.abs(g["grad_a"]).max())
+    # the user-facing route: weight files on disk -> get_loss builds mse + 0.01 lpips like the reference's get_loss
+    torch.save({"lin%d.model.1.weight" % i: p.detach() for i, p in enumerate(net.lins)}, str(tmp_path / "vgg.pth"))
+    torch.save({"features." + k: v for k, v in net.features.state_dict().items()}, str(tmp_path / "vgg16.pth"))
+    os.environ["PAPR_LPIPS_HEADS"], os.environ["PAPR_VGG16_WEIGHTS"] = str(tmp_path / "vgg.pth"), str(tmp_path / "vgg16.pth")
+    try:
+        loss_fn = get_loss({"mse": 1.0, "lpips": 0.01, "lpips_alex": 0.0})
+    finally:
+        del os.environ["PAPR_LPIPS_HEADS"], os.environ["PAPR_VGG16_WEIGHTS"]
+    want = torch.mean((a.detach() - b) ** 2).item() + 0.01 * float(g["value"])
+    assert abs(loss_fn(a.detach(), b).item() - want) <= 1e-6
 
 
 def test_c_abi_library_exports_every_declared_symbol():

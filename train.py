@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Training driver on the HIP render path -- same command line, schedule and checkpoint files as the
-reference's train.py (`python train.py --opt configs/nerfsyn/chair.yml [--resume 1]`):
+reference's train.py (`python train.py --opt configs/nerfsyn/chair.yml [--resume 1]`; add `--set training.losses.lpips=0` when the LPIPS weight
+files are not available, see papr_amd/lpips.py -- such runs train MSE-only):
 prune / add schedule (train.py:207-250), train_step call order (:155-179), evaluation every
 `eval.step` steps (and every 500 below 10,000) with chunked full-image rendering (:29-152), rank-0
 logging and checkpoints.  Launch under torch.distributed.run for ray-sharded data parallelism.
@@ -16,7 +17,7 @@ import numpy as np
 import torch
 
 from papr_amd import dist as pdist, get_loss, get_model, load_config
-from papr_amd.config import as_node, eval_config
+from papr_amd.config import as_node, eval_config, parse_overrides
 from papr_amd.dataset import get_dataset, sample_batch
 
 
@@ -89,16 +90,7 @@ def reinit(model, step, fn):
 
 def main():
     cli = parse_args()
-    over = {}
-    for kv in cli.set:
-        key, val = kv.split("=", 1)
-        node = over
-        parts = key.split(".")
-        for p in parts[:-1]:
-            node = node.setdefault(p, {})
-        import yaml
-        node[parts[-1]] = yaml.safe_load(val)
-    cfg = load_config(cli.opt, overrides=over)
+    cfg = load_config(cli.opt, overrides=parse_overrides(cli.set))
     if cli.steps > 0:
         cfg["training"]["steps"] = cli.steps
     args, eargs = as_node(cfg), as_node(eval_config(cfg))
@@ -116,10 +108,23 @@ def main():
     eval_set = get_dataset(eargs["dataset"], "test", dev, seed=args.seed)
     loss_fn = get_loss(cfg["training"]["losses"]).to(dev)
     start = 0
-    eval_psnrs, train_losses = [], []
-    if cli.resume > 0:
+    eval_psnrs, train_losses, eval_losses = [], [], []
+    if cli.resume > 0:                          # same files as the reference (train.py:313-322): either driver resumes the other's directory
         start = model.load(log_dir)
+        hist = {}
+        for name in ("train_losses", "eval_losses", "eval_psnrs"):
+            path = os.path.join(log_dir, name + ".pth")
+            hist[name] = torch.load(path).tolist() if os.path.exists(path) else []
+        train_losses, eval_losses, eval_psnrs = hist["train_losses"], hist["eval_losses"], hist["eval_psnrs"]
         print("!!!!! Resume from step %s" % start)
+    elif args.load_path:                        # start from another experiment's weights (train.py:324-332)
+        load_dir = os.path.join(args.save_dir, args.load_path)
+        try:
+            loaded = model.load(load_dir)
+        except Exception:
+            for loaded, sd in torch.load(os.path.join(load_dir, "model.pth"), map_location="cpu").items():
+                model.load_my_state_dict(sd)
+        print("!!!!! Loaded model from %s at step %s" % (args.load_path, loaded))
     T = args.training
     step, pruned, t0, run_loss = start, False, time.time(), 0.0
     print("Start step:", start, "Total steps:", T.steps)
@@ -153,10 +158,12 @@ def main():
                 img, rayd, rayo, c2w = eval_set.full_view(args.eval.img_idx % len(eval_set))
                 rgb = render_full(model, rayo, rayd, c2w, args.eval.max_height, args.eval.max_width)
                 eval_psnrs.append(psnr(rgb, img))
+                eval_losses.append(loss_fn(rgb, img).item())
                 train_losses.append(loss.item())
                 print("Eval step:", step, "train_loss:", train_losses[-1], "eval_psnr:", eval_psnrs[-1])
                 model.save(step, log_dir)
                 torch.save(torch.tensor(train_losses), os.path.join(log_dir, "train_losses.pth"))
+                torch.save(torch.tensor(eval_losses), os.path.join(log_dir, "eval_losses.pth"))
                 torch.save(torch.tensor(eval_psnrs), os.path.join(log_dir, "eval_psnrs.pth"))
                 if step % 50000 == 0:
                     torch.save(model.state_dict(), os.path.join(log_dir, "model_%d.pth" % step))
