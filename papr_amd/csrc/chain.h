@@ -29,6 +29,8 @@ struct ChainArgs {
     float* rowmax0;                       // (M) receives max |.| of every input row, or null
     long M;
     int n_layers;
+    int legacy;                           // 1: this MLP has a skip layer somewhere -- all its runs (forward and data-gradient) use chain.hip,
+                                          // whose sign-word layout differs from chain2.hip's
     int in_norm_width;                    // forward: with in_norm_stats, the input rows are standardised over their first
     float in_norm_eps;                    // in_norm_width columns while they are staged (LayerNorm core in front of the run);
     float* in_norm_stats;                 // (M, 2) = 1/(std+eps), std; in_norm_writeback: the standardised rows replace A0 in
@@ -38,6 +40,10 @@ struct ChainArgs {
     ChainLayer L[CHAIN_MAX_LAYERS];
 };
 
+// Sign words: chain.hip: word [(2 wn + h) * M + m] as described at ChainLayer::sign_bits; chain2.hip: row m owns words
+// [8 m, 8 m + 8): the 64-bit mask of column phase cc (columns 4 lane + cc) in words 8 m + 2 cc, + 1.
 size_t papr_chain_lds_bytes();
+size_t papr_chain2_lds_bytes();
+int papr_launch_chain2(const ChainArgs& a, bool dgrad, long long bytes, long long flops, hipStream_t s);
 // bytes / flops: algorithmic totals of the launch for the profiling record
 int papr_launch_chain(const ChainArgs& a, bool dgrad, long long bytes, long long flops, hipStream_t s);

@@ -1264,6 +1264,7 @@ extern "C" int papr_mlp_fwd(const papr_layer* layers, int n_layers, float* x, in
             }
             c.rowmax0 = saved ? saved + (size_t)i * M : nullptr;
             c.M = M; c.n_layers = e - i;
+            for (int l = 0; l < n_layers; ++l) c.legacy |= layers[l].n_skip > 0 ? 1 : 0;      // (sign-word layout: chain.h)
             size_t used = 0;
             SplitBatch split = {};
             long long bytes = 4LL * M * L.n_in, flops = 0;
@@ -1430,7 +1431,7 @@ extern "C" int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float*
             const int last = b == 0 ? (to_dx ? 0 : 1) : b;       // lowest layer whose data-gradient the launch computes
             ChainArgs c = {};
             c.A0 = g; c.lda0 = ldg; c.K0 = L.n_out; c.rowmax0 = runs.gmax[CHAIN_MAX_LAYERS];
-            c.M = M;
+            c.M = M; c.legacy = any_skip ? 1 : 0;
             size_t used = 0;
             SplitBatch split = {};
             long long bytes = 4LL * M * L.n_out, flops = 0;

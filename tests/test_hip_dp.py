@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import ROOT, golden
+from conftest import ROOT, golden, grad_check
 
 pytestmark = pytest.mark.gpu
 
@@ -59,7 +59,7 @@ def test_two_ranks_on_one_gpu_match_the_reference_two_image_batch(tmp_path):
                       ("proximity_attn.attention_layer.w_q.bias", "wq_bias"), ("renderer.outc.conv.bias", "outc_bias")):
         ref = g9["both/" + key]
         got = r0["avg"][name].numpy()
-        assert np.abs(got - ref).max() <= 1e-3 * np.abs(ref).max(), name
+        grad_check(got, ref, name)
     names = [str(x) for x in g9["both/names"]]
     for i, n in enumerate(names):                      # gradient norms of every parameter of the reference's batch-2 step
         ref_norm = g9["both/stats"][i][2]

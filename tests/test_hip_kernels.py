@@ -218,7 +218,8 @@ def test_segment_reduce_matches_index_put_accumulate(P, M, hot):
     order, sorted_pts, seg = _segment_inputs(flat_d, P)
     d_p, d_i, d_f = torch.zeros(P, 3, device=d), torch.zeros(P, 1, device=d), torch.zeros(P, nc, device=d)
     a = [hip.ptr(order), hip.ptr(sorted_pts), hip.ptr(seg), M, P]
-    hip.check(hip.lib().papr_segment_reduce(*a, hip.ptr(pair_pts.to(d)), hip.ptr(pair_influ.to(d)), hip.ptr(rows.to(d)), ld, col0, nc,
+    pp_d, pi_d, rows_d = pair_pts.to(d), pair_influ.to(d), rows.to(d)          # (kept alive: hip.ptr holds no reference)
+    hip.check(hip.lib().papr_segment_reduce(*a, hip.ptr(pp_d), hip.ptr(pi_d), hip.ptr(rows_d), ld, col0, nc,
                                             hip.ptr(d_p), hip.ptr(d_i), hip.ptr(d_f), 0, hip.stream_ptr()), "papr_segment_reduce")
     torch.cuda.synchronize()
     big = lambda w: 4e-6 * w.abs().max().item() + 1e-7          # fp32 sums of up to `hot` terms in another order
@@ -230,7 +231,8 @@ def test_segment_reduce_matches_index_put_accumulate(P, M, hot):
     # second pass onto the same outputs (use_ink + use_inv: features feed the key and the value branch): sums ADD
     rows2 = torch.randn(M, 120, generator=gen)
     want_f2 = want_f + torch.zeros(P, nc, dtype=torch.float64).index_put_((flat.long(),), rows2[:, 56:56 + nc].double(), accumulate=True)
-    hip.check(hip.lib().papr_segment_reduce(*a, None, None, hip.ptr(rows2.to(d)), 120, 56, nc, None, None, hip.ptr(d_f), 1,
+    rows2_d = rows2.to(d)
+    hip.check(hip.lib().papr_segment_reduce(*a, None, None, hip.ptr(rows2_d), 120, 56, nc, None, None, hip.ptr(d_f), 1,
                                             hip.stream_ptr()), "papr_segment_reduce")
     torch.cuda.synchronize()
     np.testing.assert_allclose(d_f.cpu().double().numpy(), want_f2.numpy(), rtol=0, atol=big(want_f2))
