@@ -40,8 +40,9 @@ struct ChainArgs {
     ChainLayer L[CHAIN_MAX_LAYERS];
 };
 
-// Sign words: chain.hip: word [(2 wn + h) * M + m] as described at ChainLayer::sign_bits; chain2.hip: row m owns words
-// [8 m, 8 m + 8): the 64-bit mask of column phase cc (columns 4 lane + cc) in words 8 m + 2 cc, + 1.
+// Sign words: chain.hip: word [(2 wn + h) * M + m] as described at ChainLayer::sign_bits; chain2.hip: the 16-row block b
+// (rows 16 b .. 16 b + 15) owns words [128 b, 128 b + 128): lane l of the wave that wrote it keeps words 128 b + 2 l (rows 0-7)
+// and + 1 (rows 8-15), 4 bits per row (columns 4 l .. 4 l + 3), first value in the top bit.
 size_t papr_chain_lds_bytes();
 size_t papr_chain2_lds_bytes();
 int papr_launch_chain2(const ChainArgs& a, bool dgrad, long long bytes, long long flops, hipStream_t s);

@@ -54,30 +54,6 @@ __device__ __forceinline__ float scale_from_max(unsigned bits, float& inv) {    
     return pow2_from_biased(127 + 13 - (ea - 127));
 }
 
-// r.c = mask_c bit of this lane ? r.c : r.c * slope, with the four 64-bit lane masks in scalar registers (one instruction
-// per value).  The masks come out of v_readlane: on gfx950 a VALU instruction that reads an SGPR written by a VALU
-// instruction needs two wait states in between (LLVM's VALUWriteSGPRVALURead), which hipcc does not insert in front of
-// an asm statement -- without the s_nop the selects read the PREVIOUS contents of the pair's high register.
-__device__ __forceinline__ void select_by_masks(float4& r, float slope, unsigned long long m0, unsigned long long m1, unsigned long long m2,
-                                                unsigned long long m3) {
-    const float4 f = make_float4(r.x * slope, r.y * slope, r.z * slope, r.w * slope);
-    float4 o;
-    asm("s_nop 1\n\tv_cndmask_b32_e64 %0, %4, %8, %12\n\tv_cndmask_b32_e64 %1, %5, %9, %13\n\t"
-        "v_cndmask_b32_e64 %2, %6, %10, %14\n\tv_cndmask_b32_e64 %3, %7, %11, %15"
-        : "=&v"(o.x), "=&v"(o.y), "=&v"(o.z), "=&v"(o.w)
-        : "v"(f.x), "v"(f.y), "v"(f.z), "v"(f.w), "v"(r.x), "v"(r.y), "v"(r.z), "v"(r.w), "s"(m0), "s"(m1), "s"(m2), "s"(m3));
-    r = o;
-}
-
-// lanes 4 q .. 4 q + 3 of (lo, hi) = the four 64-bit masks (scalars into single lanes of two vector registers); s_nop: the
-// masks come out of v_cmp (VALU writes SGPR -> VALU reads SGPR: two wait states, see select_by_masks)
-#define put_masks(lo, hi, q, m0, m1, m2, m3)                                                                                  \
-    asm("s_nop 1\n\tv_writelane_b32 %0, %2, %10\n\tv_writelane_b32 %1, %3, %10\n\tv_writelane_b32 %0, %4, %11\n\tv_writelane_b32 %1, %5, %11\n\t" \
-        "v_writelane_b32 %0, %6, %12\n\tv_writelane_b32 %1, %7, %12\n\tv_writelane_b32 %0, %8, %13\n\tv_writelane_b32 %1, %9, %13"                  \
-        : "+v"(lo), "+v"(hi)                                                                                                   \
-        : "s"((unsigned)(m0)), "s"((unsigned)((m0) >> 32)), "s"((unsigned)(m1)), "s"((unsigned)((m1) >> 32)), "s"((unsigned)(m2)),        \
-          "s"((unsigned)((m2) >> 32)), "s"((unsigned)(m3)), "s"((unsigned)((m3) >> 32)), "i"(4 * (q)), "i"(4 * (q) + 1), "i"(4 * (q) + 2), "i"(4 * (q) + 3))
-
 // max over the 64 lanes of four registers at once (result valid in lane 63): the four chains interleave, so that the two
 // wait states a DPP read needs behind the VALU write of its source are filled by the other rows' instructions
 #define C2_DPP4(ctrl)                                                  \
@@ -99,14 +75,17 @@ __device__ __forceinline__ float last_lane(float v) { return __int_as_float(__bu
 template <int STORE, int BITS, int RMAX, int MORE, int NORM, int FULL>
 struct RowCfg { static constexpr int store = STORE, bits = BITS, rmax = RMAX, more = MORE, norm = NORM, full = FULL; };
 
-#if defined(C2_DBG) && (C2_DBG == 8 || C2_DBG == 13)
-__device__ unsigned g_c2_dbg[16];
-#endif
 #ifdef PAPR_H3_TRACE
 __device__ long long g_chain2_trace[2][512];
 #define C2_STAMP() do { if (blockIdx.x == 100 && wn == 0 && lane == 0 && trace_slot < 512) g_chain2_trace[grp][trace_slot++] = __builtin_readcyclecounter(); } while (0)
+#ifdef PAPR_C2_TRACE_FINE
+#define C2_STAMP2() do { asm volatile("" ::: "memory"); C2_STAMP(); } while (0)
+#else
+#define C2_STAMP2() do {} while (0)
+#endif
 #else
 #define C2_STAMP() do {} while (0)
+#define C2_STAMP2() do {} while (0)
 #endif
 
 template <bool DGRAD>
@@ -159,15 +138,8 @@ __global__ __launch_bounds__(C2_THREADS, 2) void mlp_chain2_kernel(ChainArgs p, 
     auto group_sync = [&]() {
         sync_epoch += 4;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#if defined(C2_DBG) && C2_DBG == 5
-        typedef __attribute__((address_space(3))) unsigned lds_u32;
-        lds_u32* cnt3 = (lds_u32*)sync_cnt;
-        if (lane == 0) __hip_atomic_fetch_add(cnt3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        while (__hip_atomic_load(cnt3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < sync_epoch) __builtin_amdgcn_s_sleep(2);
-#else
         if (lane == 0) atomicAdd(sync_cnt, 1u);
         while (*reinterpret_cast<volatile unsigned*>(sync_cnt) < sync_epoch) __builtin_amdgcn_s_sleep(2);
-#endif
         asm volatile("" ::: "memory");
     };
 
@@ -178,76 +150,89 @@ __global__ __launch_bounds__(C2_THREADS, 2) void mlp_chain2_kernel(ChainArgs p, 
             split4(v, sc, hi, lo);
             char* dst = blk + u * 512 + (((lane >> 1) ^ u) * 16) + (lane & 1) * 8;
             *reinterpret_cast<half4*>(dst) = hi;
-#if defined(C2_DBG) && C2_DBG == 9
-            asm volatile("" ::: "memory");          // (debug: two ds_write_b64 instead of one ds_write2st64_b64)
-#endif
             *reinterpret_cast<half4*>(dst + C2_LO) = lo;
         }
     };
 
     // ---- stage the input rows of a tile (coalesced: one row per load instruction), LayerNorm core in front of the run
-    auto stage = [&](long m0) {
+    // eight rows (ub .. ub + 7 of block wn) of tile m0: issue the loads ...
+    auto stage_load = [&](long m0, int ub, float4 (&v)[8]) {
+        const int c = 4 * lane;
+        asm volatile("" : "+s"(m0));                // (keeps the row addresses out of registers that would live across the k-loop)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            long m = m0 + wn * 16 + ub + q;
+            m = m < p.M ? m : p.M - 1;              // rows beyond M: the last row again
+            const float* rowp = p.A0 + m * p.lda0;  // wave-uniform: scalar base + one lane offset
+            v[q] = c < p.K0 ? *reinterpret_cast<const float4*>(rowp + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    // ... and turn them into A-plane rows: LayerNorm core in front of the run, row maxima, scales, split
+    auto stage_rows = [&](long m0, const float4 (&va)[8], const float4 (&vb)[8]) {
         const int c = 4 * lane;
         const int kpad = p.L[0].k1steps * 16;
-        const bool in_norm = !DGRAD && p.in_norm_stats != nullptr;
-        const float* src = p.A0 + (m0 + wn * 16) * p.lda0 + c;
 #pragma unroll 1
         for (int ub = 0; ub < 16; ub += 8) {
-            float4 v[8];
+        float4 v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = ub ? vb[q] : va[q];
+        if (!DGRAD && p.in_norm_stats != nullptr) {
+            // LayerNorm core in front of the run (FeedForward.innorm): the wave holds the whole row
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                long dm = ub + q;
-                dm = m0 + wn * 16 + dm < p.M ? dm : p.M - 1 - (m0 + wn * 16);      // rows beyond M: the last row again
-                v[q] = c < p.K0 ? *reinterpret_cast<const float4*>(src + dm * p.lda0) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            if (in_norm) {
-                // LayerNorm core in front of the run (FeedForward.innorm): the wave holds the whole row
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const long mrow = m0 + wn * 16 + ub + q;
-                    const int wdt = p.in_norm_width;
-                    const bool i0 = c < wdt, i1 = c + 1 < wdt, i2 = c + 2 < wdt, i3 = c + 3 < wdt;
-                    const float mean = wave_sum(((i0 ? v[q].x : 0.f) + (i1 ? v[q].y : 0.f)) + ((i2 ? v[q].z : 0.f) + (i3 ? v[q].w : 0.f))) / (float)wdt;
-                    float4 dl = make_float4(i0 ? v[q].x - mean : 0.f, i1 ? v[q].y - mean : 0.f, i2 ? v[q].z - mean : 0.f, i3 ? v[q].w - mean : 0.f);
-                    const float sigma = sqrtf(wave_sum((dl.x * dl.x + dl.y * dl.y) + (dl.z * dl.z + dl.w * dl.w)) / (float)(wdt - 1));
-                    const float rinv = 1.0f / (sigma + p.in_norm_eps);
-                    v[q] = make_float4(dl.x * rinv, dl.y * rinv, dl.z * rinv, dl.w * rinv);
-                    if (mrow < p.M) {
-                        if (p.in_norm_writeback && c < p.K0) *reinterpret_cast<float4*>(p.A0 + mrow * p.lda0 + c) = v[q];
-                        if (lane == 0) { p.in_norm_stats[mrow * 2] = rinv; p.in_norm_stats[mrow * 2 + 1] = sigma; }
-                    }
+                const long mrow = m0 + wn * 16 + ub + q;
+                const int wdt = p.in_norm_width;
+                const bool i0 = c < wdt, i1 = c + 1 < wdt, i2 = c + 2 < wdt, i3 = c + 3 < wdt;
+                const float mean = wave_sum(((i0 ? v[q].x : 0.f) + (i1 ? v[q].y : 0.f)) + ((i2 ? v[q].z : 0.f) + (i3 ? v[q].w : 0.f))) / (float)wdt;
+                float4 dl = make_float4(i0 ? v[q].x - mean : 0.f, i1 ? v[q].y - mean : 0.f, i2 ? v[q].z - mean : 0.f, i3 ? v[q].w - mean : 0.f);
+                const float sigma = sqrtf(wave_sum((dl.x * dl.x + dl.y * dl.y) + (dl.z * dl.z + dl.w * dl.w)) / (float)(wdt - 1));
+                const float rinv = 1.0f / (sigma + p.in_norm_eps);
+                v[q] = make_float4(dl.x * rinv, dl.y * rinv, dl.z * rinv, dl.w * rinv);
+                if (mrow < p.M) {
+                    if (p.in_norm_writeback && c < p.K0) *reinterpret_cast<float4*>(p.A0 + mrow * p.lda0 + c) = v[q];
+                    if (lane == 0) { p.in_norm_stats[mrow * 2] = rinv; p.in_norm_stats[mrow * 2 + 1] = sigma; }
                 }
             }
+        }
 #pragma unroll
-            for (int h = 0; h < 8; h += 4) {
-                float mx[4];
+        for (int h = 0; h < 8; h += 4) {
+            float mx[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) mx[q] = fmaxf(fmaxf(fabsf(v[h + q].x), fabsf(v[h + q].y)), fmaxf(fabsf(v[h + q].z), fabsf(v[h + q].w)));
-                wave_max4(mx[0], mx[1], mx[2], mx[3]);
-                float smx[4];
+            for (int q = 0; q < 4; ++q) mx[q] = fmaxf(fmaxf(fabsf(v[h + q].x), fabsf(v[h + q].y)), fmaxf(fabsf(v[h + q].z), fabsf(v[h + q].w)));
+            wave_max4(mx[0], mx[1], mx[2], mx[3]);
+            float smx[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) smx[q] = last_lane(mx[q]);
-                float mx4 = 0.f;
-                put4(mx4, 0, smx[0], smx[1], smx[2], smx[3]);
-                if (p.rowmax0 && lane < 4 && m0 + wn * 16 + ub + h + lane < p.M) p.rowmax0[m0 + wn * 16 + ub + h + lane] = mx4;
-                float inv[4];
+            for (int q = 0; q < 4; ++q) smx[q] = last_lane(mx[q]);
+            float mx4 = 0.f;
+            put4(mx4, 0, smx[0], smx[1], smx[2], smx[3]);
+            if (p.rowmax0 && lane < 4 && m0 + wn * 16 + ub + h + lane < p.M) p.rowmax0[m0 + wn * 16 + ub + h + lane] = mx4;
+            float inv[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float sc = scale_from_max(__float_as_uint(smx[q]), inv[q]);
-                    write_planes(ub + h + q, v[h + q], sc, kpad);
-                }
-                *reinterpret_cast<float4*>(inv_tab + ub + h) = make_float4(inv[0], inv[1], inv[2], inv[3]);
+            for (int q = 0; q < 4; ++q) {
+                const float sc = scale_from_max(__float_as_uint(smx[q]), inv[q]);
+                write_planes(ub + h + q, v[h + q], sc, kpad);
             }
+            *reinterpret_cast<float4*>(inv_tab + ub + h) = make_float4(inv[0], inv[1], inv[2], inv[3]);
+        }
         }
     };
 
     long tile = 2L * blockIdx.x + grp;
     const long tstride = 2L * gridDim.x;
-    stage(tile * C2_ROWS);
+    {
+        float4 sa[8], sb[8];
+        stage_load(tile * C2_ROWS, 0, sa);
+        stage_load(tile * C2_ROWS, 8, sb);
+        stage_rows(tile * C2_ROWS, sa, sb);
+    }
 #pragma unroll
     for (int u = 0; u < WD - 1; ++u) load_w(0, u, wfh[u], wfl[u]);
     lds_barrier();                                  // planes ready (and the sync counters zeroed)
+#ifndef C2_FREE
     if (grp == 1) lds_barrier();                    // group 1 runs half a period behind group 0
+#else
+    if (grp == 1) { for (int z = 0; z < 32; ++z) __builtin_amdgcn_s_sleep(127); }      // (experiment: free-running groups, group 1 starts ~4k cycles late)
+#endif
 
 #pragma unroll 1
     for (int it = 0; it < iters; ++it, tile += tstride) {
@@ -269,15 +254,6 @@ __global__ __launch_bounds__(C2_THREADS, 2) void mlp_chain2_kernel(ChainArgs p, 
 
             // =========================== multiplying role: k-loop ===========================
             C2_STAMP();
-#if defined(C2_DBG) && C2_DBG == 13
-            unsigned chk[16];                   // debug: fold of every plane row of block wn before the k-loop ...
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const uint4 t = *reinterpret_cast<const uint4*>(blk + (lane >> 5) * C2_LO + u * 512 + (lane & 31) * 16);
-                chk[u] = t.x ^ t.y ^ t.z ^ t.w;
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
             {
                 const int kb = 0, ke = ksteps;
                 auto a_addr = [&](int ks) { return a_base + (((unsigned)ks * 32u) ^ a_xor); };
@@ -399,26 +375,20 @@ __global__ __launch_bounds__(C2_THREADS, 2) void mlp_chain2_kernel(ChainArgs p, 
 #endif
             }
             C2_STAMP();
-#if defined(C2_DBG) && C2_DBG == 13
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {      // ... and after it: nobody may have written this group's planes in between
-                const uint4 t = *reinterpret_cast<const uint4*>(blk + (lane >> 5) * C2_LO + u * 512 + (lane & 31) * 16);
-                if ((t.x ^ t.y ^ t.z ^ t.w) != chk[u]) atomicAdd(&g_c2_dbg[u], 1u);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
+#ifndef C2_FREE
             lds_barrier();                          // (a) this group's A reads are complete: its planes are dead until the split
-#if defined(C2_DBG) && C2_DBG == 3
-            __builtin_amdgcn_s_sleep(127);
-#endif
-#if defined(C2_DBG) && C2_DBG == 4
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#else
+            group_sync();
 #endif
             C2_STAMP();
 
             // =========================== the other role: row phases ===========================
+#ifdef C2_PPRIO
+            __builtin_amdgcn_s_setprio(C2_PPRIO);
+#endif
             const bool more = l + 1 < p.n_layers;
             const bool next_tile = !more && it + 1 < iters;
+            float4 sa[8], sb[8];                    // input rows of the next tile on their way (requested before the row phase)
             {   // first weight fragments of what this wave multiplies next (they arrive while it is busy here)
                 const int ln = more ? l + 1 : 0;
 #pragma unroll
@@ -439,16 +409,6 @@ __global__ __launch_bounds__(C2_THREADS, 2) void mlp_chain2_kernel(ChainArgs p, 
                 }
             C2_STAMP();
             group_sync();
-#if defined(C2_DBG) && C2_DBG == 1
-            __builtin_amdgcn_s_sleep(127);
-#endif
-#if defined(C2_DBG) && C2_DBG == 6
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_sleep(8);
-#endif
-#if defined(C2_DBG) && C2_DBG == 7
-            if (wn == 0) __builtin_amdgcn_s_sleep(127);
-#endif
             C2_STAMP();
             // ---- rows 16 wn .. 16 wn + 15, a whole row across the wave, four rows at a time.  Straight-line code matters: with the
             // per-layer flags tested row by row the compiler cut this phase into ~25 basic blocks per row and re-read kernel
@@ -464,20 +424,18 @@ __global__ __launch_bounds__(C2_THREADS, 2) void mlp_chain2_kernel(ChainArgs p, 
                 float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (!DGRAD && L.bias && c < N) b4 = *reinterpret_cast<const float4*>(L.bias + c);
                 const int kpad_next = more ? p.L[l + 1].k1steps * 16 : 0;
-                float* const crow = L.C + (m0 + wn * 16) * L.ldc + c;                   // this lane's 16 bytes of row 16 wn
+                float* const crow = L.C + (m0 + wn * 16) * L.ldc;                       // row 16 wn (wave-uniform: scalar base + lane offset)
                 const long ldc = L.ldc;
-                unsigned* const sgn = L.sign_bits + (m0 + wn * 16) * 8;              // the wave's 512 bytes of sign words
-                // data-gradient: lane 4 u + cc holds the 64-bit mask of row u, column phase cc
-                unsigned sg_lo = 0u, sg_hi = 0u;
-                if (DGRAD && rt_bits) {
-                    long srow = m0 + wn * 16 + (lane >> 2);
-                    srow = srow < p.M ? srow : p.M - 1;
-                    const uint2 w2 = *reinterpret_cast<const uint2*>(L.sign_bits + (srow * 8 + 2 * (lane & 3)));
-                    sg_lo = w2.x; sg_hi = w2.y;
-                }
+                // sign words: lane l keeps ITS 4 x 16 bits of the wave's 16 rows (two words: rows 0-7, rows 8-15; first value in
+                // the top bit), 512 contiguous bytes per wave and layer -- written by the forward run, read back by the
+                // data-gradient run, whose lanes hold the same columns of the same rows
+                unsigned* const sgn = L.sign_bits + ((m0 + wn * 16) >> 4) * 128 + 2 * lane;
+                unsigned sw[2] = {0u, 0u};
+                if (DGRAD && rt_bits) { const uint2 w2 = *reinterpret_cast<const uint2*>(sgn); sw[0] = w2.x; sw[1] = w2.y; }
                 // the loads above are waited for HERE: a wait inside the batch loop would also wait for the row stores of the
-                // batch before it (loads and stores share vmcnt)
-                asm volatile("" : "+v"(b4.x), "+v"(b4.y), "+v"(b4.z), "+v"(b4.w), "+v"(sg_lo), "+v"(sg_hi));
+                // batch before it (loads and stores share vmcnt); the next tile's first input rows are requested behind them
+                if (next_tile) stage_load((tile + tstride) * C2_ROWS, 0, sa);
+                asm volatile("" : "+v"(b4.x), "+v"(b4.y), "+v"(b4.z), "+v"(b4.w), "+v"(sw[0]), "+v"(sw[1]));
                 auto rows = [&](auto cfg) {
                     using Cfg = decltype(cfg);
                     const bool f_store = Cfg::store == 2 ? rt_store : Cfg::store == 1;
@@ -488,43 +446,26 @@ __global__ __launch_bounds__(C2_THREADS, 2) void mlp_chain2_kernel(ChainArgs p, 
                     const bool f_full = Cfg::full == 2 ? rt_full : Cfg::full == 1;
                     const bool col_ok = f_full || c < N;
 #pragma unroll 1
-                    for (int ub = 0; ub < 16; ub += 4) {
-                        float4 r[4];
-                        unsigned bt_lo = 0u, bt_hi = 0u;        // forward: lane 4 q + cc collects the sign mask of row ub + q, column phase cc
+                    for (int ub = 0; ub < 16; ub += 8) {            // eight rows in flight: two independent chains of four for the scheduler
+                        float4 r[8];
+                        unsigned sword = DGRAD ? (ub ? sw[1] : sw[0]) : 0u;
 #pragma unroll
-                        for (int q = 0; q < 4; ++q)
+                        for (int q = 0; q < 8; ++q)
                             r[q] = *reinterpret_cast<const float4*>(blk + r_base + (ub + q) * 512 + ((r_chunk ^ (unsigned)((ub + q) & 7)) * 16));
-                        const float4 inv4 = *reinterpret_cast<const float4*>(inv_tab + ub);
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the four rows are in registers: their bytes may be overwritten
-#if defined(C2_DBG) && C2_DBG == 8
-                        {   // debug: read the four rows and the scales a second time; do they still hold the same values?
-                            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+                        const float4 inv4a = *reinterpret_cast<const float4*>(inv_tab + ub), inv4b = *reinterpret_cast<const float4*>(inv_tab + ub + 4);
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the eight rows are in registers: their bytes may be overwritten
+                        C2_STAMP2();
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const volatile float* tp = reinterpret_cast<const volatile float*>(blk + r_base + (ub + q) * 512 + ((r_chunk ^ (unsigned)((ub + q) & 7)) * 16));
-                                const float4 t = make_float4(tp[0], tp[1], tp[2], tp[3]);
-                                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                                if (t.x != r[q].x || t.y != r[q].y || t.z != r[q].z || t.w != r[q].w) atomicAdd(&g_c2_dbg[q], 1u);
-                            }
-                            const volatile float* tp = inv_tab + ub;
-                            const float4 t = make_float4(tp[0], tp[1], tp[2], tp[3]);
-                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                            if (t.x != inv4.x || t.y != inv4.y || t.z != inv4.z || t.w != inv4.w) atomicAdd(&g_c2_dbg[4], 1u);
-                            if (lane == 0) atomicAdd(&g_c2_dbg[5], 1u);
-                        }
-#endif
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
+                        for (int q = 0; q < 8; ++q) {
                             const int u = ub + q;
-                            const float inv = q == 0 ? inv4.x : q == 1 ? inv4.y : q == 2 ? inv4.z : inv4.w;
+                            const float4 iv = q < 4 ? inv4a : inv4b;
+                            const float inv = (q & 3) == 0 ? iv.x : (q & 3) == 1 ? iv.y : (q & 3) == 2 ? iv.z : iv.w;
                             if (DGRAD) {
                                 r[q] = make_float4(r[q].x * inv, r[q].y * inv, r[q].z * inv, r[q].w * inv);
                                 if (f_bits) {
-                                    auto word2 = [&](int cc) {
-                                        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)sg_lo, 4 * u + cc), hi = (unsigned)__builtin_amdgcn_readlane((int)sg_hi, 4 * u + cc);
-                                        return ((unsigned long long)hi << 32) | lo;
-                                    };
-                                    select_by_masks(r[q], slope, word2(0), word2(1), word2(2), word2(3));
+                                    r[q].x = (int)sword < 0 ? r[q].x : r[q].x * slope; r[q].y = (int)(sword << 1) < 0 ? r[q].y : r[q].y * slope;
+                                    r[q].z = (int)(sword << 2) < 0 ? r[q].z : r[q].z * slope; r[q].w = (int)(sword << 3) < 0 ? r[q].w : r[q].w * slope;
+                                    sword <<= 4;
                                 } else if (mask_rows) {
                                     long row = m0 + wn * 16 + u;
                                     row = row < p.M ? row : p.M - 1;
@@ -552,48 +493,43 @@ __global__ __launch_bounds__(C2_THREADS, 2) void mlp_chain2_kernel(ChainArgs p, 
                                 r[q] = make_float4(dl.x * rinv, dl.y * rinv, dl.z * rinv, dl.w * rinv);
                                 if (lane == 0 && row < p.M) { p.norm_stats[row * 2] = rinv; p.norm_stats[row * 2 + 1] = sigma; }
                             }
-                            if (f_store && col_ok && (f_full || m0 + wn * 16 + u < p.M)) *reinterpret_cast<float4*>(crow + u * ldc) = r[q];
+                            if (f_store && col_ok && (f_full || m0 + wn * 16 + u < p.M)) *reinterpret_cast<float4*>(crow + u * ldc + c) = r[q];
                             if (!DGRAD && f_bits) {
-                                const unsigned long long k0 = __ballot(r[q].x > 0.f), k1 = __ballot(r[q].y > 0.f), k2 = __ballot(r[q].z > 0.f), k3 = __ballot(r[q].w > 0.f);
-                                put_masks(bt_lo, bt_hi, q, k0, k1, k2, k3);
+                                sword = (sword << 1) | (r[q].x > 0.f ? 1u : 0u); sword = (sword << 1) | (r[q].y > 0.f ? 1u : 0u);
+                                sword = (sword << 1) | (r[q].z > 0.f ? 1u : 0u); sword = (sword << 1) | (r[q].w > 0.f ? 1u : 0u);
                             }
                         }
+                        if (!DGRAD && f_bits) { if (ub) sw[1] = sword; else sw[0] = sword; }
+                        C2_STAMP2();
                         if (f_more || f_rmax) {
-                            float mx[4];
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) mx[q] = fmaxf(fmaxf(fabsf(r[q].x), fabsf(r[q].y)), fmaxf(fabsf(r[q].z), fabsf(r[q].w)));
-                            float smx[4];
-#if defined(C2_DBG) && (C2_DBG == 10 || C2_DBG == 11)
+                            for (int h = 0; h < 8; h += 4) {
+                                float mx[4];
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) smx[q] = wave64_max(mx[q]);
-#else
-                            wave_max4(mx[0], mx[1], mx[2], mx[3]);
+                                for (int q = 0; q < 4; ++q) mx[q] = fmaxf(fmaxf(fabsf(r[h + q].x), fabsf(r[h + q].y)), fmaxf(fabsf(r[h + q].z), fabsf(r[h + q].w)));
+                                wave_max4(mx[0], mx[1], mx[2], mx[3]);
+                                float smx[4];
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) smx[q] = last_lane(mx[q]);
-#endif
-                            if (f_rmax) {
-                                float mx4 = 0.f;
-#if defined(C2_DBG) && (C2_DBG == 10 || C2_DBG == 12)
-                                mx4 = lane == 0 ? smx[0] : lane == 1 ? smx[1] : lane == 2 ? smx[2] : smx[3];
-#else
-                                put4(mx4, 0, smx[0], smx[1], smx[2], smx[3]);
-#endif
-                                if (lane < 4 && (f_full || m0 + wn * 16 + ub + lane < p.M)) L.rowmax[m0 + wn * 16 + ub + lane] = mx4;
-                            }
-                            if (f_more) {
-                                float inv_n[4];
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) {
-                                    const float sc = scale_from_max(__float_as_uint(smx[q]), inv_n[q]);
-                                    write_planes(ub + q, r[q], sc, kpad_next);
+                                for (int q = 0; q < 4; ++q) smx[q] = last_lane(mx[q]);
+                                if (f_rmax) {
+                                    float mx4 = 0.f;
+                                    put4(mx4, 0, smx[0], smx[1], smx[2], smx[3]);
+                                    if (lane < 4 && (f_full || m0 + wn * 16 + ub + h + lane < p.M)) L.rowmax[m0 + wn * 16 + ub + h + lane] = mx4;
                                 }
-                                *reinterpret_cast<float4*>(inv_tab + ub) = make_float4(inv_n[0], inv_n[1], inv_n[2], inv_n[3]);
+                                if (f_more) {
+                                    float inv_n[4];
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q) {
+                                        const float sc = scale_from_max(__float_as_uint(smx[q]), inv_n[q]);
+                                        write_planes(ub + h + q, r[h + q], sc, kpad_next);
+                                    }
+                                    *reinterpret_cast<float4*>(inv_tab + ub + h) = make_float4(inv_n[0], inv_n[1], inv_n[2], inv_n[3]);
+                                }
                             }
                         }
-                        // 128 contiguous bytes per batch: word pair 4 q + cc of rows ub .. ub + 3
-                        if (!DGRAD && f_bits && lane < 16 && (f_full || m0 + wn * 16 + ub + (lane >> 2) < p.M))
-                            *reinterpret_cast<uint2*>(sgn + (ub * 8 + 2 * lane)) = make_uint2(bt_lo, bt_hi);
+                        C2_STAMP2();
                     }
+                    if (!DGRAD && f_bits) *reinterpret_cast<uint2*>(sgn) = make_uint2(sw[0], sw[1]);
                 };
                 // hot combinations (everything 256 wide, tile inside M): training middle layer / inference middle layer / data-gradient
                 if (!generic_only && rt_full && more && !rt_norm && !mask_rows && rt_store && rt_bits && rt_rmax) rows(RowCfg<1, 1, 1, 1, 0, 1>());
@@ -601,16 +537,24 @@ __global__ __launch_bounds__(C2_THREADS, 2) void mlp_chain2_kernel(ChainArgs p, 
                 else rows(RowCfg<2, 2, 2, 2, 2, 2>());
             }
             C2_STAMP();
-            if (next_tile) stage((tile + tstride) * C2_ROWS);
+            if (next_tile) {
+                stage_load((tile + tstride) * C2_ROWS, 8, sb);
+                stage_rows((tile + tstride) * C2_ROWS, sa, sb);
+            }
             C2_STAMP();
-#if defined(C2_DBG) && C2_DBG == 2
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_sleep(127);
+#ifdef C2_PPRIO
+            __builtin_amdgcn_s_setprio(0);
 #endif
+#ifndef C2_FREE
             lds_barrier();                          // (c) planes of the next layer (or tile) ready
+#else
+            group_sync();
+#endif
         }
     }
+#ifndef C2_FREE
     if (grp == 0) lds_barrier();                    // group 0 ends half a period early
+#endif
 }
 
 }  // namespace
@@ -619,9 +563,6 @@ __global__ __launch_bounds__(C2_THREADS, 2) void mlp_chain2_kernel(ChainArgs p, 
 extern "C" int papr_chain2_trace_read(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chain2_trace), sizeof(long long) * 1024) == hipSuccess ? 0 : 1; }
 #endif
 
-#if defined(C2_DBG) && (C2_DBG == 8 || C2_DBG == 13)
-extern "C" int papr_chain2_dbg_read(unsigned* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_c2_dbg), sizeof(unsigned) * 16) == hipSuccess ? 0 : 1; }
-#endif
 
 size_t papr_chain2_lds_bytes() { return C2_LDS_BYTES; }
 

@@ -18,15 +18,17 @@ torch.cuda.synchronize()
 buf = (ctypes.c_longlong * 1024)()
 hip.lib().papr_chain2_trace_read(buf)
 t = list(buf)
-names = ["k-loop", "bar(a)", "dump", "gsync", "rows", "stage", "bar(c)"]
+fine = os.environ.get("FINE") == "1"       # library built with -DPAPR_C2_TRACE_FINE: six more stamps inside the row phase
+names = ["k-loop", "bar(a)", "dump", "gsync"] + (["rd0", "math0", "max+split0", "rd1", "math1", "max+split1", "tail"] if fine else ["rows"]) + ["stage", "bar(c)"]
 for g in range(2):
     tt = t[512 * g: 512 * (g + 1)]
     print("group %d  (first stamp %d)" % (g, tt[0] - min(t[0], t[512])))
     print("   layer: " + "  ".join("%8s" % s for s in names) + "     total")
     i = 0
-    for it in range(3):
+    for it in range(2):
         for l in range(n):
-            seg = [tt[i + 1 + j] - tt[i + j] for j in range(7)]
-            # (the seventh interval ends at the next k-loop's first stamp)
-            print("   %d.%d:   " % (it, l) + "  ".join("%8d" % v for v in seg) + "  %8d" % (tt[i + 7] - tt[i]))
-            i += 7
+            ns = len(names)
+            seg = [tt[i + 1 + j] - tt[i + j] for j in range(ns)]
+            # (the last interval ends at the next k-loop's first stamp)
+            print("   %d.%d:   " % (it, l) + "  ".join("%8d" % v for v in seg) + "  %8d" % (tt[i + ns] - tt[i]))
+            i += ns
