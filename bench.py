@@ -274,6 +274,14 @@ def main():
                          "avg_launch_ms": knn_ms, "logical_bytes_per_launch": knn_bytes,
                          "note": "logical bytes (12P+12+4k per ray); the cloud is L2-resident so physical HBM traffic is far lower"},
     }
+    if os.environ.get("PAPR_BENCH_LAUNCHES"):           # per-shape launch table of the timed steps, on stderr
+        tab = {}
+        for r in recs:
+            c = tab.setdefault(tuple(r[:4]), [0, 0.0])
+            c[0] += 1; c[1] += r[4]
+        for key in sorted(tab, key=lambda t: -tab[t][1]):
+            n, ms = tab[key]
+            print("kernel %2d  M=%-8d N=%-5d K=%-5d  %4d launches  %.3f ms each  %.3f ms/step" % (*key, n, ms / n, ms / args.steps), file=sys.stderr)
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, init_state, args.cpu_rays, args.cpu_steps)
     print(json.dumps(out))

@@ -10,7 +10,7 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libpapr_hip.so")
-SOURCES = ["error.hip", "knn.hip", "features.hip", "rowops.hip", "gemm.hip", "chain.hip", "chain2.hip", "conv.hip"]
+SOURCES = ["error.hip", "knn.hip", "features.hip", "rowops.hip", "gemm.hip", "chain.hip", "chain2.hip", "chain3.hip", "conv.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics",
          "-Wall", "-Wno-unused-function"]
 # chain2.hip: no packed-fp32 VALU (v_pk_mul_f32 / v_pk_add_f32 come from the SLP vectoriser).  Measured on MI355X (round 2,
@@ -18,7 +18,10 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # products for a few rows per launch, non-deterministically (packed fp32 runs on the matrix pipe); the same source built with
 # -fno-slp-vectorize is bit-identical to the reference kernel on every run.  Packed fp32 beside MFMAs is also slower
 # (MI355X_MICROARCH.md, "price of one filler beside MFMAs").
-EXTRA_FLAGS = {"chain2.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"chain2.hip": ["-fno-slp-vectorize"], "chain3.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0"]}
+# chain3.hip keeps its weight fragments in a[0:127] by name, from inline asm; the compiler does not know they are taken in between
+# and moves values of its own into AGPRs when it runs out of VGPRs.  A build whose device code holds any v_accvgpr_* is wrong.
+NO_ACCVGPR = ["chain3.hip"]
 
 
 def _stale(target, deps):
@@ -46,6 +49,15 @@ def build_library(force=False, verbose=True):
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed on %s" % src)
+    for src, _ in procs:
+        if src in NO_ACCVGPR:
+            asm = subprocess.run([hipcc] + [f for f in FLAGS if f != "-fPIC"] + EXTRA_FLAGS.get(src, []) + ["-w", "-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", "-"],
+                                 check=True, capture_output=True, text=True).stdout
+            n = asm.count("v_accvgpr_")
+            if n:
+                os.remove(os.path.join(objdir, src.replace(".hip", ".o")))
+                raise RuntimeError("%s: the compiler uses AGPRs itself (%d v_accvgpr instructions): register pressure too high for the by-name "
+                                   "weight fragments, see the comment in the source" % (src, n))
     if force or procs or _stale(LIB, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined"]
         if verbose:

@@ -40,11 +40,16 @@ struct ChainArgs {
     ChainLayer L[CHAIN_MAX_LAYERS];
 };
 
-// Sign words: chain.hip: word [(2 wn + h) * M + m] as described at ChainLayer::sign_bits; chain2.hip: the 16-row block b
-// (rows 16 b .. 16 b + 15) owns words [128 b, 128 b + 128): lane l of the wave that wrote it keeps words 128 b + 2 l (rows 0-7)
-// and + 1 (rows 8-15), 4 bits per row (columns 4 l .. 4 l + 3), first value in the top bit.
+// Sign words: chain.hip: word [(2 wn + h) * M + m] as described at ChainLayer::sign_bits; chain2.hip: the RB-row block b
+// (RB = 8 or 16 rows per wave, chain2.hip) owns words [8 RB b, 8 RB (b + 1)): lane l of the wave that wrote it keeps word 8 RB b +
+// (RB / 8) l (rows 0-7; + 1: rows 8-15), 4 bits per row (columns 4 l .. 4 l + 3), first value in the top bit.
 size_t papr_chain_lds_bytes();
 size_t papr_chain2_lds_bytes();
 int papr_launch_chain2(const ChainArgs& a, bool dgrad, long long bytes, long long flops, hipStream_t s);
+// chain3.hip: chain2.hip's layout at RB = 8; only blocks with a row inside M are written or read.
+size_t papr_chain3_lds_bytes();
+int papr_launch_chain3(const ChainArgs& a, bool dgrad, long long bytes, long long flops, hipStream_t s);
+// rows of a layer's sign-word area: M rounded up to whole 8-row blocks (the area is CHAIN_SIGN_WORDS words per row)
+inline long chain_sign_rows(long M) { return (M + 7) / 8 * 8; }
 // bytes / flops: algorithmic totals of the launch for the profiling record
 int papr_launch_chain(const ChainArgs& a, bool dgrad, long long bytes, long long flops, hipStream_t s);

@@ -37,13 +37,20 @@
 
 namespace {
 
-constexpr int C2_THREADS = 512;
+#ifndef C2_NJ
+#define C2_NJ 1                                 // 32-column tiles per multiplying wave: 1 = eight waves per group (64 x 32 each), 2 = four (64 x 64)
+#endif
+constexpr int NI = 2, NJ = C2_NJ;               // a multiplying wave: 64 rows x 32 NJ columns
+constexpr int GW = 8 / NJ;                      // waves per group
+constexpr int RB = 64 / GW;                     // rows per wave in the row phases (one block of the planes): 8 or 16
+constexpr int C2_THREADS = 2 * GW * 64;
 constexpr int C2_ROWS = 64;                     // rows per group tile
-constexpr int C2_GROUP_BYTES = 65536;           // A planes of one group: 4 blocks of 16 rows
-constexpr int C2_BLK_BYTES = 16384;             // one block: hi rows (16 x 512 B) | lo rows (16 x 512 B); fp32 overlay of row u: columns 0-127 over hi row u, 128-255 over lo row u
-constexpr int C2_LO = 8192;
+constexpr int C2_GROUP_BYTES = 65536;           // A planes of one group: GW blocks of RB rows
+constexpr int C2_BLK_BYTES = RB * 1024;         // one block: hi rows (RB x 512 B) | lo rows (RB x 512 B); fp32 overlay of row u: columns 0-127 over hi row u, 128-255 over lo row u
+constexpr int C2_LO = RB * 512;
+constexpr int RQ = NJ == 1 ? 4 : 8;             // rows a wave carries through the row phase at a time (register budget: 128 or 256 VGPRs per wave)
+constexpr bool C2_EARLY_STAGE = NJ == 2;        // the next tile's input rows are requested before the last row phase (32 registers) or after it
 constexpr size_t C2_LDS_BYTES = 2 * C2_GROUP_BYTES + 64 + 512;      // planes, the two sync counters, 1 / scale of every A-plane row
-constexpr int NI = 2, NJ = 2;                   // a multiplying wave: 64 rows x 64 columns = 2 x 2 MFMA tiles
 constexpr int WD = 4;                           // weight-fragment ring depth (k-steps)
 
 __device__ __forceinline__ float wave64_max(float v) { return wave_max(v); }
@@ -77,7 +84,11 @@ struct RowCfg { static constexpr int store = STORE, bits = BITS, rmax = RMAX, mo
 
 #ifdef PAPR_H3_TRACE
 __device__ long long g_chain2_trace[2][512];
+#ifdef PAPR_C2_TRACE_ALL       // every wave of the workgroup, 64 stamps each
+#define C2_STAMP() do { if (blockIdx.x == 100 && lane == 0 && trace_slot < 64) g_chain2_trace[0][(grp * GW + wn) * (1024 / (2 * GW)) + trace_slot++] = __builtin_readcyclecounter(); } while (0)
+#else
 #define C2_STAMP() do { if (blockIdx.x == 100 && wn == 0 && lane == 0 && trace_slot < 512) g_chain2_trace[grp][trace_slot++] = __builtin_readcyclecounter(); } while (0)
+#endif
 #ifdef PAPR_C2_TRACE_FINE
 #define C2_STAMP2() do { asm volatile("" ::: "memory"); C2_STAMP(); } while (0)
 #else
@@ -89,10 +100,10 @@ __device__ long long g_chain2_trace[2][512];
 #endif
 
 template <bool DGRAD>
-__global__ __launch_bounds__(C2_THREADS, 2) void mlp_chain2_kernel(ChainArgs p, int iters, int generic_only) {
+__global__ __launch_bounds__(C2_THREADS, C2_THREADS / 256) void mlp_chain2_kernel(ChainArgs p, int iters, int generic_only) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2, wn = wave & 3;       // group; column quarter while multiplying = 16-row block in the row phases
+    const int grp = wave / GW, wn = wave % GW;      // group; column slice while multiplying = row block in the row phases
     char* const planes = smem + grp * C2_GROUP_BYTES;
     unsigned* const sync_cnt = reinterpret_cast<unsigned*>(smem + 2 * C2_GROUP_BYTES) + grp * 8;
     if (tid == 0) { sync_cnt[0] = 0u; sync_cnt[8] = 0u; }
@@ -104,12 +115,13 @@ __global__ __launch_bounds__(C2_THREADS, 2) void mlp_chain2_kernel(ChainArgs p, 
 
     // ---- addresses (bytes inside the group's planes)
     // multiplying layout: A fragment of 32-row tile i, k-step ks: row = 32 i + (lane & 31), 16-byte chunk 2 ks + hh
+    // (row r of the tile lives in block r / RB at row r % RB; its 16-byte chunks are XOR-ed with r & 15 in the planes, r & 7 in the overlay)
     const int arow = lane & 31, ax = arow & 15;
-    const unsigned a_base = (unsigned)((arow >> 4) * C2_BLK_BYTES + ax * 512 + ((hh ^ (ax & 1)) * 16));
+    const unsigned a_base = (unsigned)((arow / RB) * C2_BLK_BYTES + (arow % RB) * 512 + ((hh ^ (ax & 1)) * 16));
     const unsigned a_xor = (unsigned)((ax & ~1) * 16);
-    // dump: accumulator run (i, j, g) = row 32 i + arow, fp32 chunk 16 wn + 8 j + 2 g + hh of the row's overlay: half wn >> 1,
-    // chunk 16 (wn & 1) + 8 j + 2 g + hh inside the half
-    const unsigned d_base = (unsigned)((arow >> 4) * C2_BLK_BYTES + (wn >> 1) * C2_LO + ax * 512);
+    // dump: accumulator run (i, j, g) = row 32 i + arow, fp32 chunk 8 (NJ wn + j) + 2 g + hh of the row's overlay (64 chunks: the
+    // first 32 over the hi row, the rest over the lo row)
+    const unsigned d_base = (unsigned)((arow / RB) * C2_BLK_BYTES + (arow % RB) * 512);
     const unsigned d_x = (unsigned)(ax & 7);
     // row layout: lane holds columns 4 lane .. 4 lane + 3 = chunk lane & 31 of half lane >> 5
     const unsigned r_base = (unsigned)((lane >> 5) * C2_LO);
@@ -117,8 +129,8 @@ __global__ __launch_bounds__(C2_THREADS, 2) void mlp_chain2_kernel(ChainArgs p, 
     // row layout: this wave owns block wn; lane holds columns 4 lane .. 4 lane + 3 of a row
     char* const blk = planes + wn * C2_BLK_BYTES;
 
-    // 1 / scale of A-plane rows 16 wn .. 16 wn + 15: written and read by this wave only (all lanes store the same value)
-    float* const inv_tab = reinterpret_cast<float*>(smem + 2 * C2_GROUP_BYTES + 64) + grp * 64 + wn * 16;
+    // 1 / scale of A-plane rows RB wn .. RB wn + RB - 1: written and read by this wave only (all lanes store the same value)
+    float* const inv_tab = reinterpret_cast<float*>(smem + 2 * C2_GROUP_BYTES + 64) + grp * 64 + wn * RB;
 
     // ---- weight fragments: fragment (n-tile t, k-step s) of a layer's planes starts at ((t * ksteps + s) * 64 + lane) * 8 halfs
     half8 wfh[WD][NJ], wfl[WD][NJ];
@@ -134,9 +146,9 @@ __global__ __launch_bounds__(C2_THREADS, 2) void mlp_chain2_kernel(ChainArgs p, 
         }
     };
 
-    // ---- 4-wave barrier of this group only (LDS counter): the other group is in its k-loop and must not be held up
+    // ---- barrier of this group's waves only (LDS counter): the other group is in its k-loop and must not be held up
     auto group_sync = [&]() {
-        sync_epoch += 4;
+        sync_epoch += GW;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) atomicAdd(sync_cnt, 1u);
         while (*reinterpret_cast<volatile unsigned*>(sync_cnt) < sync_epoch) __builtin_amdgcn_s_sleep(2);
@@ -148,7 +160,7 @@ __global__ __launch_bounds__(C2_THREADS, 2) void mlp_chain2_kernel(ChainArgs p, 
         if (4 * lane < kpad) {
             half4 hi, lo;
             split4(v, sc, hi, lo);
-            char* dst = blk + u * 512 + (((lane >> 1) ^ u) * 16) + (lane & 1) * 8;
+            char* dst = blk + u * 512 + (((lane >> 1) ^ ((wn * RB + u) & 15)) * 16) + (lane & 1) * 8;
             *reinterpret_cast<half4*>(dst) = hi;
             *reinterpret_cast<half4*>(dst + C2_LO) = lo;
         }
@@ -161,7 +173,7 @@ __global__ __launch_bounds__(C2_THREADS, 2) void mlp_chain2_kernel(ChainArgs p, 
         asm volatile("" : "+s"(m0));                // (keeps the row addresses out of registers that would live across the k-loop)
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            long m = m0 + wn * 16 + ub + q;
+            long m = m0 + wn * RB + ub + q;
             m = m < p.M ? m : p.M - 1;              // rows beyond M: the last row again
             const float* rowp = p.A0 + m * p.lda0;  // wave-uniform: scalar base + one lane offset
             v[q] = c < p.K0 ? *reinterpret_cast<const float4*>(rowp + c) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -172,15 +184,15 @@ __global__ __launch_bounds__(C2_THREADS, 2) void mlp_chain2_kernel(ChainArgs p, 
         const int c = 4 * lane;
         const int kpad = p.L[0].k1steps * 16;
 #pragma unroll 1
-        for (int ub = 0; ub < 16; ub += 8) {
+        for (int ub = 0; ub < RB; ub += 8) {
         float4 v[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = ub ? vb[q] : va[q];
+        for (int q = 0; q < 8; ++q) v[q] = (RB == 16 && ub) ? vb[q] : va[q];
         if (!DGRAD && p.in_norm_stats != nullptr) {
             // LayerNorm core in front of the run (FeedForward.innorm): the wave holds the whole row
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                const long mrow = m0 + wn * 16 + ub + q;
+                const long mrow = m0 + wn * RB + ub + q;
                 const int wdt = p.in_norm_width;
                 const bool i0 = c < wdt, i1 = c + 1 < wdt, i2 = c + 2 < wdt, i3 = c + 3 < wdt;
                 const float mean = wave_sum(((i0 ? v[q].x : 0.f) + (i1 ? v[q].y : 0.f)) + ((i2 ? v[q].z : 0.f) + (i3 ? v[q].w : 0.f))) / (float)wdt;
@@ -205,7 +217,7 @@ __global__ __launch_bounds__(C2_THREADS, 2) void mlp_chain2_kernel(ChainArgs p, 
             for (int q = 0; q < 4; ++q) smx[q] = last_lane(mx[q]);
             float mx4 = 0.f;
             put4(mx4, 0, smx[0], smx[1], smx[2], smx[3]);
-            if (p.rowmax0 && lane < 4 && m0 + wn * 16 + ub + h + lane < p.M) p.rowmax0[m0 + wn * 16 + ub + h + lane] = mx4;
+            if (p.rowmax0 && lane < 4 && m0 + wn * RB + ub + h + lane < p.M) p.rowmax0[m0 + wn * RB + ub + h + lane] = mx4;
             float inv[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -222,12 +234,15 @@ __global__ __launch_bounds__(C2_THREADS, 2) void mlp_chain2_kernel(ChainArgs p, 
     {
         float4 sa[8], sb[8];
         stage_load(tile * C2_ROWS, 0, sa);
-        stage_load(tile * C2_ROWS, 8, sb);
+        if constexpr (RB == 16) stage_load(tile * C2_ROWS, 8, sb);
         stage_rows(tile * C2_ROWS, sa, sb);
     }
 #pragma unroll
     for (int u = 0; u < WD - 1; ++u) load_w(0, u, wfh[u], wfl[u]);
     lds_barrier();                                  // planes ready (and the sync counters zeroed)
+#ifdef C2_G1PRIO
+    if (grp == 1) __builtin_amdgcn_s_setprio(C2_G1PRIO);
+#endif
 #ifndef C2_FREE
     if (grp == 1) lds_barrier();                    // group 1 runs half a period behind group 0
 #else
@@ -262,8 +277,8 @@ __global__ __launch_bounds__(C2_THREADS, 2) void mlp_chain2_kernel(ChainArgs p, 
                     const unsigned o = a_addr(ks);
 #pragma unroll
                     for (int i = 0; i < NI; ++i) {
-                        ah[i] = *reinterpret_cast<const half8*>(planes + i * 2 * C2_BLK_BYTES + o);
-                        al[i] = *reinterpret_cast<const half8*>(planes + i * 2 * C2_BLK_BYTES + o + C2_LO);
+                        ah[i] = *reinterpret_cast<const half8*>(planes + i * 32768 + o);
+                        al[i] = *reinterpret_cast<const half8*>(planes + i * 32768 + o + C2_LO);
                     }
                 };
                 auto mma_live = [&](const half8 (&qh)[NJ], const half8 (&ql)[NJ], const half8 (&ah)[NI], const half8 (&al)[NI]) {
@@ -331,8 +346,8 @@ __global__ __launch_bounds__(C2_THREADS, 2) void mlp_chain2_kernel(ChainArgs p, 
                             else nh[j] = *reinterpret_cast<const half8*>(wb_h[j] + (size_t)kw * 1024 + lane16);
                         } else if (q < 2 * NJ + 2 * NI) {
                             const int a = q - 2 * NJ, i = a >> 1;
-                            if (a & 1) yl[i] = *reinterpret_cast<const half8*>(planes + i * 2 * C2_BLK_BYTES + ao + C2_LO);
-                            else yh[i] = *reinterpret_cast<const half8*>(planes + i * 2 * C2_BLK_BYTES + ao);
+                            if (a & 1) yl[i] = *reinterpret_cast<const half8*>(planes + i * 32768 + ao + C2_LO);
+                            else yh[i] = *reinterpret_cast<const half8*>(planes + i * 32768 + ao);
                         }
                     };
                     int q = 0;
@@ -368,8 +383,10 @@ __global__ __launch_bounds__(C2_THREADS, 2) void mlp_chain2_kernel(ChainArgs p, 
 #ifdef C2_SETPRIO
                 __builtin_amdgcn_s_setprio(1);
 #endif
+#ifndef C2_NOK           // (timing experiment: the row phases alone)
                 if (live[NJ - 1]) k_loop_full();
                 else if (live[0]) k_loop(mma_live);
+#endif
 #ifdef C2_SETPRIO
                 __builtin_amdgcn_s_setprio(0);
 #endif
@@ -402,8 +419,9 @@ __global__ __launch_bounds__(C2_THREADS, 2) void mlp_chain2_kernel(ChainArgs p, 
                     if (!live[j]) continue;
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const unsigned c32 = (unsigned)((wn & 1) * 16 + j * 8 + 2 * g) + (unsigned)hh;
-                        *reinterpret_cast<float4*>(planes + i * 2 * C2_BLK_BYTES + d_base + ((c32 ^ d_x) * 16)) =
+                        const int c64 = 8 * (NJ * wn + j) + 2 * g;          // (+ hh: the chunk's lowest bit)
+                        const unsigned c32 = (unsigned)(c64 & 31) + (unsigned)hh;
+                        *reinterpret_cast<float4*>(planes + i * 32768 + d_base + (c64 >> 5) * C2_LO + ((c32 ^ d_x) * 16)) =
                             make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
                     }
                 }
@@ -424,17 +442,21 @@ __global__ __launch_bounds__(C2_THREADS, 2) void mlp_chain2_kernel(ChainArgs p, 
                 float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (!DGRAD && L.bias && c < N) b4 = *reinterpret_cast<const float4*>(L.bias + c);
                 const int kpad_next = more ? p.L[l + 1].k1steps * 16 : 0;
-                float* const crow = L.C + (m0 + wn * 16) * L.ldc;                       // row 16 wn (wave-uniform: scalar base + lane offset)
+                float* const crow = L.C + (m0 + wn * RB) * L.ldc;                       // row 16 wn (wave-uniform: scalar base + lane offset)
                 const long ldc = L.ldc;
                 // sign words: lane l keeps ITS 4 x 16 bits of the wave's 16 rows (two words: rows 0-7, rows 8-15; first value in
                 // the top bit), 512 contiguous bytes per wave and layer -- written by the forward run, read back by the
                 // data-gradient run, whose lanes hold the same columns of the same rows
-                unsigned* const sgn = L.sign_bits + ((m0 + wn * 16) >> 4) * 128 + 2 * lane;
+                unsigned* const sgn = L.sign_bits + ((m0 + wn * RB) / RB) * (RB * 8) + (RB / 8) * lane;
                 unsigned sw[2] = {0u, 0u};
-                if (DGRAD && rt_bits) { const uint2 w2 = *reinterpret_cast<const uint2*>(sgn); sw[0] = w2.x; sw[1] = w2.y; }
+                const bool blk_in = m0 + wn * RB < p.M;      // (blocks beyond M have no words: the area is chain_sign_rows(M) rows long)
+                if (DGRAD && rt_bits && blk_in) {
+                    if constexpr (RB == 16) { const uint2 w2 = *reinterpret_cast<const uint2*>(sgn); sw[0] = w2.x; sw[1] = w2.y; }
+                    else sw[0] = *sgn;
+                }
                 // the loads above are waited for HERE: a wait inside the batch loop would also wait for the row stores of the
                 // batch before it (loads and stores share vmcnt); the next tile's first input rows are requested behind them
-                if (next_tile) stage_load((tile + tstride) * C2_ROWS, 0, sa);
+                if (C2_EARLY_STAGE && next_tile) stage_load((tile + tstride) * C2_ROWS, 0, sa);
                 asm volatile("" : "+v"(b4.x), "+v"(b4.y), "+v"(b4.z), "+v"(b4.w), "+v"(sw[0]), "+v"(sw[1]));
                 auto rows = [&](auto cfg) {
                     using Cfg = decltype(cfg);
@@ -445,18 +467,20 @@ __global__ __launch_bounds__(C2_THREADS, 2) void mlp_chain2_kernel(ChainArgs p, 
                     const bool f_norm = Cfg::norm == 2 ? rt_norm : Cfg::norm == 1;
                     const bool f_full = Cfg::full == 2 ? rt_full : Cfg::full == 1;
                     const bool col_ok = f_full || c < N;
+                    unsigned sword = DGRAD ? sw[0] : 0u;            // (one word per eight rows)
 #pragma unroll 1
-                    for (int ub = 0; ub < 16; ub += 8) {            // eight rows in flight: two independent chains of four for the scheduler
-                        float4 r[8];
-                        unsigned sword = DGRAD ? (ub ? sw[1] : sw[0]) : 0u;
+                    for (int ub = 0; ub < RB; ub += RQ) {           // RQ rows in flight: independent chains of four for the scheduler
+                        float4 r[RQ];
+                        if (RB == 16 && ub == 8) { if (DGRAD) sword = sw[1]; else { sw[0] = sword; sword = 0u; } }
 #pragma unroll
-                        for (int q = 0; q < 8; ++q)
+                        for (int q = 0; q < RQ; ++q)
                             r[q] = *reinterpret_cast<const float4*>(blk + r_base + (ub + q) * 512 + ((r_chunk ^ (unsigned)((ub + q) & 7)) * 16));
-                        const float4 inv4a = *reinterpret_cast<const float4*>(inv_tab + ub), inv4b = *reinterpret_cast<const float4*>(inv_tab + ub + 4);
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the eight rows are in registers: their bytes may be overwritten
+                        const float4 inv4a = *reinterpret_cast<const float4*>(inv_tab + ub);
+                        const float4 inv4b = RQ == 8 ? *reinterpret_cast<const float4*>(inv_tab + ub + 4) : inv4a;
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the rows are in registers: their bytes may be overwritten
                         C2_STAMP2();
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) {
+                        for (int q = 0; q < RQ; ++q) {
                             const int u = ub + q;
                             const float4 iv = q < 4 ? inv4a : inv4b;
                             const float inv = (q & 3) == 0 ? iv.x : (q & 3) == 1 ? iv.y : (q & 3) == 2 ? iv.z : iv.w;
@@ -467,7 +491,7 @@ __global__ __launch_bounds__(C2_THREADS, 2) void mlp_chain2_kernel(ChainArgs p, 
                                     r[q].z = (int)(sword << 2) < 0 ? r[q].z : r[q].z * slope; r[q].w = (int)(sword << 3) < 0 ? r[q].w : r[q].w * slope;
                                     sword <<= 4;
                                 } else if (mask_rows) {
-                                    long row = m0 + wn * 16 + u;
+                                    long row = m0 + wn * RB + u;
                                     row = row < p.M ? row : p.M - 1;
                                     const float4 a4 = col_ok ? *reinterpret_cast<const float4*>(L.mask + row * L.ld_mask + c) : make_float4(0.f, 0.f, 0.f, 0.f);
                                     r[q].x *= a4.x > 0.f ? 1.f : slope; r[q].y *= a4.y > 0.f ? 1.f : slope;
@@ -485,7 +509,7 @@ __global__ __launch_bounds__(C2_THREADS, 2) void mlp_chain2_kernel(ChainArgs p, 
                             if (f_norm) {
                                 // LayerNorm core behind the run (FeedForward.outnorm, act = none): two-pass mean / unbiased std over the
                                 // row's N columns, wave reductions in a fixed order
-                                const long row = m0 + wn * 16 + u;
+                                const long row = m0 + wn * RB + u;
                                 const float mean = wave_sum((r[q].x + r[q].y) + (r[q].z + r[q].w)) / (float)N;
                                 float4 dl = col_ok ? make_float4(r[q].x - mean, r[q].y - mean, r[q].z - mean, r[q].w - mean) : make_float4(0.f, 0.f, 0.f, 0.f);
                                 const float sigma = sqrtf(wave_sum((dl.x * dl.x + dl.y * dl.y) + (dl.z * dl.z + dl.w * dl.w)) / (float)(N - 1));
@@ -493,17 +517,16 @@ __global__ __launch_bounds__(C2_THREADS, 2) void mlp_chain2_kernel(ChainArgs p, 
                                 r[q] = make_float4(dl.x * rinv, dl.y * rinv, dl.z * rinv, dl.w * rinv);
                                 if (lane == 0 && row < p.M) { p.norm_stats[row * 2] = rinv; p.norm_stats[row * 2 + 1] = sigma; }
                             }
-                            if (f_store && col_ok && (f_full || m0 + wn * 16 + u < p.M)) *reinterpret_cast<float4*>(crow + u * ldc + c) = r[q];
+                            if (f_store && col_ok && (f_full || m0 + wn * RB + u < p.M)) *reinterpret_cast<float4*>(crow + u * ldc + c) = r[q];
                             if (!DGRAD && f_bits) {
                                 sword = (sword << 1) | (r[q].x > 0.f ? 1u : 0u); sword = (sword << 1) | (r[q].y > 0.f ? 1u : 0u);
                                 sword = (sword << 1) | (r[q].z > 0.f ? 1u : 0u); sword = (sword << 1) | (r[q].w > 0.f ? 1u : 0u);
                             }
                         }
-                        if (!DGRAD && f_bits) { if (ub) sw[1] = sword; else sw[0] = sword; }
                         C2_STAMP2();
                         if (f_more || f_rmax) {
 #pragma unroll
-                            for (int h = 0; h < 8; h += 4) {
+                            for (int h = 0; h < RQ; h += 4) {
                                 float mx[4];
 #pragma unroll
                                 for (int q = 0; q < 4; ++q) mx[q] = fmaxf(fmaxf(fabsf(r[h + q].x), fabsf(r[h + q].y)), fmaxf(fabsf(r[h + q].z), fabsf(r[h + q].w)));
@@ -514,7 +537,7 @@ __global__ __launch_bounds__(C2_THREADS, 2) void mlp_chain2_kernel(ChainArgs p, 
                                 if (f_rmax) {
                                     float mx4 = 0.f;
                                     put4(mx4, 0, smx[0], smx[1], smx[2], smx[3]);
-                                    if (lane < 4 && (f_full || m0 + wn * 16 + ub + h + lane < p.M)) L.rowmax[m0 + wn * 16 + ub + h + lane] = mx4;
+                                    if (lane < 4 && (f_full || m0 + wn * RB + ub + h + lane < p.M)) L.rowmax[m0 + wn * RB + ub + h + lane] = mx4;
                                 }
                                 if (f_more) {
                                     float inv_n[4];
@@ -529,16 +552,23 @@ __global__ __launch_bounds__(C2_THREADS, 2) void mlp_chain2_kernel(ChainArgs p, 
                         }
                         C2_STAMP2();
                     }
-                    if (!DGRAD && f_bits) *reinterpret_cast<uint2*>(sgn) = make_uint2(sw[0], sw[1]);
+                    if (!DGRAD && f_bits && blk_in) {
+                        if constexpr (RB == 16) *reinterpret_cast<uint2*>(sgn) = make_uint2(sw[0], sword);
+                        else *sgn = sword;
+                    }
                 };
                 // hot combinations (everything 256 wide, tile inside M): training middle layer / inference middle layer / data-gradient
+#ifdef C2_NOROWS         // (timing experiment: the k-loops alone)
+                if (p.M < 0)
+#endif
                 if (!generic_only && rt_full && more && !rt_norm && !mask_rows && rt_store && rt_bits && rt_rmax) rows(RowCfg<1, 1, 1, 1, 0, 1>());
                 else if (!generic_only && !DGRAD && rt_full && more && !rt_norm && !rt_store && !rt_bits && !rt_rmax) rows(RowCfg<0, 0, 0, 1, 0, 1>());
                 else rows(RowCfg<2, 2, 2, 2, 2, 2>());
             }
             C2_STAMP();
             if (next_tile) {
-                stage_load((tile + tstride) * C2_ROWS, 8, sb);
+                if constexpr (!C2_EARLY_STAGE) stage_load((tile + tstride) * C2_ROWS, 0, sa);
+                if constexpr (RB == 16) stage_load((tile + tstride) * C2_ROWS, 8, sb);
                 stage_rows((tile + tstride) * C2_ROWS, sa, sb);
             }
             C2_STAMP();

@@ -1157,12 +1157,12 @@ __global__ __launch_bounds__(256) void act_grad_kernel(float* g, long ldg, const
 constexpr size_t TN_SLAB_BYTES = (size_t)TN_BATCH * TN_JOB_FLOATS * sizeof(float);      // partial tiles of a batch of weight-gradients
 
 extern "C" size_t papr_mlp_fwd_workspace_bytes(int64_t M) { return H3Scratch::bytes(M); }
-extern "C" size_t papr_mlp_saved_floats(int32_t n_layers, int64_t M) { return (size_t)n_layers * M * (1 + CHAIN_SIGN_WORDS); }
+extern "C" size_t papr_mlp_saved_floats(int32_t n_layers, int64_t M) { return (size_t)n_layers * (M + CHAIN_SIGN_WORDS * chain_sign_rows(M)); }
 
 // Layout of the `row_absmax` buffer of papr_mlp_fwd / papr_mlp_bwd (papr_mlp_saved_floats(n_layers, M) floats):
-// [n_layers][M] row maxima, then [n_layers][CHAIN_SIGN_WORDS][M] sign words of the layer outputs (fused runs, chain.h).
+// [n_layers][M] row maxima, then [n_layers][CHAIN_SIGN_WORDS][chain_sign_rows(M)] sign words of the layer outputs (fused runs, chain.h).
 static unsigned* saved_sign_words(const float* saved, int n_layers, long M, int layer) {
-    return reinterpret_cast<unsigned*>(const_cast<float*>(saved)) + (size_t)n_layers * M + (size_t)layer * CHAIN_SIGN_WORDS * M;
+    return reinterpret_cast<unsigned*>(const_cast<float*>(saved)) + (size_t)n_layers * M + (size_t)layer * CHAIN_SIGN_WORDS * chain_sign_rows(M);
 }
 
 // layer i runs on the split-f16 forward kernel (and so leaves the row maxima of its input behind)

@@ -9,7 +9,7 @@ objs=""
 for f in papr_amd/csrc/*.hip; do
     o=scripts/probes/bin/obj_$tag/$(basename $f .hip).o
     X=""
-    if [ "$(basename $f)" = "chain2.hip" ] && [ "$C2_SLP" != "1" ]; then X=-fno-slp-vectorize; fi
+    case "$(basename $f)" in chain2.hip) if [ "$C2_SLP" != "1" ]; then X=-fno-slp-vectorize; fi;; chain3.hip) X="-fno-slp-vectorize -mllvm -amdgpu-spill-vgpr-to-agpr=0";; esac
     /opt/rocm/bin/hipcc $FLAGS $X "$@" -c $f -o $o &
     objs="$objs $o"
 done
