@@ -479,6 +479,24 @@ __global__ __launch_bounds__(C3_THREADS, 2) void mlp_chain3_kernel(ChainArgs p, 
         }
     };
 
+    // ---- what the next row phases read from memory before they can start (this lane's bias values / sign word), requested a
+    // slot ahead: an L2 round trip at the top of every row phase was 5 % of the slot
+    float4 b4n = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned swn = 0u;
+    auto rows_prefetch = [&](long m0, int l) {
+        C3_LANE();
+        l = __builtin_amdgcn_readfirstlane(l);
+        const ChainLayer& L = p.L[l];
+        if (!DGRAD) {
+            b4n = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (L.bias && 4 * lane < L.N) b4n = *reinterpret_cast<const float4*>(L.bias + 4 * lane);
+        } else {
+            const int r0 = __builtin_amdgcn_readfirstlane((int)m0) + wn * RB;
+            swn = 0u;
+            if (L.sign_bits != nullptr && r0 < (int)p.M) swn = L.sign_bits[(long)(r0 / RB) * (RB * 8) + lane];
+        }
+    };
+
     // ---- row phases of layer l for the tile at rows m0 (dumped into `planes`): rows RB wn .. RB wn + 7, a whole row across the
     // wave, RQ rows at a time.  Straight-line code matters (chain2.hip): the hot flag combinations are instantiated with the
     // flags as constants, everything else takes the generic instantiation.
@@ -500,8 +518,7 @@ __global__ __launch_bounds__(C3_THREADS, 2) void mlp_chain3_kernel(ChainArgs p, 
         const bool rt_full = N == 256 && t0 + C3_ROWS <= M32;
         const bool mask_rows = DGRAD && !rt_bits && L.mask != nullptr;
         const bool blk_in = r0 < M32;                                           // this wave's block has rows inside M
-        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (!DGRAD && L.bias && c < N) b4 = *reinterpret_cast<const float4*>(L.bias + c);
+        float4 b4 = b4n;                            // (requested by rows_prefetch one slot ago)
         const int kpad_next = more ? p.L[l + 1].k1steps * 16 : 0;
         float* const crow = L.C + (long)r0 * L.ldc;                             // row RB wn (wave-uniform: scalar base + lane offset)
         const long ldc = L.ldc;
@@ -509,11 +526,12 @@ __global__ __launch_bounds__(C3_THREADS, 2) void mlp_chain3_kernel(ChainArgs p, 
         // wave and layer -- written by the forward run, read back by the data-gradient run, whose lanes hold the same columns
         // of the same rows
         unsigned* const sgn = L.sign_bits + (long)(r0 / RB) * (RB * 8) + lane;
-        unsigned sw = 0u;
-        if (DGRAD && rt_bits && blk_in) sw = *sgn;
-        // the loads above are waited for HERE: a wait inside the batch loop would also wait for the row stores of the
-        // batch before it (loads and stores share vmcnt)
+        unsigned sw = swn;
+        // they are waited for HERE: a wait inside the batch loop would also wait for the row stores of the batch before it (loads
+        // and stores share vmcnt)
         asm volatile("" : "+v"(b4.x), "+v"(b4.y), "+v"(b4.z), "+v"(b4.w), "+v"(sw));
+        float* rmax = L.rowmax;                     // (opaque copy: the compiler reloaded the pointer from the kernel arguments in
+        asm volatile("" : "+s"(rmax));              // every batch -- an s_load and a wait for everything the LDS still owes)
         const char* const blk = planes + wn * C3_BLK_BYTES + (lane >> 5) * C3_LO;
         float* const inv_w = inv_tab + wn * RB;
         auto rows = [&](auto cfg) {
@@ -583,7 +601,9 @@ __global__ __launch_bounds__(C3_THREADS, 2) void mlp_chain3_kernel(ChainArgs p, 
                     float mx[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) mx[q] = fmaxf(fmaxf(fabsf(r[q].x), fabsf(r[q].y)), fmaxf(fabsf(r[q].z), fabsf(r[q].w)));
+#ifndef C3_X_NOMAX                                  // (timing experiments: pieces of the row phases left out, results wrong)
                     wave_max4(mx[0], mx[1], mx[2], mx[3]);
+#endif
                     float smx[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) smx[q] = last_lane(mx[q]);
@@ -591,14 +611,18 @@ __global__ __launch_bounds__(C3_THREADS, 2) void mlp_chain3_kernel(ChainArgs p, 
                     if (f_rmax) {
                         float mx4 = 0.f;
                         put4(mx4, 0, smx[0], smx[1], smx[2], smx[3]);
-                        if (lane < 4 && (f_full || r0 + ub + lane < M32)) L.rowmax[r0 + ub + lane] = mx4;
+                        if (lane < 4 && (f_full || r0 + ub + lane < M32)) rmax[r0 + ub + lane] = mx4;
                     }
                     if (f_more) {
                         float inv_n[4];
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             const float sc = scale_from_max(__float_as_uint(smx[q]), inv_n[q]);
+#ifndef C3_X_NOSPLIT
                             write_planes(planes, wp, wq, ub + q, r[q], sc, Cfg::full == 1 || c < kpad_next);  // (full: N = 256 = the next layer's input width)
+#else
+                            asm volatile("" :: "s"(sc));
+#endif
                         }
                         *reinterpret_cast<float4*>(inv_w + ub) = make_float4(inv_n[0], inv_n[1], inv_n[2], inv_n[3]);
                     }
@@ -671,6 +695,17 @@ __global__ __launch_bounds__(C3_THREADS, 2) void mlp_chain3_kernel(ChainArgs p, 
         else k_run(kpl, l, ln);
 #endif
 #endif
+        {   // the row phases of the NEXT slot (the slot state advanced by one), or the ones behind the loop
+            int h2 = h + 1, l2 = l;
+            long pair2 = pair;
+            if (h2 == 2) { h2 = 0; if (++l2 == n_layers) { l2 = 0; pair2 += pstride; } }
+            const long nX = 2 * pair2 * C3_ROWS, nY = nX + C3_ROWS;
+            int npl; long npm0;
+            if (slot + 1 == n_slots) { npl = n_layers - 1; npm0 = mY; }
+            else if (h2 == 0) { if (l2 > 0) { npl = l2 - 1; npm0 = nY; } else { npl = n_layers - 1; npm0 = nY - 2 * pstride * C3_ROWS; } }
+            else { npl = l2; npm0 = nX; }
+            rows_prefetch(npm0, npl);
+        }
         C3_STAMP();
         lds_barrier();                              // the multiplied tile's planes are dead, the other tile's are written
         C3_STAMP();
