@@ -101,6 +101,13 @@ int papr_build_features_bwd_pairs(const papr_feature_desc* d, const float* point
  * caller (groups that straddle the kernel's fixed-size chunks are completed with atomic adds; the other rows
  * are overwritten); accumulate = 1: every sum is ADDED to what the outputs hold (a second pass: point features
  * that feed both the key and the value branch, use_ink + use_inv). */
+/* The grouping papr_segment_reduce consumes, from idx (M = R*k selected point per pair, 0 <= idx < P): order = the stable sort
+ * permutation of idx (pair ids ascending inside a group: torch.sort(idx, stable=True).indices), sorted_pts = idx[order],
+ * seg[p] = first entry of point p's group, seg[P] = M.  workspace: papr_group_pairs_workspace_bytes(M, P) bytes of device memory. */
+size_t papr_group_pairs_workspace_bytes(int64_t M, int64_t P);
+int papr_group_pairs(const int32_t* idx, int64_t M, int64_t P, int64_t* order, int32_t* sorted_pts, int64_t* seg,
+                     void* workspace, size_t workspace_bytes, papr_stream_t stream);
+
 int papr_segment_reduce(const int64_t* order, const int32_t* sorted_pts, const int64_t* seg, int64_t M, int64_t P,
                         const float* pair_points, const float* pair_influ, const float* rows, int ld, int col0,
                         int ncols, float* d_points, float* d_influ, float* d_feats, int accumulate, papr_stream_t stream);

@@ -383,6 +383,20 @@ def rownorm_bwd_(dy, y, stats, width, eps):
     return dy
 
 
+def group_pairs(flat_idx, P):
+    """(order int64, sorted_pts int32, seg int64[P+1]) of papr_group_pairs: the pairs grouped by selected point."""
+    M, dev = flat_idx.numel(), flat_idx.device
+    lib = hip.lib()
+    order = torch.empty(M, device=dev, dtype=torch.int64)
+    sorted_pts = torch.empty(M, device=dev, dtype=torch.int32)
+    seg = torch.empty(P + 1, device=dev, dtype=torch.int64)
+    nb = lib.papr_group_pairs_workspace_bytes(M, P)
+    ws = torch.empty(nb, device=dev, dtype=torch.uint8)
+    hip.check(lib.papr_group_pairs(hip.ptr(flat_idx), M, P, hip.ptr(order), hip.ptr(sorted_pts), hip.ptr(seg), hip.ptr(ws), nb, hip.stream_ptr()),
+              "papr_group_pairs")
+    return order, sorted_pts, seg
+
+
 def ray_knn(points, rays_o, rays_d, rays_per_image, k, eps, want_dist=False):
     """points (P,3), rays_o (N,3), rays_d (R,3) -> idx (R,k) int32 [, dist (R,k)]  (no gradient)."""
     R = rays_d.shape[0]
@@ -548,10 +562,7 @@ class _RenderFn(torch.autograd.Function):
         ctx.mark_non_differentiable(sel)
         if keep:
             # pairs grouped by selected point, for the atomic-free scatter of the per-point gradients
-            flat = idx.view(-1)
-            sorted_pts, order = torch.sort(flat, stable=True)
-            seg = torch.zeros(points.shape[0] + 1, device=dev, dtype=torch.int64)
-            torch.cumsum(torch.bincount(flat, minlength=points.shape[0]), 0, out=seg[1:])
+            order, sorted_pts, seg = group_pairs(idx.view(-1), points.shape[0])
             ctx.saved = dict(rays_o=rays_o, rays_d=rays_d, idx=idx, points=points, influ=influ, key_in=key_in, qry_in=qry_in,
                              val_in=val_in, kst=kst, qst=qst, kst2=kst2, qst2=qst2, k_outs=k_outs, q_outs=q_outs,
                              v_outs=v_outs, g=g, c0=c0, qp=qp, order=order, sorted_pts=sorted_pts, seg=seg, scores=scores, attn=attn, wb=wb, P=points.shape[0],

@@ -187,11 +187,29 @@ def test_features_backward_matches_autograd():
 
 
 def _segment_inputs(flat, P):
-    """What ops._RenderFn hands papr_segment_reduce: pairs grouped by point (stable), group bounds."""
-    sorted_pts, order = torch.sort(flat, stable=True)
-    seg = torch.zeros(P + 1, device=flat.device, dtype=torch.int64)
-    torch.cumsum(torch.bincount(flat, minlength=P), 0, out=seg[1:])
-    return order, sorted_pts, seg
+    """What ops._RenderFn hands papr_segment_reduce: pairs grouped by point (stable), group bounds (papr_group_pairs)."""
+    from papr_amd import ops
+    return ops.group_pairs(flat, P)
+
+
+@pytest.mark.parametrize("P,M,hot", [(30000, 512000, 0), (10000, 512000, 40000), (257, 1283, 0), (1, 77, 0), (5, 1, 0), (70000, 6, 0), (9, 0, 0)])
+def test_group_pairs_is_the_stable_sort_with_group_bounds(P, M, hot):
+    """papr_group_pairs (pairs.hip) against torch.sort(stable) + bincount + cumsum on the CPU, bit for bit: the permutation
+    (pair ids ascending inside a group), the sorted keys and the P + 1 bounds; full-size, one hot point, a single point, a
+    single pair, more points than pairs, no pairs."""
+    from papr_amd import ops
+    gen = torch.Generator().manual_seed(3 * P + M)
+    flat = torch.randint(0, P, (M,), generator=gen).int()
+    if hot:
+        flat[torch.randperm(M, generator=gen)[:hot]] = P // 2
+    want_pts, want_order = torch.sort(flat, stable=True)
+    want_seg = torch.zeros(P + 1, dtype=torch.int64)
+    torch.cumsum(torch.bincount(flat, minlength=P), 0, out=want_seg[1:])
+    order, sorted_pts, seg = ops.group_pairs(flat.to("cuda:0"), P)
+    torch.cuda.synchronize()
+    assert torch.equal(order.cpu(), want_order)
+    assert torch.equal(sorted_pts.cpu(), want_pts)
+    assert torch.equal(seg.cpu(), want_seg)
 
 
 @pytest.mark.parametrize("P,M,hot", [(30000, 200000, 0), (1000, 50000, 3000), (257, 1283, 0), (5, 128, 0), (3, 700, 650)])
