@@ -45,7 +45,7 @@ extern "C" size_t papr_group_pairs_workspace_bytes(int64_t M, int64_t P) {
 extern "C" int papr_group_pairs(const int32_t* idx, int64_t M, int64_t P, int64_t* order, int32_t* sorted_pts, int64_t* seg,
                                 void* workspace, size_t workspace_bytes, papr_stream_t stream) {
     PAPR_REQUIRE(P >= 1 && M >= 0, "papr_group_pairs: M = %ld pairs, P = %ld points", (long)M, (long)P);
-    PAPR_REQUIRE(idx && order && sorted_pts && seg, "papr_group_pairs: null pointer");
+    PAPR_REQUIRE(seg && (M == 0 || (idx && order && sorted_pts)), "papr_group_pairs: null pointer");
     hipStream_t s = as_stream(stream);
     if (M == 0) {
         PAPR_REQUIRE(hipMemsetAsync(seg, 0, (size_t)(P + 1) * sizeof(int64_t), s) == hipSuccess, "papr_group_pairs: memset failed");
