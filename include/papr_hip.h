@@ -101,6 +101,17 @@ int papr_build_features_bwd_pairs(const papr_feature_desc* d, const float* point
  * caller (groups that straddle the kernel's fixed-size chunks are completed with atomic adds; the other rows
  * are overwritten); accumulate = 1: every sum is ADDED to what the outputs hold (a second pass: point features
  * that feed both the key and the value branch, use_ink + use_inv). */
+/* ------------------------------------------------------------------------------------
+ * K6  point -> k nearest points of the cloud      replaces the two scipy KDTree queries of add_points_knn
+ *                                                  (models/utils.py:27-29 `tree.query(points, k=sample_k)`, :59 `tree.query(query, k=k+1)`).
+ * points (P,3); query_idx (Q) int32 indices into points, or NULL for Q = P "every point".  nn_idx (Q,k) int32 and nn_dist
+ * (Q,k) double (or NULL): Euclidean distances computed in double from the float32 coordinates like the KDTree does, ascending
+ * in (distance, point index) -- entry 0 is the query point itself (distance 0) unless the cloud holds a duplicate with a lower
+ * index.  Requires 1 <= k <= 16 and k <= P.
+ */
+int papr_points_knn(const float* points, int64_t P, const int32_t* query_idx, int64_t Q, int32_t k, int32_t* nn_idx,
+                    double* nn_dist, papr_stream_t stream);
+
 /* The grouping papr_segment_reduce consumes, from idx (M = R*k selected point per pair, 0 <= idx < P): order = the stable sort
  * permutation of idx (pair ids ascending inside a group: torch.sort(idx, stable=True).indices), sorted_pts = idx[order],
  * seg[p] = first entry of point p's group, seg[P] = M.  workspace: papr_group_pairs_workspace_bytes(M, P) bytes of device memory. */

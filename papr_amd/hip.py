@@ -13,12 +13,12 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PAPR_HIP_LIB", os.path.join(_PKG, "libpapr_hip.so"))   # override: instrumented builds (scripts/probes)
 
 ACT = {"none": 0, "relu": 1, "leakyrelu": 2}
-EXPECTED_ABI = 10          # papr_abi_version() of the library these argtypes were written for
+EXPECTED_ABI = 11          # papr_abi_version() of the library these argtypes were written for
 
 EXPORTS = [
     "papr_abi_version", "papr_last_error", "papr_ray_knn_workspace_bytes", "papr_ray_knn",
     "papr_feature_widths", "papr_build_features_fwd", "papr_build_features_bwd", "papr_build_features_bwd_pairs",
-    "papr_segment_reduce", "papr_group_pairs_workspace_bytes", "papr_group_pairs",
+    "papr_segment_reduce", "papr_group_pairs_workspace_bytes", "papr_group_pairs", "papr_points_knn",
     "papr_rownorm_fwd", "papr_rownorm_bwd", "papr_ln_fold_fwd", "papr_ln_fold_bwd", "papr_mlp_fwd_workspace_bytes", "papr_mlp_bwd_workspace_bytes", "papr_mlp_saved_floats", "papr_mlp_bwd_needs_weight_t", "papr_mlp_fwd",
     "papr_mlp_bwd",
     "papr_attn_tail_fwd", "papr_attn_tail_bwd", "papr_conv3x3_weight_halfs", "papr_conv3x3_workspace_bytes", "papr_conv3x3_fwd", "papr_conv3x3_wgrad_workspace_bytes", "papr_conv3x3_wgrad", "papr_profile_enable", "papr_profile_collect",
@@ -86,6 +86,7 @@ def lib():
     L.papr_group_pairs_workspace_bytes.argtypes = [i64, i64]
     L.papr_group_pairs_workspace_bytes.restype = C.c_size_t
     L.papr_group_pairs.argtypes = [vp, i64, i64, vp, vp, vp, vp, C.c_size_t, vp]
+    L.papr_points_knn.argtypes = [vp, i64, vp, i64, i32, vp, vp, vp]
     L.papr_rownorm_fwd.argtypes = [vp, i64, i32, i32, f32, vp, vp, vp]
     L.papr_rownorm_bwd.argtypes = [vp, vp, vp, i64, i32, i32, f32, vp, vp]
     L.papr_conv3x3_weight_halfs.restype = C.c_size_t

@@ -19,7 +19,7 @@ import torch.nn as nn
 from . import dist as pdist
 from .config import as_node
 from .ops import RenderPath, prepare_mlp_weights, render_rays
-from .pointcloud import grow_points
+from .pointcloud import grow_points, grow_points_device
 from .schedule import create_learning_rate_fn, fast_forward
 from .unet import get_generator
 
@@ -291,21 +291,24 @@ class PAPR(nn.Module):
         return n_drop
 
     def add_points(self, add_num):
-        pts = self.points.detach().cpu()
-        cur = pts.shape[0]
+        cur = self.points.shape[0]
         if "max_points" in self.args and self.args.max_points > 0 and (cur + add_num) >= self.args.max_points:
             add_num = self.args.max_points - cur
             if add_num <= 0:
                 return 0
-        feats = self.pc_feats.detach().cpu() if self.use_pc_feats else None
         g = self.args.geoms.points
-        new_pts, n_new, new_influ, new_feats = grow_points(pts, self.points_influ_scores.detach().cpu(), add_num=add_num, k=g.add_k,
-                                                           comb_type=g.add_type, sample_k=g.add_sample_k,
-                                                           sample_type=g.add_sample_type, feats=feats)
+        kw = dict(add_num=add_num, k=g.add_k, comb_type=g.add_type, sample_k=g.add_sample_k, sample_type=g.add_sample_type)
+        if self.points.is_cuda:     # the cloud stays on the device (papr_points_knn); the numpy draws are the host's
+            pts = self.points.detach()
+            new_pts, n_new, new_influ, new_feats = grow_points_device(pts, self.points_influ_scores, feats=self.pc_feats if self.use_pc_feats else None, **kw)
+        else:                       # a model on the CPU: the reference's own host procedure
+            pts = self.points.detach().cpu()
+            new_pts, n_new, new_influ, new_feats = grow_points(pts, self.points_influ_scores.detach().cpu(),
+                                                               feats=self.pc_feats.detach().cpu() if self.use_pc_feats else None, **kw)
         print("@@@@@@@@@  added {} points".format(n_new))
         if n_new > 0:
             dev = self.points.device
-            self._replace_points(torch.cat([pts, new_pts], dim=0),
+            self._replace_points(torch.cat([pts, new_pts.to(dev)], dim=0),
                                  torch.cat([self.points_influ_scores.data, new_influ.to(dev)], dim=0),
                                  torch.cat([self.pc_feats.data, new_feats.to(dev)], dim=0) if self.use_pc_feats else None)
             self._sync_points()

@@ -383,6 +383,17 @@ def rownorm_bwd_(dy, y, stats, width, eps):
     return dy
 
 
+def points_knn(points, k, query_idx=None, want_dist=True):
+    """points (P,3) float32 device tensor -> nn_idx (Q,k) int32 [, nn_dist (Q,k) float64] of papr_points_knn (Q = P without query_idx)."""
+    P, dev = points.shape[0], points.device
+    Q = P if query_idx is None else query_idx.numel()
+    nn_idx = torch.empty((Q, k), device=dev, dtype=torch.int32)
+    nn_dist = torch.empty((Q, k), device=dev, dtype=torch.float64) if want_dist else None
+    hip.check(hip.lib().papr_points_knn(hip.ptr(points), P, None if query_idx is None else hip.ptr(query_idx), Q, k, hip.ptr(nn_idx),
+                                        None if nn_dist is None else hip.ptr(nn_dist), hip.stream_ptr()), "papr_points_knn")
+    return (nn_idx, nn_dist) if want_dist else nn_idx
+
+
 def group_pairs(flat_idx, P):
     """(order int64, sorted_pts int32, seg int64[P+1]) of papr_group_pairs: the pairs grouped by selected point."""
     M, dev = flat_idx.numel(), flat_idx.device

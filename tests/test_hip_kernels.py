@@ -589,3 +589,47 @@ def test_mlp_generator_matches_torch(act, skips, hw):
         np.testing.assert_allclose(g.numpy(), r.numpy(), rtol=0, atol=3e-5 * (r.abs().max().item() + 1e-12))
     with torch.no_grad():                                   # inference route (nothing saved) gives the same numbers
         assert torch.equal(gen_d(xd.detach()), y.detach())
+
+
+@pytest.mark.parametrize("P,k", [(10000, 10), (3001, 4), (17, 16), (5, 5)])
+def test_points_knn_matches_kdtree(P, k):
+    """papr_points_knn (cloud.hip) against scipy's KDTree -- what add_points_knn queries (models/utils.py:27-29, 59): the same
+    neighbours in the same order and the same double-precision distances, for every point of the cloud and for a subset."""
+    from scipy.spatial import KDTree
+    from papr_amd import ops
+    gen = torch.Generator().manual_seed(P + k)
+    pts = (torch.rand(P, 3, generator=gen) * 2 - 1).float()
+    tree = KDTree(pts.numpy())
+    d, i = tree.query(pts.numpy(), k=k)
+    d, i = d.reshape(P, k), i.reshape(P, k)
+    nn_i, nn_d = ops.points_knn(pts.to("cuda:0"), k)
+    torch.cuda.synchronize()
+    assert np.array_equal(nn_i.cpu().numpy(), i)
+    np.testing.assert_allclose(nn_d.cpu().numpy(), d, rtol=1e-15, atol=0)
+    q = torch.randperm(P, generator=gen)[: max(1, P // 3)].int()
+    nn_i, nn_d = ops.points_knn(pts.to("cuda:0"), k, query_idx=q.to("cuda:0"))
+    torch.cuda.synchronize()
+    assert np.array_equal(nn_i.cpu().numpy(), i[q.long().numpy()])
+    np.testing.assert_allclose(nn_d.cpu().numpy(), d[q.long().numpy()], rtol=1e-15, atol=0)
+
+
+@pytest.mark.parametrize("comb,sample", [("random", "top-knn-std"), ("mean", "top-knn-max"), ("weighted", "random"), ("random-softmax", "influ-scores-max"),
+                                         ("duplicate", "top-knn-mean")])
+def test_grow_points_on_the_device_equals_the_host_procedure(comb, sample):
+    """pointcloud.grow_points_device (the cloud stays on the GPU; neighbour searches, ranking and blends on the device) against
+    pointcloud.grow_points (the reference's host procedure, models/utils.py:9-109, pinned by tests/test_host_model.py) under the
+    same numpy seed: the same sites, the same new points / influence scores / features."""
+    from papr_amd.pointcloud import grow_points, grow_points_device
+    gen = torch.Generator().manual_seed(11)
+    P, add, k = 4000, 300, 3
+    pts = (torch.rand(P, 3, generator=gen) * 2 - 1).float()
+    influ = torch.randn(P, 1, generator=gen)
+    feats = torch.randn(P, 64, generator=gen)
+    np.random.seed(5)
+    want = grow_points(pts, influ, add, k, comb_type=comb, sample_type=sample, sample_k=10, feats=feats)
+    np.random.seed(5)
+    got = grow_points_device(pts.to("cuda:0"), influ.to("cuda:0"), add, k, comb_type=comb, sample_type=sample, sample_k=10, feats=feats.to("cuda:0"))
+    torch.cuda.synchronize()
+    assert got[1] == want[1] == add
+    for g, w, name in ((got[0], want[0], "coords"), (got[2], want[2], "influ"), (got[3], want[3], "feats")):
+        np.testing.assert_allclose(g.cpu().numpy(), np.asarray(w), rtol=0, atol=2e-6, err_msg=name)
