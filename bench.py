@@ -15,6 +15,7 @@ The JSON line also carries
                 data-gradient), timed live with HIP events on the launch stream during the timed steps; `frac` counts the
                 three f16 MFMA products of every fp32 product as work, `frac_algorithmic` only the fp32 flops
   roofline_knn  the ray -> k-nearest-points kernel against its logical HBM byte count (north_star)
+  throughput_mode_h1   the same run in the reduced-precision mode of the fused MLP runs (a child process; never `value`)
   cpu_baseline  the CPU oracle's train step (torch fp32, same math) on this host's cores, on a
                 bounded sample (1,024 rays against the same 10,000-point cloud)
 """
@@ -42,9 +43,11 @@ def parse():
     ap.add_argument("--points", type=int, default=10000, help="point-cloud size (chair.yml: 10000 at init, <=30000 late)")
     ap.add_argument("--scene", default="nerfsyn/chair.yml")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gemm-mode", default="h3", choices=["f32", "fwd", "dgrad", "layers", "h3"],
+    ap.add_argument("--gemm-mode", default="h3", choices=["f32", "fwd", "dgrad", "layers", "h3", "h1"],
                     help="h3 (default): split-f16 MFMA everywhere, consecutive layers fused into one launch; layers: the same "
-                         "arithmetic, one launch per layer; dgrad: forward + data-gradient only; fwd: forward only; f32: fp32 MFMA everywhere")
+                         "arithmetic, one launch per layer; dgrad: forward + data-gradient only; fwd: forward only; f32: fp32 MFMA everywhere; "
+                         "h1: h3 with one f16 product per fp32 product in the fused runs (reduced precision, reported as throughput_mode_h1)")
+    ap.add_argument("--no-amp-line", action="store_true", help="skip the second measurement (throughput_mode_h1: a child process in --gemm-mode h1)")
     ap.add_argument("--cpu-rays", type=int, default=32, help="edge of the CPU-baseline patch (32 -> 1,024 rays)")
     ap.add_argument("--cpu-steps", type=int, default=8)
     ap.add_argument("--amp", action="store_true",
@@ -282,6 +285,22 @@ def main():
         for key in sorted(tab, key=lambda t: -tab[t][1]):
             n, ms = tab[key]
             print("kernel %2d  M=%-8d N=%-5d K=%-5d  %4d launches  %.3f ms each  %.3f ms/step" % (*key, n, ms / n, ms / args.steps), file=sys.stderr)
+    if args.gemm_mode == "h1":
+        out["dtype"] = "f32 rows, fused MLP runs multiply one f16 product per fp32 product (fp32 accumulate): the reduced-precision throughput mode"
+    if world == 1 and args.gemm_mode == "h3" and not args.no_amp_line:
+        # second line: the reduced-precision throughput mode (the library reads the mode when it loads: a child process)
+        import subprocess
+        cmd = [sys.executable, os.path.abspath(__file__), "--gemm-mode", "h1", "--no-cpu-baseline", "--steps", str(args.steps), "--warmup", str(args.warmup),
+               "--scene", args.scene, "--points", str(args.points)] + (["--amp"] if args.amp else [])
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        try:
+            j = json.loads(r.stdout.strip().splitlines()[-1])
+            out["throughput_mode_h1"] = {"value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "final_loss": j["config"]["final_loss"],
+                                         "note": "PAPR_GEMM_MODE=h1: one f16 product per fp32 product in the fused embedding-MLP runs (the counterpart of the reference's "
+                                                 "fp16 autocast of the attention block, models/attn.py:248); tolerance in tests/test_hip_h1.py; NOT the headline `value`",
+                                         "roofline_mlp_chain": j.get("roofline") if "mlp_chain" in (j.get("roofline") or {}).get("kernel", "") else j.get("roofline_mlp_chain")}
+        except Exception as e:      # the headline line must not depend on the second one
+            out["throughput_mode_h1"] = {"error": "%s: %s" % (type(e).__name__, (r.stderr or "")[-300:])}
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, init_state, args.cpu_rays, args.cpu_steps)
     print(json.dumps(out))

@@ -29,6 +29,7 @@ struct ChainArgs {
     float* rowmax0;                       // (M) receives max |.| of every input row, or null
     long M;
     int n_layers;
+    int one_product;                      // 1 (PAPR_GEMM_MODE=h1, chain3.hip only): one f16 product per fp32 product -- hi planes only
     int legacy;                           // 1: this MLP has a skip layer somewhere -- all its runs (forward and data-gradient) use chain.hip,
                                           // whose sign-word layout differs from chain2.hip's
     int in_norm_width;                    // forward: with in_norm_stats, the input rows are standardised over their first

@@ -84,9 +84,15 @@ __device__ long long g_chain3_trace[1024];      // 8 waves x 128 stamps
 #else
 #define C3_STAMP2() do {} while (0)
 #endif
+#ifdef PAPR_C3_TRACE_K                              // four more stamps inside k_run: entry, fragments landed, blocks issued, results out
+#define C3_STAMPK() do { asm volatile("" ::: "memory"); C3_STAMP(); } while (0)
+#else
+#define C3_STAMPK() do {} while (0)
+#endif
 #else
 #define C3_STAMP() do {} while (0)
 #define C3_STAMP2() do {} while (0)
+#define C3_STAMPK() do {} while (0)
 #endif
 
 __device__ __forceinline__ long uniform64(long v) {       // a wave-uniform value the compiler keeps in scalar registers and does not move out of loops
@@ -95,7 +101,9 @@ __device__ __forceinline__ long uniform64(long v) {       // a wave-uniform valu
     return (long)(((unsigned long)(unsigned)hi << 32) | (unsigned)lo);
 }
 
-template <bool DGRAD>
+// ONE: the reduced-precision mode (PAPR_GEMM_MODE=h1, the counterpart of the reference's fp16 autocast, models/attn.py:248): one
+// f16 product per fp32 product -- only the hi planes of weights and activations are loaded, multiplied and written.
+template <bool DGRAD, bool ONE>
 __global__ __launch_bounds__(C3_THREADS, 2) void mlp_chain3_kernel(ChainArgs p, int iters, int generic_only) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane0 = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -215,9 +223,15 @@ __global__ __launch_bounds__(C3_THREADS, 2) void mlp_chain3_kernel(ChainArgs p, 
 #define C3_OFF2 "2048"
 #define C3_OFF3 "3072"
 #define C3_WLOAD(ks, q, bh, bl)                                                                                                 \
-    asm volatile("global_load_dwordx4 " C3_CAT(C3_WH, ks) ", %0, %1 offset:" C3_CAT(C3_OFF, q) "\n\t"                              \
-                 "global_load_dwordx4 " C3_CAT(C3_WL, ks) ", %0, %2 offset:" C3_CAT(C3_OFF, q)                                       \
-                 : : "v"(w_lane), "s"((bh) + ((ks) >> 2) * 4096), "s"((bl) + ((ks) >> 2) * 4096) : C3_CAT(C3_WCLOB, ks), "memory")
+    do {                                                                                                                        \
+        if constexpr (ONE)                                                                                                      \
+            asm volatile("global_load_dwordx4 " C3_CAT(C3_WH, ks) ", %0, %1 offset:" C3_CAT(C3_OFF, q)                               \
+                         : : "v"(w_lane), "s"((bh) + ((ks) >> 2) * 4096) : C3_CAT(C3_CH, ks), "memory");                        \
+        else                                                                                                                    \
+            asm volatile("global_load_dwordx4 " C3_CAT(C3_WH, ks) ", %0, %1 offset:" C3_CAT(C3_OFF, q) "\n\t"                      \
+                         "global_load_dwordx4 " C3_CAT(C3_WL, ks) ", %0, %2 offset:" C3_CAT(C3_OFF, q)                               \
+                         : : "v"(w_lane), "s"((bh) + ((ks) >> 2) * 4096), "s"((bl) + ((ks) >> 2) * 4096) : C3_CAT(C3_WCLOB, ks), "memory"); \
+    } while (0)
 #define C3_WLOAD_IF(ks, q, n, bh, bl) if ((ks) < (n)) C3_WLOAD(ks, q, bh, bl)
 #define C3_WLOAD_ALL(n, bh, bl)                                                                                                 \
     C3_WLOAD_IF(0, 0, n, bh, bl); C3_WLOAD_IF(1, 1, n, bh, bl); C3_WLOAD_IF(2, 2, n, bh, bl); C3_WLOAD_IF(3, 3, n, bh, bl);     \
@@ -244,8 +258,73 @@ __global__ __launch_bounds__(C3_THREADS, 2) void mlp_chain3_kernel(ChainArgs p, 
         const unsigned ab = (unsigned)((arow / RB) * C3_BLK_BYTES + (arow % RB) * 512 + (((lane >> 5) ^ (ax & 1)) * 16));
         const unsigned axr = (unsigned)((ax & ~1) * 16);
         const unsigned w_lane = (unsigned)lane * 16u;   // (weight loads: a wave-uniform base + this lane offset)
+        C3_STAMPK();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this layer's fragments (requested a slot ago) have landed
-        if (live && ksteps == KS) {
+        C3_STAMPK();
+        if (ONE && live && ksteps == KS) {
+            // ---- the hot form of the one-product mode: two matrix instructions per k-step (hi . hi for both row tiles), the hi
+            // fragments of k-step ks + 2 read into their registers behind their use, the weight fragment refilled behind its second use
+            const unsigned pb = (unsigned)(size_t)planes + ab;
+            half8 fo[2][2];                         // [buffer][hi0, hi1]
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:32768" : "=v"(fo[0][0]), "=v"(fo[0][1]) : "v"(pb + axr));
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:32768\n\ts_nop 1" : "=v"(fo[1][0]), "=v"(fo[1][1]) : "v"(pb + (32u ^ axr)));
+#define C3_MF(acc, w, x) "v_mfma_f32_32x32x16_f16 %[" acc "], " w ", %[" x "], %[" acc "]\n\t"
+#define C3_RD(dst, off) "ds_read_b128 %[" dst "], %[ad] offset:" off "\n\t"
+#define C3_WT(n) "s_waitcnt lgkmcnt(" n ")\n\t"
+#define C3_CLOB(...) __VA_ARGS__, "memory"
+#define C3_NOCLOB "memory"
+#define C3_LDH(ks, q) "global_load_dwordx4 " C3_CAT(C3_WH, ks) ", %[wv], %[bh] offset:" C3_CAT(C3_OFF, q) "\n\t"
+#define C3_OBLOCK(ks, n7, o0, o1, ld, clob)                                                                                     \
+            asm volatile(C3_WT("3") C3_MF("a0", C3_CAT(C3_WH, ks), "h0") C3_RD("h0", o0) C3_WT("3") C3_MF("a1", C3_CAT(C3_WH, ks), "h1") C3_RD("h1", o1) ld \
+                         : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [h0] "+v"(fo[(ks) & 1][0]), [h1] "+v"(fo[(ks) & 1][1])           \
+                         : [ad] "v"(pb + (((unsigned)(n7) * 32u) ^ axr)), [wv] "v"(w_lane), [bh] "s"(nh + ((ks) >> 2) * 4096) : clob)
+#define C3_OTAIL(ks, w0, w1, ld, clob)                                                                                          \
+            asm volatile(C3_WT(w0) C3_MF("a0", C3_CAT(C3_WH, ks), "h0") C3_WT(w1) C3_MF("a1", C3_CAT(C3_WH, ks), "h1") ld             \
+                         : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]) : [h0] "v"(fo[(ks) & 1][0]), [h1] "v"(fo[(ks) & 1][1]),           \
+                           [wv] "v"(w_lane), [bh] "s"(nh + ((ks) >> 2) * 4096) : clob)
+            if (nks == KS) {
+                C3_OBLOCK(0, 2, "0", "32768", C3_LDH(0, 0), C3_CLOB(C3_CH0));
+                C3_OBLOCK(1, 3, "0", "32768", C3_LDH(1, 1), C3_CLOB(C3_CH1));
+                C3_OBLOCK(2, 4, "0", "32768", C3_LDH(2, 2), C3_CLOB(C3_CH2));
+                C3_OBLOCK(3, 5, "0", "32768", C3_LDH(3, 3), C3_CLOB(C3_CH3));
+                C3_OBLOCK(4, 6, "0", "32768", C3_LDH(4, 0), C3_CLOB(C3_CH4));
+                C3_OBLOCK(5, 7, "0", "32768", C3_LDH(5, 1), C3_CLOB(C3_CH5));
+                C3_OBLOCK(6, 0, "256", "33024", C3_LDH(6, 2), C3_CLOB(C3_CH6));
+                C3_OBLOCK(7, 1, "256", "33024", C3_LDH(7, 3), C3_CLOB(C3_CH7));
+                C3_OBLOCK(8, 2, "256", "33024", C3_LDH(8, 0), C3_CLOB(C3_CH8));
+                C3_OBLOCK(9, 3, "256", "33024", C3_LDH(9, 1), C3_CLOB(C3_CH9));
+                C3_OBLOCK(10, 4, "256", "33024", C3_LDH(10, 2), C3_CLOB(C3_CH10));
+                C3_OBLOCK(11, 5, "256", "33024", C3_LDH(11, 3), C3_CLOB(C3_CH11));
+                C3_OBLOCK(12, 6, "256", "33024", C3_LDH(12, 0), C3_CLOB(C3_CH12));
+                C3_OBLOCK(13, 7, "256", "33024", C3_LDH(13, 1), C3_CLOB(C3_CH13));
+                C3_OTAIL(14, "3", "2", C3_LDH(14, 2), C3_CLOB(C3_CH14));
+                C3_OTAIL(15, "1", "0", C3_LDH(15, 3), C3_CLOB(C3_CH15));
+            } else {
+                C3_OBLOCK(0, 2, "0", "32768", "", C3_NOCLOB);
+                C3_OBLOCK(1, 3, "0", "32768", "", C3_NOCLOB);
+                C3_OBLOCK(2, 4, "0", "32768", "", C3_NOCLOB);
+                C3_OBLOCK(3, 5, "0", "32768", "", C3_NOCLOB);
+                C3_OBLOCK(4, 6, "0", "32768", "", C3_NOCLOB);
+                C3_OBLOCK(5, 7, "0", "32768", "", C3_NOCLOB);
+                C3_OBLOCK(6, 0, "256", "33024", "", C3_NOCLOB);
+                C3_OBLOCK(7, 1, "256", "33024", "", C3_NOCLOB);
+                C3_OBLOCK(8, 2, "256", "33024", "", C3_NOCLOB);
+                C3_OBLOCK(9, 3, "256", "33024", "", C3_NOCLOB);
+                C3_OBLOCK(10, 4, "256", "33024", "", C3_NOCLOB);
+                C3_OBLOCK(11, 5, "256", "33024", "", C3_NOCLOB);
+                C3_OBLOCK(12, 6, "256", "33024", "", C3_NOCLOB);
+                C3_OBLOCK(13, 7, "256", "33024", "", C3_NOCLOB);
+                C3_OTAIL(14, "3", "2", "", C3_NOCLOB);
+                C3_OTAIL(15, "1", "0", "", C3_NOCLOB);
+                C3_WLOAD_ALL(nks, nh, nl);
+            }
+#undef C3_MF
+#undef C3_RD
+#undef C3_WT
+#undef C3_CLOB
+#undef C3_NOCLOB
+#undef C3_LDH
+        } else if (!ONE && live && ksteps == KS) {
             // ---- the hot form (256-wide input).  One wave keeps the matrix pipe busy only if its matrix instructions issue back to
             // back (scripts/probes/mfma_chain_rate.hip: 33 cycles per instruction; with the four A-fragment reads of the next
             // k-step in a bunch between the blocks: 52): every gap between two of them holds exactly one memory instruction --
@@ -332,7 +411,7 @@ __global__ __launch_bounds__(C3_THREADS, 2) void mlp_chain3_kernel(ChainArgs p, 
 #pragma unroll
                 for (int i = 0; i < NI; ++i) {
                     qh[i] = *reinterpret_cast<const half8*>(planes + i * 32768 + o);
-                    ql[i] = *reinterpret_cast<const half8*>(planes + i * 32768 + o + C3_LO);
+                    if constexpr (!ONE) ql[i] = *reinterpret_cast<const half8*>(planes + i * 32768 + o + C3_LO);
                 }
             };
             if (live) load_a(0, ah[0], al[0]);
@@ -341,6 +420,10 @@ __global__ __launch_bounds__(C3_THREADS, 2) void mlp_chain3_kernel(ChainArgs p, 
 #define C3_KSTEP(ks, q)                                                                                                         \
             if (live && (ks) < ksteps) {                                                                                        \
                 load_a((ks) + 1, ah[((ks) + 1) & 1], al[((ks) + 1) & 1]);                                                       \
+                if constexpr (ONE)                                                                                              \
+                    asm volatile("v_mfma_f32_32x32x16_f16 %0, " C3_CAT(C3_WH, ks) ", %2, %0\n\tv_mfma_f32_32x32x16_f16 %1, " C3_CAT(C3_WH, ks) ", %3, %1" \
+                                 : "+v"(acc[0]), "+v"(acc[1]) : "v"(ah[(ks) & 1][0]), "v"(ah[(ks) & 1][1]));                    \
+                else                                                                                                            \
                 asm volatile("v_mfma_f32_32x32x16_f16 %0, " C3_CAT(C3_WH, ks) ", %4, %0\n\tv_mfma_f32_32x32x16_f16 %1, " C3_CAT(C3_WH, ks) ", %5, %1\n\t" \
                              "v_mfma_f32_32x32x16_f16 %0, " C3_CAT(C3_WL, ks) ", %2, %0\n\tv_mfma_f32_32x32x16_f16 %1, " C3_CAT(C3_WL, ks) ", %3, %1\n\t" \
                              "v_mfma_f32_32x32x16_f16 %0, " C3_CAT(C3_WH, ks) ", %2, %0\n\tv_mfma_f32_32x32x16_f16 %1, " C3_CAT(C3_WH, ks) ", %3, %1"       \
@@ -353,8 +436,10 @@ __global__ __launch_bounds__(C3_THREADS, 2) void mlp_chain3_kernel(ChainArgs p, 
             C3_KSTEP(8, 0); C3_KSTEP(9, 1); C3_KSTEP(10, 2); C3_KSTEP(11, 3); C3_KSTEP(12, 0); C3_KSTEP(13, 1); C3_KSTEP(14, 2); C3_KSTEP(15, 3);
 #undef C3_KSTEP
         }
+        C3_STAMPK();
         // the last results leave the matrix pipe 16 passes after issue; hipcc does not count wait states behind inline asm
         asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]));
+        C3_STAMPK();
     };
 
     // ---- a multiply-first wave carries its accumulators through its row phases: 32 registers next to the 128 of the weights
@@ -411,11 +496,20 @@ __global__ __launch_bounds__(C3_THREADS, 2) void mlp_chain3_kernel(ChainArgs p, 
     // rows interleave)
     auto write_planes = [&](char* planes, unsigned wp, unsigned wq, int u, const float4& v, float sc, bool in_k) {
         if (in_k) {
-            half4 hi, lo;
-            split4(v, sc, hi, lo);
             char* dst = planes + wn * C3_BLK_BYTES + u * 512 + (wp ^ (unsigned)(((wn * RB + u) & 15) * 16)) + wq;
-            *reinterpret_cast<half4*>(dst) = hi;
-            *reinterpret_cast<half4*>(dst + C3_LO) = lo;
+            if constexpr (ONE) {                    // hi = f16(v * s) only
+                unsigned h01, h23;
+                asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h01) : "v"(v.x), "v"(sc));
+                asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h23) : "v"(v.z), "v"(sc));
+                asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h01) : "v"(v.y), "v"(sc));
+                asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h23) : "v"(v.w), "v"(sc));
+                *reinterpret_cast<uint2*>(dst) = make_uint2(h01, h23);
+            } else {
+                half4 hi, lo;
+                split4(v, sc, hi, lo);
+                *reinterpret_cast<half4*>(dst) = hi;
+                *reinterpret_cast<half4*>(dst + C3_LO) = lo;
+            }
         }
     };
 
@@ -739,8 +833,10 @@ int papr_launch_chain3(const ChainArgs& a, bool dgrad, long long bytes, long lon
     if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu <= 0) n_cu = 256; }
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_chain3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C3_LDS_BYTES);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_chain3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C3_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_chain3_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C3_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_chain3_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C3_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_chain3_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C3_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_chain3_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C3_LDS_BYTES);
         attr_set = true;
     }
     const long pairs = (tiles + 1) / 2;             // a workgroup carries two tiles at a time
@@ -749,8 +845,14 @@ int papr_launch_chain3(const ChainArgs& a, bool dgrad, long long bytes, long lon
     const bool prof = papr_prof_on();
     if (prof) papr_prof_begin2(dgrad ? 10 : 9, a.M, a.n_layers, a.K0, bytes, flops, s);
     static const int generic_only = getenv("PAPR_C2_GENERIC") ? atoi(getenv("PAPR_C2_GENERIC")) : 0;      // (test switch: the hot instantiations off)
-    if (dgrad) mlp_chain3_kernel<true><<<dim3(grid), dim3(C3_THREADS), C3_LDS_BYTES, s>>>(a, iters, generic_only == 1 || generic_only == 3);
-    else mlp_chain3_kernel<false><<<dim3(grid), dim3(C3_THREADS), C3_LDS_BYTES, s>>>(a, iters, generic_only == 1 || generic_only == 2);
+    const int g_d = generic_only == 1 || generic_only == 3, g_f = generic_only == 1 || generic_only == 2;
+    if (a.one_product) {
+        if (dgrad) mlp_chain3_kernel<true, true><<<dim3(grid), dim3(C3_THREADS), C3_LDS_BYTES, s>>>(a, iters, g_d);
+        else mlp_chain3_kernel<false, true><<<dim3(grid), dim3(C3_THREADS), C3_LDS_BYTES, s>>>(a, iters, g_f);
+    } else {
+        if (dgrad) mlp_chain3_kernel<true, false><<<dim3(grid), dim3(C3_THREADS), C3_LDS_BYTES, s>>>(a, iters, g_d);
+        else mlp_chain3_kernel<false, false><<<dim3(grid), dim3(C3_THREADS), C3_LDS_BYTES, s>>>(a, iters, g_f);
+    }
     if (prof) papr_prof_end(s);
     PAPR_CHECK_LAUNCH("mlp_chain3");
     return 0;

@@ -516,6 +516,7 @@ static const int NT_VARIANT = getenv("PAPR_NT_VARIANT") ? atoi(getenv("PAPR_NT_V
 //   dgrad: forward layers and data-gradients.
 //   fwd  : forward layers only.
 //   f32  : every GEMM on v_mfma_f32_32x32x2_f32.
+//   h1   : see GEMM_ONE_PRODUCT below.
 // All three pass the same parity suite (RGB / fused / attention within 1e-4 of the reference, gradients
 // within 2e-3, bitwise chunk invariance, reference loss trajectory within 5e-6).  The one measurable
 // difference: after the reference's three Adam steps the point positions agree to 5e-5 in f32 mode and to
@@ -526,8 +527,12 @@ static const int GEMM_MODE = [] {
     if (e && !strcmp(e, "fwd")) return 1;
     if (e && !strcmp(e, "dgrad")) return 2;
     if (e && !strcmp(e, "layers")) return 3;
+    if (e && !strcmp(e, "h1")) return 5;
     return 4;
 }();
+// h1: h3, and the fused runs (chain3.hip) multiply one f16 product per fp32 product: the throughput mode that stands for the
+// reference's fp16 autocast of the attention block (models/attn.py:248, `use_amp: true`); own tolerance in the tests.
+static const bool GEMM_ONE_PRODUCT = GEMM_MODE == 5;
 static const bool GEMM_H3_FWD = GEMM_MODE >= 1, GEMM_H3 = GEMM_MODE >= 2, GEMM_H3_WGRAD = GEMM_MODE >= 3, GEMM_CHAIN = GEMM_MODE >= 4;
 
 // Caller-provided scratch of the split-f16 mode, carved from the workspace argument of papr_mlp_fwd / _bwd:
@@ -1265,6 +1270,7 @@ extern "C" int papr_mlp_fwd(const papr_layer* layers, int n_layers, float* x, in
             c.rowmax0 = saved ? saved + (size_t)i * M : nullptr;
             c.M = M; c.n_layers = e - i;
             for (int l = 0; l < n_layers; ++l) c.legacy |= layers[l].n_skip > 0 ? 1 : 0;      // (sign-word layout: chain.h)
+            c.one_product = GEMM_ONE_PRODUCT ? 1 : 0;
             size_t used = 0;
             SplitBatch split = {};
             long long bytes = 4LL * M * L.n_in, flops = 0;
@@ -1431,7 +1437,7 @@ extern "C" int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float*
             const int last = b == 0 ? (to_dx ? 0 : 1) : b;       // lowest layer whose data-gradient the launch computes
             ChainArgs c = {};
             c.A0 = g; c.lda0 = ldg; c.K0 = L.n_out; c.rowmax0 = runs.gmax[CHAIN_MAX_LAYERS];
-            c.M = M; c.legacy = any_skip ? 1 : 0;
+            c.M = M; c.legacy = any_skip ? 1 : 0; c.one_product = GEMM_ONE_PRODUCT ? 1 : 0;
             size_t used = 0;
             SplitBatch split = {};
             long long bytes = 4LL * M * L.n_out, flops = 0;
