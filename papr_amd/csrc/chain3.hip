@@ -29,6 +29,7 @@
 #include "papr_common.h"
 #include "h3_common.h"
 #include "chain.h"
+#include "chain3_kloop.inc"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -261,147 +262,35 @@ __global__ __launch_bounds__(C3_THREADS, 2) void mlp_chain3_kernel(ChainArgs p, 
         C3_STAMPK();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this layer's fragments (requested a slot ago) have landed
         C3_STAMPK();
-        if (ONE && live && ksteps == KS) {
-            // ---- the hot form of the one-product mode: two matrix instructions per k-step (hi . hi for both row tiles), the hi
-            // fragments of k-step ks + 2 read into their registers behind their use, the weight fragment refilled behind its second use
+        if (live && ksteps == KS) {
+            // ---- the hot form (256-wide input): ONE asm statement for the whole k-loop (chain3_kloop.inc, generated by
+            // scripts/gen_chain3_kloop.py; the why is in that script).  One wave keeps the matrix pipe busy only if its matrix
+            // instructions issue back to back (scripts/probes/mfma_chain_rate.hip: 33.5 cycles per instruction; with the four
+            // A-fragment reads of the next k-step in a bunch between the blocks: 52; one per gap with hand-counted waits: 35.2,
+            // mfma_block_pattern.hip): every gap between two of them holds exactly one memory instruction -- the four LDS reads
+            // of k-step ks + 2's fragments, IN PLACE behind the last use of each register (10-12 matrix instructions of lead with
+            // two buffers: an LDS round trip beside seven other busy waves is longer than one block), and the two weight loads that
+            // refill the k-step's registers with the next layer's fragment behind their last use.
             const unsigned pb = (unsigned)(size_t)planes + ab;
-            half8 fo[2][2];                         // [buffer][hi0, hi1]
-            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:32768" : "=v"(fo[0][0]), "=v"(fo[0][1]) : "v"(pb + axr));
-            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:32768\n\ts_nop 1" : "=v"(fo[1][0]), "=v"(fo[1][1]) : "v"(pb + (32u ^ axr)));
-#define C3_MF(acc, w, x) "v_mfma_f32_32x32x16_f16 %[" acc "], " w ", %[" x "], %[" acc "]\n\t"
-#define C3_RD(dst, off) "ds_read_b128 %[" dst "], %[ad] offset:" off "\n\t"
-#define C3_WT(n) "s_waitcnt lgkmcnt(" n ")\n\t"
-#define C3_CLOB(...) __VA_ARGS__, "memory"
-#define C3_NOCLOB "memory"
-#define C3_LDH(ks, q) "global_load_dwordx4 " C3_CAT(C3_WH, ks) ", %[wv], %[bh] offset:" C3_CAT(C3_OFF, q) "\n\t"
-#define C3_OBLOCK(ks, n7, o0, o1, ld, clob)                                                                                     \
-            asm volatile(C3_WT("3") C3_MF("a0", C3_CAT(C3_WH, ks), "h0") C3_RD("h0", o0) C3_WT("3") C3_MF("a1", C3_CAT(C3_WH, ks), "h1") C3_RD("h1", o1) ld \
-                         : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [h0] "+v"(fo[(ks) & 1][0]), [h1] "+v"(fo[(ks) & 1][1])           \
-                         : [ad] "v"(pb + (((unsigned)(n7) * 32u) ^ axr)), [wv] "v"(w_lane), [bh] "s"(nh + ((ks) >> 2) * 4096) : clob)
-#define C3_OTAIL(ks, w0, w1, ld, clob)                                                                                          \
-            asm volatile(C3_WT(w0) C3_MF("a0", C3_CAT(C3_WH, ks), "h0") C3_WT(w1) C3_MF("a1", C3_CAT(C3_WH, ks), "h1") ld             \
-                         : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]) : [h0] "v"(fo[(ks) & 1][0]), [h1] "v"(fo[(ks) & 1][1]),           \
-                           [wv] "v"(w_lane), [bh] "s"(nh + ((ks) >> 2) * 4096) : clob)
+            unsigned ad[8];                         // LDS address of k-step j's fragments (k-step j + 8: + 256)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ad[j] = pb + (((unsigned)j * 32u) ^ axr);
+            half8 f00, f01, f02, f03, f10, f11, f12, f13;       // fragment buffers (asm temporaries)
+#define C3_KLOOP_OPERANDS                                                                                                       \
+            [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [f00] "=&v"(f00), [f01] "=&v"(f01), [f02] "=&v"(f02), [f03] "=&v"(f03),         \
+            [f10] "=&v"(f10), [f11] "=&v"(f11), [f12] "=&v"(f12), [f13] "=&v"(f13)                                              \
+            : [ad0] "v"(ad[0]), [ad1] "v"(ad[1]), [ad2] "v"(ad[2]), [ad3] "v"(ad[3]), [ad4] "v"(ad[4]), [ad5] "v"(ad[5]),       \
+              [ad6] "v"(ad[6]), [ad7] "v"(ad[7]), [wv] "v"(w_lane), [bh0] "s"(nh), [bh1] "s"(nh + 4096), [bh2] "s"(nh + 8192),  \
+              [bh3] "s"(nh + 12288), [bl0] "s"(nl), [bl1] "s"(nl + 4096), [bl2] "s"(nl + 8192), [bl3] "s"(nl + 12288)
             if (nks == KS) {
-                C3_OBLOCK(0, 2, "0", "32768", C3_LDH(0, 0), C3_CLOB(C3_CH0));
-                C3_OBLOCK(1, 3, "0", "32768", C3_LDH(1, 1), C3_CLOB(C3_CH1));
-                C3_OBLOCK(2, 4, "0", "32768", C3_LDH(2, 2), C3_CLOB(C3_CH2));
-                C3_OBLOCK(3, 5, "0", "32768", C3_LDH(3, 3), C3_CLOB(C3_CH3));
-                C3_OBLOCK(4, 6, "0", "32768", C3_LDH(4, 0), C3_CLOB(C3_CH4));
-                C3_OBLOCK(5, 7, "0", "32768", C3_LDH(5, 1), C3_CLOB(C3_CH5));
-                C3_OBLOCK(6, 0, "256", "33024", C3_LDH(6, 2), C3_CLOB(C3_CH6));
-                C3_OBLOCK(7, 1, "256", "33024", C3_LDH(7, 3), C3_CLOB(C3_CH7));
-                C3_OBLOCK(8, 2, "256", "33024", C3_LDH(8, 0), C3_CLOB(C3_CH8));
-                C3_OBLOCK(9, 3, "256", "33024", C3_LDH(9, 1), C3_CLOB(C3_CH9));
-                C3_OBLOCK(10, 4, "256", "33024", C3_LDH(10, 2), C3_CLOB(C3_CH10));
-                C3_OBLOCK(11, 5, "256", "33024", C3_LDH(11, 3), C3_CLOB(C3_CH11));
-                C3_OBLOCK(12, 6, "256", "33024", C3_LDH(12, 0), C3_CLOB(C3_CH12));
-                C3_OBLOCK(13, 7, "256", "33024", C3_LDH(13, 1), C3_CLOB(C3_CH13));
-                C3_OTAIL(14, "3", "2", C3_LDH(14, 2), C3_CLOB(C3_CH14));
-                C3_OTAIL(15, "1", "0", C3_LDH(15, 3), C3_CLOB(C3_CH15));
+                if constexpr (ONE) asm volatile(C3_KLOOP1_LD : C3_KLOOP_OPERANDS : C3_KLOOP_AGPRS, "memory");
+                else asm volatile(C3_KLOOP3_LD : C3_KLOOP_OPERANDS : C3_KLOOP_AGPRS, "memory");
             } else {
-                C3_OBLOCK(0, 2, "0", "32768", "", C3_NOCLOB);
-                C3_OBLOCK(1, 3, "0", "32768", "", C3_NOCLOB);
-                C3_OBLOCK(2, 4, "0", "32768", "", C3_NOCLOB);
-                C3_OBLOCK(3, 5, "0", "32768", "", C3_NOCLOB);
-                C3_OBLOCK(4, 6, "0", "32768", "", C3_NOCLOB);
-                C3_OBLOCK(5, 7, "0", "32768", "", C3_NOCLOB);
-                C3_OBLOCK(6, 0, "256", "33024", "", C3_NOCLOB);
-                C3_OBLOCK(7, 1, "256", "33024", "", C3_NOCLOB);
-                C3_OBLOCK(8, 2, "256", "33024", "", C3_NOCLOB);
-                C3_OBLOCK(9, 3, "256", "33024", "", C3_NOCLOB);
-                C3_OBLOCK(10, 4, "256", "33024", "", C3_NOCLOB);
-                C3_OBLOCK(11, 5, "256", "33024", "", C3_NOCLOB);
-                C3_OBLOCK(12, 6, "256", "33024", "", C3_NOCLOB);
-                C3_OBLOCK(13, 7, "256", "33024", "", C3_NOCLOB);
-                C3_OTAIL(14, "3", "2", "", C3_NOCLOB);
-                C3_OTAIL(15, "1", "0", "", C3_NOCLOB);
-                C3_WLOAD_ALL(nks, nh, nl);
-            }
-#undef C3_MF
-#undef C3_RD
-#undef C3_WT
-#undef C3_CLOB
-#undef C3_NOCLOB
-#undef C3_LDH
-        } else if (!ONE && live && ksteps == KS) {
-            // ---- the hot form (256-wide input).  One wave keeps the matrix pipe busy only if its matrix instructions issue back to
-            // back (scripts/probes/mfma_chain_rate.hip: 33 cycles per instruction; with the four A-fragment reads of the next
-            // k-step in a bunch between the blocks: 52): every gap between two of them holds exactly one memory instruction --
-            // four LDS reads (next k-step's A fragments, into the other buffer), then the two weight loads that refill this
-            // k-step's registers behind their last use.  All of it is one asm statement per k-step, so the waits are counted
-            // by hand (the reads run two k-steps ahead: an LDS round trip beside seven other busy waves is longer than one block).
-            const unsigned pb = (unsigned)(size_t)planes + ab;
-            half8 fa[2][4];                         // [buffer][lo0, lo1, hi0, hi1]: k-step ks multiplies buffer ks & 1
-            asm volatile("ds_read_b128 %0, %4 offset:4096\n\tds_read_b128 %1, %4 offset:36864\n\tds_read_b128 %2, %4\n\tds_read_b128 %3, %4 offset:32768"
-                         : "=v"(fa[0][0]), "=v"(fa[0][1]), "=v"(fa[0][2]), "=v"(fa[0][3]) : "v"(pb + axr));
-            asm volatile("ds_read_b128 %0, %4 offset:4096\n\tds_read_b128 %1, %4 offset:36864\n\tds_read_b128 %2, %4\n\tds_read_b128 %3, %4 offset:32768\n\ts_nop 1"
-                         : "=v"(fa[1][0]), "=v"(fa[1][1]), "=v"(fa[1][2]), "=v"(fa[1][3]) : "v"(pb + (32u ^ axr)));
-#define C3_MF(acc, w, x) "v_mfma_f32_32x32x16_f16 %[" acc "], " w ", %[" x "], %[" acc "]\n\t"
-#define C3_RD(dst, off) "ds_read_b128 %[" dst "], %[ad] offset:" off "\n\t"
-#define C3_WT(n) "s_waitcnt lgkmcnt(" n ")\n\t"
-#define C3_CLOB(...) __VA_ARGS__, "memory"
-#define C3_NOCLOB "memory"
-#define C3_LDL(ks, q) "global_load_dwordx4 " C3_CAT(C3_WL, ks) ", %[wv], %[bl] offset:" C3_CAT(C3_OFF, q) "\n\t"
-#define C3_LDH(ks, q) "global_load_dwordx4 " C3_CAT(C3_WH, ks) ", %[wv], %[bh] offset:" C3_CAT(C3_OFF, q) "\n\t"
-            // k-step ks <= 13.  Each of its four fragment registers takes k-step ks + 2's fragment (n7 = (ks + 2) & 7, offsets o*)
-            // right behind its last use here, two blocks = ten to twelve matrix instructions before it is needed: an LDS round
-            // trip beside seven other busy waves is longer than one block.  At the top eight reads are in flight (k-steps ks,
-            // ks + 1: lo0, lo1, hi0, hi1 each).  ld3: this wave's hi weights of k-step km1 (last used by the block before), ld4:
-            // the lo weights of this k-step (last used by the fourth instruction), or "".
-#define C3_FBLOCK(ks, km1, n7, o0, o1, o2, o3, ld3, ld4, clob)                                                                  \
-            asm volatile(C3_WT("7") C3_MF("a0", C3_CAT(C3_WH, ks), "l0") C3_RD("l0", o0) C3_WT("7") C3_MF("a1", C3_CAT(C3_WH, ks), "l1") C3_RD("l1", o1) \
-                         C3_WT("7") C3_MF("a0", C3_CAT(C3_WL, ks), "h0") ld3 C3_WT("6") C3_MF("a1", C3_CAT(C3_WL, ks), "h1") ld4        \
-                         C3_MF("a0", C3_CAT(C3_WH, ks), "h0") C3_RD("h0", o2) C3_MF("a1", C3_CAT(C3_WH, ks), "h1") C3_RD("h1", o3)      \
-                         : [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [l0] "+v"(fa[(ks) & 1][0]), [l1] "+v"(fa[(ks) & 1][1]),          \
-                           [h0] "+v"(fa[(ks) & 1][2]), [h1] "+v"(fa[(ks) & 1][3])                                               \
-                         : [ad] "v"(pb + (((unsigned)(n7) * 32u) ^ axr)), [wv] "v"(w_lane),                                      \
-                           [bh] "s"(nh + ((km1) >> 2) * 4096), [bl] "s"(nl + ((ks) >> 2) * 4096) : clob)
-            // the last two k-steps: nothing more to request (w0 .. w3: reads still allowed in flight at the first four instructions)
-#define C3_FTAIL(ks, km1, w0, w1, w2, w3, ld3, ld4, clob)                                                                       \
-            asm volatile(C3_WT(w0) C3_MF("a0", C3_CAT(C3_WH, ks), "l0") C3_WT(w1) C3_MF("a1", C3_CAT(C3_WH, ks), "l1")                \
-                         C3_WT(w2) C3_MF("a0", C3_CAT(C3_WL, ks), "h0") ld3 C3_WT(w3) C3_MF("a1", C3_CAT(C3_WL, ks), "h1") ld4        \
-                         C3_MF("a0", C3_CAT(C3_WH, ks), "h0") C3_MF("a1", C3_CAT(C3_WH, ks), "h1")                                    \
-                         : [a0] "+v"(acc[0]), [a1] "+v"(acc[1])                                                                 \
-                         : [l0] "v"(fa[(ks) & 1][0]), [l1] "v"(fa[(ks) & 1][1]), [h0] "v"(fa[(ks) & 1][2]), [h1] "v"(fa[(ks) & 1][3]), \
-                           [wv] "v"(w_lane), [bh] "s"(nh + ((km1) >> 2) * 4096), [bl] "s"(nl + ((ks) >> 2) * 4096) : clob)
-            if (nks == KS) {
-                C3_FBLOCK(0, 0, 2, "4096", "36864", "0", "32768", "", C3_LDL(0, 0), C3_CLOB(C3_CL0));
-                C3_FBLOCK(1, 0, 3, "4096", "36864", "0", "32768", C3_LDH(0, 0), C3_LDL(1, 1), C3_CLOB(C3_CH0, C3_CL1));
-                C3_FBLOCK(2, 1, 4, "4096", "36864", "0", "32768", C3_LDH(1, 1), C3_LDL(2, 2), C3_CLOB(C3_CH1, C3_CL2));
-                C3_FBLOCK(3, 2, 5, "4096", "36864", "0", "32768", C3_LDH(2, 2), C3_LDL(3, 3), C3_CLOB(C3_CH2, C3_CL3));
-                C3_FBLOCK(4, 3, 6, "4096", "36864", "0", "32768", C3_LDH(3, 3), C3_LDL(4, 0), C3_CLOB(C3_CH3, C3_CL4));
-                C3_FBLOCK(5, 4, 7, "4096", "36864", "0", "32768", C3_LDH(4, 0), C3_LDL(5, 1), C3_CLOB(C3_CH4, C3_CL5));
-                C3_FBLOCK(6, 5, 0, "4352", "37120", "256", "33024", C3_LDH(5, 1), C3_LDL(6, 2), C3_CLOB(C3_CH5, C3_CL6));
-                C3_FBLOCK(7, 6, 1, "4352", "37120", "256", "33024", C3_LDH(6, 2), C3_LDL(7, 3), C3_CLOB(C3_CH6, C3_CL7));
-                C3_FBLOCK(8, 7, 2, "4352", "37120", "256", "33024", C3_LDH(7, 3), C3_LDL(8, 0), C3_CLOB(C3_CH7, C3_CL8));
-                C3_FBLOCK(9, 8, 3, "4352", "37120", "256", "33024", C3_LDH(8, 0), C3_LDL(9, 1), C3_CLOB(C3_CH8, C3_CL9));
-                C3_FBLOCK(10, 9, 4, "4352", "37120", "256", "33024", C3_LDH(9, 1), C3_LDL(10, 2), C3_CLOB(C3_CH9, C3_CL10));
-                C3_FBLOCK(11, 10, 5, "4352", "37120", "256", "33024", C3_LDH(10, 2), C3_LDL(11, 3), C3_CLOB(C3_CH10, C3_CL11));
-                C3_FBLOCK(12, 11, 6, "4352", "37120", "256", "33024", C3_LDH(11, 3), C3_LDL(12, 0), C3_CLOB(C3_CH11, C3_CL12));
-                C3_FBLOCK(13, 12, 7, "4352", "37120", "256", "33024", C3_LDH(12, 0), C3_LDL(13, 1), C3_CLOB(C3_CH12, C3_CL13));
-                C3_FTAIL(14, 13, "7", "6", "5", "4", C3_LDH(13, 1), C3_LDL(14, 2), C3_CLOB(C3_CH13, C3_CL14));
-                C3_FTAIL(15, 14, "3", "2", "1", "0", C3_LDH(14, 2), C3_LDL(15, 3), C3_CLOB(C3_CH14, C3_CL15));
-                asm volatile("global_load_dwordx4 " C3_WH15 ", %0, %1 offset:3072" : : "v"(w_lane), "s"(nh + 3 * 4096) : C3_CH15, "memory");
-            } else {
-                C3_FBLOCK(0, 0, 2, "4096", "36864", "0", "32768", "", "", C3_NOCLOB);
-                C3_FBLOCK(1, 0, 3, "4096", "36864", "0", "32768", "", "", C3_NOCLOB);
-                C3_FBLOCK(2, 1, 4, "4096", "36864", "0", "32768", "", "", C3_NOCLOB);
-                C3_FBLOCK(3, 2, 5, "4096", "36864", "0", "32768", "", "", C3_NOCLOB);
-                C3_FBLOCK(4, 3, 6, "4096", "36864", "0", "32768", "", "", C3_NOCLOB);
-                C3_FBLOCK(5, 4, 7, "4096", "36864", "0", "32768", "", "", C3_NOCLOB);
-                C3_FBLOCK(6, 5, 0, "4352", "37120", "256", "33024", "", "", C3_NOCLOB);
-                C3_FBLOCK(7, 6, 1, "4352", "37120", "256", "33024", "", "", C3_NOCLOB);
-                C3_FBLOCK(8, 7, 2, "4352", "37120", "256", "33024", "", "", C3_NOCLOB);
-                C3_FBLOCK(9, 8, 3, "4352", "37120", "256", "33024", "", "", C3_NOCLOB);
-                C3_FBLOCK(10, 9, 4, "4352", "37120", "256", "33024", "", "", C3_NOCLOB);
-                C3_FBLOCK(11, 10, 5, "4352", "37120", "256", "33024", "", "", C3_NOCLOB);
-                C3_FBLOCK(12, 11, 6, "4352", "37120", "256", "33024", "", "", C3_NOCLOB);
-                C3_FBLOCK(13, 12, 7, "4352", "37120", "256", "33024", "", "", C3_NOCLOB);
-                C3_FTAIL(14, 13, "7", "6", "5", "4", "", "", C3_NOCLOB);
-                C3_FTAIL(15, 14, "3", "2", "1", "0", "", "", C3_NOCLOB);
+                if constexpr (ONE) asm volatile(C3_KLOOP1_NL : C3_KLOOP_OPERANDS : "memory");
+                else asm volatile(C3_KLOOP3_NL : C3_KLOOP_OPERANDS : "memory");
                 C3_WLOAD_ALL(nks, nh, nl);          // (a narrower next layer: its fragments in a bunch)
             }
+#undef C3_KLOOP_OPERANDS
         } else {
             // ---- any other width: the plain form (the compiler places the LDS reads and their waits)
             half8 ah[2][NI], al[2][NI];
@@ -438,6 +327,7 @@ __global__ __launch_bounds__(C3_THREADS, 2) void mlp_chain3_kernel(ChainArgs p, 
         }
         C3_STAMPK();
         // the last results leave the matrix pipe 16 passes after issue; hipcc does not count wait states behind inline asm
+        // (the hot form ends with the same wait states inside its statement)
         asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]));
         C3_STAMPK();
     };
@@ -638,19 +528,25 @@ __global__ __launch_bounds__(C3_THREADS, 2) void mlp_chain3_kernel(ChainArgs p, 
             const bool f_full = Cfg::full == 2 ? rt_full : Cfg::full == 1;
             const bool col_ok = f_full || c < N;
             unsigned sword = DGRAD ? sw : 0u;
+            // rows in flight: all eight of the wave in the hot forms (twice the independent chains for the scheduler, one LDS round
+            // trip instead of two: inference -4 %, data-gradient -1 %, h1 -3 % on the 4-layer run) except the training forward
+            // one (eight row stores in a bunch: +2 %); four where the flags are looked at at run time
+            constexpr int RQL = Cfg::full == 1 && (DGRAD || ONE || Cfg::store == 0) ? 8 : RQ;
 #pragma unroll 1
-            for (int ub = 0; ub < RB; ub += RQ) {           // RQ rows in flight: independent chains for the scheduler
-                float4 r[RQ];
+            for (int ub = 0; ub < RB; ub += RQL) {
+                float4 r[RQL];
 #pragma unroll
-                for (int q = 0; q < RQ; ++q)
+                for (int q = 0; q < RQL; ++q)
                     r[q] = *reinterpret_cast<const float4*>(blk + (ub + q) * 512 + (rc ^ (unsigned)(((ub + q) & 7) * 16)));
                 const float4 inv4 = *reinterpret_cast<const float4*>(inv_w + ub);
+                const float4 inv4b = RQL == 8 ? *reinterpret_cast<const float4*>(inv_w + ub + 4) : inv4;
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the rows are in registers: their bytes may be overwritten
                 C3_STAMP2();
 #pragma unroll
-                for (int q = 0; q < RQ; ++q) {
+                for (int q = 0; q < RQL; ++q) {
                     const int u = ub + q;
-                    const float inv = q == 0 ? inv4.x : q == 1 ? inv4.y : q == 2 ? inv4.z : inv4.w;
+                    const float4 iv = q < 4 ? inv4 : inv4b;
+                    const float inv = (q & 3) == 0 ? iv.x : (q & 3) == 1 ? iv.y : (q & 3) == 2 ? iv.z : iv.w;
                     if (DGRAD) {
                         r[q] = make_float4(r[q].x * inv, r[q].y * inv, r[q].z * inv, r[q].w * inv);
                         if (f_bits) {
@@ -692,9 +588,11 @@ __global__ __launch_bounds__(C3_THREADS, 2) void mlp_chain3_kernel(ChainArgs p, 
                 }
                 C3_STAMP2();
                 if (f_more || f_rmax) {
+#pragma unroll
+                  for (int h = 0; h < RQL; h += 4) {
                     float mx[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) mx[q] = fmaxf(fmaxf(fabsf(r[q].x), fabsf(r[q].y)), fmaxf(fabsf(r[q].z), fabsf(r[q].w)));
+                    for (int q = 0; q < 4; ++q) mx[q] = fmaxf(fmaxf(fabsf(r[h + q].x), fabsf(r[h + q].y)), fmaxf(fabsf(r[h + q].z), fabsf(r[h + q].w)));
 #ifndef C3_X_NOMAX                                  // (timing experiments: pieces of the row phases left out, results wrong)
                     wave_max4(mx[0], mx[1], mx[2], mx[3]);
 #endif
@@ -705,7 +603,7 @@ __global__ __launch_bounds__(C3_THREADS, 2) void mlp_chain3_kernel(ChainArgs p, 
                     if (f_rmax) {
                         float mx4 = 0.f;
                         put4(mx4, 0, smx[0], smx[1], smx[2], smx[3]);
-                        if (lane < 4 && (f_full || r0 + ub + lane < M32)) rmax[r0 + ub + lane] = mx4;
+                        if (lane < 4 && (f_full || r0 + ub + h + lane < M32)) rmax[r0 + ub + h + lane] = mx4;
                     }
                     if (f_more) {
                         float inv_n[4];
@@ -713,13 +611,14 @@ __global__ __launch_bounds__(C3_THREADS, 2) void mlp_chain3_kernel(ChainArgs p, 
                         for (int q = 0; q < 4; ++q) {
                             const float sc = scale_from_max(__float_as_uint(smx[q]), inv_n[q]);
 #ifndef C3_X_NOSPLIT
-                            write_planes(planes, wp, wq, ub + q, r[q], sc, Cfg::full == 1 || c < kpad_next);  // (full: N = 256 = the next layer's input width)
+                            write_planes(planes, wp, wq, ub + h + q, r[h + q], sc, Cfg::full == 1 || c < kpad_next);  // (full: N = 256 = the next layer's input width)
 #else
                             asm volatile("" :: "s"(sc));
 #endif
                         }
-                        *reinterpret_cast<float4*>(inv_w + ub) = make_float4(inv_n[0], inv_n[1], inv_n[2], inv_n[3]);
+                        *reinterpret_cast<float4*>(inv_w + ub + h) = make_float4(inv_n[0], inv_n[1], inv_n[2], inv_n[3]);
                     }
+                  }
                 }
                 C3_STAMP2();
             }
