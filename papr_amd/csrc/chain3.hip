@@ -277,7 +277,7 @@ __global__ __launch_bounds__(C3_THREADS, 2) void mlp_chain3_kernel(ChainArgs p, 
             for (int j = 0; j < 8; ++j) ad[j] = pb + (((unsigned)j * 32u) ^ axr);
             half8 f00, f01, f02, f03, f10, f11, f12, f13;       // fragment buffers (asm temporaries)
 #define C3_KLOOP_OPERANDS                                                                                                       \
-            [a0] "+v"(acc[0]), [a1] "+v"(acc[1]), [f00] "=&v"(f00), [f01] "=&v"(f01), [f02] "=&v"(f02), [f03] "=&v"(f03),         \
+            [a0] "=&v"(acc[0]), [a1] "=&v"(acc[1]), [f00] "=&v"(f00), [f01] "=&v"(f01), [f02] "=&v"(f02), [f03] "=&v"(f03),         \
             [f10] "=&v"(f10), [f11] "=&v"(f11), [f12] "=&v"(f12), [f13] "=&v"(f13)                                              \
             : [ad0] "v"(ad[0]), [ad1] "v"(ad[1]), [ad2] "v"(ad[2]), [ad3] "v"(ad[3]), [ad4] "v"(ad[4]), [ad5] "v"(ad[5]),       \
               [ad6] "v"(ad[6]), [ad7] "v"(ad[7]), [wv] "v"(w_lane), [bh0] "s"(nh), [bh1] "s"(nh + 4096), [bh2] "s"(nh + 8192),  \
