@@ -33,7 +33,7 @@ def _stale(target, deps):
 
 def build_library(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    headers = [os.path.join(CSRC, h) for h in ("papr_common.h", "h3_common.h", "chain.h", "chain3_kloop.inc")] + [os.path.join(os.path.dirname(PKG), "include", "papr_hip.h")]
+    headers = [os.path.join(CSRC, h) for h in ("papr_common.h", "h3_common.h", "chain.h", "chain3_kloop.inc", "chain3_fused.inc")] + [os.path.join(os.path.dirname(PKG), "include", "papr_hip.h")]
     objdir = os.path.join(PKG, "build")
     os.makedirs(objdir, exist_ok=True)
     objs, procs = [], []

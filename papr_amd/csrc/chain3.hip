@@ -30,6 +30,7 @@
 #include "h3_common.h"
 #include "chain.h"
 #include "chain3_kloop.inc"
+#include "chain3_fused.inc"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -105,7 +106,7 @@ __device__ __forceinline__ long uniform64(long v) {       // a wave-uniform valu
 // ONE: the reduced-precision mode (PAPR_GEMM_MODE=h1, the counterpart of the reference's fp16 autocast, models/attn.py:248): one
 // f16 product per fp32 product -- only the hi planes of weights and activations are loaded, multiplied and written.
 template <bool DGRAD, bool ONE>
-__global__ __launch_bounds__(C3_THREADS, 2) void mlp_chain3_kernel(ChainArgs p, int iters, int generic_only) {
+__global__ __launch_bounds__(C3_THREADS, 2) void mlp_chain3_kernel(ChainArgs p, int iters, int generic_only, int fused_on) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane0 = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool k_first = wn < 4;                    // waves w and w + 4 share a SIMD
@@ -630,6 +631,53 @@ __global__ __launch_bounds__(C3_THREADS, 2) void mlp_chain3_kernel(ChainArgs p, 
         else rows(RowCfg<2, 2, 2, 2, 2, 2>());
     };
 
+    // ---- the hot slot as ONE statement: the k-loop of tile A (layer l) and the row phases of tile B (layer pl) interleaved
+    // instruction by instruction (chain3_fused.inc, generated by scripts/gen_chain3_fused.py -- the why and the how are there).
+    // Every wave does both at once; no multiply-first / rows-first split, no parking.  mode: 0 training forward middle layer,
+    // 1 inference middle layer, 2 data-gradient middle layer (what rows() calls its hot forms).
+    auto fused_slot = [&](char* kpl, int l, int ln, char* ppl, float* pinv, long pm0, int pl, int mode) {
+        C3_LANE();
+        l = __builtin_amdgcn_readfirstlane(l);
+        pl = __builtin_amdgcn_readfirstlane(pl);
+        const ChainLayer& LP = p.L[pl];
+        const int r0 = __builtin_amdgcn_readfirstlane((int)pm0) + wn * RB;
+        const char *nh = nullptr, *nl = nullptr;
+        if (ln >= 0) { nh = frag_base(p.L[ln], p.L[ln].w_hi); nl = frag_base(p.L[ln], p.L[ln].w_lo); }
+        const bool ld = ln >= 0 && p.L[ln].ksteps == KS;
+        const int arow = lane & 31, ax = arow & 15;
+        const unsigned pb = (unsigned)(size_t)kpl + (unsigned)((arow / RB) * C3_BLK_BYTES + (arow % RB) * 512 + (((lane >> 5) ^ (ax & 1)) * 16));
+        const unsigned axr = (unsigned)((ax & ~1) * 16);
+        const unsigned wv = (unsigned)lane * 16u;
+        const unsigned rdb = (unsigned)(size_t)ppl + wn * C3_BLK_BYTES + (lane >> 5) * C3_LO, rc = (unsigned)(lane & 31) * 16u;
+        const unsigned wrb = (unsigned)(size_t)ppl + wn * C3_BLK_BYTES + (unsigned)(lane & 1) * 8u, wp = (unsigned)(lane >> 1) * 16u;
+        const float4 b4 = b4n;
+        unsigned sw = DGRAD ? swn : 0u;
+        const char* crow = reinterpret_cast<const char*>(LP.C + (long)r0 * LP.ldc);
+        const unsigned ldcb = (unsigned)LP.ldc * 4u;
+        const char* rmp = reinterpret_cast<const char*>(LP.rowmax + r0);
+        const float slope = LP.act == PAPR_ACT_RELU ? 0.f : (LP.act == PAPR_ACT_LEAKY_RELU ? 0.2f : 1.f);
+        const unsigned invb = (unsigned)(size_t)(pinv + wn * RB), wnb = (unsigned)(wn & 1) * 128u;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this layer's fragments (requested a slot ago) have landed
+#define C3_FUSED_OPERANDS                                                                                                       \
+        [a0] "=&v"(acc[0]), [a1] "=&v"(acc[1]), [sw] "+v"(sw)                                                                   \
+        : [pb] "v"(pb), [axr] "v"(axr), [wv] "v"(wv), [rdb] "v"(rdb), [rc] "v"(rc), [wrb] "v"(wrb), [wp] "v"(wp),                \
+          [b0] "v"(b4.x), [b1] "v"(b4.y), [b2] "v"(b4.z), [b3] "v"(b4.w), [nh] "s"(nh), [nl] "s"(nl), [crow] "s"(crow),           \
+          [ldcb] "s"(ldcb), [rmp] "s"(rmp), [slope] "s"(slope), [invb] "s"(invb), [wnb] "s"(wnb)
+        if constexpr (DGRAD) {
+            if (ld) asm volatile(C3_FUSED_DGRAD_LD : C3_FUSED_OPERANDS : C3_FUSED_AGPRS, C3_FUSED_CLOBBERS);
+            else asm volatile(C3_FUSED_DGRAD_NL : C3_FUSED_OPERANDS : C3_FUSED_CLOBBERS);
+        } else if (mode == 0) {
+            if (ld) asm volatile(C3_FUSED_FWD_LD : C3_FUSED_OPERANDS : C3_FUSED_AGPRS, C3_FUSED_CLOBBERS);
+            else asm volatile(C3_FUSED_FWD_NL : C3_FUSED_OPERANDS : C3_FUSED_CLOBBERS);
+        } else {
+            if (ld) asm volatile(C3_FUSED_INF_LD : C3_FUSED_OPERANDS : C3_FUSED_AGPRS, C3_FUSED_CLOBBERS);
+            else asm volatile(C3_FUSED_INF_NL : C3_FUSED_OPERANDS : C3_FUSED_CLOBBERS);
+        }
+#undef C3_FUSED_OPERANDS
+        if (!ld && ln >= 0) { const int nks = p.L[ln].ksteps; const unsigned w_lane = wv; C3_WLOAD_ALL(nks, nh, nl); }     // (a narrower next layer)
+        if (!DGRAD && mode == 0) LP.sign_bits[(long)(r0 / RB) * (RB * 8) + lane] = sw;
+    };
+
     // ---- schedule
     const int n_layers = p.n_layers;
     long pair = blockIdx.x;
@@ -644,6 +692,9 @@ __global__ __launch_bounds__(C3_THREADS, 2) void mlp_chain3_kernel(ChainArgs p, 
         C3_WLOAD_ALL(n0, bh, bl);
     }
     lds_barrier();                                  // planes of the first X ready
+#ifdef C3_YPRIO
+    if (!k_first) __builtin_amdgcn_s_setprio(C3_YPRIO);      // (the younger wave of every SIMD loses the issue arbitration to its partner at equal priority)
+#endif
 
     int it = 0, l = 0, h = 0;                       // slot: multiply tile h (X, Y) of pair `it` by layer l | row phases of the other tile
     const int n_slots = iters * n_layers * 2;
@@ -665,6 +716,19 @@ __global__ __launch_bounds__(C3_THREADS, 2) void mlp_chain3_kernel(ChainArgs p, 
         }
         const int ln = h == 1 ? (l + 1 < n_layers ? l + 1 : 0) : -1;
         C3_STAMP();
+        // is this a hot slot (both layers 256 wide, the rows' tile inside M, a middle layer, one of the three hot flag sets)?
+        int fmode = -1;
+        if (!ONE && !generic_only && fused_on && pl >= 0 && sm0 < 0 && p.L[l].ksteps == KS && p.L[l].N == 256 && p.L[pl].N == 256 && pl + 1 < n_layers &&
+            pm0 + C3_ROWS <= p.M) {
+            const ChainLayer& LP = p.L[pl];
+            const bool st = LP.C != nullptr, bi = LP.sign_bits != nullptr, rm = LP.rowmax != nullptr;
+            if (st && bi && rm) fmode = DGRAD ? 2 : 0;
+            else if (fused_on > 1 && !DGRAD && !st && !bi && !rm) fmode = 1;        // (inference: the two-role slot with eight rows in flight is 5 % faster: PAPR_C3_FUSED=2 to compare)
+        }
+        if (!ONE && fmode >= 0) {
+            if constexpr (!ONE) fused_slot(kpl, l, ln, ppl, pinv, pm0, pl, fmode);
+            C3_STAMP(); C3_STAMP(); C3_STAMP();
+        } else {
         // (two copies of the multiplying code around one copy of the row phases: on every path from the row phases to the dump
         // the accumulators are redefined, so the compiler has their 32 registers for the row phases)
 #ifndef C3_NOK
@@ -688,6 +752,7 @@ __global__ __launch_bounds__(C3_THREADS, 2) void mlp_chain3_kernel(ChainArgs p, 
         else k_run(kpl, l, ln);
 #endif
 #endif
+        }
         {   // the row phases of the NEXT slot (the slot state advanced by one), or the ones behind the loop
             int h2 = h + 1, l2 = l;
             long pair2 = pair;
@@ -745,12 +810,13 @@ int papr_launch_chain3(const ChainArgs& a, bool dgrad, long long bytes, long lon
     if (prof) papr_prof_begin2(dgrad ? 10 : 9, a.M, a.n_layers, a.K0, bytes, flops, s);
     static const int generic_only = getenv("PAPR_C2_GENERIC") ? atoi(getenv("PAPR_C2_GENERIC")) : 0;      // (test switch: the hot instantiations off)
     const int g_d = generic_only == 1 || generic_only == 3, g_f = generic_only == 1 || generic_only == 2;
+    static const int fused_on = getenv("PAPR_C3_FUSED") ? atoi(getenv("PAPR_C3_FUSED")) : 1;        // (A/B switch: 0 = the two-role slots everywhere)
     if (a.one_product) {
-        if (dgrad) mlp_chain3_kernel<true, true><<<dim3(grid), dim3(C3_THREADS), C3_LDS_BYTES, s>>>(a, iters, g_d);
-        else mlp_chain3_kernel<false, true><<<dim3(grid), dim3(C3_THREADS), C3_LDS_BYTES, s>>>(a, iters, g_f);
+        if (dgrad) mlp_chain3_kernel<true, true><<<dim3(grid), dim3(C3_THREADS), C3_LDS_BYTES, s>>>(a, iters, g_d, fused_on);
+        else mlp_chain3_kernel<false, true><<<dim3(grid), dim3(C3_THREADS), C3_LDS_BYTES, s>>>(a, iters, g_f, fused_on);
     } else {
-        if (dgrad) mlp_chain3_kernel<true, false><<<dim3(grid), dim3(C3_THREADS), C3_LDS_BYTES, s>>>(a, iters, g_d);
-        else mlp_chain3_kernel<false, false><<<dim3(grid), dim3(C3_THREADS), C3_LDS_BYTES, s>>>(a, iters, g_f);
+        if (dgrad) mlp_chain3_kernel<true, false><<<dim3(grid), dim3(C3_THREADS), C3_LDS_BYTES, s>>>(a, iters, g_d, fused_on);
+        else mlp_chain3_kernel<false, false><<<dim3(grid), dim3(C3_THREADS), C3_LDS_BYTES, s>>>(a, iters, g_f, fused_on);
     }
     if (prof) papr_prof_end(s);
     PAPR_CHECK_LAUNCH("mlp_chain3");
