@@ -1,0 +1,45 @@
+"""One MLP through the fused-run kernels in a fresh process (the library reads PAPR_CHAIN / PAPR_C3_FUSED / PAPR_C2_GENERIC when it
+loads):   python tests/chain_variants_worker.py <out.pt> <M> <n_layers> <act>
+
+Training forward (every layer saved), data-gradient run with the saved sign words, the same without them, an inference pass;
+tests/test_hip_chain_variants.py compares the files bit for bit."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main(out, M, n, act):
+    from papr_amd import ops
+    d_in, width, d_out = 117, 256, 256
+    gen = torch.Generator().manual_seed(M + n)
+    spec = ops.MlpSpec("t", d_in, dict(n_ff_layer=n, d_ff=width, d_ff_out=d_out, norm="none", ff_act=act, ff_last_act="none", skip_layers=[]))
+    d = torch.device("cuda:0")
+    ws, bs = [], []
+    for i in range(n):
+        fi = d_in if i == 0 else width
+        fo = d_out if i == n - 1 else width
+        w = torch.zeros(fo, spec.layers[i]["n_in"])
+        w[:, :fi] = (torch.rand(fo, fi, generator=gen) * 2 - 1) * (6.0 / (fi + fo)) ** 0.5
+        ws.append(w.to(d))
+        bs.append(((torch.rand(fo, generator=gen) * 2 - 1) * 0.1).to(d))
+    xp = torch.zeros(M, spec.ld_in)
+    xp[:, :d_in] = torch.randn(M, d_in, generator=gen)
+    xd = xp.to(d)
+    outs = ops.mlp_forward(spec, ws, bs, xd, M, keep=True)
+    gp = torch.randn(M, spec.ld_out[-1], generator=gen).to(d)
+    scratch = [torch.empty((M, 256), device=d) for _ in range(2)]
+    rowmax = outs.row_absmax[: n * M].clone()
+    d_ws, d_bs, d_x = ops.mlp_backward(spec, ws, bs, xd, M, outs, gp.clone(), scratch, True)
+    d_ws2, _, d_x2 = ops.mlp_backward(spec, ws, bs, xd, M, list(outs), gp.clone(), scratch, True)      # without the saved state: fp32 masks
+    inf = ops.mlp_forward(spec, ws, bs, xd, M, keep=False)[-1].clone()
+    torch.cuda.synchronize()
+    torch.save({"outs": [o.cpu() for o in outs], "rowmax": rowmax.cpu(), "d_ws": [t.cpu() for t in d_ws], "d_bs": [t.cpu() for t in d_bs], "d_x": d_x.cpu(),
+                "d_ws2": [t.cpu() for t in d_ws2], "d_x2": d_x2.cpu(), "inf": inf.cpu()}, out)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4])
