@@ -106,20 +106,22 @@ def k_stream(ld):
         if nx is not None:
             pre += [("raw", t) for t in xad(KAD, "%[axr]", (nx & 7) * 32, "%[pb]", SK)]
         s = []
-        s.append(dict(pre=pre, need=[("l0", ks)], mf=mf("a0", wh(ks), "l0", first), post=[rd("l0", nx)] if nx is not None else []))
-        s.append(dict(pre=[], need=[("l1", ks)], mf=mf("a1", wh(ks), "l1", first), post=[rd("l1", nx)] if nx is not None else []))
+        # (one wait for the two lo fragments, one for the two hi ones: the second of each pair was requested one MFMA slot after the
+        # first, and every s_waitcnt is an issue slot of a SIMD that is bound by instruction issue)
+        s.append(dict(pre=pre, need=[("l0", ks), ("l1", ks)], mf=mf("a0", wh(ks), "l0", first), post=[rd("l0", nx)] if nx is not None else []))
+        s.append(dict(pre=[], need=[], mf=mf("a1", wh(ks), "l1", first), post=[rd("l1", nx)] if nx is not None else []))
         p3 = []
         if ld and ks >= 1:
             if (ks - 1) % 4 == 0 and ks - 1 > 0:
                 p3 += [("raw", "s_add_u32 %s, %s, 4096" % (SBH[0], SBH[0])), ("raw", "s_addc_u32 %s, %s, 0" % (SBH[1], SBH[1]))]
             p3.append(("raw", "global_load_dwordx4 %s, %%[wv], s[96:97] offset:%d" % (wh(ks - 1), ((ks - 1) & 3) * 1024)))
-        s.append(dict(pre=[], need=[("h0", ks)], mf=mf("a0", wl(ks), "h0"), post=p3))
+        s.append(dict(pre=[], need=[("h0", ks), ("h1", ks)], mf=mf("a0", wl(ks), "h0"), post=p3))
         p4 = []
         if ld:
             if ks % 4 == 0 and ks > 0:
                 p4 += [("raw", "s_add_u32 %s, %s, 4096" % (SBL[0], SBL[0])), ("raw", "s_addc_u32 %s, %s, 0" % (SBL[1], SBL[1]))]
             p4.append(("raw", "global_load_dwordx4 %s, %%[wv], s[98:99] offset:%d" % (wl(ks), (ks & 3) * 1024)))
-        s.append(dict(pre=[], need=[("h1", ks)], mf=mf("a1", wl(ks), "h1"), post=p4))
+        s.append(dict(pre=[], need=[], mf=mf("a1", wl(ks), "h1"), post=p4))
         s.append(dict(pre=[], need=[], mf=mf("a0", wh(ks), "h0"), post=[rd("h0", nx)] if nx is not None else []))
         p6 = [rd("h1", nx)] if nx is not None else []
         if ld and ks == 15:
