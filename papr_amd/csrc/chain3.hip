@@ -663,7 +663,13 @@ __global__ __launch_bounds__(C3_THREADS, 2) void mlp_chain3_kernel(ChainArgs p, 
         : [pb] "v"(pb), [axr] "v"(axr), [wv] "v"(wv), [rdb] "v"(rdb), [rc] "v"(rc), [wrb] "v"(wrb), [wp] "v"(wp),                \
           [b0] "v"(b4.x), [b1] "v"(b4.y), [b2] "v"(b4.z), [b3] "v"(b4.w), [nh] "s"(nh), [nl] "s"(nl), [crow] "s"(crow),           \
           [ldcb] "s"(ldcb), [rmp] "s"(rmp), [slope] "s"(slope), [invb] "s"(invb), [wnb] "s"(wnb)
-        if constexpr (DGRAD) {
+        if constexpr (ONE && DGRAD) {
+            if (ld) asm volatile(C3_FUSED1_DGRAD_LD : C3_FUSED_OPERANDS : C3_FUSED_AGPRS, C3_FUSED_CLOBBERS);
+            else asm volatile(C3_FUSED1_DGRAD_NL : C3_FUSED_OPERANDS : C3_FUSED_CLOBBERS);
+        } else if constexpr (ONE) {
+            if (ld) asm volatile(C3_FUSED1_FWD_LD : C3_FUSED_OPERANDS : C3_FUSED_AGPRS, C3_FUSED_CLOBBERS);
+            else asm volatile(C3_FUSED1_FWD_NL : C3_FUSED_OPERANDS : C3_FUSED_CLOBBERS);
+        } else if constexpr (DGRAD) {
             if (ld) asm volatile(C3_FUSED_DGRAD_LD : C3_FUSED_OPERANDS : C3_FUSED_AGPRS, C3_FUSED_CLOBBERS);
             else asm volatile(C3_FUSED_DGRAD_NL : C3_FUSED_OPERANDS : C3_FUSED_CLOBBERS);
         } else if (mode == 0) {
@@ -718,15 +724,15 @@ __global__ __launch_bounds__(C3_THREADS, 2) void mlp_chain3_kernel(ChainArgs p, 
         C3_STAMP();
         // is this a hot slot (both layers 256 wide, the rows' tile inside M, a middle layer, one of the three hot flag sets)?
         int fmode = -1;
-        if (!ONE && !generic_only && fused_on && pl >= 0 && sm0 < 0 && p.L[l].ksteps == KS && p.L[l].N == 256 && p.L[pl].N == 256 && pl + 1 < n_layers &&
+        if (!generic_only && fused_on && pl >= 0 && sm0 < 0 && p.L[l].ksteps == KS && p.L[l].N == 256 && p.L[pl].N == 256 && pl + 1 < n_layers &&
             pm0 + C3_ROWS <= p.M) {
             const ChainLayer& LP = p.L[pl];
             const bool st = LP.C != nullptr, bi = LP.sign_bits != nullptr, rm = LP.rowmax != nullptr;
             if (st && bi && rm) fmode = DGRAD ? 2 : 0;
-            else if (fused_on > 1 && !DGRAD && !st && !bi && !rm) fmode = 1;        // (inference: the two-role slot with eight rows in flight is 5 % faster: PAPR_C3_FUSED=2 to compare)
+            else if (!ONE && fused_on > 1 && !DGRAD && !st && !bi && !rm) fmode = 1;        // (inference: the two-role slot with eight rows in flight is 5 % faster: PAPR_C3_FUSED=2 to compare)
         }
-        if (!ONE && fmode >= 0) {
-            if constexpr (!ONE) fused_slot(kpl, l, ln, ppl, pinv, pm0, pl, fmode);
+        if (fmode >= 0) {
+            fused_slot(kpl, l, ln, ppl, pinv, pm0, pl, fmode);
             C3_STAMP(); C3_STAMP(); C3_STAMP();
         } else {
         // (two copies of the multiplying code around one copy of the row phases: on every path from the row phases to the dump

@@ -93,9 +93,25 @@ def wh(ks): return "a[%d:%d]" % (8 * ks, 8 * ks + 3)
 def wl(ks): return "a[%d:%d]" % (8 * ks + 4, 8 * ks + 7)
 
 
-def k_stream(ld):
-    """list of slots; a slot = (needs, mfma text, post: list of ('lds', text, key) / ('raw', text))"""
+def k_stream(ld, one=False):
+    """list of slots; a slot = (needs, mfma text, post: list of ('lds', text, key) / ('raw', text)).  one: the one-product mode (h1):
+    hi . hi only, two MFMAs per k-step"""
     slots = []
+    if one:
+        rd_off = {"h0": 0, "h1": 32768}
+        for ks in range(16):
+            nx = ks + 1 if ks < 15 else None
+            def rd1(kind): return ("lds", "ds_read_b128 %s, %s offset:%d" % (F[kind], KAD, rd_off[kind] + (256 if nx >= 8 else 0)), (kind, nx))
+            def mf1(acc, kind): return "v_mfma_f32_32x32x16_f16 %%[%s], %s, %s, %s" % (acc, wh(ks), F[kind], "0" if ks == 0 else "%%[%s]" % acc)
+            pre = [("raw", t) for t in xad(KAD, "%[axr]", (nx & 7) * 32, "%[pb]", SK)] if nx is not None else []
+            slots.append(dict(pre=pre, need=[("h0", ks), ("h1", ks)], mf=mf1("a0", "h0"), post=[rd1("h0")] if nx is not None else []))
+            p2 = [rd1("h1")] if nx is not None else []
+            if ld:
+                if ks % 4 == 0 and ks > 0:
+                    p2 += [("raw", "s_add_u32 %s, %s, 4096" % (SBH[0], SBH[0])), ("raw", "s_addc_u32 %s, %s, 0" % (SBH[1], SBH[1]))]
+                p2.append(("raw", "global_load_dwordx4 %s, %%[wv], s[96:97] offset:%d" % (wh(ks), (ks & 3) * 1024)))
+            slots.append(dict(pre=[], need=[], mf=mf1("a1", "h1"), post=p2))
+        return slots
     rd_off = {"l0": 4096, "l1": 36864, "h0": 0, "h1": 32768}
     def rd(kind, ks): return ("lds", "ds_read_b128 %s, %s offset:%d" % (F[kind], KAD, rd_off[kind] + (256 if ks >= 8 else 0)), (kind, ks))
     for ks in range(16):
@@ -131,7 +147,7 @@ def k_stream(ld):
     return slots
 
 
-def rows_stream(mode):
+def rows_stream(mode, one=False):
     """mode: 'fwd' = training forward middle layer (store, sign bits, row maximum, planes), 'inf' = inference middle layer (planes only),
     'dgrad' = data-gradient middle layer.  Returns a list of ops: ('raw', text) | ('lds', text, key) | ('need', [keys]) | ('group', [raw texts])"""
     ops = []
@@ -213,25 +229,29 @@ def rows_stream(mode):
             A(("raw", "v_fma_mixlo_f16 %s, %s, %s, 0" % (t[1], x[2], s)))
             A(("raw", "v_fma_mixhi_f16 %s, %s, %s, 0" % (t[0], x[1], s)))
             A(("raw", "v_fma_mixhi_f16 %s, %s, %s, 0" % (t[1], x[3], s)))
-            A(("raw", "v_fma_mixlo_f16 %s, %s, %s, -%s op_sel_hi:[0,0,1]" % (t[2], x[0], s, t[0])))
-            A(("raw", "v_fma_mixlo_f16 %s, %s, %s, -%s op_sel_hi:[0,0,1]" % (t[3], x[2], s, t[1])))
-            A(("raw", "v_fma_mixhi_f16 %s, %s, %s, -%s op_sel:[0,0,1] op_sel_hi:[0,0,1]" % (t[2], x[1], s, t[0])))
-            A(("raw", "v_fma_mixhi_f16 %s, %s, %s, -%s op_sel:[0,0,1] op_sel_hi:[0,0,1]" % (t[3], x[3], s, t[1])))
+            if not one:
+                A(("raw", "v_fma_mixlo_f16 %s, %s, %s, -%s op_sel_hi:[0,0,1]" % (t[2], x[0], s, t[0])))
+                A(("raw", "v_fma_mixlo_f16 %s, %s, %s, -%s op_sel_hi:[0,0,1]" % (t[3], x[2], s, t[1])))
+                A(("raw", "v_fma_mixhi_f16 %s, %s, %s, -%s op_sel:[0,0,1] op_sel_hi:[0,0,1]" % (t[2], x[1], s, t[0])))
+                A(("raw", "v_fma_mixhi_f16 %s, %s, %s, -%s op_sel:[0,0,1] op_sel_hi:[0,0,1]" % (t[3], x[3], s, t[1])))
             A(("raw", "s_or_b32 %s, %%[wnb], %d" % (ST, u * 16)))
             A(("raw", "v_xad_u32 %s, %%[wp], %s, %%[wrb]" % (TA, ST)))
             tn = int(t[0][1:])
-            A(("lds", "ds_write2st64_b64 %s, v[%d:%d], v[%d:%d] offset0:%d offset1:%d" % (TA, tn, tn + 1, tn + 2, tn + 3, u, u + 8), ("pw", u)))
+            if one:
+                A(("lds", "ds_write_b64 %s, v[%d:%d] offset:%d" % (TA, tn, tn + 1, u * 512), ("pw", u)))
+            else:
+                A(("lds", "ds_write2st64_b64 %s, v[%d:%d], v[%d:%d] offset0:%d offset1:%d" % (TA, tn, tn + 1, tn + 2, tn + 3, u, u + 8), ("pw", u)))
         for q in range(4):
             A(("raw", "v_mov_b32 %s, %s" % (INV[q], SIN[q])))
         A(("lds", "ds_write_b128 %s, %s offset:%d" % (TI, INVT, b * 16), ("invw", b)))
     return ops
 
 
-def fuse(mode, ld):
+def fuse(mode, ld, one=False):
     em = Emit()
     ids = {}
-    ks = k_stream(ld)
-    ro = rows_stream(mode)
+    ks = k_stream(ld, one)
+    ro = rows_stream(mode, one)
     # flatten groups so that they count as one unit of the rows stream
     units = []
     for o in ro:
@@ -250,11 +270,12 @@ def fuse(mode, ld):
 
     if ld:
         em.raw("s_mov_b64 s[96:97], %[nh]")
-        em.raw("s_mov_b64 s[98:99], %[nl]")
+        if not one:
+            em.raw("s_mov_b64 s[98:99], %[nl]")
     # k-step 0's fragments, then the first instructions of the rows stream (its LDS reads) before the first MFMA
     em.raw("v_xad_u32 %s, %%[axr], 0, %%[pb]" % KAD)
     off = {"l0": 4096, "l1": 36864, "h0": 0, "h1": 32768}
-    for kind in ("l0", "l1", "h0", "h1"):
+    for kind in (("h0", "h1") if one else ("l0", "l1", "h0", "h1")):
         ids[(kind, 0)] = em.lds("ds_read_b128 %s, %s offset:%d" % (F[kind], KAD, off[kind]))
     pos = 0
     head = 0
@@ -299,5 +320,7 @@ if __name__ == "__main__":
     for mode in ("fwd", "inf", "dgrad"):
         for ld in (True, False):
             emit_macro("C3_FUSED_%s_%s" % (mode.upper(), "LD" if ld else "NL"), fuse(mode, ld))
+            if mode != "inf":
+                emit_macro("C3_FUSED1_%s_%s" % (mode.upper(), "LD" if ld else "NL"), fuse(mode, ld, True))
     print("#define C3_FUSED_CLOBBERS " + ", ".join('"%s"' % r for r in CLOB_V + CLOB_S) + ', "vcc", "scc", "memory"')
     print("#define C3_FUSED_AGPRS " + ", ".join('"a%d"' % i for i in range(128)))

@@ -35,6 +35,10 @@ def _run(tmp_path, name, env, M, n, act):
     return torch.load(out)
 
 
+H1_VARIANTS = [("h1 two-role", {"PAPR_CHAIN": "3", "PAPR_C3_FUSED": "0", "PAPR_GEMM_MODE": "h1"}), ("h1", {"PAPR_CHAIN": "3", "PAPR_C3_FUSED": "1", "PAPR_GEMM_MODE": "h1"}),
+               ("h1 generic rows", {"PAPR_CHAIN": "3", "PAPR_C2_GENERIC": "1", "PAPR_GEMM_MODE": "h1"})]
+
+
 def _flat(res):
     for k, v in sorted(res.items()):
         if isinstance(v, list):
@@ -56,3 +60,15 @@ def test_fused_run_kernels_agree_bit_for_bit(tmp_path, M, n, act):
             assert a.shape == b.shape, (name, k)
             same = torch.equal(a, b)
             assert same, "%s: %s differs from chain.hip in %d of %d elements (max |diff| %g)" % (name, k, int((a != b).sum()), a.numel(), float((a - b).abs().max()))
+
+
+def test_one_product_mode_forms_agree_bit_for_bit(tmp_path):
+    """The same for the reduced-precision mode (PAPR_GEMM_MODE=h1): its two-role slots, its fused slots and its generic row phases."""
+    ref = None
+    for name, env in H1_VARIANTS:
+        res = _run(tmp_path, name, env, 40000, 5, "relu")
+        if ref is None:
+            ref = res
+            continue
+        for (k, a), (_, b) in zip(_flat(ref), _flat(res)):
+            assert torch.equal(a, b), "%s: %s differs in %d of %d elements" % (name, k, int((a != b).sum()), a.numel())
