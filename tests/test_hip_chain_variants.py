@@ -48,7 +48,7 @@ def _flat(res):
             yield k, v
 
 
-@pytest.mark.parametrize("M,n,act", [(40000, 5, "relu"), (45, 3, "leakyrelu")])
+@pytest.mark.parametrize("M,n,act", [(40000, 5, "relu"), (45, 3, "leakyrelu"), (20000, 4, "leakyrelu")])
 def test_fused_run_kernels_agree_bit_for_bit(tmp_path, M, n, act):
     ref = None
     for name, env in VARIANTS:
