@@ -276,6 +276,37 @@ int papr_conv3x3_wgrad(const float* d_out, const float* x, int32_t B, int32_t H,
                        void* workspace, int32_t slot, papr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * K5b  the other layers of the U-Net render head (reference models/unet.py), all over NHWC maps (rows = pixels):
+ *
+ * MaxPool2d(2) of the Down stages (models/unet.py:36-49 `nn.MaxPool2d(2)`): out (B, H/2, W/2, C), C % 4 == 0; an odd last
+ * row / column is dropped.  `which` (one byte per output element, packed four to a word like the float4 they belong to, so
+ * B*(H/2)*(W/2)*C/4 words; may be NULL at inference) keeps the window position 0 .. 3 of the maximum -- the FIRST one in
+ * scan order, torch's rule -- for papr_maxpool2_bwd, which writes every element of d_in (B, H, W, C). */
+int papr_maxpool2_fwd(const float* x, int32_t B, int32_t H, int32_t W, int32_t C, float* out, uint32_t* which, papr_stream_t stream);
+int papr_maxpool2_bwd(const float* d_out, const uint32_t* which, int32_t B, int32_t H, int32_t W, int32_t C, float* d_in, papr_stream_t stream);
+/* ConvTranspose2d(c_in, c_out, kernel_size=2, stride=2) of the Up stages (models/unet.py:62 `nn.ConvTranspose2d(in_channels,
+ * in_channels // 2, kernel_size=2, stride=2)`), split-f16 MFMA, one launch per call, no workspace.  x (B, H, W, c_in),
+ * out / d_out (B, 2H, 2W, c_out); wm = the weight as a contiguous (c_in, 2, 2, c_out) array, i.e. the reference's (c_in,
+ * c_out, 2, 2) parameter in channels-last memory format (d_wm likewise); channels multiples of 64.
+ * d_bias (c_out) = column sums of d_out, or NULL.  The weight-gradient reduces the pixels chunk by chunk (workspace
+ * papr_upconv2x2_wgrad_workspace_bytes(): the chunks' partial tiles, added in a fixed order by a second launch). */
+int papr_upconv2x2_fwd(const float* x, int32_t B, int32_t H, int32_t W, int32_t c_in, const float* wm, const float* bias, int32_t c_out,
+                       float* out, papr_stream_t stream);
+int papr_upconv2x2_dgrad(const float* d_out, int32_t B, int32_t H, int32_t W, int32_t c_in, const float* wm, int32_t c_out, float* d_x,
+                         papr_stream_t stream);
+size_t papr_upconv2x2_wgrad_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t c_in, int32_t c_out);
+int papr_upconv2x2_wgrad(const float* d_out, const float* x, int32_t B, int32_t H, int32_t W, int32_t c_in, int32_t c_out, float* d_wm,
+                         float* d_bias, void* workspace, papr_stream_t stream);
+/* The 1x1 output convolution (models/unet.py:86-93 OutConv, `nn.Conv2d(in_channels, out_channels, kernel_size=1)`) for up to
+ * four output channels: out (M, c_out) = bias + x (M, c_in) w^T, w (c_out, c_in) contiguous; plain fp32 (the layer is
+ * HBM-bound).  Backward: d_x (M, c_in) or NULL; d_w (c_out, c_in) and d_bias (c_out) or NULL (pixels reduced chunk by chunk,
+ * chunks added in a fixed order; workspace papr_conv1x1_bwd_workspace_bytes()); c_in a power of two 32 .. 256. */
+int papr_conv1x1_fwd(const float* x, int64_t M, int32_t c_in, const float* w, const float* bias, int32_t c_out, float* out, papr_stream_t stream);
+size_t papr_conv1x1_bwd_workspace_bytes(int64_t M, int32_t c_in, int32_t c_out);
+int papr_conv1x1_bwd(const float* d_out, const float* x, int64_t M, int32_t c_in, const float* w, int32_t c_out, float* d_x, float* d_w,
+                     float* d_bias, void* workspace, papr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * Optional timing of the GEMM / kNN launches with HIP events recorded on the launch stream
  * (used by bench.py for the live roofline figure; off by default, process-wide switch).
  * kernel ids: 0 gemm_nt<128x256> (fp32 MFMA)  1 gemm_nt<128x128>  2 gemm_nt<256x64>  3 gemm_nt<256x32>

@@ -216,17 +216,21 @@ struct ConvWArgs {
     long px_per_chunk;                           // multiple of 32
 };
 
+// CT = channels of x per tile: 128, or 32 for the network's first layer (32 input channels: a 128-wide tile would multiply
+// three quarters of zeros) -- then the four waves stack along n, 32 x 32 each.
+template <int CT>
 __global__ __launch_bounds__(256, 3) void conv3x3_wgrad_h3_kernel(ConvWArgs p) {
+    constexpr int NI = CT == 128 ? 2 : 1, NJ = NI, CQ = CT / 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     _Float16* Gh = reinterpret_cast<_Float16*>(smem);
     _Float16* Gl = Gh + CV_PLANE;
     _Float16* Xh = Gl + CV_PLANE;
     _Float16* Xl = Xh + CV_PLANE;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = CT == 128 ? wave >> 1 : wave, wn = CT == 128 ? wave & 1 : 0;
     const long M = (long)p.B * p.H * p.W;
-    const int cb = (p.C + 127) / 128;
-    const int n0 = (blockIdx.y / cb) * 128, c0 = (blockIdx.y % cb) * 128;
+    const int cb = (p.C + CT - 1) / CT;
+    const int n0 = (blockIdx.y / cb) * 128, c0 = (blockIdx.y % cb) * CT;
     const int tap = blockIdx.z, dy_ = tap / 3 - 1, dx_ = tap - (tap / 3) * 3 - 1;
     const long pbeg = (long)blockIdx.x * p.px_per_chunk;
     long pend = pbeg + p.px_per_chunk;
@@ -242,7 +246,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wgrad_h3_kernel(ConvWArgs p) {
 
     // block of the thread: channels 4 q .. 4 q + 3 (q = tid % 32), pixels 4 r .. 4 r + 3 of the 32-pixel slab (r = tid / 32)
     const int q = tid & 31, r = tid >> 5;
-    const bool n_ok = n0 + 4 * q < p.N, c_ok = c0 + 4 * q < p.C;
+    const bool n_ok = n0 + 4 * q < p.N, c_ok = q < CQ && c0 + 4 * q < p.C;
     const int ncol = n_ok ? n0 + 4 * q : 0, ccol = c_ok ? c0 + 4 * q : 0;
     float4 rg[4], rx[4];
     bool okg[4], okx[4];
@@ -265,19 +269,19 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wgrad_h3_kernel(ConvWArgs p) {
             const int yy = py[j] + dy_, xx = px[j] + dx_;
             okx[j] = c_ok && pix < pend && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
             const long src = okx[j] ? pc + (long)dy_ * p.W + dx_ : pc;
-            rx[j] = *reinterpret_cast<const float4*>(p.x + src * p.C + ccol);
+            if (CT == 128 || q < CQ) rx[j] = *reinterpret_cast<const float4*>(p.x + src * p.C + ccol);
             px[j] += 32;                                  // the same thread's pixel of the next slab
             while (px[j] >= p.W) { px[j] -= p.W; if (++py[j] == p.H) py[j] = 0; }
         }
     };
-    auto put = [&](const float4 (&v)[4], const bool (&ok)[4], float sc, _Float16* hi_plane, _Float16* lo_plane) {
+    auto put = [&](const float4 (&v)[4], const bool (&ok)[4], float sc, _Float16* hi_plane, _Float16* lo_plane, int rq) {
         const float s0 = ok[0] ? sc : 0.f, s1 = ok[1] ? sc : 0.f, s2 = ok[2] ? sc : 0.f, s3 = ok[3] ? sc : 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {                    // channel 4 q + j: its four pixels
             const float4 col = make_float4(comp4c(v[0], j) * s0, comp4c(v[1], j) * s1, comp4c(v[2], j) * s2, comp4c(v[3], j) * s3);
             half4 hi, lo;
             split4(col, 1.0f, hi, lo);
-            const int off = (q + 32 * j) * CV_HP + 4 * r;
+            const int off = (q + rq * j) * CV_HP + 4 * r;
             *reinterpret_cast<half4*>(hi_plane + off) = hi;
             *reinterpret_cast<half4*>(lo_plane + off) = lo;
         }
@@ -291,15 +295,15 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wgrad_h3_kernel(ConvWArgs p) {
             for (int j = 0; j < 4; ++j)
                 if (okg[j]) { bsum.x += rg[j].x; bsum.y += rg[j].y; bsum.z += rg[j].z; bsum.w += rg[j].w; }
         }
-        put(rg, okg, g_scale, Gh, Gl);
-        put(rx, okx, x_scale, Xh, Xl);
+        put(rg, okg, g_scale, Gh, Gl, 32);
+        if (CT == 128 || q < CQ) put(rx, okx, x_scale, Xh, Xl, CQ);
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[NI][NJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     const int frag = (lane & 31) * CV_HP + 8 * (lane >> 5);
@@ -311,19 +315,19 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wgrad_h3_kernel(ConvWArgs p) {
             if (ps + 32 < pend) load_slab(ps + 32);
 #pragma unroll
             for (int ks = 0; ks < CV_BK; ks += 16) {
-                half8 xh[2], xl[2];
+                half8 xh[NJ], xl[NJ];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < NJ; ++j) {
                     const int o = (wn * 64 + j * 32) * CV_HP + frag + ks;
                     xh[j] = *reinterpret_cast<const half8*>(Xh + o);
                     xl[j] = *reinterpret_cast<const half8*>(Xl + o);
                 }
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int o = (wm * 64 + i * 32) * CV_HP + frag + ks;
+                for (int i = 0; i < NI; ++i) {
+                    const int o = (wm * 32 * NI + i * 32) * CV_HP + frag + ks;
                     const half8 gh = *reinterpret_cast<const half8*>(Gh + o), gl = *reinterpret_cast<const half8*>(Gl + o);
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
+                    for (int j = 0; j < NJ; ++j) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gl, xh[j], acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, xl[j], acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, xh[j], acc[i][j], 0, 0, 0);
@@ -347,19 +351,19 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wgrad_h3_kernel(ConvWArgs p) {
         }
     }
     // acc[i][j][e]: LDS rows (n) 64 wm + 32 i + (e & 3) + 8 (e >> 2) + 4 (lane >> 5), LDS row (c) 64 wn + 32 j + (lane & 31);
-    // LDS row R holds channel 4 (R % 32) + R / 32 of the block
+    // LDS row R holds channel 4 (R % 32) + R / 32 of the n block, 4 (R % CQ) + R / CQ of the c block
     float* out = p.partial + (long)blockIdx.x * p.N * 9 * p.C;
     const float inv = g_inv * x_inv;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NJ; ++j) {
         const int rc = 64 * wn + 32 * j + (lane & 31);
-        const int c = c0 + 4 * (rc & 31) + (rc >> 5);
+        const int c = c0 + 4 * (rc % CQ) + rc / CQ;
         if (c >= p.C) continue;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int rn = 64 * wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                const int rn = 32 * NI * wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
                 const int n = n0 + 4 * (rn & 31) + (rn >> 5);
                 if (n < p.N) out[((long)n * 9 + tap) * p.C + c] = acc[i][j][e] * inv;
             }
@@ -528,13 +532,16 @@ extern "C" int papr_conv3x3_wgrad(const float* d_out, const float* x, int32_t B,
     a.px_per_chunk = px;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_h3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CV_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_h3_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CV_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_h3_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CV_LDS_BYTES);
         attr_set = true;
     }
-    const int tiles = ((c_out + 127) / 128) * ((c_in + 127) / 128);
+    const int ct = c_in <= 32 ? 32 : 128;
+    const int tiles = ((c_out + 127) / 128) * ((c_in + ct - 1) / ct);
     const bool prof = papr_prof_on();
     if (prof) papr_prof_begin2(12, M, c_out, 9 * c_in, 4LL * M * (c_in + c_out), 2LL * M * c_out * 9 * c_in, s);
-    conv3x3_wgrad_h3_kernel<<<dim3((unsigned)chunks, (unsigned)tiles, 9), dim3(256), CV_LDS_BYTES, s>>>(a);
+    if (ct == 32) conv3x3_wgrad_h3_kernel<32><<<dim3((unsigned)chunks, (unsigned)tiles, 9), dim3(256), CV_LDS_BYTES, s>>>(a);
+    else conv3x3_wgrad_h3_kernel<128><<<dim3((unsigned)chunks, (unsigned)tiles, 9), dim3(256), CV_LDS_BYTES, s>>>(a);
     PAPR_CHECK_LAUNCH("conv3x3_wgrad_h3");
     const long n4 = (long)c_out * 9 * c_in / 4;
     conv_wgrad_reduce_kernel<<<dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s>>>(reinterpret_cast<const float4*>(a.partial), (int)chunks, n4, reinterpret_cast<float4*>(d_w),

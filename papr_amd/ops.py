@@ -128,6 +128,7 @@ def conv3x3_wgrad_rows(d_y, x, want_bias=True, d_y_max=None, x_max=None):
 
 
 _OWN_CONV_WGRAD = os.environ.get("PAPR_UNET_WGRAD", "1") == "1"
+_OWN_WGRAD_MIN_CIN = int(os.environ.get("PAPR_UNET_WGRAD_MIN_CIN", "32"))      # (64: the first layer's weight gradient on MIOpen, A/B)
 
 
 class _Conv3x3Fn(torch.autograd.Function):
@@ -154,8 +155,8 @@ class _Conv3x3Fn(torch.autograd.Function):
         if own_dx:
             d_x, dy_max = conv3x3_rows(d_y, weight, None, False, transposed=True, want_max=True)
         lib_dx = ctx.needs_input_grad[0] and not own_dx
-        # (a 128 x 128 tile of (c_out, c_in): the 32-channel first layer would waste three quarters of it -- MIOpen is faster there)
-        own_dw = _OWN_CONV_WGRAD and weight.shape[0] % 4 == 0 and weight.shape[1] % 4 == 0 and weight.shape[1] >= 64
+        # (the 32-channel first layer has its own tile shape in the kernel: 128 x 32 instead of 128 x 128)
+        own_dw = _OWN_CONV_WGRAD and weight.shape[0] % 4 == 0 and weight.shape[1] % 4 == 0 and weight.shape[1] >= _OWN_WGRAD_MIN_CIN
         if own_dw:
             d_w, d_b = conv3x3_wgrad_rows(d_y, x, ctx.needs_input_grad[2], _conv_max_ptr(dy_max, x.device) if dy_max else None,
                                           _conv_max_ptr(ctx.x_max, x.device))
@@ -167,6 +168,107 @@ class _Conv3x3Fn(torch.autograd.Function):
             if lib_dx:
                 d_x = g_x.permute(0, 2, 3, 1)
         return d_x, d_w, d_b, None
+
+
+def _need_hip_rows(t, what):
+    if not t.is_cuda:
+        raise RuntimeError("papr_amd: %s runs only on a ROCm device (HIP); there is no CPU fallback" % what)
+    assert t.dtype == torch.float32 and t.is_contiguous()
+
+
+class _MaxPool2Fn(torch.autograd.Function):
+    """MaxPool2d(2) over an NHWC map (papr_maxpool2_fwd / _bwd; the reference's Down stage, models/unet.py:36-49).  The
+    gradient goes to the first maximum of a window in scan order, like torch's."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _need_hip_rows(x, "the max-pool kernel")
+        B, H, W, Cn = x.shape
+        out = torch.empty((B, H // 2, W // 2, Cn), device=x.device, dtype=torch.float32)
+        which = torch.empty((out.numel() // 4,), device=x.device, dtype=torch.int32) if ctx.needs_input_grad[0] else None
+        hip.check(hip.lib().papr_maxpool2_fwd(hip.ptr(x), B, H, W, Cn, hip.ptr(out), hip.ptr(which), hip.stream_ptr()), "papr_maxpool2_fwd")
+        ctx.shape = (B, H, W, Cn)
+        ctx.save_for_backward(which)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        which, = ctx.saved_tensors
+        B, H, W, Cn = ctx.shape
+        d_out = d_out.contiguous()
+        d_in = torch.empty((B, H, W, Cn), device=d_out.device, dtype=torch.float32)
+        hip.check(hip.lib().papr_maxpool2_bwd(hip.ptr(d_out), hip.ptr(which), B, H, W, Cn, hip.ptr(d_in), hip.stream_ptr()), "papr_maxpool2_bwd")
+        return d_in
+
+
+class _UpConv2x2Fn(torch.autograd.Function):
+    """ConvTranspose2d(kernel 2, stride 2) over an NHWC map with the reference's (C_in, C_out, 2, 2) weight (models/unet.py:62):
+    forward, data-gradient and weight-gradient each one launch of the split-f16 kernel of unet.hip (papr_upconv2x2_*)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _need_hip_rows(x, "the transposed-convolution kernel")
+        B, H, W, c_in = x.shape
+        c_out = weight.shape[1]
+        wm = weight.detach().permute(0, 2, 3, 1).contiguous()        # (no copy for a channels-last parameter)
+        out = torch.empty((B, 2 * H, 2 * W, c_out), device=x.device, dtype=torch.float32)
+        hip.check(hip.lib().papr_upconv2x2_fwd(hip.ptr(x), B, H, W, c_in, hip.ptr(wm), hip.ptr(bias.detach() if bias is not None else None), c_out,
+                                               hip.ptr(out), hip.stream_ptr()), "papr_upconv2x2_fwd")
+        ctx.save_for_backward(x, wm)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        x, wm = ctx.saved_tensors
+        B, H, W, c_in = x.shape
+        c_out = wm.shape[3]
+        d_out = d_out.contiguous()
+        lib = hip.lib()
+        d_x = d_w = d_b = None
+        if ctx.needs_input_grad[0]:
+            d_x = torch.empty_like(x)
+            hip.check(lib.papr_upconv2x2_dgrad(hip.ptr(d_out), B, H, W, c_in, hip.ptr(wm), c_out, hip.ptr(d_x), hip.stream_ptr()), "papr_upconv2x2_dgrad")
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            d_wm = torch.empty_like(wm)
+            d_b = torch.empty((c_out,), device=x.device, dtype=torch.float32) if ctx.needs_input_grad[2] else None
+            ws = torch.empty(((lib.papr_upconv2x2_wgrad_workspace_bytes(B, H, W, c_in, c_out) + 3) // 4,), device=x.device, dtype=torch.float32)
+            hip.check(lib.papr_upconv2x2_wgrad(hip.ptr(d_out), hip.ptr(x), B, H, W, c_in, c_out, hip.ptr(d_wm), hip.ptr(d_b), hip.ptr(ws), hip.stream_ptr()),
+                      "papr_upconv2x2_wgrad")
+            d_w = d_wm.permute(0, 3, 1, 2)
+        return d_x, d_w, d_b
+
+
+class _Conv1x1Fn(torch.autograd.Function):
+    """The 1x1 output convolution (models/unet.py:86-93) over an NHWC map, (C_out <= 4, C_in, 1, 1) weight: papr_conv1x1_fwd / _bwd."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _need_hip_rows(x, "the 1x1 convolution kernel")
+        B, H, W, c_in = x.shape
+        c_out = weight.shape[0]
+        w2 = weight.detach().reshape(c_out, c_in).contiguous()
+        out = torch.empty((B, H, W, c_out), device=x.device, dtype=torch.float32)
+        hip.check(hip.lib().papr_conv1x1_fwd(hip.ptr(x), B * H * W, c_in, hip.ptr(w2), hip.ptr(bias.detach() if bias is not None else None), c_out,
+                                             hip.ptr(out), hip.stream_ptr()), "papr_conv1x1_fwd")
+        ctx.save_for_backward(x, w2)
+        ctx.wshape = weight.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        x, w2 = ctx.saved_tensors
+        B, H, W, c_in = x.shape
+        c_out, M = w2.shape[0], B * H * W
+        d_out = d_out.contiguous()
+        lib = hip.lib()
+        d_x = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        want_w = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        d_w = torch.empty_like(w2) if want_w else None
+        d_b = torch.empty((c_out,), device=x.device, dtype=torch.float32) if ctx.needs_input_grad[2] else None
+        ws = torch.empty(((lib.papr_conv1x1_bwd_workspace_bytes(M, c_in, c_out) + 3) // 4,), device=x.device, dtype=torch.float32) if want_w else None
+        hip.check(lib.papr_conv1x1_bwd(hip.ptr(d_out), hip.ptr(x), M, c_in, hip.ptr(w2), c_out, hip.ptr(d_x), hip.ptr(d_w), hip.ptr(d_b), hip.ptr(ws),
+                                       hip.stream_ptr()), "papr_conv1x1_bwd")
+        return d_x, (d_w.reshape(ctx.wshape) if want_w else None), d_b
 
 
 class _LnFoldFn(torch.autograd.Function):

@@ -1,10 +1,12 @@
-"""Small U-Net render head (32 -> 128 -> 256 -> 512 -> 256 -> 128 -> 3) on torch / MIOpen.
+"""Small U-Net render head (32 -> 128 -> 256 -> 512 -> 256 -> 128 -> 3).
 
 Counterpart of the reference's SmallUNet (models/unet.py:182-258) in its only shipped
 configuration (single conv per stage, transposed-conv upsampling, no normalisation, no affine
-modulation).  It is convolutional over the whole patch rather than per ray, so it is not part of
-the hand-written per-ray kernels; it keeps the reference's module
-attribute names so that state-dict keys are interchangeable.
+modulation); it keeps the reference's module attribute names so that state-dict keys are
+interchangeable.  On the device, in fp32, every layer runs on this library's kernels over NHWC maps:
+the 3x3 convolutions on conv.hip, max-pooling, the transposed convolutions and the 1x1 output layer
+on unet.hip.  Under autocast (use_amp), on the CPU, or with
+PAPR_UNET_CONV=0 the layers are torch's (MIOpen on the device).
 """
 import os
 
@@ -13,6 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 _OWN_CONV = os.environ.get("PAPR_UNET_CONV", "1") == "1"
+_OWN_REST = os.environ.get("PAPR_UNET_REST", "1") == "1"       # (0: pooling, transposed and 1x1 convolutions on torch / MIOpen, A/B)
 
 
 class ConvStage(nn.Module):
@@ -35,12 +38,22 @@ class ConvStage(nn.Module):
         return self.double_conv(x)
 
 
+def _own_path(x):
+    return _OWN_CONV and _OWN_REST and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled()
+
+
 class DownStage(nn.Module):
+    """MaxPool2d(2) + ConvStage (models/unet.py:36-49); the pooling on papr_maxpool2_fwd / _bwd."""
+
     def __init__(self, c_in, c_out):
         super().__init__()
         self.maxpool_conv = nn.Sequential(nn.MaxPool2d(2), ConvStage(c_in, c_out))
 
     def forward(self, x):
+        if _own_path(x) and x.shape[1] % 4 == 0 and x.shape[2] >= 2 and x.shape[3] >= 2:
+            from .ops import _MaxPool2Fn
+            pooled = _MaxPool2Fn.apply(x.permute(0, 2, 3, 1).contiguous()).permute(0, 3, 1, 2)
+            return self.maxpool_conv[1](pooled)
         return self.maxpool_conv(x)
 
 
@@ -51,7 +64,11 @@ class UpStage(nn.Module):
         self.conv = ConvStage(c_in, c_out)
 
     def forward(self, low, skip):
-        low = self.up(low)
+        if _own_path(low) and self.up.in_channels % 64 == 0 and self.up.out_channels % 64 == 0:
+            from .ops import _UpConv2x2Fn                      # (papr_upconv2x2_*: forward and both gradients one launch each)
+            low = _UpConv2x2Fn.apply(low.permute(0, 2, 3, 1).contiguous(), self.up.weight, self.up.bias).permute(0, 3, 1, 2)
+        else:
+            low = self.up(low)
         dy, dx = skip.shape[2] - low.shape[2], skip.shape[3] - low.shape[3]
         if dx or dy:                                   # (F.pad with nothing to pad still copies the map, forward and backward)
             low = F.pad(low, [dx // 2, dx - dx // 2, dy // 2, dy - dy // 2])
@@ -64,6 +81,10 @@ class Head(nn.Module):
         self.conv = nn.Conv2d(c_in, c_out, kernel_size=1)
 
     def forward(self, x):
+        c_in, c_out = self.conv.in_channels, self.conv.out_channels
+        if _own_path(x) and c_out <= 4 and c_in in (32, 64, 128, 256):
+            from .ops import _Conv1x1Fn
+            return _Conv1x1Fn.apply(x.permute(0, 2, 3, 1).contiguous(), self.conv.weight, self.conv.bias).permute(0, 3, 1, 2)
         return self.conv(x)
 
 

@@ -543,6 +543,107 @@ def test_conv3x3_forward_and_gradients_match_torch(B, H, W, c_in, c_out, relu):
     np.testing.assert_allclose(bd.grad.cpu().numpy(), b.grad.numpy(), rtol=0, atol=2e-5 * b.grad.abs().max().item())
 
 
+@pytest.mark.parametrize("B,H,W,C", [(1, 40, 40, 128), (2, 7, 9, 4), (1, 20, 20, 256), (3, 2, 5, 36)])
+def test_maxpool2_matches_torch_exactly(B, H, W, C):
+    """papr_maxpool2_fwd / _bwd against torch.nn.functional.max_pool2d on the CPU, bit for bit, on a map with many ties (a
+    ReLU output, like the maps the reference pools: models/unet.py:36-49) and with odd sizes (last row / column dropped)."""
+    from papr_amd import ops
+    gen = torch.Generator().manual_seed(B * H * W + C)
+    x = torch.relu(torch.randn(B, C, H, W, generator=gen)).requires_grad_(True)
+    y = torch.nn.functional.max_pool2d(x, 2)
+    gy = torch.randn(y.shape, generator=gen)
+    (y * gy).sum().backward()
+    d = dev()
+    xd = x.detach().permute(0, 2, 3, 1).contiguous().to(d).requires_grad_(True)
+    yd = ops._MaxPool2Fn.apply(xd)
+    (yd * gy.permute(0, 2, 3, 1).contiguous().to(d)).sum().backward()
+    assert torch.equal(yd.detach().cpu().permute(0, 3, 1, 2), y.detach())
+    assert torch.equal(xd.grad.cpu().permute(0, 3, 1, 2), x.grad)
+    with torch.no_grad():
+        assert torch.equal(ops._MaxPool2Fn.apply(xd.detach()), yd.detach())
+
+
+@pytest.mark.parametrize("B,H,W,c_in,c_out", [(1, 10, 10, 512, 256), (1, 20, 20, 256, 128), (2, 5, 7, 64, 64), (1, 33, 50, 128, 64)])
+def test_upconv2x2_forward_and_gradients_match_torch(B, H, W, c_in, c_out):
+    """papr_upconv2x2_fwd / _dgrad / _wgrad against torch.nn.functional.conv_transpose2d(stride 2) in float64 on the CPU -- the
+    upsampling layers of the reference's SmallUNet (models/unet.py:62); same bars as the 3x3 layers."""
+    from papr_amd import ops
+    gen = torch.Generator().manual_seed(B * H + c_out)
+    x = torch.randn(B, c_in, H, W, generator=gen).requires_grad_(True)
+    w = (torch.randn(c_in, c_out, 2, 2, generator=gen) * (1.0 / c_in) ** 0.5).requires_grad_(True)
+    b = (torch.randn(c_out, generator=gen) * 0.1).requires_grad_(True)
+    y = torch.nn.functional.conv_transpose2d(x.double(), w.double(), b.double(), stride=2)
+    gy = torch.randn(B, c_out, 2 * H, 2 * W, generator=gen) * 1e-3
+    (y * gy.double()).sum().backward()
+    d = dev()
+    xd = x.detach().permute(0, 2, 3, 1).contiguous().to(d).requires_grad_(True)
+    wd = w.detach().to(d).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    bd = b.detach().to(d).requires_grad_(True)
+    yd = ops._UpConv2x2Fn.apply(xd, wd, bd)
+    (yd * gy.permute(0, 2, 3, 1).contiguous().to(d)).sum().backward()
+    np.testing.assert_allclose(yd.detach().cpu().permute(0, 3, 1, 2).numpy(), y.detach().float().numpy(), rtol=0, atol=2e-6 * y.abs().max().item())
+    np.testing.assert_allclose(xd.grad.cpu().permute(0, 3, 1, 2).numpy(), x.grad.numpy(), rtol=0, atol=3e-6 * x.grad.abs().max().item())
+    np.testing.assert_allclose(wd.grad.cpu().numpy(), w.grad.numpy(), rtol=0, atol=2e-5 * w.grad.abs().max().item())
+    np.testing.assert_allclose(bd.grad.cpu().numpy(), b.grad.numpy(), rtol=0, atol=2e-5 * b.grad.abs().max().item())
+    # a weight that is not channels-last (a freshly constructed module's) gives the same numbers
+    w2 = w.detach().to(d).requires_grad_(True)
+    assert torch.equal(ops._UpConv2x2Fn.apply(xd.detach(), w2, bd.detach()), yd.detach())
+
+
+@pytest.mark.parametrize("B,H,W,c_in,c_out", [(1, 40, 40, 128, 3), (2, 9, 11, 32, 4), (1, 3, 5, 256, 1)])
+def test_conv1x1_forward_and_gradients_match_torch(B, H, W, c_in, c_out):
+    """papr_conv1x1_fwd / _bwd against torch.nn.functional.conv2d(kernel 1) in float64 on the CPU -- the output layer of the
+    reference's SmallUNet (models/unet.py:86-93)."""
+    from papr_amd import ops
+    gen = torch.Generator().manual_seed(B * H + c_in)
+    x = torch.randn(B, c_in, H, W, generator=gen).requires_grad_(True)
+    w = (torch.randn(c_out, c_in, 1, 1, generator=gen) * (1.0 / c_in) ** 0.5).requires_grad_(True)
+    b = (torch.randn(c_out, generator=gen) * 0.1).requires_grad_(True)
+    y = torch.nn.functional.conv2d(x.double(), w.double(), b.double())
+    gy = torch.randn(B, c_out, H, W, generator=gen)
+    (y * gy.double()).sum().backward()
+    d = dev()
+    xd = x.detach().permute(0, 2, 3, 1).contiguous().to(d).requires_grad_(True)
+    wd, bd = w.detach().to(d).requires_grad_(True), b.detach().to(d).requires_grad_(True)
+    yd = ops._Conv1x1Fn.apply(xd, wd, bd)
+    (yd * gy.permute(0, 2, 3, 1).contiguous().to(d)).sum().backward()
+    np.testing.assert_allclose(yd.detach().cpu().permute(0, 3, 1, 2).numpy(), y.detach().float().numpy(), rtol=0, atol=1e-6 * y.abs().max().item())
+    np.testing.assert_allclose(xd.grad.cpu().permute(0, 3, 1, 2).numpy(), x.grad.numpy(), rtol=0, atol=1e-6 * x.grad.abs().max().item())
+    np.testing.assert_allclose(wd.grad.cpu().numpy(), w.grad.numpy(), rtol=0, atol=3e-6 * w.grad.abs().max().item())
+    np.testing.assert_allclose(bd.grad.cpu().numpy(), b.grad.numpy(), rtol=0, atol=3e-6 * b.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("hw", [(40, 40), (24, 36)])
+def test_small_unet_on_own_kernels_matches_torch_module(hw):
+    """The whole SmallUNet (reference models/unet.py:182-258) on this library's kernels against the same module run by torch
+    in float64 on the CPU: output and every parameter / input gradient; and no layer of the device run may go through
+    aten / MIOpen convolution or pooling (profiler check of the launched kernels)."""
+    import copy
+    from papr_amd.unet import SmallUNet
+    torch.manual_seed(3)
+    net = SmallUNet(32, 3)
+    x = torch.randn(1, 32, *hw)
+    gy = torch.randn(1, 3, *hw) * 1e-2
+    ref = copy.deepcopy(net).double()
+    xr = x.double().requires_grad_(True)
+    yr = ref(xr)
+    (yr * gy.double()).sum().backward()
+    d = dev()
+    net_d = net.to(d)
+    xd = x.to(d).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA]) as prof:
+        yd = net_d(xd)
+        (yd * gy.to(d)).sum().backward()
+        torch.cuda.synchronize()
+    names = [e.key for e in prof.key_averages()]
+    foreign = [n for n in names if any(t in n.lower() for t in ("igemm", "miopen", "max_pool", "naive_conv", "cijk_"))]
+    assert not foreign, foreign
+    np.testing.assert_allclose(yd.detach().cpu().numpy(), yr.detach().float().numpy(), rtol=0, atol=1e-5 * yr.abs().max().item())
+    np.testing.assert_allclose(xd.grad.cpu().numpy(), xr.grad.float().numpy(), rtol=0, atol=2e-5 * xr.grad.abs().max().item())
+    for (name, pd), pr in zip(net_d.named_parameters(), ref.parameters()):
+        np.testing.assert_allclose(pd.grad.cpu().numpy(), pr.grad.float().numpy(), rtol=0, atol=5e-5 * pr.grad.abs().max().item(), err_msg=name)
+
+
 @pytest.mark.parametrize("mode", ["f32", "fwd", "dgrad", "layers"])
 def test_other_gemm_modes_meet_the_same_mlp_parity(mode):
     """PAPR_GEMM_MODE selects which wide GEMMs use the split-f16 (hi/lo, 3 MFMA) kernels (default `h3`: forward
