@@ -22,11 +22,15 @@ struct ChainLayer {
     int k1steps;               // = ksteps, or for a skip layer ([previous output | x] as input): the k-steps of the first
                                // segment (a multiple of 4); the remaining ones multiply the run's input rows A0 again
     int act;                   // forward: activation; data-gradient: activation whose derivative is applied
+    int c_half;                // 1 (chain3.hip, one_product, not the run's last layer): C receives f16 rows instead of fp32 ones (ldc counts
+                               // halfs) -- the hi plane the next layer multiplies, i.e. each row times the power of two that brings its
+                               // maximum (rowmax, required) into [2^13, 2^14); the weight-gradient kernel reads them back with that scale
 };
 
 struct ChainArgs {
     float* A0; long lda0; int K0;         // input rows (M, lda0), K0 <= 256 real columns (written only with in_norm_writeback)
     float* rowmax0;                       // (M) receives max |.| of every input row, or null
+    _Float16* a0_half; long lda0_half;    // (chain3.hip, one_product) copy of the staged input rows as scaled f16 rows (see c_half), or null
     long M;
     int n_layers;
     int one_product;                      // 1 (PAPR_GEMM_MODE=h1, chain3.hip only): one f16 product per fp32 product -- hi planes only

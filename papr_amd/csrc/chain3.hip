@@ -385,7 +385,8 @@ __global__ __launch_bounds__(C3_THREADS, 2) void mlp_chain3_kernel(ChainArgs p, 
     // (wp = (lane >> 1) * 16, wq = (lane & 1) * 8 of the caller: see there)
     // (in_k: this lane's columns are inside the next layer's input; a constant true in the hot forms, so that the splits of four
     // rows interleave)
-    auto write_planes = [&](char* planes, unsigned wp, unsigned wq, int u, const float4& v, float sc, bool in_k) {
+    // (ONE: gdst = where this lane's four halfs go in memory as well -- the f16 rows the weight-gradient reads -- or null)
+    auto write_planes = [&](char* planes, unsigned wp, unsigned wq, int u, const float4& v, float sc, bool in_k, _Float16* gdst = nullptr) {
         if (in_k) {
             char* dst = planes + wn * C3_BLK_BYTES + u * 512 + (wp ^ (unsigned)(((wn * RB + u) & 15) * 16)) + wq;
             if constexpr (ONE) {                    // hi = f16(v * s) only
@@ -395,6 +396,7 @@ __global__ __launch_bounds__(C3_THREADS, 2) void mlp_chain3_kernel(ChainArgs p, 
                 asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h01) : "v"(v.y), "v"(sc));
                 asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h23) : "v"(v.w), "v"(sc));
                 *reinterpret_cast<uint2*>(dst) = make_uint2(h01, h23);
+                if (gdst) *reinterpret_cast<uint2*>(gdst) = make_uint2(h01, h23);
             } else {
                 half4 hi, lo;
                 split4(v, sc, hi, lo);
@@ -458,7 +460,9 @@ __global__ __launch_bounds__(C3_THREADS, 2) void mlp_chain3_kernel(ChainArgs p, 
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float sc = scale_from_max(__float_as_uint(smx[q]), inv[q]);
-                write_planes(planes, wp, wq, h + q, v[h + q], sc, c < kpad);
+                _Float16* gdst = nullptr;
+                if (ONE && p.a0_half != nullptr && r0 + h + q < M32) gdst = p.a0_half + (long)(r0 + h + q) * p.lda0_half + c;
+                write_planes(planes, wp, wq, h + q, v[h + q], sc, c < kpad, gdst);
             }
             *reinterpret_cast<float4*>(inv_tab + wn * RB + h) = make_float4(inv[0], inv[1], inv[2], inv[3]);
         }
@@ -498,7 +502,8 @@ __global__ __launch_bounds__(C3_THREADS, 2) void mlp_chain3_kernel(ChainArgs p, 
         const int N = L.N;
         const bool more = l + 1 < p.n_layers;
         const float slope = L.act == PAPR_ACT_RELU ? 0.f : (L.act == PAPR_ACT_LEAKY_RELU ? 0.2f : 1.f);
-        const bool rt_store = L.C != nullptr, rt_bits = L.sign_bits != nullptr, rt_rmax = L.rowmax != nullptr;
+        const bool rt_half = ONE && L.c_half != 0 && L.C != nullptr;          // f16 rows out (with the split for the next layer), no fp32 rows
+        const bool rt_store = L.C != nullptr && !rt_half, rt_bits = L.sign_bits != nullptr, rt_rmax = L.rowmax != nullptr;
         const bool rt_norm = !DGRAD && !more && p.norm_stats != nullptr;
         const bool rt_full = N == 256 && t0 + C3_ROWS <= M32;
         const bool mask_rows = DGRAD && !rt_bits && L.mask != nullptr;
@@ -522,6 +527,7 @@ __global__ __launch_bounds__(C3_THREADS, 2) void mlp_chain3_kernel(ChainArgs p, 
         auto rows = [&](auto cfg) {
             using Cfg = decltype(cfg);
             const bool f_store = Cfg::store == 2 ? rt_store : Cfg::store == 1;
+            const bool f_half = ONE && (Cfg::store == 2 ? rt_half : Cfg::store == 3);
             const bool f_bits = Cfg::bits == 2 ? rt_bits : Cfg::bits == 1;
             const bool f_rmax = Cfg::rmax == 2 ? rt_rmax : Cfg::rmax == 1;
             const bool f_more = Cfg::more == 2 ? more : Cfg::more == 1;
@@ -612,7 +618,10 @@ __global__ __launch_bounds__(C3_THREADS, 2) void mlp_chain3_kernel(ChainArgs p, 
                         for (int q = 0; q < 4; ++q) {
                             const float sc = scale_from_max(__float_as_uint(smx[q]), inv_n[q]);
 #ifndef C3_X_NOSPLIT
-                            write_planes(planes, wp, wq, ub + h + q, r[h + q], sc, Cfg::full == 1 || c < kpad_next);  // (full: N = 256 = the next layer's input width)
+                            _Float16* gdst = nullptr;
+                            if (f_half && (f_full || r0 + ub + h + q < M32))
+                                gdst = reinterpret_cast<_Float16*>(L.C) + (long)(r0 + ub + h + q) * ldc + c;
+                            write_planes(planes, wp, wq, ub + h + q, r[h + q], sc, Cfg::full == 1 || c < kpad_next, gdst);  // (full: N = 256 = the next layer's input width)
 #else
                             asm volatile("" :: "s"(sc));
 #endif
@@ -627,6 +636,7 @@ __global__ __launch_bounds__(C3_THREADS, 2) void mlp_chain3_kernel(ChainArgs p, 
         };
         // hot combinations (everything 256 wide, tile inside M): training middle layer / inference middle layer / data-gradient
         if (!generic_only && rt_full && more && !rt_norm && !mask_rows && rt_store && rt_bits && rt_rmax) rows(RowCfg<1, 1, 1, 1, 0, 1>());
+        else if (ONE && !generic_only && rt_full && more && !rt_norm && !mask_rows && rt_half && rt_bits && rt_rmax) rows(RowCfg<3, 1, 1, 1, 0, 1>());
         else if (!generic_only && !DGRAD && rt_full && more && !rt_norm && !rt_store && !rt_bits && !rt_rmax) rows(RowCfg<0, 0, 0, 1, 0, 1>());
         else rows(RowCfg<2, 2, 2, 2, 2, 2>());
     };
@@ -728,7 +738,7 @@ __global__ __launch_bounds__(C3_THREADS, 2) void mlp_chain3_kernel(ChainArgs p, 
             pm0 + C3_ROWS <= p.M) {
             const ChainLayer& LP = p.L[pl];
             const bool st = LP.C != nullptr, bi = LP.sign_bits != nullptr, rm = LP.rowmax != nullptr;
-            if (st && bi && rm) fmode = DGRAD ? 2 : 0;
+            if (st && bi && rm && !(ONE && LP.c_half)) fmode = DGRAD ? 2 : 0;        // (f16 rows out: the two-role slot, whose split stores them)
             else if (!ONE && fused_on > 1 && !DGRAD && !st && !bi && !rm) fmode = 1;        // (inference: the two-role slot with eight rows in flight is 5 % faster: PAPR_C3_FUSED=2 to compare)
         }
         if (fmode >= 0) {
@@ -796,6 +806,8 @@ int papr_launch_chain3(const ChainArgs& a, bool dgrad, long long bytes, long lon
     for (int l = 0; l < a.n_layers; ++l) {
         PAPR_REQUIRE(a.L[l].k1steps == a.L[l].ksteps, "mlp_chain3: skip layers run on mlp_chain_kernel");
         PAPR_REQUIRE(a.L[l].ksteps >= 1 && a.L[l].ksteps <= KS, "mlp_chain3: %d k-steps", a.L[l].ksteps);
+        PAPR_REQUIRE(!a.L[l].c_half || (a.one_product && l + 1 < a.n_layers && a.L[l].rowmax && a.L[l].ldc % 4 == 0),
+                     "mlp_chain3: layer %d: f16 rows need the one-product mode, a following layer and the row maxima", l);
     }
     if (a.M <= 0) return 0;
     const long tiles = (a.M + C3_ROWS - 1) / C3_ROWS;

@@ -24,6 +24,7 @@
 #include "chain.h"
 #include <stdlib.h>
 #include <algorithm>
+#include <type_traits>
 #include <string.h>
 
 namespace {
@@ -838,7 +839,15 @@ struct TNH3Args {
     long M; long rows_per_slice;
     const float* gmax; const float* xmax;      // per-row max |.| of G and of X
     float* slab; float* bias_slab;
+    int g_half, x_half;                        // (ONE instantiation) the operand is f16 rows, each row scaled by the power of two that
+                                               // scale_from_row_max() makes of its maximum (what the fused-run kernels of the h1 mode
+                                               // store); ldg / ldx then count halfs
 };
+__device__ __forceinline__ float inv_scale_from_row_max(float m) {       // 1 / (the fused-run kernels' row scale), chain3.hip: scale_from_max
+    const unsigned bits = __float_as_uint(m);
+    const int ea = bits ? (int)((bits >> 23) & 0xff) : 127 + 13;
+    return pow2_from_biased(127 - 13 + (ea - 127));
+}
 // Several weight-gradients in one launch: a workgroup streams its slice of job 0, then of job 1, ...  The partial
 // tile of a job (256 KB per workgroup) drains to memory while the next job's first rows are already on their way,
 // and the launch ramp and tail are paid once per batch instead of once per layer.
@@ -857,8 +866,11 @@ __device__ __forceinline__ half8 lds_read8(const _Float16* q) {
 // FULL: every 32-column tile holds real columns (N, K > 131): the hot loop has no tile tests
 __device__ __forceinline__ float comp4(const float4& v, int j) { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); }
 
-template <bool FULL>
+// FMT 0: fp32 operands, three f16 products per fp32 product.  PAPR_GEMM_MODE=h1: FMT 1 = fp32 operands, one product (hi planes
+// only); FMT 2 = both operands are f16 rows (g_half / x_half), one product, two stages of rows in flight.
+template <bool FULL, int FMT>
 __global__ __launch_bounds__(512, 2) void gemm_tn_h3_kernel(TNH3Batch batch) {
+    constexpr bool ONE = FMT != 0, HALF = FMT == 2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     _Float16* lds = reinterpret_cast<_Float16*>(smem);
     __shared__ float red[2][8];
@@ -870,6 +882,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_h3_kernel(TNH3Batch batch) {
     long mend = mbeg + p.rows_per_slice;
     if (mend > p.M) mend = p.M;
     if (mbeg >= mend) continue;                  // (workgroup-uniform: a job with fewer slices than the launch has workgroups)
+    constexpr bool gh = HALF, xh = HALF;
 
     // slice scales
     float gm = 0.f, xm = 0.f;
@@ -905,20 +918,61 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_h3_kernel(TNH3Batch batch) {
     // stage = 32 rows; wave w carries rows 4 w .. 4 w + 3 of it, lane l the columns 4 l .. 4 l + 3 (one full row per load)
     const int cg = 4 * lane < p.N ? 4 * lane : 0, cx = 4 * lane < p.K ? 4 * lane : 0;
     float4 rg[4], rx[4];
+    // (f16 rows: the four halfs of a lane ride in .x and .y of the float4)
+    auto load_g = [&](long m) {
+        if (gh) { const float2 t = *reinterpret_cast<const float2*>(reinterpret_cast<const _Float16*>(p.G) + m * p.ldg + cg); return make_float4(t.x, t.y, 0.f, 0.f); }
+        return *reinterpret_cast<const float4*>(p.G + m * p.ldg + cg);
+    };
+    auto load_x = [&](long m) {
+        if (xh) { const float2 t = *reinterpret_cast<const float2*>(reinterpret_cast<const _Float16*>(p.X) + m * p.ldx + cx); return make_float4(t.x, t.y, 0.f, 0.f); }
+        return *reinterpret_cast<const float4*>(p.X + m * p.ldx + cx);
+    };
     auto load_stage = [&](long st, float4 (&qg)[4], float4 (&qx)[4]) {      // unconditional, from clamped rows
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             long m = mbeg + st * TN_ROWS + 4 * wave + r;
             m = m < mend ? m : mend - 1;
-            qg[r] = *reinterpret_cast<const float4*>(p.G + m * p.ldg + cg);
-            qx[r] = *reinterpret_cast<const float4*>(p.X + m * p.ldx + cx);
+            qg[r] = load_g(m);
+            qx[r] = load_x(m);
         }
     };
-    auto put_block = [&](const float4 (&q)[4], const float (&sc)[4], _Float16* hi_plane, _Float16* lo_plane) {
-        const float y[4][4] = {{q[0].x * sc[0], q[0].y * sc[0], q[0].z * sc[0], q[0].w * sc[0]},
-                               {q[1].x * sc[1], q[1].y * sc[1], q[1].z * sc[1], q[1].w * sc[1]},
-                               {q[2].x * sc[2], q[2].y * sc[2], q[2].z * sc[2], q[2].w * sc[2]},
-                               {q[3].x * sc[3], q[3].y * sc[3], q[3].z * sc[3], q[3].w * sc[3]}};
+    // element j of a lane's four columns of one row, as fp32 (an f16 row: still times the row's scale)
+    auto elem = [&](const float4& q, int j, bool half) {
+        if (!half) return comp4(q, j);
+        const unsigned w = __float_as_uint(j < 2 ? q.x : q.y);
+        const unsigned short hb = (unsigned short)((j & 1) ? (w >> 16) : (w & 0xffffu));
+        return (float)*reinterpret_cast<const _Float16*>(&hb);
+    };
+    // per-row factors of stage st: scale of the slice (times 1 / the row's own scale for f16 rows), 0 for rows past the slice;
+    // fg: what turns an element of G into its true value (bias gradient)
+    // (f16 rows: the wave's four row maxima of a stage are one 16-byte scalar load, asked for a stage ahead -- at the top of a stage
+    //  it would wait for a round trip to L2 before the first fragment read.  The index is clamped to the slice; up to three floats
+    //  behind the array may be read for rows past M, whose factors are 0 anyway: both arrays have memory behind them.)
+    auto row_maxima = [&](long st, float4& mg, float4& mx) {
+        if (!HALF) return;
+        long base = mbeg + st * TN_ROWS + 4 * wave;
+        const long top = (mend - 1) & ~3L;
+        base = base < top ? base : top;
+        mg = *reinterpret_cast<const float4*>(p.gmax + base);
+        mx = *reinterpret_cast<const float4*>(p.xmax + base);
+    };
+    auto row_factors = [&](long st, const float4& mg, const float4& mx, float (&sg)[4], float (&sx)[4], float (&fg)[4]) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long m = mbeg + st * TN_ROWS + 4 * wave + r;
+            const bool ok = m < mend;
+            const float ig = gh ? inv_scale_from_row_max(comp4(mg, r)) : 1.f, ix = xh ? inv_scale_from_row_max(comp4(mx, r)) : 1.f;
+            sg[r] = ok ? g_scale * ig : 0.f;
+            sx[r] = ok ? x_scale * ix : 0.f;
+            fg[r] = ok ? ig : 0.f;
+        }
+    };
+    auto put_block = [&](const float4 (&q)[4], const float (&sc)[4], _Float16* hi_plane, _Float16* lo_plane, bool half) {
+        float y[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[r][j] = elem(q[r], j, half) * sc[r];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             half4 hi = half4{(_Float16)y[0][j], (_Float16)y[1][j], (_Float16)y[2][j], (_Float16)y[3][j]};
@@ -926,28 +980,50 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_h3_kernel(TNH3Batch batch) {
                              (_Float16)(y[2][j] - (float)hi[2]), (_Float16)(y[3][j] - (float)hi[3])};
             const int off = (lane + 64 * j) * T3_HP + 4 * wave;
             *reinterpret_cast<half4*>(hi_plane + off) = hi;
-            *reinterpret_cast<half4*>(lo_plane + off) = lo;
+            if (!ONE) *reinterpret_cast<half4*>(lo_plane + off) = lo;
         }
     };
     auto store_stage = [&](long st, const float4 (&qg)[4], const float4 (&qx)[4]) {
         _Float16* base = lds + (st & 1) * (4 * T3_PLANE);
-        float sg[4], sx[4];
+        float sg[4], sx[4], fg[4];
+        float4 mg0 = make_float4(0.f, 0.f, 0.f, 0.f), mx0 = mg0;
+        row_maxima(st, mg0, mx0);
+        row_factors(st, mg0, mx0, sg, sx, fg);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const bool ok = mbeg + st * TN_ROWS + 4 * wave + r < mend;
-            sg[r] = ok ? g_scale : 0.f;
-            sx[r] = ok ? x_scale : 0.f;
-            if (ok) { colsum[0] += qg[r].x; colsum[1] += qg[r].y; colsum[2] += qg[r].z; colsum[3] += qg[r].w; }
-        }
-        put_block(qg, sg, base, base + T3_PLANE);
-        put_block(qx, sx, base + 2 * T3_PLANE, base + 3 * T3_PLANE);
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) colsum[j] = __builtin_fmaf(elem(qg[r], j, gh), fg[r], colsum[j]);
+        put_block(qg, sg, base, base + T3_PLANE, gh);
+        put_block(qx, sx, base + 2 * T3_PLANE, base + 3 * T3_PLANE, xh);
     };
     const int frag = (lane & 31) * T3_HP + 8 * (lane >> 5);
     // One register set of 32 rows in flight (a second set does not fit beside the 128 accumulator registers).
     const long nst = (mend - mbeg + TN_ROWS - 1) / TN_ROWS;
     load_stage(0, rg, rx);
     store_stage(0, rg, rx);
-    load_stage(1, rg, rx);
+    // deep (both operands f16 rows): the rows are half as many bytes, so TWO stages ride in the same registers -- stage s in
+    // (.x, .y) of the float4 when s is even, in (.z, .w) when it is odd -- and a load has two stage times to arrive instead of one
+    constexpr bool deep = HALF;
+    auto load_half_stage = [&](long st, auto oddc, bool do_g, bool do_x) {          // oddc: the parity of st, as a type
+        constexpr bool odd_slot = decltype(oddc)::value;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            long m = mbeg + st * TN_ROWS + 4 * wave + r;
+            m = m < mend ? m : mend - 1;
+            if (do_g) {
+                const float2 t = *reinterpret_cast<const float2*>(reinterpret_cast<const _Float16*>(p.G) + m * p.ldg + cg);
+                if (odd_slot) { rg[r].z = t.x; rg[r].w = t.y; } else { rg[r].x = t.x; rg[r].y = t.y; }
+            }
+            if (do_x) {
+                const float2 t = *reinterpret_cast<const float2*>(reinterpret_cast<const _Float16*>(p.X) + m * p.ldx + cx);
+                if (odd_slot) { rx[r].z = t.x; rx[r].w = t.y; } else { rx[r].x = t.x; rx[r].y = t.y; }
+            }
+        }
+    };
+    if (deep) { load_half_stage(1, std::true_type(), true, true); load_half_stage(2, std::false_type(), true, true); }
+    else load_stage(1, rg, rx);
+    float4 mgn = make_float4(0.f, 0.f, 0.f, 0.f), mxn = mgn;      // row maxima of the stage the next iteration splits
+    row_maxima(1, mgn, mxn);
     lds_barrier();
     {
         // The split of stage st+1 rides between the matrix instructions of stage st.  A wave issues in order and a
@@ -959,22 +1035,20 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_h3_kernel(TNH3Batch batch) {
         // alternate, so that no instruction waits for the result of the one just before it.  An operand's four rows are
         // requested again (stage st+2) when its fourth column has left the registers.
         const int tile_x0 = (wk * 2) * 32 * T3_HP + frag, tile_x1 = (wk * 2 + 1) * 32 * T3_HP + frag;
-        for (long st = 0; st < nst; ++st) {
+        auto stage_body = [&](long st, auto oddc) {      // oddc: parity of st + 1 (only looked at when two stages are in flight)
             const _Float16* Gh = lds + (st & 1) * (4 * T3_PLANE);
             const _Float16* Gl = Gh + T3_PLANE;
             const _Float16* Xh = Gh + 2 * T3_PLANE;
             const _Float16* Xl = Gh + 3 * T3_PLANE;
             _Float16* nb = lds + ((st + 1) & 1) * (4 * T3_PLANE);        // stage st+1 goes here (rows past the slice: zeros)
             float sg[4], sx[4], okf[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool ok = mbeg + (st + 1) * TN_ROWS + 4 * wave + r < mend;
-                sg[r] = ok ? g_scale : 0.f;
-                sx[r] = ok ? x_scale : 0.f;
-                okf[r] = ok ? 1.f : 0.f;
-            }
-            half8 xh0 = lds_read8(Xh + tile_x0), xl0 = lds_read8(Xl + tile_x0), xh1 = lds_read8(Xh + tile_x1), xl1 = lds_read8(Xl + tile_x1);
-            half8 gh = lds_read8(Gh + (wn * 4) * 32 * T3_HP + frag), gl = lds_read8(Gl + (wn * 4) * 32 * T3_HP + frag);
+            row_factors(st + 1, mgn, mxn, sg, sx, okf);
+            row_maxima(st + 2, mgn, mxn);
+            constexpr bool odd = deep && decltype(oddc)::value;      // where the rows being split (stage st + 1) sit in their registers
+            auto hsrc = [&](const float4& q, int j) { return odd ? (j < 2 ? q.z : q.w) : (j < 2 ? q.x : q.y); };
+            half8 xh0 = lds_read8(Xh + tile_x0), xh1 = lds_read8(Xh + tile_x1), xl0 = xh0, xl1 = xh1;
+            half8 gfh = lds_read8(Gh + (wn * 4) * 32 * T3_HP + frag), gfl = gfh;
+            if (!ONE) { xl0 = lds_read8(Xl + tile_x0); xl1 = lds_read8(Xl + tile_x1); gfl = lds_read8(Gl + (wn * 4) * 32 * T3_HP + frag); }
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
                 const int i = g & 3;
@@ -985,18 +1059,45 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_h3_kernel(TNH3Batch batch) {
                 const int j = g & 3;
                 const float4 (&q)[4] = is_g ? rg : rx;
                 const float (&sc)[4] = is_g ? sg : sx;
+                const bool qhalf = is_g ? gh : xh;
                 _Float16* hi_plane = nb + (is_g ? 0 : 2 * T3_PLANE);
                 const bool on = FULL || live_n[i], k0 = FULL || live_k[0], k1 = FULL || live_k[1];
-                half8 ghn = gh, gln = gl;
+                half8 ghn = gfh, gln = gfl;
                 unsigned h01, h23, l01, l23;             // packed f16 pairs (rows 0,1 and 2,3 of a column)
                 // hi = f16(q * scale), two rows per register; lo = f16(q * scale - hi) in one fused instruction each (the
                 // scale is a power of two, so the product is exact and this rounds like the two-step form)
                 auto split_hi = [&](const int j) {
-                    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h01) : "v"(comp4(q[0], j)), "v"(sc[0]));
-                    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h23) : "v"(comp4(q[2], j)), "v"(sc[2]));
-                    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h01) : "v"(comp4(q[1], j)), "v"(sc[1]));
-                    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h23) : "v"(comp4(q[3], j)), "v"(sc[3]));
+                    if (ONE && qhalf) {                  // f16 source: half j & 1 of register j >> 1 of the row, times its factor
+                        if (j & 1) {
+                            asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(h01) : "v"(hsrc(q[0], j)), "v"(sc[0]));
+                            asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(h23) : "v"(hsrc(q[2], j)), "v"(sc[2]));
+                            asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(h01) : "v"(hsrc(q[1], j)), "v"(sc[1]));
+                            asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(h23) : "v"(hsrc(q[3], j)), "v"(sc[3]));
+                        } else {
+                            asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(h01) : "v"(hsrc(q[0], j)), "v"(sc[0]));
+                            asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(h23) : "v"(hsrc(q[2], j)), "v"(sc[2]));
+                            asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "+v"(h01) : "v"(hsrc(q[1], j)), "v"(sc[1]));
+                            asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "+v"(h23) : "v"(hsrc(q[3], j)), "v"(sc[3]));
+                        }
+                    } else {
+                        asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h01) : "v"(comp4(q[0], j)), "v"(sc[0]));
+                        asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h23) : "v"(comp4(q[2], j)), "v"(sc[2]));
+                        asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h01) : "v"(comp4(q[1], j)), "v"(sc[1]));
+                        asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h23) : "v"(comp4(q[3], j)), "v"(sc[3]));
+                    }
                     *reinterpret_cast<uint2*>(hi_plane + (lane + 64 * j) * T3_HP + 4 * wave) = make_uint2(h01, h23);
+                };
+                auto add_colsum = [&](const int j) {     // bias gradient: the true values of G's column j (okf: 1 / row scale, or 1, or 0)
+                    if (ONE && qhalf) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            if (j & 1) asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(colsum[j]) : "v"(hsrc(q[r], j)), "v"(okf[r]));
+                            else asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(colsum[j]) : "v"(hsrc(q[r], j)), "v"(okf[r]));
+                        }
+                    } else {
+                        colsum[j] = __builtin_fmaf(comp4(q[3], j), okf[3], __builtin_fmaf(comp4(q[2], j), okf[2],
+                                    __builtin_fmaf(comp4(q[1], j), okf[1], __builtin_fmaf(comp4(q[0], j), okf[0], colsum[j]))));
+                    }
                 };
                 auto split_lo = [&](const int j) {
                     asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l01) : "v"(comp4(q[0], j)), "v"(sc[0]), "v"(h01));
@@ -1004,58 +1105,80 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_h3_kernel(TNH3Batch batch) {
                     asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l01) : "v"(comp4(q[1], j)), "v"(sc[1]), "v"(h01));
                     asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l23) : "v"(comp4(q[3], j)), "v"(sc[3]), "v"(h23));
                     *reinterpret_cast<uint2*>(hi_plane + T3_PLANE + (lane + 64 * j) * T3_HP + 4 * wave) = make_uint2(l01, l23);
-                    if (is_g) colsum[j] = __builtin_fmaf(comp4(q[3], j), okf[3], __builtin_fmaf(comp4(q[2], j), okf[2],
-                                          __builtin_fmaf(comp4(q[1], j), okf[1], __builtin_fmaf(comp4(q[0], j), okf[0], colsum[j]))));
                 };
-                if (on && k0) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gl, xh0, acc[i][0], 0, 0, 0);
+                if (!ONE && on && k0) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gfl, xh0, acc[i][0], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 if (g < 7) {                             // next group's G fragments
                     const int o = (wn * 4 + ((g + 1) & 3)) * 32 * T3_HP + frag + 16 * ((g + 1) >> 2);
-                    ghn = lds_read8(Gh + o); gln = lds_read8(Gl + o);
+                    ghn = lds_read8(Gh + o);
+                    if (!ONE) gln = lds_read8(Gl + o);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if (on && k1) acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gl, xh1, acc[i][1], 0, 0, 0);
+                if (!ONE && on && k1) acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gfl, xh1, acc[i][1], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
+                if (ONE && on && k0) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gfh, xh0, acc[i][0], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#ifndef TN_ABL_NO_SPLIT
                 split_hi(j);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
-                if (on && k0) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, xl0, acc[i][0], 0, 0, 0);
+                if (!ONE && on && k0) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gfh, xl0, acc[i][0], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (on && k1) acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, xl1, acc[i][1], 0, 0, 0);
+                if (!ONE && on && k1) acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gfh, xl1, acc[i][1], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                split_lo(j);
+                if (ONE && on && k1) acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gfh, xh1, acc[i][1], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (on && k0) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, xh0, acc[i][0], 0, 0, 0);
+                if (!ONE) split_lo(j);
+#ifndef TN_ABL_NO_COLSUM
+                if (is_g) add_colsum(j);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
-                if (on && k1) acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, xh1, acc[i][1], 0, 0, 0);
+                if (!ONE && on && k0) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gfh, xh0, acc[i][0], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (!ONE && on && k1) acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gfh, xh1, acc[i][1], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
 #ifndef TN_ABL_NO_LOAD
-                if (g == 3) {                            // the G block has left the registers: its rows of stage st+2
+                if (g == 3) {                            // the G block has left the registers: its rows of stage st+2 (deep: st+3)
+                    if (deep) load_half_stage(st + 3, oddc, true, false);
+                    else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        long m = mbeg + (st + 2) * TN_ROWS + 4 * wave + r;
-                        m = m < mend ? m : mend - 1;
-                        rg[r] = *reinterpret_cast<const float4*>(p.G + m * p.ldg + cg);
+                        for (int r = 0; r < 4; ++r) {
+                            long m = mbeg + (st + 2) * TN_ROWS + 4 * wave + r;
+                            m = m < mend ? m : mend - 1;
+                            rg[r] = load_g(m);
+                        }
                     }
                 }
 #endif
                 if (g == 3) {                            // second k step of the stage: its X fragments
-                    xh0 = lds_read8(Xh + tile_x0 + 16); xl0 = lds_read8(Xl + tile_x0 + 16);
-                    xh1 = lds_read8(Xh + tile_x1 + 16); xl1 = lds_read8(Xl + tile_x1 + 16);
+                    xh0 = lds_read8(Xh + tile_x0 + 16); xh1 = lds_read8(Xh + tile_x1 + 16);
+                    if (!ONE) { xl0 = lds_read8(Xl + tile_x0 + 16); xl1 = lds_read8(Xl + tile_x1 + 16); }
                 }
                 if (g == 7) {                            // the X rows of stage st+2
 #ifndef TN_ABL_NO_LOAD
+                    if (deep) load_half_stage(st + 3, oddc, false, true);
+                    else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        long m = mbeg + (st + 2) * TN_ROWS + 4 * wave + r;
-                        m = m < mend ? m : mend - 1;
-                        rx[r] = *reinterpret_cast<const float4*>(p.X + m * p.ldx + cx);
+                        for (int r = 0; r < 4; ++r) {
+                            long m = mbeg + (st + 2) * TN_ROWS + 4 * wave + r;
+                            m = m < mend ? m : mend - 1;
+                            rx[r] = load_x(m);
+                        }
                     }
 #endif
                 }
-                gh = ghn; gl = gln;
+                gfh = ghn; gfl = gln;
                 __builtin_amdgcn_sched_barrier(0);
             }
             lds_barrier();
+        };
+        if (deep) {
+            for (long st = 0; st < nst; st += 2) {
+                stage_body(st, std::true_type());
+                if (st + 1 < nst) stage_body(st + 1, std::false_type());
+            }
+        } else {
+            for (long st = 0; st < nst; ++st) stage_body(st, std::false_type());
         }
     }
 
@@ -1095,20 +1218,22 @@ struct TNH3Queue {
     TNH3Batch batch;
     ReduceBatch red;
     bool full = false;
+    int half = 0;
     int grid = 0;
     long long bytes = 0, flops = 0;
     void* workspace;
     hipStream_t s;
     TNH3Queue(void* ws, hipStream_t st) : workspace(ws), s(st) { batch.n = 0; }
     int push(const float* G, long ldg, int N, const float* X, long ldx, int K, long M, const float* gmax, const float* xmax,
-             float* dW, int ldw, float* db) {
+             float* dW, int ldw, float* db, int g_half = 0, int x_half = 0) {
         PAPR_REQUIRE(N <= SLAB && K <= SLAB, "gemm_tn_h3: N=%d, K=%d exceed %d", N, K, SLAB);
         PAPR_REQUIRE(N % 4 == 0 && K % 4 == 0 && ldg % 4 == 0 && ldx % 4 == 0, "gemm_tn_h3: sizes must be multiples of 4");
         if (M <= 0) return 0;
         const bool job_full = N > 131 && K > 131;                       // 128 + 3 < N: all eight tiles live
-        if (batch.n == TN_BATCH || (batch.n > 0 && job_full != full))
+        PAPR_REQUIRE(g_half == x_half, "gemm_tn_h3: one operand f16, the other fp32");
+        if (batch.n == TN_BATCH || (batch.n > 0 && (job_full != full || g_half != half)))
             if (int e = flush()) return e;
-        full = job_full;
+        full = job_full; half = g_half;
         static int n_cu = 0;
         if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu <= 0 || n_cu > MAX_SLICES) n_cu = MAX_SLICES; }
         long stages = (M + TN_ROWS - 1) / TN_ROWS;
@@ -1117,12 +1242,12 @@ struct TNH3Queue {
         S = (int)((M + rows_per_slice - 1) / rows_per_slice);
         TNH3Args& a = batch.job[batch.n];
         a.G = G; a.ldg = ldg; a.N = N; a.X = X; a.ldx = ldx; a.K = K; a.M = M; a.rows_per_slice = rows_per_slice;
-        a.gmax = gmax; a.xmax = xmax;
+        a.gmax = gmax; a.xmax = xmax; a.g_half = g_half; a.x_half = x_half;
         a.slab = static_cast<float*>(workspace) + (size_t)batch.n * TN_JOB_FLOATS;
         a.bias_slab = a.slab + (size_t)MAX_SLICES * SLAB * SLAB;
         red.job[batch.n] = ReduceJob{a.slab, a.bias_slab, S, N, K, dW, ldw, db};
         grid = S > grid ? S : grid;
-        bytes += 4LL * M * (N + K); flops += 2LL * M * N * K;
+        bytes += (g_half ? 2LL : 4LL) * M * N + (x_half ? 2LL : 4LL) * M * K; flops += 2LL * M * N * K;
         ++batch.n;
         return 0;
     }
@@ -1130,14 +1255,24 @@ struct TNH3Queue {
         if (batch.n == 0) return 0;
         static bool attr_set = false;
         if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_h3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T3_LDS_BYTES);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_h3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T3_LDS_BYTES);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_h3_kernel<true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T3_LDS_BYTES);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_h3_kernel<false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T3_LDS_BYTES);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_h3_kernel<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T3_LDS_BYTES);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_h3_kernel<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T3_LDS_BYTES);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_h3_kernel<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T3_LDS_BYTES);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_h3_kernel<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T3_LDS_BYTES);
             attr_set = true;
         }
         const bool prof = papr_prof_on();
         if (prof) papr_prof_begin2(8, batch.job[0].M, batch.n, 0, bytes, flops, s);
-        if (full) gemm_tn_h3_kernel<true><<<dim3(grid), dim3(512), T3_LDS_BYTES, s>>>(batch);
-        else gemm_tn_h3_kernel<false><<<dim3(grid), dim3(512), T3_LDS_BYTES, s>>>(batch);
+        if (GEMM_ONE_PRODUCT && half) {
+            if (full) gemm_tn_h3_kernel<true, 2><<<dim3(grid), dim3(512), T3_LDS_BYTES, s>>>(batch);
+            else gemm_tn_h3_kernel<false, 2><<<dim3(grid), dim3(512), T3_LDS_BYTES, s>>>(batch);
+        } else if (GEMM_ONE_PRODUCT) {
+            if (full) gemm_tn_h3_kernel<true, 1><<<dim3(grid), dim3(512), T3_LDS_BYTES, s>>>(batch);
+            else gemm_tn_h3_kernel<false, 1><<<dim3(grid), dim3(512), T3_LDS_BYTES, s>>>(batch);
+        } else if (full) gemm_tn_h3_kernel<true, 0><<<dim3(grid), dim3(512), T3_LDS_BYTES, s>>>(batch);
+        else gemm_tn_h3_kernel<false, 0><<<dim3(grid), dim3(512), T3_LDS_BYTES, s>>>(batch);
         if (prof) papr_prof_end(s);
         PAPR_CHECK_LAUNCH("gemm_tn_h3");
         slab_reduce_kernel<true><<<dim3(SLAB * SLAB / 4 / 16, batch.n), dim3(256), 0, s>>>(red);
@@ -1201,6 +1336,24 @@ static bool layer_rowmax_saved(const papr_layer* layers, int n_layers, int i) {
         } else ++b;
     }
     return layer_on_h3(layers[i]);
+}
+
+// h1 mode, chain3.hip: the rows a fused run leaves for its weight-gradients are f16 (scaled per row, chain.h: c_half) instead
+// of fp32 -- the weight-gradient kernel is HBM-bound, so half the bytes is half its time.  The buffers stay the caller's
+// fp32-sized ones: the f16 rows of a layer's output occupy the first half of outs[l] (row stride ld_out[l] halfs), and the f16
+// copy of the run's input rows the second half of the run's first output buffer; likewise the gradient-row slots of the
+// backward scratch.  Only the run's last output (forward) / the gradient that leaves the run (backward) remain fp32 rows.
+// PAPR_H1_ROWS=f32 keeps fp32 rows (A/B).
+static const bool H1_HALF_ROWS = GEMM_ONE_PRODUCT && !(getenv("PAPR_H1_ROWS") && !strcmp(getenv("PAPR_H1_ROWS"), "f32")) &&
+                                 (!getenv("PAPR_CHAIN") || atoi(getenv("PAPR_CHAIN")) == 3);
+// forward run [b, e) of a training pass stores f16 rows (the backward pass asks the same question)
+static bool run_half_rows(const papr_layer* layers, int n_layers, int b, int e, const int32_t* ld_out, bool training) {
+    if (!H1_HALF_ROWS || !training || e - b < 2) return false;
+    for (int l = 0; l < n_layers; ++l) if (layers[l].n_skip > 0) return false;          // (runs of such an MLP go to chain.hip)
+    const int k0pad = (layers[b].n_in + 31) / 32 * 32;
+    if (k0pad > ld_out[b]) return false;                                                // the input copy must fit behind outs[b]'s rows
+    for (int l = b; l < e - 1; ++l) if (ld_out[l] % 4 || layers[l].n_out % 32) return false;
+    return true;
 }
 
 // pre-split W (N x K, leading dimension ldw) into fragment-order planes at `planes`; returns the halfs used
@@ -1271,6 +1424,8 @@ extern "C" int papr_mlp_fwd(const papr_layer* layers, int n_layers, float* x, in
             c.M = M; c.n_layers = e - i;
             for (int l = 0; l < n_layers; ++l) c.legacy |= layers[l].n_skip > 0 ? 1 : 0;      // (sign-word layout: chain.h)
             c.one_product = GEMM_ONE_PRODUCT ? 1 : 0;
+            const bool half_rows = run_half_rows(layers, n_layers, i, e, ld_out, saved != nullptr);
+            if (half_rows) { c.a0_half = reinterpret_cast<_Float16*>(outs[i]) + (size_t)M * ld_out[i]; c.lda0_half = ld_out[i]; }
             size_t used = 0;
             SplitBatch split = {};
             long long bytes = 4LL * M * L.n_in, flops = 0;
@@ -1281,8 +1436,9 @@ extern "C" int papr_mlp_fwd(const papr_layer* layers, int n_layers, float* x, in
                 if (layers[l].n_skip > 0) cl.k1steps = layers[l].n_in / 16;      // [previous output | x]: the second segment multiplies the run's input again
                 cl.bias = layers[l].bias; cl.act = layers[l].act;
                 cl.C = (saved || l == e - 1) ? outs[l] : nullptr; cl.ldc = ld_out[l];
+                cl.c_half = half_rows && l < e - 1 ? 1 : 0;
                 cl.sign_bits = saved && layers[l].act != PAPR_ACT_NONE ? saved_sign_words(saved, n_layers, M, l) : nullptr;
-                if (cl.C) bytes += 4LL * M * layers[l].n_out;
+                if (cl.C) bytes += (cl.c_half ? 2LL : 4LL) * M * layers[l].n_out;
                 bytes += 4LL * layers[l].n_out * (layers[l].n_in + layers[l].n_skip) + 4LL * M * layers[l].n_skip;
                 flops += 2LL * M * layers[l].n_out * (layers[l].n_in + layers[l].n_skip);
                 cl.rowmax = l + 1 < n_layers ? (saved ? saved + (size_t)(l + 1) * M : (l == e - 1 ? reinterpret_cast<float*>(h3.out()) : nullptr)) : nullptr;
@@ -1347,7 +1503,7 @@ struct BwdRunScratch {
         for (int i = 0; i < CHAIN_MAX_LAYERS; ++i) { g[i] = q; q += (size_t)M * G_LD; }
         for (int i = 0; i <= CHAIN_MAX_LAYERS; ++i) { gmax[i] = q; q += M; }
     }
-    static size_t bytes(long M) { return GEMM_CHAIN ? ((size_t)CHAIN_MAX_LAYERS * M * G_LD + (size_t)(CHAIN_MAX_LAYERS + 1) * M) * sizeof(float) : 0; }
+    static size_t bytes(long M) { return GEMM_CHAIN ? ((size_t)CHAIN_MAX_LAYERS * M * G_LD + (size_t)(CHAIN_MAX_LAYERS + 1) * M + 4) * sizeof(float) : 0; }
 };
 
 extern "C" int papr_mlp_bwd_needs_weight_t(const papr_layer* layers, int n_layers, int need_dx) {
@@ -1409,16 +1565,17 @@ extern "C" int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float*
         }
     }
     TNH3Queue tnq(workspace, s);             // split-f16 weight-gradients collect here; the fp32 kernel shares the workspace, so flush before it
-    auto wgrad = [&](int i, const float* gi, long ldgi, const float* gmax_i) -> int {
+    auto wgrad = [&](int i, const float* gi, long ldgi, const float* gmax_i, int g_half = 0, int x_half = 0, const float* x_rows = nullptr, long ld_x_rows = 0) -> int {
         const papr_layer& L = layers[i];
-        const float* in = i == 0 ? x : outs[i - 1];
-        const long ld_in = i == 0 ? ldx : ld_out[i - 1];
+        const float* in = x_half ? x_rows : (i == 0 ? x : outs[i - 1]);
+        const long ld_in = x_half ? ld_x_rows : (i == 0 ? ldx : ld_out[i - 1]);
         PAPR_REQUIRE(d_weight[i], "papr_mlp_bwd: layer %d has null d_weight", i);
         // split-f16 when the forward pass left the row maxima of this layer's input
         const bool h3w = GEMM_H3_WGRAD && row_absmax && gmax_i && layer_rowmax_saved(layers, n_layers, i) && L.n_out <= SLAB && L.n_in <= SLAB;
         if (h3w) {
-            if (int e = tnq.push(gi, ldgi, L.n_out, in, ld_in, L.n_in, M, gmax_i, row_absmax + (size_t)i * M, d_weight[i], L.ldw, d_bias[i])) return e;
+            if (int e = tnq.push(gi, ldgi, L.n_out, in, ld_in, L.n_in, M, gmax_i, row_absmax + (size_t)i * M, d_weight[i], L.ldw, d_bias[i], g_half, x_half)) return e;
         } else {
+            PAPR_REQUIRE(!g_half && !x_half, "papr_mlp_bwd: layer %d: f16 rows without the split-f16 weight-gradient", i);
             if (int e = tnq.flush()) return e;
             if (int e = gemm_tn(gi, ldgi, L.n_out, in, ld_in, L.n_in, M, d_weight[i], L.ldw, d_bias[i], workspace, s)) return e;
         }
@@ -1438,6 +1595,12 @@ extern "C" int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float*
             ChainArgs c = {};
             c.A0 = g; c.lda0 = ldg; c.K0 = L.n_out; c.rowmax0 = runs.gmax[CHAIN_MAX_LAYERS];
             c.M = M; c.legacy = any_skip ? 1 : 0; c.one_product = GEMM_ONE_PRODUCT ? 1 : 0;
+            // h1 mode: f16 rows (see run_half_rows).  x_half: what the forward run stored; g_half: this launch, if it has a layer
+            // that is not its last (the copy of the top gradient rows goes behind that layer's rows)
+            const bool x_half = run_half_rows(layers, n_layers, b, i + 1, ld_out, row_absmax != nullptr);
+            const bool g_half = x_half && i - last >= 1;
+            auto slot0 = [&](int l) { return l - (b > 0 ? b - 1 : 0); };
+            if (g_half) { c.a0_half = reinterpret_cast<_Float16*>(runs.g[slot0(i - 1)]) + (size_t)M * G_LD; c.lda0_half = G_LD; }
             size_t used = 0;
             SplitBatch split = {};
             long long bytes = 4LL * M * L.n_out, flops = 0;
@@ -1455,7 +1618,8 @@ extern "C" int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float*
                     }
                     cl.C = runs.g[l - 1 - (b > 0 ? b - 1 : 0)]; cl.ldc = G_LD;
                     cl.rowmax = runs.gmax[l - 1 - (b > 0 ? b - 1 : 0)];
-                    bytes += (cl.sign_bits ? 4LL * M * Ll.n_in + 32LL * M : cl.mask ? 8LL * M * Ll.n_in : 4LL * M * Ll.n_in);
+                    cl.c_half = g_half && l > last ? 1 : 0;
+                    bytes += (cl.sign_bits ? (cl.c_half ? 2LL : 4LL) * M * Ll.n_in + 32LL * M : cl.mask ? 8LL * M * Ll.n_in : 4LL * M * Ll.n_in);
                 } else {
                     cl.C = d_x; cl.ldc = ldx; cl.act = PAPR_ACT_NONE;
                     bytes += 4LL * M * Ll.n_in;
@@ -1474,9 +1638,20 @@ extern "C" int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float*
                 if (int err = launch_row_absmax(g, M, L.n_out, ldg, reinterpret_cast<unsigned*>(runs.gmax[CHAIN_MAX_LAYERS]), s)) return err;
             for (int l = i; l >= b; --l) {
                 const float* gl = l == i ? g : runs.g[slot(l)];
-                const long ldl = l == i ? ldg : G_LD;
+                long ldl = l == i ? ldg : G_LD;
                 const float* gm = l == i ? runs.gmax[CHAIN_MAX_LAYERS] : runs.gmax[slot(l)];
-                if (int err = wgrad(l, gl, ldl, gm)) return err;
+                // f16 operands: G_l -- the top rows' copy, or what chain layer l + 1 stored (it is not the launch's last: l >= last);
+                // X_l -- the input copy of the forward run, or what forward layer l - 1 stored
+                int gh = 0, xh = 0;
+                const float* xin = nullptr; long ldxin = 0;
+                if (g_half && l == i) { gl = reinterpret_cast<const float*>(c.a0_half); ldl = G_LD; gh = 1; }
+                else if (g_half && l >= last) gh = 1;
+                if (x_half && gh) {                  // (a layer whose gradient rows are fp32 -- layer 0 when the launch stops above it -- reads its fp32 input)
+                    xh = 1;
+                    if (l == b) { xin = reinterpret_cast<const float*>(reinterpret_cast<const _Float16*>(outs[b]) + (size_t)M * ld_out[b]); ldxin = ld_out[b]; }
+                    else { xin = outs[l - 1]; ldxin = ld_out[l - 1]; }
+                }
+                if (int err = wgrad(l, gl, ldl, gm, gh, xh, xin, ldxin)) return err;
             }
             if (int err = tnq.flush()) return err;               // (the next run reuses the gradient-row slots)
             if (b == 0 && d_x && !to_dx) {                       // d_x accumulates (a skip layer wrote into it): separate launch
