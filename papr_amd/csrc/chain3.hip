@@ -662,8 +662,9 @@ __global__ __launch_bounds__(C3_THREADS, 2) void mlp_chain3_kernel(ChainArgs p, 
         const unsigned wrb = (unsigned)(size_t)ppl + wn * C3_BLK_BYTES + (unsigned)(lane & 1) * 8u, wp = (unsigned)(lane >> 1) * 16u;
         const float4 b4 = b4n;
         unsigned sw = DGRAD ? swn : 0u;
-        const char* crow = reinterpret_cast<const char*>(LP.C + (long)r0 * LP.ldc);
-        const unsigned ldcb = (unsigned)LP.ldc * 4u;
+        const bool halfrows = ONE && LP.c_half != 0;            // f16 rows out: 2-byte elements
+        const char* crow = reinterpret_cast<const char*>(LP.C) + (long)r0 * LP.ldc * (halfrows ? 2 : 4);
+        const unsigned ldcb = (unsigned)LP.ldc * (halfrows ? 2u : 4u);
         const char* rmp = reinterpret_cast<const char*>(LP.rowmax + r0);
         const float slope = LP.act == PAPR_ACT_RELU ? 0.f : (LP.act == PAPR_ACT_LEAKY_RELU ? 0.2f : 1.f);
         const unsigned invb = (unsigned)(size_t)(pinv + wn * RB), wnb = (unsigned)(wn & 1) * 128u;
@@ -674,11 +675,21 @@ __global__ __launch_bounds__(C3_THREADS, 2) void mlp_chain3_kernel(ChainArgs p, 
           [b0] "v"(b4.x), [b1] "v"(b4.y), [b2] "v"(b4.z), [b3] "v"(b4.w), [nh] "s"(nh), [nl] "s"(nl), [crow] "s"(crow),           \
           [ldcb] "s"(ldcb), [rmp] "s"(rmp), [slope] "s"(slope), [invb] "s"(invb), [wnb] "s"(wnb)
         if constexpr (ONE && DGRAD) {
-            if (ld) asm volatile(C3_FUSED1_DGRAD_LD : C3_FUSED_OPERANDS : C3_FUSED_AGPRS, C3_FUSED_CLOBBERS);
-            else asm volatile(C3_FUSED1_DGRAD_NL : C3_FUSED_OPERANDS : C3_FUSED_CLOBBERS);
+            if (halfrows) {
+                if (ld) asm volatile(C3_FUSED1H_DGRAD_LD : C3_FUSED_OPERANDS : C3_FUSED_AGPRS, C3_FUSED_CLOBBERS);
+                else asm volatile(C3_FUSED1H_DGRAD_NL : C3_FUSED_OPERANDS : C3_FUSED_CLOBBERS);
+            } else {
+                if (ld) asm volatile(C3_FUSED1_DGRAD_LD : C3_FUSED_OPERANDS : C3_FUSED_AGPRS, C3_FUSED_CLOBBERS);
+                else asm volatile(C3_FUSED1_DGRAD_NL : C3_FUSED_OPERANDS : C3_FUSED_CLOBBERS);
+            }
         } else if constexpr (ONE) {
-            if (ld) asm volatile(C3_FUSED1_FWD_LD : C3_FUSED_OPERANDS : C3_FUSED_AGPRS, C3_FUSED_CLOBBERS);
-            else asm volatile(C3_FUSED1_FWD_NL : C3_FUSED_OPERANDS : C3_FUSED_CLOBBERS);
+            if (halfrows) {
+                if (ld) asm volatile(C3_FUSED1H_FWD_LD : C3_FUSED_OPERANDS : C3_FUSED_AGPRS, C3_FUSED_CLOBBERS);
+                else asm volatile(C3_FUSED1H_FWD_NL : C3_FUSED_OPERANDS : C3_FUSED_CLOBBERS);
+            } else {
+                if (ld) asm volatile(C3_FUSED1_FWD_LD : C3_FUSED_OPERANDS : C3_FUSED_AGPRS, C3_FUSED_CLOBBERS);
+                else asm volatile(C3_FUSED1_FWD_NL : C3_FUSED_OPERANDS : C3_FUSED_CLOBBERS);
+            }
         } else if constexpr (DGRAD) {
             if (ld) asm volatile(C3_FUSED_DGRAD_LD : C3_FUSED_OPERANDS : C3_FUSED_AGPRS, C3_FUSED_CLOBBERS);
             else asm volatile(C3_FUSED_DGRAD_NL : C3_FUSED_OPERANDS : C3_FUSED_CLOBBERS);
@@ -738,7 +749,7 @@ __global__ __launch_bounds__(C3_THREADS, 2) void mlp_chain3_kernel(ChainArgs p, 
             pm0 + C3_ROWS <= p.M) {
             const ChainLayer& LP = p.L[pl];
             const bool st = LP.C != nullptr, bi = LP.sign_bits != nullptr, rm = LP.rowmax != nullptr;
-            if (st && bi && rm && !(ONE && LP.c_half)) fmode = DGRAD ? 2 : 0;        // (f16 rows out: the two-role slot, whose split stores them)
+            if (st && bi && rm) fmode = DGRAD ? 2 : 0;
             else if (!ONE && fused_on > 1 && !DGRAD && !st && !bi && !rm) fmode = 1;        // (inference: the two-role slot with eight rows in flight is 5 % faster: PAPR_C3_FUSED=2 to compare)
         }
         if (fmode >= 0) {

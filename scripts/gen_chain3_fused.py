@@ -44,6 +44,7 @@ SST = ("s94", "s95")                                                            
 SBH, SBL = ("s96", "s97"), ("s98", "s99")                                         # weight bases
 CLOB_V = ["v%d" % i for i in range(72, 128)]
 CLOB_S = ["s%d" % i for i in range(70, 100)]
+TH = "v84"                                                                        # one-product variants with f16 row stores: lane * 8 (the lo fragments' registers are free there)
 SK, SR = "s70", "s71"                                                             # constants beyond the inline range (VOP3 takes no literals on gfx9)
 
 
@@ -147,14 +148,17 @@ def k_stream(ld, one=False):
     return slots
 
 
-def rows_stream(mode, one=False):
+def rows_stream(mode, one=False, half=False):
     """mode: 'fwd' = training forward middle layer (store, sign bits, row maximum, planes), 'inf' = inference middle layer (planes only),
-    'dgrad' = data-gradient middle layer.  Returns a list of ops: ('raw', text) | ('lds', text, key) | ('need', [keys]) | ('group', [raw texts])"""
+    'dgrad' = data-gradient middle layer.  half (one-product variants): the rows go to memory as f16 -- the hi plane of the split, 8 bytes
+    per lane and row -- instead of fp32.  Returns a list of ops: ('raw', text) | ('lds', text, key) | ('need', [keys]) | ('group', [raw texts])"""
     ops = []
     A = ops.append
     A(("raw", "v_mov_b32 %s, %%[invb]" % TI))
     if mode != "inf":
         A(("raw", "v_lshrrev_b32 %s, 2, %%[wv]" % TL))
+        if half:
+            A(("raw", "v_lshrrev_b32 %s, 1, %%[wv]" % TH))
         A(("raw", "s_mov_b64 s[94:95], %[crow]"))
     for b in range(2):
         rows = [4 * b + q for q in range(4)]
@@ -186,7 +190,7 @@ def rows_stream(mode, one=False):
                     A(("raw", "v_fma_f32 %s, %s, %%[slope], 0" % (tm[e], x[e])))
                 for e in range(4):
                     A(("raw", "v_max_f32 %s, %s, %s" % (x[e], x[e], tm[e])))
-            if mode != "inf":
+            if mode != "inf" and not half:
                 A(("raw", "global_store_dwordx4 %%[wv], %s, s[94:95]" % RT[q]))
                 A(("group", ["s_add_u32 s94, s94, %[ldcb]", "s_addc_u32 s95, s95, 0"]))         # (SCC between the two: never split)
             if mode == "fwd":
@@ -237,6 +241,9 @@ def rows_stream(mode, one=False):
             A(("raw", "s_or_b32 %s, %%[wnb], %d" % (ST, u * 16)))
             A(("raw", "v_xad_u32 %s, %%[wp], %s, %%[wrb]" % (TA, ST)))
             tn = int(t[0][1:])
+            if half:                    # (64 bits of store data: read at issue, the temporaries may be written again right away)
+                A(("raw", "global_store_dwordx2 %s, v[%d:%d], s[94:95]" % (TH, tn, tn + 1)))
+                A(("group", ["s_add_u32 s94, s94, %[ldcb]", "s_addc_u32 s95, s95, 0"]))
             if one:
                 A(("lds", "ds_write_b64 %s, v[%d:%d] offset:%d" % (TA, tn, tn + 1, u * 512), ("pw", u)))
             else:
@@ -247,11 +254,11 @@ def rows_stream(mode, one=False):
     return ops
 
 
-def fuse(mode, ld, one=False):
+def fuse(mode, ld, one=False, half=False):
     em = Emit()
     ids = {}
     ks = k_stream(ld, one)
-    ro = rows_stream(mode, one)
+    ro = rows_stream(mode, one, half)
     # flatten groups so that they count as one unit of the rows stream
     units = []
     for o in ro:
@@ -322,5 +329,6 @@ if __name__ == "__main__":
             emit_macro("C3_FUSED_%s_%s" % (mode.upper(), "LD" if ld else "NL"), fuse(mode, ld))
             if mode != "inf":
                 emit_macro("C3_FUSED1_%s_%s" % (mode.upper(), "LD" if ld else "NL"), fuse(mode, ld, True))
+                emit_macro("C3_FUSED1H_%s_%s" % (mode.upper(), "LD" if ld else "NL"), fuse(mode, ld, True, True))
     print("#define C3_FUSED_CLOBBERS " + ", ".join('"%s"' % r for r in CLOB_V + CLOB_S) + ', "vcc", "scc", "memory"')
     print("#define C3_FUSED_AGPRS " + ", ".join('"a%d"' % i for i in range(128)))
