@@ -167,7 +167,7 @@ def main():
     true_k = {plan.key.ld_in: plan.key_w, plan.val.ld_in: plan.val_w, plan.qry.ld_in: plan.qry_w}
     traffic_db = {}
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
+    if os.path.exists(tpath) and args.gemm_mode != "h1":      # (the counter passes were run in the parity mode; h1 moves f16 rows: traffic null)
         traffic_db = json.load(open(tpath))
 
     def mfma_line(kernel, ids, key):

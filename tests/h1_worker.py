@@ -49,6 +49,9 @@ def main(tag, out):
             if scale > 0:
                 res["grads"][key[5:]] = {"rms_rel": float(np.sqrt(np.mean((got - ref) ** 2)) / scale), "max_rel": float(np.abs(got - ref).max() / scale),
                                          "finite": bool(np.isfinite(got).all())}
+    # (a fingerprint of the weight gradients, for the test that the f16-row path and the fp32-row path are two different computations)
+    res["digest"] = float(sum(np.abs(named[k[5:]].grad.cpu().numpy().astype(np.float64)).sum() for k in g.files
+                              if k.startswith("grad/") and named[k[5:]].grad is not None and "attn" in k))
     json.dump(res, open(out, "w"))
 
 
