@@ -307,6 +307,18 @@ int papr_conv1x1_bwd(const float* d_out, const float* x, int64_t M, int32_t c_in
                      float* d_bias, void* workspace, papr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * K8  the optimizer step: every torch.optim.Adam instance of PAPR.step (reference models/model.py:439-460, one
+ * `scaler.step(opt)` per parameter group; amsgrad off, maximize off, L2 weight decay) in one launch per 64 tensors.
+ * The arrays are HOST arrays (they travel in the kernel arguments); pointers inside them are device pointers to the
+ * optimizer's own tensors: parameter, gradient, exp_avg, exp_avg_sq (n floats each) and the step counter (one float on the
+ * device, like torch's fused Adam keeps it: the call adds one and forms the bias corrections 1 - beta^step from it). */
+#define PAPR_ADAM_MAX_TENSORS 64
+#define PAPR_ADAM_MAX_GROUPS 8
+typedef struct { float* p; const float* g; float* m; float* v; float* step; int64_t n; int32_t group; int32_t pad_; } papr_adam_tensor;
+typedef struct { double lr, beta1, beta2, eps, weight_decay; } papr_adam_group;
+int papr_adam_step(const papr_adam_tensor* tensors, int32_t n_tensors, const papr_adam_group* groups, int32_t n_groups, papr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * Optional timing of the GEMM / kNN launches with HIP events recorded on the launch stream
  * (used by bench.py for the live roofline figure; off by default, process-wide switch).
  * kernel ids: 0 gemm_nt<128x256> (fp32 MFMA)  1 gemm_nt<128x128>  2 gemm_nt<256x64>  3 gemm_nt<256x32>

@@ -1,0 +1,69 @@
+"""One launch for the optimizer step of all of PAPR's Adam instances (papr_adam_step, csrc/adam.hip).
+
+Counterpart of the loop `for opt in optimizers: scaler.step(opt)` of the reference's PAPR.step (models/model.py:439-460) for
+the case it is in by default on the device: GradScaler disabled (use_amp false), fp32 parameters, torch.optim.Adam without
+amsgrad / maximize.  The state lives in the torch optimizers (`exp_avg`, `exp_avg_sq`, `step`, created here exactly like
+torch's fused implementation creates them), so `optimizers.pth` checkpoints and `load_state_dict` are unaffected.
+"""
+import ctypes as C
+
+import torch
+
+from . import hip
+
+
+class _Tensor(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("step", C.c_void_p), ("n", C.c_int64),
+                ("group", C.c_int32), ("pad_", C.c_int32)]
+
+
+class _Group(C.Structure):
+    _fields_ = [("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double), ("weight_decay", C.c_double)]
+
+
+MAX_GROUPS = 8
+
+
+def supported(optimizers):
+    """All of them torch.optim.Adam in a configuration the kernel implements, on fp32 device parameters."""
+    n_groups = 0
+    for opt in optimizers:
+        if type(opt) is not torch.optim.Adam:
+            return False
+        for g in opt.param_groups:
+            n_groups += 1
+            if g.get("amsgrad") or g.get("maximize") or g.get("capturable") or g.get("differentiable") or isinstance(g["lr"], torch.Tensor):
+                return False
+            for p in g["params"]:
+                if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous(memory_format=torch.contiguous_format) and not p.is_contiguous(memory_format=torch.channels_last):
+                    return False
+    return 0 < n_groups <= MAX_GROUPS
+
+
+def step(optimizers):
+    """optimizer.step() of every optimizer in `optimizers` (parameters without a gradient are skipped, like torch does)."""
+    tensors, groups = [], []
+    for opt in optimizers:
+        for g in opt.param_groups:
+            gi = len(groups)
+            for p in g["params"]:
+                if p.grad is None:
+                    continue
+                st = opt.state[p]
+                if len(st) == 0:                                     # (torch/optim/adam.py: _init_group, fused flavour)
+                    st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                grad = p.grad
+                if grad.stride() != p.stride():                      # element i of the gradient must be element i of the parameter in memory
+                    grad = torch.empty_like(p, memory_format=torch.preserve_format).copy_(grad)
+                tensors.append(_Tensor(p.data_ptr(), grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), st["step"].data_ptr(),
+                                       p.numel(), gi, 0))
+                tensors[-1]._keep = grad
+            b1, b2 = g["betas"]
+            groups.append(_Group(float(g["lr"]), b1, b2, g["eps"], g["weight_decay"]))
+    if not tensors:
+        return
+    arr_t = (_Tensor * len(tensors))(*tensors)
+    arr_g = (_Group * len(groups))(*groups)
+    hip.check(hip.lib().papr_adam_step(arr_t, len(tensors), arr_g, len(groups), hip.stream_ptr()), "papr_adam_step")

@@ -10,7 +10,7 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libpapr_hip.so")
-SOURCES = ["error.hip", "knn.hip", "cloud.hip", "features.hip", "pairs.hip", "rowops.hip", "gemm.hip", "chain.hip", "chain2.hip", "chain3.hip", "conv.hip", "unet.hip"]
+SOURCES = ["error.hip", "knn.hip", "cloud.hip", "features.hip", "pairs.hip", "rowops.hip", "gemm.hip", "chain.hip", "chain2.hip", "chain3.hip", "conv.hip", "unet.hip", "adam.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics",
          "-Wall", "-Wno-unused-function"]
 # chain2.hip: no packed-fp32 VALU (v_pk_mul_f32 / v_pk_add_f32 come from the SLP vectoriser).  Measured on MI355X (round 2,

@@ -16,12 +16,15 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from . import adam as own_adam
 from . import dist as pdist
 from .config import as_node
 from .ops import RenderPath, prepare_mlp_weights, render_rays
 from .pointcloud import grow_points, grow_points_device
 from .schedule import create_learning_rate_fn, fast_forward
 from .unet import get_generator
+
+_OWN_ADAM = os.environ.get("PAPR_OWN_ADAM", "1") == "1"
 
 
 def count_parameters(module):
@@ -248,8 +251,13 @@ class PAPR(nn.Module):
         if pdist.world_size() > 1:
             pdist.average_gradients([p for o in self.optimizers.values() if o is not None
                                      for g in o.param_groups for p in g["params"]])
-        for opt in self.optimizers.values():
-            if opt is not None:
+        opts = [opt for opt in self.optimizers.values() if opt is not None]
+        # one launch for all of them (papr_adam_step) where the reference's loop is `opt.step()` anyway: GradScaler off, plain Adam on
+        # device parameters; PAPR_OWN_ADAM=0: torch's optimizers
+        if _OWN_ADAM and not self.scaler.is_enabled() and own_adam.supported(opts):
+            own_adam.step(opts)
+        else:
+            for opt in opts:
                 self.scaler.step(opt)
         for sched in self.schedulers.values():
             if sched is not None:

@@ -644,6 +644,48 @@ def test_small_unet_on_own_kernels_matches_torch_module(hw):
         np.testing.assert_allclose(pd.grad.cpu().numpy(), pr.grad.float().numpy(), rtol=0, atol=5e-5 * pr.grad.abs().max().item(), err_msg=name)
 
 
+def test_own_adam_step_matches_torch_adam():
+    """papr_adam_step (one launch for all optimizers of PAPR.step, reference models/model.py:439-460) against torch.optim.Adam on
+    the CPU in float64-free plain form: five steps, three optimizers with different learning rates / weight decay, a parameter
+    without gradient, a channels-last parameter, sizes that are no multiple of 4; the state tensors are the torch optimizers' own
+    (a state_dict round trip in the middle must not matter)."""
+    from papr_amd import adam as own_adam
+    gen = torch.Generator().manual_seed(11)
+    shapes = [[(1000, 3)], [(256, 117), (256,), (7,), (32, 16, 3, 3)], [(5, 1)]]
+    hyper = [dict(lr=2e-3, weight_decay=0.0), dict(lr=3e-4, weight_decay=1e-2), dict(lr=1e-3, weight_decay=0.0)]
+    ref_params = [[torch.randn(*sh, generator=gen).requires_grad_(True) for sh in group] for group in shapes]
+    ref_opts = [torch.optim.Adam(ps, **h) for ps, h in zip(ref_params, hyper)]
+    d = dev()
+    own_params = [[p.detach().clone().to(d).requires_grad_(True) for p in group] for group in ref_params]
+    own_params[1][3] = own_params[1][3].detach().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    own_opts = [torch.optim.Adam(ps, **h) for ps, h in zip(own_params, hyper)]
+    assert own_adam.supported(own_opts)
+    for it in range(5):
+        for gi, (rg, og) in enumerate(zip(ref_params, own_params)):
+            for pi, (rp, op) in enumerate(zip(rg, og)):
+                if gi == 1 and pi == 2 and it < 2:          # a parameter that gets no gradient at first
+                    rp.grad = op.grad = None
+                    continue
+                g = torch.randn(rp.shape, generator=gen) * (10.0 ** -it)
+                rp.grad = g.clone()
+                op.grad = g.to(d)
+        for o in ref_opts:
+            o.step()
+        own_adam.step(own_opts)
+        if it == 2:                                        # checkpoint round trip of the torch optimizers (reference model.py:562-586)
+            for o in own_opts:
+                o.load_state_dict(o.state_dict())
+        for o in ref_opts + own_opts:                       # a scheduler at work
+            o.param_groups[0]["lr"] *= 0.9
+    for rg, og, ro, oo in zip(ref_params, own_params, ref_opts, own_opts):
+        for rp, op in zip(rg, og):
+            np.testing.assert_allclose(op.detach().cpu().numpy(), rp.detach().numpy(), rtol=0, atol=2e-6 * (1 + rp.abs().max().item()))
+            if rp in ro.state:
+                assert float(oo.state[op]["step"]) == float(ro.state[rp]["step"])
+                np.testing.assert_allclose(oo.state[op]["exp_avg"].cpu().numpy(), ro.state[rp]["exp_avg"].numpy(), rtol=1e-5, atol=1e-9)
+                np.testing.assert_allclose(oo.state[op]["exp_avg_sq"].cpu().numpy(), ro.state[rp]["exp_avg_sq"].numpy(), rtol=1e-5, atol=1e-12)
+
+
 @pytest.mark.parametrize("mode", ["f32", "fwd", "dgrad", "layers"])
 def test_other_gemm_modes_meet_the_same_mlp_parity(mode):
     """PAPR_GEMM_MODE selects which wide GEMMs use the split-f16 (hi/lo, 3 MFMA) kernels (default `h3`: forward
