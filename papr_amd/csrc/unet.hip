@@ -12,8 +12,8 @@
 //   data-gradient  d_x[m][c]           = sum_{tap n}   d_out[pix(m, tap)][n] Wm[c][tap n]   M x C_in x 4 C_out,   rows gathered
 //   weight-grad    d_Wm[c][tap n]      = sum_m         x[m][c] d_out[pix(m, tap)][n]        C_in x 4 C_out x M,   both transposed
 // each ONE launch of the same 64 x 64-tile kernel on the f16 matrix pipe with split fp32 operands (a b ~ hi hi + hi lo +
-// lo hi, fp32 accumulation, as everywhere in this library).  The training maps are small (16 patches of 10 x 10 and 20 x 20
-// pixels: M = 1,600 and 6,400 rows), so the kernel is built for latency, not throughput: no weight pre-split, no absmax
+// lo hi, fp32 accumulation, as everywhere in this library).  The training maps are small (a 160 x 160 patch: the two
+// layers see 40 x 40 and 80 x 80 maps, M = 1,600 and 6,400 rows), so the kernel is built for latency, not throughput: no weight pre-split, no absmax
 // launch -- a workgroup finds the power-of-two scale of its own operand block in a first pass over it (the second pass
 // hits L2), 64-deep k-slabs with the next slab in registers.  The weight-gradient reduces over pixels: they are dealt to
 // ~512 workgroups in chunks whose partial tiles a second launch adds in a fixed order.  Operands whose contiguous dimension is not k (the weight in the forward

@@ -1,5 +1,5 @@
 """Times of the U-Net layers that are not 3x3 convolutions, own kernels (unet.hip) against torch / MIOpen, at the training
-shapes of the shipped configuration (40 x 40 patch): forward + backward of each layer, microseconds per call (events)."""
+shapes of the shipped configuration (160 x 160 patch): forward + backward of each layer, microseconds per call (events)."""
 import os
 import sys
 import torch
@@ -32,7 +32,7 @@ def fb(f, *leaves):
     return run
 
 
-for (H, c_in, c_out) in [(10, 512, 256), (20, 256, 128)]:
+for (H, c_in, c_out) in [(40, 512, 256), (80, 256, 128)]:
     x = torch.randn(1, H, H, c_in, device=d, requires_grad=True)
     w = (torch.randn(c_in, c_out, 2, 2, device=d) * 0.05).contiguous(memory_format=torch.channels_last).requires_grad_(True)
     b = torch.zeros(c_out, device=d, requires_grad=True)
@@ -42,16 +42,16 @@ for (H, c_in, c_out) in [(10, 512, 256), (20, 256, 128)]:
     fo = timeit(lambda: ops._UpConv2x2Fn.apply(x.detach(), w.detach(), b.detach()))
     fr = timeit(lambda: F.conv_transpose2d(xt.detach(), w.detach(), b.detach(), stride=2))
     print("upconv %dx%d %d->%d  fwd+bwd own %.1f us torch %.1f us | fwd own %.1f torch %.1f" % (H, H, c_in, c_out, own, ref, fo, fr))
-for (H, Cn) in [(40, 128), (20, 256)]:
+for (H, Cn) in [(160, 128), (80, 256)]:
     x = torch.relu(torch.randn(1, H, H, Cn, device=d)).requires_grad_(True)
     own = timeit(fb(lambda: ops._MaxPool2Fn.apply(x), x))
     xt = x.detach().permute(0, 3, 1, 2).requires_grad_(True)
     ref = timeit(fb(lambda: F.max_pool2d(xt, 2), xt))
     print("maxpool %dx%d C %d  fwd+bwd own %.1f us torch %.1f us" % (H, H, Cn, own, ref))
-x = torch.randn(1, 40, 40, 128, device=d, requires_grad=True)
+x = torch.randn(1, 160, 160, 128, device=d, requires_grad=True)
 w = (torch.randn(3, 128, 1, 1, device=d) * 0.05).requires_grad_(True)
 b = torch.zeros(3, device=d, requires_grad=True)
 own = timeit(fb(lambda: ops._Conv1x1Fn.apply(x, w, b), x, w, b))
 xt = x.detach().permute(0, 3, 1, 2).requires_grad_(True)
 ref = timeit(fb(lambda: F.conv2d(xt, w, b), xt, w, b))
-print("conv1x1 40x40 128->3  fwd+bwd own %.1f us torch %.1f us" % (own, ref))
+print("conv1x1 160x160 128->3  fwd+bwd own %.1f us torch %.1f us" % (own, ref))
