@@ -184,6 +184,12 @@ typedef struct {
     float* stats;       /* (M, 2) */
 } papr_row_norm;
 
+/* Arithmetic of the papr_mlp_fwd / papr_mlp_bwd calls that follow ON THIS THREAD: 0 = the library's mode (PAPR_GEMM_MODE, default
+ * the fp32-parity split products), 1 = one f16 product per fp32 product with f16 rows between a fused run and its weight
+ * gradients (the `h1` mode) -- the counterpart of the reference running its attention block under fp16 autocast when the YAML
+ * says `use_amp: true` (models/attn.py:248).  A backward call must use the setting of its forward call.  Returns the previous
+ * setting.  (Takes effect on top of the default mode only.) */
+int papr_mlp_precision(int32_t one_product);
 size_t papr_mlp_fwd_workspace_bytes(int64_t M);
 /* in_norm (optional): the same LayerNorm core in FRONT of layer 0 (FeedForward.innorm) over the first in_norm->width
  * columns of x.  x is then overwritten with its standardised rows (papr_mlp_bwd and papr_rownorm_bwd read them),

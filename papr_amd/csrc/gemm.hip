@@ -533,7 +533,13 @@ static const int GEMM_MODE = [] {
 }();
 // h1: h3, and the fused runs (chain3.hip) multiply one f16 product per fp32 product: the throughput mode that stands for the
 // reference's fp16 autocast of the attention block (models/attn.py:248, `use_amp: true`); own tolerance in the tests.
-static const bool GEMM_ONE_PRODUCT = GEMM_MODE == 5;
+static const bool GEMM_ONE_PRODUCT_ENV = GEMM_MODE == 5;
+// The one-product arithmetic can also be asked for call by call (papr_mlp_precision: the host maps the reference's `use_amp: true`
+// to it) -- on top of the default mode only, so that the A/B modes stay what they say.  Thread-local: set by
+// the caller right before papr_mlp_fwd / papr_mlp_bwd.
+static thread_local int t_one_product = 0;
+static inline bool one_product_now() { return GEMM_ONE_PRODUCT_ENV || (t_one_product != 0 && GEMM_MODE == 4); }
+#define GEMM_ONE_PRODUCT one_product_now()
 static const bool GEMM_H3_FWD = GEMM_MODE >= 1, GEMM_H3 = GEMM_MODE >= 2, GEMM_H3_WGRAD = GEMM_MODE >= 3, GEMM_CHAIN = GEMM_MODE >= 4;
 
 // Caller-provided scratch of the split-f16 mode, carved from the workspace argument of papr_mlp_fwd / _bwd:
@@ -1296,6 +1302,12 @@ __global__ __launch_bounds__(256) void act_grad_kernel(float* g, long ldg, const
 
 constexpr size_t TN_SLAB_BYTES = (size_t)TN_BATCH * TN_JOB_FLOATS * sizeof(float);      // partial tiles of a batch of weight-gradients
 
+extern "C" int papr_mlp_precision(int32_t one_product) {
+    const int prev = t_one_product;
+    t_one_product = one_product ? 1 : 0;
+    return prev;
+}
+
 extern "C" size_t papr_mlp_fwd_workspace_bytes(int64_t M) { return H3Scratch::bytes(M); }
 extern "C" size_t papr_mlp_saved_floats(int32_t n_layers, int64_t M) { return (size_t)n_layers * (M + CHAIN_SIGN_WORDS * chain_sign_rows(M)); }
 
@@ -1344,8 +1356,9 @@ static bool layer_rowmax_saved(const papr_layer* layers, int n_layers, int i) {
 // copy of the run's input rows the second half of the run's first output buffer; likewise the gradient-row slots of the
 // backward scratch.  Only the run's last output (forward) / the gradient that leaves the run (backward) remain fp32 rows.
 // PAPR_H1_ROWS=f32 keeps fp32 rows (A/B).
-static const bool H1_HALF_ROWS = GEMM_ONE_PRODUCT && !(getenv("PAPR_H1_ROWS") && !strcmp(getenv("PAPR_H1_ROWS"), "f32")) &&
-                                 (!getenv("PAPR_CHAIN") || atoi(getenv("PAPR_CHAIN")) == 3);
+static const bool H1_HALF_ROWS_OK = !(getenv("PAPR_H1_ROWS") && !strcmp(getenv("PAPR_H1_ROWS"), "f32")) &&
+                                    (!getenv("PAPR_CHAIN") || atoi(getenv("PAPR_CHAIN")) == 3);
+#define H1_HALF_ROWS (H1_HALF_ROWS_OK && one_product_now())
 // forward run [b, e) of a training pass stores f16 rows (the backward pass asks the same question)
 static bool run_half_rows(const papr_layer* layers, int n_layers, int b, int e, const int32_t* ld_out, bool training) {
     if (!H1_HALF_ROWS || !training || e - b < 2) return false;

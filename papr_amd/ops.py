@@ -30,6 +30,8 @@ class MlpSpec:
     """Static description of one embedding MLP (reference models/mlp.py:12-45 as configured by
     models/attn.py:152-163)."""
 
+    one_product = False        # True: this MLP's library calls run in the one-product (h1) arithmetic (papr_mlp_precision)
+
     def __init__(self, name, d_in, ecfg):
         self.name = name
         self.d_in = d_in
@@ -380,6 +382,7 @@ def mlp_forward(spec, ws, bs, x, M, keep=True, out_norm=None, in_norm=None):
     if out_norm is not None:
         outs.norm_stats = torch.empty((M, 2), device=dev, dtype=torch.float32)
         norm = C.byref(hip.RowNorm(out_norm[1], out_norm[0], outs.norm_stats.data_ptr()))
+    hip.lib().papr_mlp_precision(1 if spec.one_product else 0)
     hip.check(hip.lib().papr_mlp_fwd(tab, spec.n_layer, hip.ptr(x), x.shape[1], M, hip.ptr_array(outs),
                                      hip.i32_array(spec.ld_out), hip.ptr(outs.row_absmax), inorm, norm,
                                      hip.ptr(_workspace(dev, "fwd", M)), hip.stream_ptr()), "papr_mlp_fwd")
@@ -409,6 +412,7 @@ def mlp_backward(spec, ws, bs, x, M, outs, d_out, scratch, need_dx):
     d_ws = [torch.empty_like(w) for w in ws]
     d_bs = [torch.empty_like(b) for b in bs]
     d_x = torch.empty_like(x) if need_dx else None
+    hip.lib().papr_mlp_precision(1 if spec.one_product else 0)          # (the setting of this chain's forward call)
     hip.check(hip.lib().papr_mlp_bwd(tab, spec.n_layer, hip.ptr(x), x.shape[1], M, hip.ptr_array(outs),
                                      hip.i32_array(spec.ld_out), hip.ptr(getattr(outs, "row_absmax", None)),
                                      hip.ptr(d_out), hip.ptr(scratch[0]), hip.ptr(scratch[1]),
@@ -465,6 +469,7 @@ def linear_rows(x, w):
     t = tab[0]
     t.weight, t.weight_t, t.bias = w.data_ptr(), None, None
     t.n_in, t.n_out, t.ldw, t.ldwt, t.n_skip, t.skip_col, t.act = x.shape[1], n_out, w.shape[1], 0, 0, 0, 0
+    hip.lib().papr_mlp_precision(0)
     hip.check(hip.lib().papr_mlp_fwd(tab, 1, hip.ptr(x), x.shape[1], M, hip.ptr_array([out]), hip.i32_array([n_out]),
                                      None, None, None, hip.ptr(_workspace(x.device, "fwd", M)), hip.stream_ptr()), "papr_mlp_fwd")
     return out
@@ -584,6 +589,12 @@ class RenderPath:
         d.pe_factor, d.pe_mult, d.eps = float(e["pe_factor"]), float(e["pe_mult_factor"]), self.eps
         d.ld_key, d.ld_qry, d.ld_val = self.key.ld_in, self.qry.ld_in, self.val.ld_in
         self.fdesc = d
+        # `use_amp: true` (the reference's shipped default: its attention block then runs under fp16 autocast, models/attn.py:248):
+        # the embedding MLPs multiply ONE f16 product per fp32 product and keep f16 rows for their weight gradients (the library's
+        # h1 arithmetic; tolerance in tests/test_hip_h1.py).  PAPR_AMP_MLP=fp32 keeps the parity arithmetic under use_amp.
+        self.amp_mlp = bool(cfg.get("use_amp", False)) and os.environ.get("PAPR_AMP_MLP", "h1") == "h1"
+        for spec in (self.key, self.qry, self.val):
+            spec.one_product = self.amp_mlp
 
     # -------------------------------------------------------------------------------------------
     def feature_desc(self, k):
