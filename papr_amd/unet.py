@@ -15,6 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 _OWN_CONV = os.environ.get("PAPR_UNET_CONV", "1") == "1"
+_AMP_OWN = os.environ.get("PAPR_UNET_AMP", "autocast") == "own"   # (experiment: under use_amp the head on the own fp32-parity kernels instead of fp16 autocast)
 _OWN_REST = os.environ.get("PAPR_UNET_REST", "1") == "1"       # (0: pooling, transposed and 1x1 convolutions on torch / MIOpen, A/B)
 
 
@@ -104,7 +105,7 @@ class SmallUNet(nn.Module):
             self.to(memory_format=torch.channels_last)
 
     def forward(self, x, gamma=None, beta=None):
-        with torch.autocast(device_type="cuda", dtype=self.amp_dtype, enabled=self.use_amp and x.is_cuda):
+        with torch.autocast(device_type="cuda", dtype=self.amp_dtype, enabled=self.use_amp and x.is_cuda and not _AMP_OWN):
             x1 = self.inc(x)
             x2 = self.down1(x1)
             x3 = self.down2(x2)
