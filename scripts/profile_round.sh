@@ -8,7 +8,7 @@ TAG=${1:-r02}; shift
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-KEEP="ray_knn,mlp_chain,gemm_tn_h3,gemm_nt_h3,tail_,features_,segment_reduce,conv3x3,pair_"
+KEEP="ray_knn,mlp_chain,gemm_tn_h3,gemm_nt_h3,tail_,features_,segment_reduce,conv3x3,pair_,upconv,maxpool,conv1x1,adam_"
 rocprofv3 --kernel-trace -d $OUT/kt -o kt -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline "$@" > $OUT/bench_under_trace.json 2> $OUT/kt.err
 python3 scripts/rocpd_summary.py $(find $OUT/kt -name "*.db" | head -1) last:10 > $OUT/kernel_trace.txt
 pass() {   # name, counters...
