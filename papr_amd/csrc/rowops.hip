@@ -266,24 +266,24 @@ __global__ __launch_bounds__(256) void ln_fold_fwd_kernel(const float* __restric
     if (lane == 0) eff_b[o] = (c ? c[o] : 0.f) + acc;
 }
 
-// a workgroup owns 64 columns over all rows: wave q takes the rows q, q + 4, ...; the four partial column sums meet in
-// LDS in a fixed order
-__global__ __launch_bounds__(256) void ln_fold_bwd_kernel(const float* __restrict__ w, int n_out, int n_in, int ldw,
+// a workgroup of sixteen waves owns 64 columns over all rows: wave q takes the rows q, q + 16, ...; the sixteen partial column
+// sums meet in LDS in a fixed order (the matrices are tiny -- 256 x 128 -- and the launch is latency: four waves took 22 us)
+__global__ __launch_bounds__(1024) void ln_fold_bwd_kernel(const float* __restrict__ w, int n_out, int n_in, int ldw,
                                                           const float* __restrict__ a2, const float* __restrict__ b2,
                                                           const float* __restrict__ d_eff_w, int ld_eff,
                                                           const float* __restrict__ d_eff_b, float* __restrict__ d_w,
                                                           float* __restrict__ d_a2, float* __restrict__ d_b2) {
-    __shared__ float part[2][4][64];
+    __shared__ float part[2][16][64];
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + lane;
     const bool ok = i < n_in;
     const float av = ok ? a2[i] : 0.f, bv = ok ? b2[i] : 0.f;
     float sa = 0.f, sb = 0.f;
-    for (int o0 = q; o0 < n_out; o0 += 32) {            // eight rows in flight per wave (one at a time: 64 dependent round trips, 46 us)
+    for (int o0 = q; o0 < n_out; o0 += 128) {           // eight rows in flight per wave (one at a time: 64 dependent round trips, 46 us)
         float de[8], wv[8], db[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int o = o0 + 4 * u;
+            const int o = o0 + 16 * u;
             const bool live = ok && o < n_out;
             de[u] = live ? d_eff_w[(long)o * ld_eff + i] : 0.f;
             wv[u] = live ? w[(long)o * ldw + i] : 0.f;
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void ln_fold_bwd_kernel(const float* __restric
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int o = o0 + 4 * u;
+            const int o = o0 + 16 * u;
             if (ok && o < n_out) d_w[(long)o * ldw + i] = de[u] * av + db[u] * bv;
             sa += de[u] * wv[u];
             sb += db[u] * wv[u];
@@ -301,8 +301,11 @@ __global__ __launch_bounds__(256) void ln_fold_bwd_kernel(const float* __restric
     part[1][q][lane] = sb;
     __syncthreads();
     if (q == 0 && ok) {
-        d_a2[i] = ((part[0][0][lane] + part[0][1][lane]) + part[0][2][lane]) + part[0][3][lane];
-        d_b2[i] = ((part[1][0][lane] + part[1][1][lane]) + part[1][2][lane]) + part[1][3][lane];
+        float ta = part[0][0][lane], tb = part[1][0][lane];
+#pragma unroll
+        for (int w = 1; w < 16; ++w) { ta += part[0][w][lane]; tb += part[1][w][lane]; }
+        d_a2[i] = ta;
+        d_b2[i] = tb;
     }
 }
 
@@ -322,7 +325,7 @@ extern "C" int papr_ln_fold_bwd(const float* w, int32_t n_out, int32_t n_in, int
                                 papr_stream_t stream) {
     PAPR_REQUIRE(w && a2 && b2 && d_eff_w && d_eff_b && d_w && d_a2 && d_b2, "papr_ln_fold_bwd: null pointer");
     PAPR_REQUIRE(n_out >= 1 && n_in >= 1 && ldw >= n_in && ld_eff >= n_in && ld_eff <= 1024, "papr_ln_fold_bwd: n_out %d, n_in %d, ldw %d, ld_eff %d", n_out, n_in, ldw, ld_eff);
-    ln_fold_bwd_kernel<<<dim3((unsigned)((n_in + 63) / 64)), dim3(256), 0, as_stream(stream)>>>(w, n_out, n_in, ldw, a2, b2, d_eff_w, ld_eff, d_eff_b, d_w, d_a2, d_b2);
+    ln_fold_bwd_kernel<<<dim3((unsigned)((n_in + 63) / 64)), dim3(1024), 0, as_stream(stream)>>>(w, n_out, n_in, ldw, a2, b2, d_eff_w, ld_eff, d_eff_b, d_w, d_a2, d_b2);
     PAPR_CHECK_LAUNCH("ln_fold_bwd");
     return 0;
 }
