@@ -253,6 +253,17 @@ int papr_attn_tail_bwd(const papr_tail_desc* d, const float* kp, const float* qp
                        float* d_qp, float* d_v, float* d_influ, float* d_score_bias, float* d_pair_influ,
                        const float* kp_norm_stats, const float* score_bias, papr_stream_t stream);
 
+/* Background compositing, the last line of the attention tail (reference models/model.py:536-545): rgb (R, C) =
+ * fg * (1 - a) + bkg * a with normalize (normalize_topk_attn: true), fg + bkg * a without; a = attn[:, col] (the
+ * background token, attn rows of ld_attn floats), fg (R, C) the render head's output, bkg (C), C <= 8.  Backward: d_fg (R, C)
+ * or NULL; d_attn (R, ld_attn), every element written (zero outside column col), or NULL; d_bkg (C) or NULL (needs
+ * papr_composite_bwd_workspace_bytes(R); pixels summed block by block, blocks in a fixed order). */
+int papr_composite_fwd(const float* fg, const float* attn, int32_t ld_attn, int32_t col, const float* bkg, int64_t R, int32_t C,
+                       int32_t normalize, float* rgb, papr_stream_t stream);
+size_t papr_composite_bwd_workspace_bytes(int64_t R);
+int papr_composite_bwd(const float* d_rgb, const float* fg, const float* attn, int32_t ld_attn, int32_t col, const float* bkg, int64_t R,
+                       int32_t C, int32_t normalize, float* d_fg, float* d_attn, float* d_bkg, void* workspace, papr_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * K5  3x3 convolution (stride 1, zero padding 1) over an NHWC map, split-f16 MFMA implicit GEMM: the 3x3 layers of the
  * U-Net render head (reference models/unet.py:16-33 inside SmallUNet, :182-258; torch.nn.Conv2d(k=3, padding=1) + ReLU).

@@ -389,3 +389,105 @@ extern "C" int papr_attn_tail_bwd(const papr_tail_desc* d, const float* kp, cons
     PAPR_CHECK_LAUNCH("tail_bwd");
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Background compositing, the last line of the attention tail (reference models/model.py:536-545):
+//     rgb = fg * (1 - a) + bkg * a      (normalize_topk_attn)          rgb = fg + bkg * a      (otherwise)
+// with a = the background token's attention (column k of attn), fg the render head's output (R, C <= 8), bkg (C).  In torch
+// ops the line and its autograd are ~20 launches of 4-27 us over 25,600 x 3 values (0.13 ms per step); here one launch forward
+// and two backward (the second adds the workgroups' partial sums of d_bkg in a fixed order).
+namespace {
+
+constexpr int COMP_MAXC = 8;
+
+__global__ __launch_bounds__(256) void composite_fwd_kernel(const float* __restrict__ fg, const float* __restrict__ attn, int ld_attn, int col,
+                                                            const float* __restrict__ bkg, long R, int Cn, int normalize, float* __restrict__ rgb) {
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= R) return;
+    const float a = attn[p * ld_attn + col], keep = normalize ? 1.0f - a : 1.0f;
+    for (int c = 0; c < Cn; ++c) rgb[p * Cn + c] = fg[p * Cn + c] * keep + bkg[c] * a;
+}
+
+// d_fg = d_rgb * keep; d_attn row = zeros except column `col`: sum_c d_rgb (bkg - fg) (normalize) or sum_c d_rgb bkg;
+// partial[block][c] = sum over the block's pixels of d_rgb a
+__global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restrict__ d_rgb, const float* __restrict__ fg, const float* __restrict__ attn,
+                                                            int ld_attn, int col, const float* __restrict__ bkg, long R, int Cn, int normalize,
+                                                            float* __restrict__ d_fg, float* __restrict__ d_attn, float* __restrict__ partial) {
+    __shared__ float red[4][COMP_MAXC];
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    float sb[COMP_MAXC];
+#pragma unroll
+    for (int c = 0; c < COMP_MAXC; ++c) sb[c] = 0.f;
+    if (p < R) {
+        const float a = attn[p * ld_attn + col], keep = normalize ? 1.0f - a : 1.0f;
+        float da = 0.f;
+#pragma unroll
+        for (int c = 0; c < COMP_MAXC; ++c)
+            if (c < Cn) {
+                const float g = d_rgb[p * Cn + c], f = fg[p * Cn + c];
+                if (d_fg) d_fg[p * Cn + c] = g * keep;
+                da += g * (normalize ? bkg[c] - f : bkg[c]);
+                sb[c] = g * a;
+            }
+        if (d_attn) {
+            for (int j = 0; j < ld_attn; ++j) d_attn[p * ld_attn + j] = j == col ? da : 0.f;
+        }
+    }
+    if (partial) {
+#pragma unroll
+        for (int c = 0; c < COMP_MAXC; ++c) {
+            float v = sb[c];
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);      // (a butterfly: every lane ends with the same sum, in a fixed order)
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][c] = v;
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < Cn) partial[(long)blockIdx.x * COMP_MAXC + threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+    }
+}
+
+__global__ __launch_bounds__(256) void composite_bkg_reduce_kernel(const float* __restrict__ partial, int blocks, int Cn, float* __restrict__ d_bkg) {
+    __shared__ float red[4];
+    for (int c = 0; c < Cn; ++c) {
+        float v = 0.f;
+        for (int b = threadIdx.x; b < blocks; b += 256) v += partial[(long)b * COMP_MAXC + c];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) d_bkg[c] = ((red[0] + red[1]) + red[2]) + red[3];
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+extern "C" int papr_composite_fwd(const float* fg, const float* attn, int32_t ld_attn, int32_t col, const float* bkg, int64_t R, int32_t C,
+                                  int32_t normalize, float* rgb, papr_stream_t stream) {
+    PAPR_REQUIRE(fg && attn && bkg && rgb, "papr_composite_fwd: null pointer");
+    PAPR_REQUIRE(C >= 1 && C <= COMP_MAXC && col >= 0 && col < ld_attn, "papr_composite_fwd: C %d (1 .. %d), column %d of %d", C, COMP_MAXC, col, ld_attn);
+    if (R <= 0) return 0;
+    composite_fwd_kernel<<<dim3((unsigned)((R + 255) / 256)), dim3(256), 0, as_stream(stream)>>>(fg, attn, ld_attn, col, bkg, R, C, normalize, rgb);
+    PAPR_CHECK_LAUNCH("composite_fwd");
+    return 0;
+}
+
+extern "C" size_t papr_composite_bwd_workspace_bytes(int64_t R) { return (size_t)((R + 255) / 256) * COMP_MAXC * sizeof(float); }
+
+extern "C" int papr_composite_bwd(const float* d_rgb, const float* fg, const float* attn, int32_t ld_attn, int32_t col, const float* bkg, int64_t R,
+                                  int32_t C, int32_t normalize, float* d_fg, float* d_attn, float* d_bkg, void* workspace, papr_stream_t stream) {
+    PAPR_REQUIRE(d_rgb && fg && attn && bkg, "papr_composite_bwd: null pointer");
+    PAPR_REQUIRE(C >= 1 && C <= COMP_MAXC && col >= 0 && col < ld_attn, "papr_composite_bwd: C %d (1 .. %d), column %d of %d", C, COMP_MAXC, col, ld_attn);
+    PAPR_REQUIRE(!d_bkg || workspace, "papr_composite_bwd: d_bkg needs the workspace");
+    if (R <= 0) return 0;
+    const int blocks = (int)((R + 255) / 256);
+    hipStream_t s = as_stream(stream);
+    composite_bwd_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(d_rgb, fg, attn, ld_attn, col, bkg, R, C, normalize, d_fg, d_attn,
+                                                                      d_bkg ? static_cast<float*>(workspace) : nullptr);
+    PAPR_CHECK_LAUNCH("composite_bwd");
+    if (d_bkg) {
+        composite_bkg_reduce_kernel<<<dim3(1), dim3(256), 0, s>>>(static_cast<const float*>(workspace), blocks, C, d_bkg);
+        PAPR_CHECK_LAUNCH("composite_bkg_reduce");
+    }
+    return 0;
+}

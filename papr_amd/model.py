@@ -25,6 +25,7 @@ from .schedule import create_learning_rate_fn, fast_forward
 from .unet import get_generator
 
 _OWN_ADAM = os.environ.get("PAPR_OWN_ADAM", "1") == "1"
+_OWN_COMPOSITE = os.environ.get("PAPR_OWN_COMPOSITE", "1") == "1"      # (0: the compositing line in torch ops, A/B)
 
 
 def count_parameters(module):
@@ -356,6 +357,9 @@ class PAPR(nn.Module):
             fg = self.renderer(fmap.permute(0, 3, 1, 2)).permute(0, 2, 3, 1).float()
         else:
             fg = fmap
+        if _OWN_COMPOSITE and fg.is_cuda and fg.dtype == torch.float32 and fg.shape[-1] <= 8 and fg.shape[-1] == self.bkg_feats.numel():
+            from .ops import _CompositeFn                    # (one launch forward, two backward: papr_composite_fwd / _bwd)
+            return _CompositeFn.apply(fg.contiguous(), attn.reshape(-1, k + 1), self.bkg_feats, bool(self.args.models.normalize_topk_attn))
         bkg_attn = attn.reshape(N, H, W, k + 1)[..., k:]
         bkg = self.bkg_feats.reshape(1, 1, 1, -1)
         if self.args.models.normalize_topk_attn:

@@ -273,6 +273,42 @@ class _Conv1x1Fn(torch.autograd.Function):
         return d_x, (d_w.reshape(ctx.wshape) if want_w else None), d_b
 
 
+class _CompositeFn(torch.autograd.Function):
+    """rgb = fg * (1 - a) + bkg * a (normalize) or fg + bkg * a, a = the background token's attention: the last line of the
+    reference's forward (models/model.py:536-545) and its autograd as one launch forward, two backward (papr_composite_fwd / _bwd)
+    instead of ~20 elementwise / reduction launches."""
+
+    @staticmethod
+    def forward(ctx, fg, attn, bkg, normalize):
+        _need_hip_rows(fg, "the compositing kernel")
+        Cn = fg.shape[-1]
+        R = fg.numel() // Cn
+        attn = attn.contiguous()
+        bkg_c = bkg.detach().reshape(-1).contiguous()
+        rgb = torch.empty_like(fg)
+        hip.check(hip.lib().papr_composite_fwd(hip.ptr(fg), hip.ptr(attn), attn.shape[-1], attn.shape[-1] - 1, hip.ptr(bkg_c), R, Cn, 1 if normalize else 0,
+                                               hip.ptr(rgb), hip.stream_ptr()), "papr_composite_fwd")
+        ctx.save_for_backward(fg, attn, bkg_c)
+        ctx.normalize, ctx.bkg_shape = normalize, bkg.shape
+        return rgb
+
+    @staticmethod
+    def backward(ctx, d_rgb):
+        fg, attn, bkg_c = ctx.saved_tensors
+        Cn = fg.shape[-1]
+        R = fg.numel() // Cn
+        d_rgb = d_rgb.contiguous()
+        lib = hip.lib()
+        d_fg = torch.empty_like(fg) if ctx.needs_input_grad[0] else None
+        d_attn = torch.empty_like(attn) if ctx.needs_input_grad[1] else None
+        d_bkg = torch.empty_like(bkg_c) if ctx.needs_input_grad[2] else None
+        ws = torch.empty(((lib.papr_composite_bwd_workspace_bytes(R) + 3) // 4,), device=fg.device, dtype=torch.float32) if d_bkg is not None else None
+        hip.check(lib.papr_composite_bwd(hip.ptr(d_rgb), hip.ptr(fg), hip.ptr(attn), attn.shape[-1], attn.shape[-1] - 1, hip.ptr(bkg_c), R, Cn,
+                                         1 if ctx.normalize else 0, hip.ptr(d_fg), hip.ptr(d_attn), hip.ptr(d_bkg), hip.ptr(ws), hip.stream_ptr()),
+                  "papr_composite_bwd")
+        return d_fg, d_attn, (d_bkg.reshape(ctx.bkg_shape) if d_bkg is not None else None), None
+
+
 class _LnFoldFn(torch.autograd.Function):
     """(W * a_2 zero-padded to ld_eff columns, c + W b_2): the LayerNorm affine in front of a Linear layer folded into it, one
     launch each way (in torch ops: two products, a row sum and a pad forward, eight small kernels backward, two of them

@@ -644,6 +644,28 @@ def test_small_unet_on_own_kernels_matches_torch_module(hw):
         np.testing.assert_allclose(pd.grad.cpu().numpy(), pr.grad.float().numpy(), rtol=0, atol=5e-5 * pr.grad.abs().max().item(), err_msg=name)
 
 
+@pytest.mark.parametrize("R,k,Cn,normalize", [(25600, 20, 3, True), (1000, 5, 3, False), (77, 1, 8, True)])
+def test_composite_matches_torch_expression(R, k, Cn, normalize):
+    """papr_composite_fwd / _bwd against the reference's line rgb = fg (1 - a) + bkg a (models/model.py:536-545) in torch ops on the
+    CPU in float64: output and the gradients of fg, attn (zero outside the background column) and bkg_feats."""
+    from papr_amd import ops
+    gen = torch.Generator().manual_seed(R + k)
+    fg = torch.rand(1, R, 1, Cn, generator=gen).requires_grad_(True)
+    attn = torch.softmax(torch.randn(R, k + 1, generator=gen), -1).requires_grad_(True)
+    bkg = torch.rand(1, Cn, generator=gen).requires_grad_(True)
+    a = attn.double().reshape(1, R, 1, k + 1)[..., k:]
+    ref = fg.double() * (1 - a) + bkg.double().reshape(1, 1, 1, -1) * a if normalize else fg.double() + bkg.double().reshape(1, 1, 1, -1) * a
+    gy = torch.randn(ref.shape, generator=gen)
+    (ref * gy.double()).sum().backward()
+    d = dev()
+    leaves = [t.detach().to(d).requires_grad_(True) for t in (fg, attn, bkg)]
+    out = ops._CompositeFn.apply(leaves[0], leaves[1], leaves[2], normalize)
+    (out * gy.to(d)).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().float().numpy(), rtol=0, atol=3e-7)
+    for got, want in zip(leaves, (fg, attn, bkg)):
+        np.testing.assert_allclose(got.grad.cpu().numpy(), want.grad.numpy(), rtol=0, atol=2e-6 * (1 + want.grad.abs().max().item()))
+
+
 def test_own_adam_step_matches_torch_adam():
     """papr_adam_step (one launch for all optimizers of PAPR.step, reference models/model.py:439-460) against torch.optim.Adam on
     the CPU in float64-free plain form: five steps, three optimizers with different learning rates / weight decay, a parameter
