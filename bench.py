@@ -262,7 +262,8 @@ def main():
         "dtype": ("f32" if args.gemm_mode == "f32" else "f32 (wide GEMMs: operands split into f16 hi+lo, 3 MFMA, fp32 accumulate)")
                  + ("; U-Net head fp16 autocast" if args.amp else ""), "data": "synthetic",
         "config": {"workload": "configs/nerfsyn/chair.yml: P=%d points, one %dx%d patch (R=%d rays) per rank per step, k=%d, "
-                               "U-Net head, MSE loss (LPIPS weight 0: VGG weights unavailable offline), use_amp=%s"
+                               "U-Net head, MSE loss (LPIPS weight 0: VGG weights unavailable offline), use_amp=%s; "
+                               "points_influ_scores drawn U(0,1) (seed 5) instead of the untrained all-zero init so that the attention scores are not all zero"
                                % (P, H, W, R, k, "true (U-Net fp16 autocast)" if args.amp else "false"),
                    "global_batch_rays": world * R, "parallelism": "dp%d" % world, "gemm_mode": args.gemm_mode, "final_loss": float(loss.detach())},
         "roofline": dominant,

@@ -40,6 +40,19 @@ def supported(optimizers):
     return 0 < n_groups <= MAX_GROUPS
 
 
+def _adopt_state(st, p):
+    """State that came from somewhere else (an `optimizers.pth` written by torch's non-fused Adam: a CPU `step`; moments saved
+    contiguous and loaded next to a channels-last parameter): bring it into the form the kernel reads -- the step counter a
+    float32 scalar on the parameter's device, element i of each moment at element i of the parameter in memory."""
+    stp = st["step"]
+    if not (torch.is_tensor(stp) and stp.is_cuda and stp.dtype == torch.float32 and stp.device == p.device):
+        st["step"] = torch.as_tensor(float(stp), dtype=torch.float32, device=p.device)
+    for name in ("exp_avg", "exp_avg_sq"):
+        m = st[name]
+        if m.device != p.device or m.dtype != torch.float32 or m.stride() != p.stride():
+            st[name] = torch.empty_like(p, memory_format=torch.preserve_format).copy_(m)
+
+
 def step(optimizers):
     """optimizer.step() of every optimizer in `optimizers` (parameters without a gradient are skipped, like torch does)."""
     tensors, groups = [], []
@@ -54,6 +67,8 @@ def step(optimizers):
                     st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                else:
+                    _adopt_state(st, p)
                 grad = p.grad
                 if grad.stride() != p.stride():                      # element i of the gradient must be element i of the parameter in memory
                     grad = torch.empty_like(p, memory_format=torch.preserve_format).copy_(grad)

@@ -4,6 +4,7 @@ In-tree output: papr_amd/libpapr_hip.so (git-ignored, travels to the GPU box wit
 hipcc cross-compiles without a GPU, so this is also the "does it build" check.
 """
 import os
+import re
 import subprocess
 import sys
 
@@ -22,6 +23,26 @@ EXTRA_FLAGS = {"chain2.hip": ["-fno-slp-vectorize"], "chain3.hip": ["-fno-slp-ve
 # chain3.hip keeps its weight fragments in a[0:127] by name, from inline asm; the compiler does not know they are taken in between
 # and moves values of its own into AGPRs when it runs out of VGPRs.  A build whose device code holds any v_accvgpr_* is wrong.
 NO_ACCVGPR = ["chain3.hip"]
+
+
+_AGPR_OPERAND = re.compile(r"(?<![\w.$])a(\d+|\[\d+:\d+\])(?![\w.])")
+
+
+def _compiler_agpr_uses(asm):
+    """Instructions of a `-S` listing OUTSIDE the inline-asm blocks (;;#ASMSTART .. ;;#ASMEND) that name an AGPR: v_accvgpr_*
+    copies, but also the AV-class operands of loads / stores / MFMA srcC that gfx90a+ may place in AGPRs with no copy."""
+    n, inside = 0, False
+    for line in asm.splitlines():
+        t = line.strip()
+        if t.startswith(";;#ASMSTART"):
+            inside = True
+        elif t.startswith(";;#ASMEND"):
+            inside = False
+        elif not inside and t and not t.startswith((";", ".", "//")) and not t.endswith(":"):
+            code = t.split(";", 1)[0]
+            if "v_accvgpr_" in code or _AGPR_OPERAND.search(code):
+                n += 1
+    return n
 
 
 def _stale(target, deps):
@@ -53,10 +74,10 @@ def build_library(force=False, verbose=True):
         if src in NO_ACCVGPR:
             asm = subprocess.run([hipcc] + [f for f in FLAGS if f != "-fPIC"] + EXTRA_FLAGS.get(src, []) + ["-w", "-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", "-"],
                                  check=True, capture_output=True, text=True).stdout
-            n = asm.count("v_accvgpr_")
+            n = _compiler_agpr_uses(asm)
             if n:
                 os.remove(os.path.join(objdir, src.replace(".hip", ".o")))
-                raise RuntimeError("%s: the compiler uses AGPRs itself (%d v_accvgpr instructions): register pressure too high for the by-name "
+                raise RuntimeError("%s: the compiler uses AGPRs itself (%d instructions outside the inline asm name an AGPR): register pressure too high for the by-name "
                                    "weight fragments, see the comment in the source" % (src, n))
     if force or procs or _stale(LIB, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined"]

@@ -51,7 +51,9 @@ __global__ __launch_bounds__(256) void adam_step_kernel(AdamBatch b) {
         const float denom = sqrtf(v) * inv_bc2s + eps;
         p = p - lr_c * (m / denom);
     };
-    const bool vec = (t.n & 3) == 0;            // (torch allocations are 16-byte aligned at least; a size that is no multiple of 4 goes element-wise)
+    // 16-byte accesses only where all four arrays allow them: a gradient that is a view into the data-parallel flat bucket starts
+    // wherever the tensors before it end (4-byte aligned only once 3 P is no multiple of 4 after a prune)
+    const bool vec = (t.n & 3) == 0 && ((((uintptr_t)t.p) | ((uintptr_t)t.g) | ((uintptr_t)t.m) | ((uintptr_t)t.v)) & 15) == 0;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const long e = base + 4L * (u * 256 + threadIdx.x);

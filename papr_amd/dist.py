@@ -23,11 +23,18 @@ def init_from_env(device=None):
     # PAPR_DIST_BACKEND=gloo: several ranks on ONE device (tests on a 1-GPU box: RCCL refuses two ranks per GPU); the
     # collectives then bounce device tensors through the host (_all_reduce_sum / _broadcast below)
     backend = os.environ.get("PAPR_DIST_BACKEND", "nccl" if use_gpu else "gloo")
-    if use_gpu:
-        local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
-        torch.cuda.set_device(local)
+    local = int(os.environ.get("LOCAL_RANK", "0"))
     if backend == "nccl":
+        # RCCL: one rank per GPU, or the communicator errors / hangs much later -- fail here instead
+        if not use_gpu:
+            raise RuntimeError("PAPR_DIST_BACKEND=nccl needs a GPU")
+        if local >= torch.cuda.device_count():
+            raise RuntimeError("LOCAL_RANK %d but only %d GPU(s) visible: RCCL needs one GPU per rank" % (local, torch.cuda.device_count()))
+        torch.cuda.set_device(local)
         td.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    elif use_gpu:
+        torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))       # (gloo: several ranks may share a device)
+        td.init_process_group(backend=backend)
     else:
         td.init_process_group(backend=backend)
     return world
