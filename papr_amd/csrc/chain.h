@@ -54,7 +54,14 @@ int papr_launch_chain2(const ChainArgs& a, bool dgrad, long long bytes, long lon
 // chain3.hip: chain2.hip's layout at RB = 8; only blocks with a row inside M are written or read.
 size_t papr_chain3_lds_bytes();
 int papr_launch_chain3(const ChainArgs& a, bool dgrad, long long bytes, long long flops, hipStream_t s);
-// rows of a layer's sign-word area: M rounded up to whole 8-row blocks (the area is CHAIN_SIGN_WORDS words per row)
-inline long chain_sign_rows(long M) { return (M + 7) / 8 * 8; }
+// chain4.hip: one word per lane and 64-row tile: tile t owns words [512 t, 512 (t + 1)), wave w of the tile words 64 w .. 64 w + 63; bit 31 - (16 i + e)
+// of lane (row & 31, h)'s word = column 32 w + 16 h + e of row 32 i + (row & 31).  Only tiles with a row inside M are written or read.
+size_t papr_chain4_lds_bytes();
+int papr_launch_chain4(const ChainArgs& a, bool dgrad, long long bytes, long long flops, hipStream_t s);
+// which kernel carries a run (PAPR_CHAIN: 1 chain.hip, 2 chain2.hip, 3 chain3.hip, 4 = default chain4.hip); chain4.hip wants its weight
+// fragments with the column permutation of split_weight_batch_kernel(perm = 1)
+int papr_chain_version(const ChainArgs& a);
+// rows of a layer's sign-word area: M rounded up to whole 64-row tiles (the area is CHAIN_SIGN_WORDS words per row)
+inline long chain_sign_rows(long M) { return (M + 63) / 64 * 64; }
 // bytes / flops: algorithmic totals of the launch for the profiling record
 int papr_launch_chain(const ChainArgs& a, bool dgrad, long long bytes, long long flops, hipStream_t s);

@@ -664,11 +664,19 @@ extern "C" int papr_chain_trace_read(long long* out) { return hipMemcpyFromSymbo
 
 size_t papr_chain_lds_bytes() { return CH_LDS_BYTES; }
 
+int papr_chain_version(const ChainArgs& a) {
+    // PAPR_CHAIN=1: every run on this file's kernel, 2: chain2.hip, 3: chain3.hip (A/B); default: chain4.hip.  An MLP with a skip layer
+    // (legacy: the sign-word layout of this file in all its runs) stays here unless the version is 4
+    static const int version = getenv("PAPR_CHAIN") ? atoi(getenv("PAPR_CHAIN")) : 4;
+    if (version == 4) return 4;
+    return a.legacy ? 1 : version;
+}
+
 int papr_launch_chain(const ChainArgs& a, bool dgrad, long long bytes, long long flops, hipStream_t s) {
-    // PAPR_CHAIN=1: every run on this file's kernel, 2: chain2.hip (A/B); default: chain3.hip unless the MLP has a skip layer
-    static const int version = getenv("PAPR_CHAIN") ? atoi(getenv("PAPR_CHAIN")) : 3;
-    if (version == 3 && !a.legacy) return papr_launch_chain3(a, dgrad, bytes, flops, s);
-    if (version == 2 && !a.legacy) return papr_launch_chain2(a, dgrad, bytes, flops, s);
+    const int version = papr_chain_version(a);
+    if (version == 4) return papr_launch_chain4(a, dgrad, bytes, flops, s);
+    if (version == 3) return papr_launch_chain3(a, dgrad, bytes, flops, s);
+    if (version == 2) return papr_launch_chain2(a, dgrad, bytes, flops, s);
     PAPR_REQUIRE(a.n_layers >= 1 && a.n_layers <= CHAIN_MAX_LAYERS, "mlp_chain: %d layers", a.n_layers);
     PAPR_REQUIRE(a.K0 % 4 == 0 && a.lda0 % 4 == 0 && a.K0 <= 256, "mlp_chain: input width %d", a.K0);
     if (a.M <= 0) return 0;

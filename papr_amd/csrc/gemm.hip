@@ -1357,7 +1357,7 @@ static bool layer_rowmax_saved(const papr_layer* layers, int n_layers, int i) {
 // backward scratch.  Only the run's last output (forward) / the gradient that leaves the run (backward) remain fp32 rows.
 // PAPR_H1_ROWS=f32 keeps fp32 rows (A/B).
 static const bool H1_HALF_ROWS_OK = !(getenv("PAPR_H1_ROWS") && !strcmp(getenv("PAPR_H1_ROWS"), "f32")) &&
-                                    (!getenv("PAPR_CHAIN") || atoi(getenv("PAPR_CHAIN")) == 3);
+                                    (!getenv("PAPR_CHAIN") || atoi(getenv("PAPR_CHAIN")) >= 3);
 #define H1_HALF_ROWS (H1_HALF_ROWS_OK && one_product_now())
 // forward run [b, e) of a training pass stores f16 rows (the backward pass asks the same question)
 static bool run_half_rows(const papr_layer* layers, int n_layers, int b, int e, const int32_t* ld_out, bool training) {
@@ -1365,7 +1365,7 @@ static bool run_half_rows(const papr_layer* layers, int n_layers, int b, int e, 
     for (int l = 0; l < n_layers; ++l) if (layers[l].n_skip > 0) return false;          // (runs of such an MLP go to chain.hip)
     const int k0pad = (layers[b].n_in + 31) / 32 * 32;
     if (k0pad > ld_out[b]) return false;                                                // the input copy must fit behind outs[b]'s rows
-    for (int l = b; l < e - 1; ++l) if (ld_out[l] % 4 || layers[l].n_out % 32) return false;
+    for (int l = b; l < e - 1; ++l) if (ld_out[l] % 8 || layers[l].n_out % 32) return false;
     return true;
 }
 
@@ -1373,7 +1373,9 @@ static bool run_half_rows(const papr_layer* layers, int n_layers, int b, int e, 
 // All weights of a fused run are split by ONE launch (grid.y = layer).  transposed: the planes hold W^T (the
 // data-gradient run multiplies with the transposed weights; reading W column-wise here saves the caller a transpose).
 struct SplitJob { const float* W; int N, K, ldw, transposed, n_tiles, ksteps; _Float16* hi; _Float16* lo; };
-struct SplitBatch { SplitJob job[CHAIN_MAX_LAYERS]; };
+// perm: chain4.hip's fragment rows -- matrix-instruction row j of a 32-column tile carries column 16 ((j >> 2) & 1) + 4 (j >> 3) + (j & 3), so that
+// an accumulator lane's 16 registers are 16 consecutive columns
+struct SplitBatch { SplitJob job[CHAIN_MAX_LAYERS]; int perm; };
 
 __global__ __launch_bounds__(256) void split_weight_batch_kernel(SplitBatch b) {
     const SplitJob& j = b.job[blockIdx.y];
@@ -1381,7 +1383,8 @@ __global__ __launch_bounds__(256) void split_weight_batch_kernel(SplitBatch b) {
     if (idx >= j.n_tiles * j.ksteps * 512) return;
     const int e = idx & 7, l = (idx >> 3) & 63, f = idx >> 9;
     const int t = f / j.ksteps, ks = f - t * j.ksteps;
-    const int n = 32 * t + (l & 31), c = 16 * ks + 8 * (l >> 5) + e;
+    const int jr = l & 31;
+    const int n = 32 * t + (b.perm ? 16 * ((jr >> 2) & 1) + 4 * (jr >> 3) + (jr & 3) : jr), c = 16 * ks + 8 * (l >> 5) + e;
     float x = 0.f;
     if (n < j.N && c < j.K) x = j.transposed ? j.W[(long)c * j.ldw + n] : j.W[(long)n * j.ldw + c];
     const _Float16 h = (_Float16)x;
@@ -1461,6 +1464,7 @@ extern "C" int papr_mlp_fwd(const papr_layer* layers, int n_layers, float* x, in
                 c.norm_eps = out_norm->eps; c.norm_stats = out_norm->stats;      // standardised in the run's last row phase
                 norm_done = true;
             }
+            split.perm = papr_chain_version(c) == 4;
             if (int err = chain_split_launch(split, e - i, s)) return err;
             if (int err = papr_launch_chain(c, false, bytes, flops, s)) return err;
             if (!saved) h3.swap();
@@ -1642,6 +1646,7 @@ extern "C" int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float*
             }
             PAPR_REQUIRE(used <= H3_PLANE_HALFS, "papr_mlp_bwd: fused run needs %zu plane halfs", used);
             if (c.n_layers > 0) {
+                split.perm = papr_chain_version(c) == 4;
                 if (int err = chain_split_launch(split, c.n_layers, s)) return err;
                 if (int err = papr_launch_chain(c, true, bytes, flops, s)) return err;
             }

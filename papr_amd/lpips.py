@@ -85,3 +85,73 @@ class LPNet(nn.Module):
             r = torch.sum(w * (n0 - n1) ** 2, 1, keepdim=True).mean([2, 3], keepdim=True)
             val = r if val is None else val + r
         return val.squeeze().mean()
+
+
+# ---- evaluation metric of test.py (reference test.py:109-110, 188-191: `lpips.LPIPS(net='alex' | 'vgg', version='0.1')` of the
+# `lpips` package, called on rgb / img in [0, 1] WITHOUT normalize=True, i.e. the images go in as they are)
+_ALEX = [("conv", 3, 64, 11, 4, 2), "relu", ("pool", 3, 2), ("conv", 64, 192, 5, 1, 2), "relu", ("pool", 3, 2),
+         ("conv", 192, 384, 3, 1, 1), "relu", ("conv", 384, 256, 3, 1, 1), "relu", ("conv", 256, 256, 3, 1, 1), "relu"]
+_ALEX_TAPS = (1, 4, 7, 9, 11)                   # torchvision alexnet().features indices behind each ReLU
+
+
+def alexnet_features():
+    layers = []
+    for v in _ALEX:
+        if v == "relu":
+            layers.append(nn.ReLU(inplace=False))
+        elif v[0] == "pool":
+            layers.append(nn.MaxPool2d(kernel_size=v[1], stride=v[2]))
+        else:
+            layers.append(nn.Conv2d(v[1], v[2], kernel_size=v[3], stride=v[4], padding=v[5]))
+    return nn.Sequential(*layers)
+
+
+class TestLPIPS(nn.Module):
+    """LPIPS v0.1 as the `lpips` package evaluates it (Zhang et al. 2018): scaling layer, backbone taps, channel-unit-normalised
+    features, squared difference, learnt 1x1 heads, spatial mean, sum over taps.  Weights (none ship here, no network):
+      vgg : heads $PAPR_LPIPS_HEADS or ./vgg.pth (the package's weights/v0.1/vgg.pth = the reference's vgg.pth), backbone
+            $PAPR_VGG16_WEIGHTS or ./vgg16.pth (torchvision state dict);
+      alex: heads $PAPR_LPIPS_HEADS_ALEX or ./alex.pth (weights/v0.1/alex.pth), backbone $PAPR_ALEX_WEIGHTS or ./alexnet.pth
+            (torchvision alexnet-owt-7be5be79.pth)."""
+    FILES = {"vgg": (("PAPR_LPIPS_HEADS", "vgg.pth"), ("PAPR_VGG16_WEIGHTS", "vgg16.pth")),
+             "alex": (("PAPR_LPIPS_HEADS_ALEX", "alex.pth"), ("PAPR_ALEX_WEIGHTS", "alexnet.pth"))}
+
+    def __init__(self, net, heads=None, backbone=None):
+        super().__init__()
+        self.register_buffer("shift", torch.tensor([-.030, -.088, -.188])[None, :, None, None])
+        self.register_buffer("scale", torch.tensor([.458, .448, .450])[None, :, None, None])
+        self.features = vgg16_features() if net == "vgg" else alexnet_features()
+        self.taps = _TAPS if net == "vgg" else _ALEX_TAPS
+        chans = (64, 128, 256, 512, 512) if net == "vgg" else (64, 192, 384, 256, 256)
+        self.lins = nn.ParameterList([nn.Parameter(torch.zeros(1, c, 1, 1), requires_grad=False) for c in chans])
+        if heads is not None:
+            for i, p in enumerate(self.lins):
+                p.data.copy_(heads["lin%d.model.1.weight" % i])
+        if backbone is not None:
+            self.features.load_state_dict({k[len("features."):]: v for k, v in backbone.items() if k.startswith("features.")})
+        self.eval()
+
+    @classmethod
+    def paths(cls, net):
+        return [os.environ.get(env) or os.path.abspath(os.path.join(".", default)) for env, default in cls.FILES[net]]
+
+    @classmethod
+    def try_build(cls, net, device):
+        heads, backbone = cls.paths(net)
+        if not (os.path.exists(heads) and os.path.exists(backbone)):
+            return None
+        return cls(net, torch.load(heads, map_location="cpu"), torch.load(backbone, map_location="cpu")).to(device)
+
+    @torch.no_grad()
+    def forward(self, in0, in1):
+        """in0, in1: (N, 3, H, W); returns (N,) distances."""
+        f0, f1 = (in0 - self.shift) / self.scale, (in1 - self.shift) / self.scale
+        val = 0
+        for i, layer in enumerate(self.features):
+            f0, f1 = layer(f0), layer(f1)
+            if i in self.taps:
+                w = self.lins[self.taps.index(i)]
+                n0 = f0 / (torch.sqrt(torch.sum(f0 ** 2, dim=1, keepdim=True)) + 1e-10)
+                n1 = f1 / (torch.sqrt(torch.sum(f1 ** 2, dim=1, keepdim=True)) + 1e-10)
+                val = val + torch.sum(w * (n0 - n1) ** 2, 1, keepdim=True).mean([2, 3])
+        return val.reshape(-1)

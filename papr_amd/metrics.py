@@ -6,7 +6,7 @@ function's defaults: uniform 11 x 11 window (scipy.ndimage.uniform_filter, refle
 K1 = 0.01, K2 = 0.03, float64, the (win-1)/2 border of the SSIM map dropped before averaging, mean over channels
 (Wang et al., "Image quality assessment: from error visibility to structural similarity", 2004).  scikit-image is not
 available in this environment, so the restatement is not pinned against it; tests check its defining properties.
-LPIPS needs pretrained VGG / AlexNet weights and is not computed.
+LPIPS: papr_amd/lpips.py (TestLPIPS), computed when the pretrained weights are at hand.  depth_map: test.py:113-119.
 """
 import numpy as np
 from scipy.ndimage import uniform_filter
@@ -34,3 +34,16 @@ def ssim(gt, img, win_size=11, data_range=1.0, k1=0.01, k2=0.03):
         s = ((2 * ux * uy + c1) * (2 * vxy + c2)) / ((ux * ux + uy * uy + c1) * (vx + vy + c2))
         vals.append(s[pad:-pad, pad:-pad].mean())
     return float(np.mean(vals))
+
+
+def depth_map(selected_points, attn, rays_o):
+    """Expected depth of a rendered view as the reference's test_step forms it (test.py:113-119): distance of every selected point
+    from the camera plane through the origin of the rays (normal -o, offset |o|^2), weighted with the attention over the k
+    points (the background token counts with distance 0).  selected_points (1,H,W,k,3), attn (1,H,W,k+1,1), rays_o (1,3) torch
+    tensors -> (H,W) float32 numpy, scene units (the PNG scales by 65536 / 10 / coord_scale, test.py:126-128)."""
+    import torch
+    od = -rays_o
+    D = torch.sum(od * rays_o)
+    dists = torch.abs(torch.sum(selected_points.to(od.device) * od, -1) - D) / torch.norm(od)
+    dists = torch.cat([dists, torch.zeros_like(dists[..., :1])], dim=-1)
+    return torch.sum(attn.squeeze(-1).to(od.device) * dists, dim=-1).detach().cpu().squeeze().numpy().astype(np.float32)

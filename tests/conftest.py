@@ -41,6 +41,21 @@ PARITY = {"use_amp": False, "training": {"losses": {"mse": 1.0, "lpips": 0.0, "l
 VARIANTS = {"geoms": {"points": {"init_num": 1000}, "point_feats": {"use_ink": True, "use_inv": True}},
             "models": {"normalize_topk_attn": False, "attn": {"embed": {"embed_type": 2}}}}
 
+# G13: the tiny model whose checkpoint directory the REFERENCE's own PAPR.save wrote (tests/golden/g13_ref_ckpt, make_golden.py --round3)
+G13 = {"geoms": {"points": {"init_num": 400, "select_k": 12}, "point_feats": {"dim": 16}},
+       "models": {"use_renderer": False, "attn": {"d_model": 64, "embed": {
+           "k_L": [4, 4, 4], "q_L": [4], "v_L": [4, 4],
+           "key": {"d_ff": 64, "d_ff_out": 64, "n_ff_layer": 3},
+           "query": {"d_ff": 64, "d_ff_out": 64, "n_ff_layer": 3},
+           "value": {"d_ff": 64, "d_ff_out": 3, "n_ff_layer": 4}}}}}
+G13_DIR = os.path.join(GOLDEN, "g13_ref_ckpt")
+
+
+def g13_cfg():
+    from papr_amd.config import load_config, deep_merge
+    return deep_merge(load_config("nerfsyn/chair.yml", overrides=G13), PARITY)
+
+
 CASES = {
     "chair1k": ("nerfsyn/chair.yml", SMALL, dict(n_img=1, hw=16, seed=0)),
     "lego1k": ("nerfsyn/lego.yml", SMALL, dict(n_img=1, hw=16, seed=0)),

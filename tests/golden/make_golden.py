@@ -355,8 +355,51 @@ def g12_lpips():
          lin_sums=np.array([float(l.weight.sum()) for l in net.lins]))
 
 
+# ----------------------------------------------------------------------------------- G13 (round 3)
+G13_CFG = {"geoms": {"points": {"init_num": 400, "select_k": 12}, "point_feats": {"dim": 16}},
+           "models": {"use_renderer": False, "attn": {"d_model": 64, "embed": {
+               "k_L": [4, 4, 4], "q_L": [4], "v_L": [4, 4],
+               "key": {"d_ff": 64, "d_ff_out": 64, "n_ff_layer": 3},
+               "query": {"d_ff": 64, "d_ff_out": 64, "n_ff_layer": 3},
+               "value": {"d_ff": 64, "d_ff_out": 3, "n_ff_layer": 4}}}}}
+
+
+def g13_ref_checkpoint():
+    """A checkpoint directory written by the REFERENCE's own PAPR.save (models/model.py:562-586) after three of its own train
+    steps from a random (seeded) initialisation, and what the reference renders from it: the files a user of the reference
+    has on disk (model.pth = {str(step): state_dict}, optimizers.pth, schedulers.pth, scaler.pth)."""
+    cfg = load_cfg("nerfsyn/chair.yml", **G13_CFG)
+    setup_seed(3)                                       # (seed 1 happens to give q.k < 0 for every pair of this tiny model: all scores 0 behind the ReLU; seed 3: 44 % positive)
+    model = get_model(DictAsMember(copy.deepcopy(cfg)), "cpu")
+    with torch.no_grad():                               # untrained influence scores are exactly zero: give the attention something to weigh
+        model.points_influ_scores.uniform_(0.0, 1.0, generator=torch.Generator().manual_seed(7))
+    ro, rd, c2w = synth_rays(2, 8, 8, seed=11)
+    tgt = torch.rand(2, 8, 8, 3, generator=torch.Generator().manual_seed(12))
+    loss_fn = get_loss(cfg["training"]["losses"])
+
+    class DS:                                           # what train_step asks of the dataset (train.py:158-161)
+        def get_c2w(self, idx): return c2w[idx]
+
+    args = DictAsMember(copy.deepcopy(cfg))
+    for step in range(3):
+        ref_train.train_step(step, model, "cpu", DS(), (torch.tensor([0, 1]), None, tgt, rd, ro), loss_fn, args)
+    out_dir = os.path.join(HERE, "g13_ref_ckpt")
+    os.makedirs(out_dir, exist_ok=True)
+    model.save(3, out_dir)
+    with torch.no_grad():
+        fused, attn = model.evaluate(ro, rd, c2w)
+        rgb = model(ro, rd, c2w)
+    save("g13_ref_ckpt_outputs.npz", rays_o=npf(ro), rays_d=npf(rd), c2w=npf(c2w), fused=npf(fused.squeeze(-2)), attn=npf(attn.squeeze(-1)),
+         rgb=npf(rgb), idx=npf(model.select_k_ind).astype(np.int32), points=npf(model.points))
+    for f in sorted(os.listdir(out_dir)):
+        print("wrote g13_ref_ckpt/%s %.1f KB" % (f, os.path.getsize(os.path.join(out_dir, f)) / 1024))
+
+
 if __name__ == "__main__":
     small = {"geoms": {"points": {"init_num": 1000}}}
+    if "--round3" in sys.argv:
+        g13_ref_checkpoint()
+        sys.exit(0)
     if "--lpips" in sys.argv:
         sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
         g12_lpips()

@@ -478,3 +478,39 @@ def test_chair_yml_verbatim_full_size_amp_step():
     for n in names:
         assert seen[n] > 0 and torch.isfinite(dict(m.named_parameters())[n]).all(), n
     assert float(grads["points"].abs().max()) < 1e3, "gradients must be unscaled by the time the optimizers see them"
+
+
+def test_renders_from_the_checkpoint_directory_the_reference_wrote():
+    """a `model.pth` written by the reference's own PAPR.save (tests/golden/g13_ref_ckpt, after three of its
+    train steps from a random init) loads into papr_amd.PAPR and renders through the HIP path what the reference rendered from it,
+    within the 1e-4 bar; then training resumes from the loaded optimizer state (one step with the fused and the torch Adam agree)."""
+    import os
+    from conftest import G13_DIR, g13_cfg
+    from papr_amd import get_model
+    g = golden("g13_ref_ckpt_outputs.npz")
+    torch.manual_seed(5)
+    m = get_model(g13_cfg(), device="cuda")
+    assert m.load(G13_DIR, load_optimizer=True) == 3
+    ro, rd, c2w = cuda(T(g["rays_o"]), T(g["rays_d"]), T(g["c2w"]))
+    with torch.no_grad():
+        fused, attn = m.evaluate(ro, rd, c2w)
+        rgb = m(ro, rd, c2w)
+    k = g["idx"].shape[-1]
+    idx = m.select_k_ind.cpu().numpy()
+    assert np.array_equal(np.sort(idx, -1), np.sort(g["idx"], -1)), "kNN sets differ"
+    mine = attn.squeeze(-1).cpu().numpy()
+    a_got = np.concatenate([np.take_along_axis(mine[..., :k], np.argsort(idx, -1), -1), mine[..., k:]], -1)
+    a_ref = np.concatenate([np.take_along_axis(g["attn"][..., :k], np.argsort(g["idx"], -1), -1), g["attn"][..., k:]], -1)
+    err = {"fused": np.abs(fused.squeeze(-2).cpu().numpy() - g["fused"]).max(), "attn": np.abs(a_got - a_ref).max(),
+           "rgb": np.abs(rgb.cpu().numpy() - g["rgb"]).max()}
+    print("reference-written checkpoint, L-inf vs reference:", err)
+    assert max(err.values()) <= RGB_TOL, err
+    # resume: one more train step from the loaded Adam state
+    tgt = torch.rand(2, 8, 8, 3, generator=torch.Generator().manual_seed(12)).cuda()
+    m.clear_grad()
+    loss = torch.mean((m(ro, rd, c2w, 3) - tgt) ** 2)
+    loss.backward()
+    before = m.points.detach().clone()
+    m.step(3)
+    assert torch.isfinite(m.points).all() and not torch.equal(before, m.points.detach())
+    assert float(m.optimizers["points"].state_dict()["state"][0]["step"]) == 4.0

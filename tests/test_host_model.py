@@ -304,3 +304,67 @@ def test_ssim_restatement_properties():
     x, y = np.full((20, 20, 1), 0.3), np.full((20, 20, 1), 0.6)
     assert ssim(x, y) == pytest.approx((2 * 0.3 * 0.6 + 1e-4) / (0.09 + 0.36 + 1e-4), rel=1e-9)
     assert psnr(x, y) == pytest.approx(-10 * np.log10(0.09), rel=1e-12)
+
+
+def test_loads_the_checkpoint_directory_the_reference_wrote():
+    """tests/golden/g13_ref_ckpt: model.pth / optimizers.pth / schedulers.pth / scaler.pth as the reference's PAPR.save
+    (models/model.py:562-586) left them after three of its own train steps.  PAPR.load(dir, load_optimizer=True) must take all of it:
+    every state-dict entry bit for bit, the Adam moments and step counters, the scheduler positions."""
+    from conftest import G13_DIR, g13_cfg
+    from papr_amd import get_model
+    seed_all(9)
+    m = get_model(g13_cfg(), device="cpu")
+    step = m.load(G13_DIR, load_optimizer=True)
+    assert step == 3
+    ref = torch.load(os.path.join(G13_DIR, "model.pth"), map_location="cpu")["3"]
+    own = m.state_dict()
+    assert list(own.keys()) == list(ref.keys())
+    for k, v in ref.items():
+        assert torch.equal(own[k], v), k
+    osd = torch.load(os.path.join(G13_DIR, "optimizers.pth"), map_location="cpu")
+    assert set(osd) == set(m.optimizers)
+    for name, opt in m.optimizers.items():
+        got = opt.state_dict()
+        assert len(got["state"]) == len(osd[name]["state"]) > 0, name
+        for i, st in osd[name]["state"].items():
+            assert float(got["state"][i]["step"]) == 3.0
+            assert torch.equal(got["state"][i]["exp_avg"], st["exp_avg"]) and torch.equal(got["state"][i]["exp_avg_sq"], st["exp_avg_sq"])
+    ssd = torch.load(os.path.join(G13_DIR, "schedulers.pth"), map_location="cpu")
+    for name, sch in m.schedulers.items():
+        assert sch.state_dict()["last_epoch"] == ssd[name]["last_epoch"] == 3, name
+
+
+def test_test_time_lpips_is_the_pinned_network_without_input_rescaling():
+    """test.py's LPIPS (papr_amd/lpips.py: TestLPIPS, the `lpips` package's v0.1 metric as reference test.py:109-110 calls it) on the VGG
+    arm is the arithmetic of the training loss's network -- which G12 pins against the reference's LPNet -- minus the 2x-1 input
+    rescaling (the reference hands [0,1] images to the package without normalize=True); the AlexNet arm has the package's tap layout."""
+    from papr_amd.lpips import LPNet, TestLPIPS
+    torch.manual_seed(0)
+    ln = LPNet(load=False)
+    for p in ln.features.parameters():
+        p.data.normal_(0, 0.05)
+    for p in ln.lins:
+        p.data.uniform_(0, 1)
+    t = TestLPIPS("vgg")
+    t.features.load_state_dict(ln.features.state_dict())
+    for a, b in zip(t.lins, ln.lins):
+        a.data.copy_(b.data)
+    x, y = torch.rand(2, 32, 32, 3), torch.rand(2, 32, 32, 3)
+    got = t((2 * x - 1).permute(0, 3, 1, 2), (2 * y - 1).permute(0, 3, 1, 2))
+    assert got.shape == (2,)
+    assert abs(float(got.mean()) - float(ln(x, y).detach())) < 1e-6
+    assert float(t(x.permute(0, 3, 1, 2), x.permute(0, 3, 1, 2)).abs().max()) == 0.0
+    al = TestLPIPS("alex")
+    assert [al.features[i].out_channels for i in (0, 3, 6, 8, 10)] == [64, 192, 384, 256, 256] and al.taps == (1, 4, 7, 9, 11)
+    assert TestLPIPS.try_build("alex", "cpu") is None       # no weights in this environment: test.py reports nan
+
+
+def test_depth_map_is_attention_weighted_plane_distance():
+    from papr_amd.metrics import depth_map
+    g = torch.Generator().manual_seed(3)
+    o = torch.tensor([[0.0, 0.0, 40.0]])
+    sel = torch.randn(1, 5, 6, 4, 3, generator=g) * 3
+    attn = torch.softmax(torch.randn(1, 5, 6, 5, 1, generator=g), dim=-2)
+    d = depth_map(sel, attn, o)
+    want = (attn[0, ..., :4, 0] * (40.0 - sel[0, ..., 2]).abs()).sum(-1).numpy()     # camera on the z axis: distance to the plane z = 40
+    assert d.shape == (5, 6) and np.allclose(d, want, atol=1e-5)

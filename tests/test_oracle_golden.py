@@ -170,3 +170,23 @@ def test_g9_two_image_batch_is_mean_of_single_image_grads():
     for n in ("points", "points_influ_scores", "renderer.outc.conv.bias"):
         mean = 0.5 * (g0[n] + g1[n])
         np.testing.assert_allclose(both[n].numpy(), mean.numpy(), rtol=0, atol=2e-8 + 1e-5 * mean.abs().max().item())
+
+
+def test_g13_oracle_renders_the_reference_written_checkpoint():
+    """The state the reference's own PAPR.save wrote after three of its train steps (random init, not formula weights), through
+    the oracle: same neighbour sets, same fused features / attention / RGB as the reference rendered from it."""
+    from conftest import G13_DIR, g13_cfg
+    g = golden("g13_ref_ckpt_outputs.npz")
+    ck = torch.load(os.path.join(G13_DIR, "model.pth"), map_location="cpu")
+    assert list(ck) == ["3"]
+    st = {k: v.detach().clone() for k, v in ck["3"].items()}
+    assert np.array_equal(st["points"].numpy(), g["points"])
+    with torch.no_grad():
+        out = O.render(st, g13_cfg(), T(g["rays_o"]), T(g["rays_d"]))
+    assert np.array_equal(np.sort(out["idx"].numpy(), -1), np.sort(g["idx"], -1))
+    k = g["idx"].shape[-1]
+    a_got = np.concatenate([np.take_along_axis(out["attn"].numpy()[..., :k], np.argsort(out["idx"].numpy(), -1), -1), out["attn"].numpy()[..., k:]], -1)
+    a_ref = np.concatenate([np.take_along_axis(g["attn"][..., :k], np.argsort(g["idx"], -1), -1), g["attn"][..., k:]], -1)
+    np.testing.assert_allclose(a_got, a_ref, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(out["fused"].numpy(), g["fused"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(out["rgb"].numpy(), g["rgb"], rtol=0, atol=2e-5)

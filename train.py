@@ -38,20 +38,24 @@ def setup_seed(seed):
     random.seed(seed)
 
 
-def render_full(model, rayo, rayd, c2w, max_h, max_w):
-    """Chunked evaluate() + render head + compositing (reference eval_step / test_step)."""
+def render_full(model, rayo, rayd, c2w, max_h, max_w, extras=False):
+    """Chunked evaluate() + render head + compositing (reference eval_step / test_step).  extras: also the foreground image, the
+    background mask, the attention weights and the selected points (what test.py:120-141 turns into depth / fgrgb / bkgmask PNGs)."""
     args = model.args
     N, H, W, _ = rayd.shape
     topk = min(model.points.shape[0], int(model.select_k))
     C = args.models.attn.embed.value.d_ff_out
     fmap = torch.zeros(N, H, W, 1, C, device=rayd.device)
     attn = torch.zeros(N, H, W, topk + 1, 1, device=rayd.device)
+    sel = torch.zeros(1, H, W, topk, 3, device=rayd.device) if extras else None
     with torch.no_grad():
         for h0 in range(0, H, max_h):
             for w0 in range(0, W, max_w):
                 f, a = model.evaluate(rayo, rayd[:, h0:h0 + max_h, w0:w0 + max_w].contiguous(), c2w)
                 fmap[:, h0:h0 + max_h, w0:w0 + max_w] = f
                 attn[:, h0:h0 + max_h, w0:w0 + max_w] = a
+                if extras:
+                    sel[:, h0:h0 + max_h, w0:w0 + max_w] = model.selected_points[:1]
         if args.models.use_renderer:
             fg = model.renderer(fmap.squeeze(-2).permute(0, 3, 1, 2)).permute(0, 2, 3, 1).unsqueeze(-2).float()
         else:
@@ -59,7 +63,10 @@ def render_full(model, rayo, rayd, c2w, max_h, max_w):
         bkg_attn = attn[..., topk:, :]
         bkg = model.bkg_feats.expand(N, H, W, -1, -1)
         rgb = fg * (1 - bkg_attn) + bkg * bkg_attn if args.models.normalize_topk_attn else fg + bkg * bkg_attn
-        return torch.clamp(model.last_act(rgb.squeeze(-2)), 0, 1)
+        out = torch.clamp(model.last_act(rgb.squeeze(-2)), 0, 1)
+        if extras:
+            return out, fg.squeeze(-2), (bkg * bkg_attn).squeeze(-2), attn, sel
+        return out
 
 
 def psnr(rgb, img):
