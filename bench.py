@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--no-amp-line", action="store_true", help="skip the second measurement (throughput_mode_h1: a child process in --gemm-mode h1)")
     ap.add_argument("--cpu-rays", type=int, default=32, help="edge of the CPU-baseline patch (32 -> 1,024 rays)")
     ap.add_argument("--cpu-steps", type=int, default=8)
+    ap.add_argument("--psnr-steps", type=int, default=3000,
+                    help="N = 1 only: after the timed region, train.py runs this many steps of the same scene file from seed 1 on the procedural scene "
+                         "(a child process) and its last evaluation PSNR goes into the JSON line as psnr_after_steps (BASELINE's metric is rays/s + test PSNR); 0 = skip")
     ap.add_argument("--amp", action="store_true",
                     help="run with the scene file's own `use_amp: true` (the U-Net head under fp16 autocast + GradScaler, as the "
                          "reference trains); default is fp32 everywhere, the mode the 1e-4 parity bar is stated for")
@@ -96,6 +99,29 @@ def cpu_baseline(cfg, state, edge, steps):
     return {"value": R * steps / dt, "unit": "rays/s", "cores": torch.get_num_threads(), "host_cores": os.cpu_count(), "kind": "port",
             "sample": "%d train steps of %dx%d=%d rays vs P=%d (oracle/papr_oracle.py, torch %s fp32 CPU, Adam, MSE)"
                       % (steps, edge, edge, R, state["points"].shape[0], torch.__version__)}
+
+
+def psnr_after_steps(args):
+    """Quality leg of BASELINE's metric ("train rays/sec + test PSNR"): train.py (the reference's driver protocol: patch sampling, eval
+    every 500 steps below 10,000, full-image chunked render, test.py:107 PSNR) for --psnr-steps steps, fixed seed, same kernels."""
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        cmd = [sys.executable, os.path.join(ROOT, "train.py"), "--opt", os.path.join(ROOT, "configs", args.scene), "--steps", str(args.psnr_steps),
+               "--set", "use_amp=%s" % ("true" if args.amp else "false"), "training.losses.lpips=0", "seed=1", "index=bench_psnr", "save_dir=%s" % tmp,
+               "geoms.points.init_num=%d" % args.points]
+        t0 = time.perf_counter()
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=1800, cwd=ROOT)
+        wall = time.perf_counter() - t0
+    evals = [l for l in r.stdout.splitlines() if l.startswith("Eval step:")]
+    if r.returncode != 0 or not evals:
+        return {"error": (r.stderr or r.stdout)[-300:]}
+    last = evals[-1].split()
+    return {"steps": int(last[2]), "eval_psnr_db": float(last[-1]), "first_eval_psnr_db": float(evals[0].split()[-1]), "train_loss": float(last[4]),
+            "wall_s_incl_evals_and_startup": wall, "seed": 1,
+            "scene": "procedural chair-like solid on white (papr_amd/data.py; no dataset offline), 100 train views, eval view img_idx 50 at 800x800, "
+                     "train.py protocol (MSE-only), PSNR = test.py:107 formula",
+            "note": "seed spread of this quantity over long runs: profiles/r03_seed_study/summary.txt"}
 
 
 def main():
@@ -303,6 +329,8 @@ def main():
                                          "roofline_mlp_chain": j.get("roofline") if "mlp_chain" in (j.get("roofline") or {}).get("kernel", "") else j.get("roofline_mlp_chain")}
         except Exception as e:      # the headline line must not depend on the second one
             out["throughput_mode_h1"] = {"error": "%s: %s" % (type(e).__name__, (r.stderr or "")[-300:])}
+    if world == 1 and args.psnr_steps > 0 and args.gemm_mode == "h3":
+        out["psnr_after_steps"] = psnr_after_steps(args)
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, init_state, args.cpu_rays, args.cpu_steps)
     print(json.dumps(out))

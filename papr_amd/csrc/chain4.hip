@@ -77,9 +77,14 @@ __device__ __forceinline__ float last_lane(float v) { return __int_as_float(__bu
     asm("s_nop 1\n\tv_writelane_b32 %0, %1, %5\n\tv_writelane_b32 %0, %2, %6\n\tv_writelane_b32 %0, %3, %7\n\tv_writelane_b32 %0, %4, %8" \
         : "+v"(vec) : "s"(s0), "s"(s1), "s"(s2), "s"(s3), "i"(l0), "i"((l0) + 1), "i"((l0) + 2), "i"((l0) + 3))
 
-// both lanes of a pair (l, l ^ 32) receive op(own, partner's) -- lanes 0-31 hold the row's columns 0-15 of the wave, lanes 32-63 columns 16-31
+// both lanes of a pair (l, l ^ 32) receive op(own, partner's) -- lanes 0-31 hold the row's columns 0-15 of the wave, lanes 32-63 columns 16-31.
+// v_permlane32_swap exchanges the upper half of its first operand with the lower half of its second.  Through the builtin, NOT inline
+// asm: the instruction needs wait states behind the VALU writes of its operands, which the compiler only counts for instructions it
+// knows (the first version, as asm right behind the two copies, read stale registers for some rows)
 __device__ __forceinline__ void pair_swap(float& lo_copy, float& hi_copy) {      // in: both = v; out: lo_copy = v of the pair's lower lane, hi_copy = of its upper lane, in both lanes
-    asm("v_permlane32_swap_b32 %0, %1" : "+v"(lo_copy), "+v"(hi_copy));
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo_copy), __float_as_uint(hi_copy), false, false);
+    lo_copy = __uint_as_float(r[0]);
+    hi_copy = __uint_as_float(r[1]);
 }
 __device__ __forceinline__ float pair_max(float v) { float a = v, b = v; pair_swap(a, b); return fmaxf(a, b); }
 __device__ __forceinline__ float pair_sum(float v) { float a = v, b = v; pair_swap(a, b); return a + b; }
@@ -87,8 +92,8 @@ __device__ __forceinline__ float pair_sum(float v) { float a = v, b = v; pair_sw
 // uniform per-layer flags of the row phases: 0 / 1 = known at compile time (the hot instantiations), 2 = look at run time
 template <int RELU, int STORE, int BITS, int FULL>
 struct P1Cfg { static constexpr int relu = RELU, store = STORE, bits = BITS, full = FULL; };
-template <int RMAX, int MORE, int FULL>
-struct P2Cfg { static constexpr int rmax = RMAX, more = MORE, full = FULL; };
+template <int RMAX, int MORE, int FULL, int ROWS>
+struct P2Cfg { static constexpr int rmax = RMAX, more = MORE, full = FULL, rows = ROWS; };
 
 #define C4_WH0 "a[0:3]"
 #define C4_WL0 "a[4:7]"
@@ -188,6 +193,13 @@ struct C4Plan {                                 // (one packed word per step: th
     void push(int layer, int kbeg, int kcnt, int flags) { w[n_steps++] = layer | (kbeg << 8) | (kcnt << 16) | (flags << 24); }
 };
 
+#ifdef PAPR_C4_TRACE                                // cycle stamps of one workgroup: 8 waves x 256 stamps (scripts/probes/chain4_trace.py)
+__device__ long long g_chain4_trace[2048];
+#define C4_STAMP() do { asm volatile("" ::: "memory"); if (blockIdx.x == 100 && lane0 == 0 && trace_slot < 256) g_chain4_trace[wn * 256 + trace_slot++] = __builtin_readcyclecounter(); asm volatile("" ::: "memory"); } while (0)
+#else
+#define C4_STAMP() do {} while (0)
+#endif
+
 __device__ __forceinline__ long uniform64(long v) {       // a wave-uniform value the compiler keeps in scalar registers and does not move out of loops
     int lo = __builtin_amdgcn_readfirstlane((int)v), hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
     asm volatile("" : "+s"(lo), "+s"(hi));
@@ -201,6 +213,9 @@ __global__ __launch_bounds__(C4_THREADS, 2) void mlp_chain4_kernel(ChainArgs p, 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane0 = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool k_first = wn < 4;                    // waves w and w + 4 share a SIMD
+#ifdef PAPR_C4_TRACE
+    int trace_slot = 0;
+#endif
     // Every piece below derives its lane addresses from its own opaque copy of the lane number: values the compiler can compute
     // once ahead of the slot loop live across everything, and with two accumulator sets there is nothing to spare.
 #define C4_LANE() int lane = lane0; asm volatile("" : "+v"(lane))
@@ -240,7 +255,8 @@ __global__ __launch_bounds__(C4_THREADS, 2) void mlp_chain4_kernel(ChainArgs p, 
         const unsigned ab = (unsigned)((arow / RB) * C4_BLK_BYTES + (arow % RB) * 512 + (((lane >> 5) ^ (ax & 1)) * 16));
         const unsigned axr = (unsigned)((ax & ~1) * 16);
         const unsigned w_lane = (unsigned)lane * 16u;   // (weight loads: a wave-uniform base + this lane offset)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this step's fragments (requested a slot ago) have landed
+        // (this step's fragments were requested a slot ago and waited for in `pending` -- ahead of the row stores: a wait here would
+        // also wait for those, loads and stores share the counter)
         if (live && ksteps == KS && first) {
             // ---- the hot form: ONE asm statement for the whole k-loop (chain4_kloop.inc, scripts/gen_chain4_kloop.py)
             const unsigned pb = (unsigned)(size_t)planes + ab;
@@ -423,7 +439,7 @@ __global__ __launch_bounds__(C4_THREADS, 2) void mlp_chain4_kernel(ChainArgs p, 
         const float slope = L.act == PAPR_ACT_RELU ? 0.f : (L.act == PAPR_ACT_LEAKY_RELU ? 0.2f : 1.f);
         const bool rt_half = ONE && L.c_half != 0 && L.C != nullptr;          // f16 rows out (written by P2 with the split), no fp32 rows
         const bool mask_rows = DGRAD && L.sign_bits == nullptr && L.mask != nullptr;
-        const bool rt_store = L.C != nullptr && !rt_half && !rt_norm, rt_bits = L.sign_bits != nullptr || mask_rows;
+        const bool rt_store = L.C != nullptr && !rt_half && !rt_norm && N % 32 != 0, rt_bits = L.sign_bits != nullptr || mask_rows;       // (fp32 rows of a width that is a multiple of 32 leave in P2, whole cache lines at a time)
         const bool rt_full = N == 256 && t0 + C4_ROWS <= M32;
         const float* const inv_tab = inv_all + h * C4_ROWS;
         const float* const bias = bias_all + l * 256 + cb;
@@ -467,11 +483,15 @@ __global__ __launch_bounds__(C4_THREADS, 2) void mlp_chain4_kernel(ChainArgs p, 
                         }
                     }
                     if (!f_full && !col_ok) { y[0] = 0.f; y[1] = 0.f; y[2] = 0.f; y[3] = 0.f; }       // columns beyond N: zero weights, but a bias-free zero all the same
+#ifndef C4_X_NOSTORE                                // (timing experiments: pieces left out, results wrong)
                     if (f_store && col_ok && in_m) *reinterpret_cast<float4*>(L.C + (long)m * ldc + cb + 4 * g) = make_float4(y[0], y[1], y[2], y[3]);
+#endif
+#ifndef C4_X_NOBITS
                     if (!DGRAD && f_bits) {
 #pragma unroll
                         for (int c = 0; c < 4; ++c) word = (word << 1) | (y[c] > 0.f ? 1u : 0u);
                     }
+#endif
                     lmax = fmaxf(fmaxf(lmax, fabsf(y[0])), fmaxf(fabsf(y[1]), fmaxf(fabsf(y[2]), fabsf(y[3]))));
 #pragma unroll
                     for (int c = 0; c < 4; ++c) a[i][4 * g + c] = y[c];
@@ -517,7 +537,6 @@ __global__ __launch_bounds__(C4_THREADS, 2) void mlp_chain4_kernel(ChainArgs p, 
         const bool relu = L.act == PAPR_ACT_RELU;
         // hot combinations (everything 256 wide, tile inside M, no norm): training / inference / data-gradient, ReLU or any slope
         if (generic_only || !rt_full || rt_norm) rows(P1Cfg<2, 2, 2, 2>());
-        else if (rt_store && rt_bits) { if (relu) rows(P1Cfg<1, 1, 1, 1>()); else rows(P1Cfg<2, 1, 1, 1>()); }
         else if (!rt_store && rt_bits) { if (relu) rows(P1Cfg<1, 0, 1, 1>()); else rows(P1Cfg<2, 0, 1, 1>()); }
         else if (!DGRAD && !rt_store && !rt_bits) { if (relu) rows(P1Cfg<1, 0, 0, 1>()); else rows(P1Cfg<2, 0, 0, 1>()); }
         else rows(P1Cfg<2, 2, 2, 2>());
@@ -538,15 +557,49 @@ __global__ __launch_bounds__(C4_THREADS, 2) void mlp_chain4_kernel(ChainArgs p, 
         const bool more = l + 1 < n_layers;
         const bool rt_norm = !DGRAD && !more && p.norm_stats != nullptr;
         const bool rt_rmax = L.rowmax != nullptr;
-        if (!more && !rt_rmax && !rt_norm) return;
+        const bool rt_half = ONE && L.c_half != 0 && L.C != nullptr;
+        const bool rt_rows = L.C != nullptr && !rt_half && N % 32 == 0;         // this layer's fp32 rows go to memory from here
+        if (!more && !rt_rmax && !rt_norm && !rt_rows) return;
         const bool live = 32 * wn < N;
         const int cb = 32 * wn + 16 * hh;
-        const bool rt_half = ONE && L.c_half != 0 && L.C != nullptr;
         const bool rt_full = N == 256 && t0 + C4_ROWS <= M32;
         const float* const pm = pmax_all + h * GW * C4_ROWS;
         float* const inv_tab = inv_all + h * C4_ROWS;
         char* const planes = smem + h * C4_TILE_BYTES;
         const bool skip_next = more && p.L[l + 1].k1steps < p.L[l + 1].ksteps;
+        // ---- row stores through LDS.  A lane owns one row and 64 of its bytes: stored directly (chain.hip did), an instruction touches 32
+        // cache lines with two 16-byte pieces each -- the store path, not the matrix pipe, bounded the training runs (NOSTORE experiment:
+        // 1099 -> 793 us per 4-layer run).  Here the wave's 64 x 32 block (8 KB) takes a round trip through LDS so that eight consecutive
+        // lanes write one row's 128 bytes.  The space is the wave's OWN piece of the tile's dead planes, no other wave touches it meanwhile:
+        //   with a following layer: the 128 bytes per row that this wave's split overwrites right afterwards (hi and lo chunks 4 wn .. 4 wn + 3,
+        //     XOR-ed with the row like the planes themselves);
+        //   last layer of the run: block wn (rows 8 wn .. 8 wn + 7 of the planes, 8 KB), which this wave's staging of the next tile
+        //     overwrites afterwards -- the other waves' splits do not exist then.
+        auto store_rows = [&](bool full) __attribute__((always_inline)) {
+            if (!live) return;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int rt = 32 * i + arow;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    char* dst = more ? planes + (rt >> 3) * C4_BLK_BYTES + (rt & 7) * 512 + hh * C4_LO + ((((unsigned)(4 * wn + g)) ^ (unsigned)(rt & 15)) * 16)
+                                     : planes + wn * C4_BLK_BYTES + rt * 128 + ((((unsigned)(4 * hh + g)) ^ (unsigned)(rt & 7)) * 16);
+                    *reinterpret_cast<float4*>(dst) = make_float4(a[i][4 * g], a[i][4 * g + 1], a[i][4 * g + 2], a[i][4 * g + 3]);
+                }
+            }
+            const int q = lane >> 3, pc = lane & 7;     // store instruction s: row slot q, 16-byte piece pc of the row's 128 bytes
+#pragma unroll
+            for (int sx = 0; sx < 8; ++sx) {
+                if ((sx & 1) == 0 && sx) asm volatile("" ::: "memory");     // (two rows' pieces in flight: 8 registers -- with two accumulator sets there is little room)
+                // (chunk-private layout: the four rows that meet in one service group of a 16-byte LDS read differ in bits 2-3, i.e. in their XOR pattern)
+                const int r = more ? (sx & 3) + 4 * (q & 3) + 16 * (q >> 2) + 32 * (sx >> 2) : 8 * sx + q;
+                const char* src = more ? planes + (r >> 3) * C4_BLK_BYTES + (r & 7) * 512 + (pc >> 2) * C4_LO + ((((unsigned)(4 * wn + (pc & 3))) ^ (unsigned)(r & 15)) * 16)
+                                       : planes + wn * C4_BLK_BYTES + r * 128 + ((((unsigned)pc) ^ (unsigned)(r & 7)) * 16);
+                const float4 v = *reinterpret_cast<const float4*>(src);
+                const int m = t0 + r;
+                if (full || m < M32) *reinterpret_cast<float4*>(L.C + (long)m * L.ldc + 32 * wn + 4 * pc) = v;
+            }
+        };
         if (rt_norm) {
             const int nw = N / 32;                  // (the launcher keeps the norm in the run only for N a multiple of 32)
             const float2* const nr = nrm_all + h * GW * C4_ROWS;
@@ -561,7 +614,7 @@ __global__ __launch_bounds__(C4_THREADS, 2) void mlp_chain4_kernel(ChainArgs p, 
                 m2 += 32.f * dm;
                 const float sigma = sqrtf(m2 / (float)(N - 1));
                 const float rinv = 1.0f / (sigma + p.norm_eps);
-                if (live && m < M32 && L.C != nullptr) {
+                if (live && m < M32 && L.C != nullptr) {     // (direct stores: one layer per run, and a third copy of the staged path costs the kernel its registers)
 #pragma unroll
                     for (int g = 0; g < 4; ++g)
                         *reinterpret_cast<float4*>(L.C + (long)m * L.ldc + cb + 4 * g) =
@@ -576,6 +629,10 @@ __global__ __launch_bounds__(C4_THREADS, 2) void mlp_chain4_kernel(ChainArgs p, 
             const bool f_rmax = Cfg::rmax == 2 ? rt_rmax : Cfg::rmax == 1;
             const bool f_more = Cfg::more == 2 ? more : Cfg::more == 1;
             const bool f_full = Cfg::full == 2 ? rt_full : Cfg::full == 1;
+            const bool f_rows = Cfg::rows == 2 ? rt_rows : Cfg::rows == 1;
+#ifndef C4_X_NOSTORE
+            if (f_rows) store_rows(f_full);
+#endif
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 const int rt = 32 * i + arow, m = t0 + rt;
@@ -624,8 +681,9 @@ __global__ __launch_bounds__(C4_THREADS, 2) void mlp_chain4_kernel(ChainArgs p, 
                 }
             }
         };
-        if (!generic_only && rt_full && more && !skip_next) { if (rt_rmax) rows(P2Cfg<1, 1, 1>()); else rows(P2Cfg<0, 1, 1>()); }
-        else rows(P2Cfg<2, 2, 2>());
+        if (!generic_only && rt_full && more && !skip_next && rt_rmax && rt_rows) rows(P2Cfg<1, 1, 1, 1>());       // training forward / data-gradient
+        else if (!generic_only && rt_full && more && !skip_next && !rt_rmax && !rt_rows) rows(P2Cfg<0, 1, 1, 0>());       // inference
+        else rows(P2Cfg<2, 2, 2, 2>());
     };
 
     // ---- schedule
@@ -650,6 +708,7 @@ __global__ __launch_bounds__(C4_THREADS, 2) void mlp_chain4_kernel(ChainArgs p, 
         const unsigned w_lane = (unsigned)lane0 * 16u;
         C4_WLOAD_ALL(n0, bh, bl);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the first step's fragments
     lds_barrier();                                  // planes of the first X, the bias table
 
     f32x16 accX[NI], accY[NI];
@@ -681,6 +740,9 @@ __global__ __launch_bounds__(C4_THREADS, 2) void mlp_chain4_kernel(ChainArgs p, 
         if (DGRAD && (st.flags & C4_LAST) && p.L[st.layer].sign_bits != nullptr && mT < p.M)
             sw = p.L[st.layer].sign_bits[(long)(mT / C4_ROWS) * (GW * 64) + wn * 64 + lane0];
         auto pending = [&]() __attribute__((always_inline)) {
+            // the next k-loop's weight fragments (requested behind the last k-loop of tile Y, at least one P1 ago) have landed: waited for
+            // HERE, in front of this wave's row stores -- at the top of the k-loop the same wait sat behind them (1044 -> us per 4-layer run)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (psi >= 0) {
                 const C4Step sp = plan_step(psi);
                 if (sp.flags & C4_LAST) p2_run(aU, 1 - h, pm0, sp.layer);
@@ -688,10 +750,23 @@ __global__ __launch_bounds__(C4_THREADS, 2) void mlp_chain4_kernel(ChainArgs p, 
             }
             if (sm0 >= 0) stage(planesU, invU, xmaxU, sm0, false, kpad0);
         };
+        C4_STAMP();                                 // five stamps per slot: start | rows-first P2 done | K done | P1 done | k-first P2 done | (next start = barrier passed)
+#ifndef C4_X_NOP2
         if (!k_first) pending();
+#endif
+        C4_STAMP();
+#ifndef C4_X_NOK
         k_run(planesT, st, h == 1, sn, aT);
+#endif
+        C4_STAMP();
+#ifndef C4_X_NOP1
         if (st.flags & C4_LAST) p1_run(aT, h, mT, st.layer, sw);
+#endif
+        C4_STAMP();
+#ifndef C4_X_NOP2
         if (k_first) pending();
+#endif
+        C4_STAMP();
         lds_barrier();
     };
 #pragma unroll 1
@@ -708,6 +783,10 @@ __global__ __launch_bounds__(C4_THREADS, 2) void mlp_chain4_kernel(ChainArgs p, 
 }
 
 }  // namespace
+
+#ifdef PAPR_C4_TRACE
+extern "C" int papr_chain4_trace_read(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chain4_trace), sizeof(long long) * 2048) == hipSuccess ? 0 : 1; }
+#endif
 
 size_t papr_chain4_lds_bytes() { return C4_LDS_BYTES; }
 

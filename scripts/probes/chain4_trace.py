@@ -1,0 +1,40 @@
+"""Cycle stamps of every wave of one workgroup of mlp_chain4_kernel (library built with -DPAPR_C4_TRACE):
+   bash scripts/probes/c4_variant.sh trace -DPAPR_C4_TRACE; PAPR_HIP_LIB=$PWD/scripts/probes/bin/libpapr_trace.so python scripts/probes/chain4_trace.py [keep|bwd]
+   per slot and wave: cycles spent in  P2 (rows-first waves) | K | P1 | P2 (k-first waves) | barrier wait."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from papr_amd import ops, hip
+M = 512000
+mode = sys.argv[1] if len(sys.argv) > 1 else "inf"
+d = torch.device("cuda:0")
+n = 4
+spec = ops.MlpSpec("b", 256, dict(n_ff_layer=n, d_ff=256, d_ff_out=256, norm="none", ff_act="relu", ff_last_act="none"))
+ws = [(torch.randn(256, 256) * 0.1).to(d) for _ in range(n)]
+bs = [torch.zeros(256, device=d) for _ in range(n)]
+x = torch.randn(M, 256, device=d)
+gy = torch.randn(M, 256, device=d)
+scratch = [torch.empty((M, 256), device=d) for _ in range(2)]
+for _ in range(3):
+    outs = ops.mlp_forward(spec, ws, bs, x, M, keep=mode != "inf")
+    if mode == "bwd":
+        ops.mlp_backward(spec, ws, bs, x, M, outs, gy.clone(), scratch, True)
+torch.cuda.synchronize()
+buf = (ctypes.c_longlong * 2048)()
+hip.lib().papr_chain4_trace_read(buf)
+t = list(buf)
+names = ["P2 first", "K", "P1", "P2 last", "barrier"]
+tot = [0.0] * 5
+cnt = 0
+s0, s1 = int(os.environ.get("S0", "4")), int(os.environ.get("S1", "12"))
+for sl in range(s0, s1):
+    print("slot %d (tile %s)" % (sl, "XY"[sl & 1]))
+    print("  wave  " + "  ".join("%9s" % s for s in names) + "      total")
+    for w in range(8):
+        tt = t[w * 256: (w + 1) * 256]
+        i = 5 * sl
+        dts = [tt[i + j + 1] - tt[i + j] for j in range(5)]
+        print("  %2d    " % w + "  ".join("%9d" % v for v in dts) + "  %9d" % sum(dts))
+        for j in range(5): tot[j] += dts[j]
+        cnt += 1
+print("mean per wave and slot: " + "  ".join("%s %.0f" % (n_, v / cnt) for n_, v in zip(names, tot)) + "   slot %.0f" % (sum(tot) / cnt))
