@@ -35,6 +35,7 @@
 #include "h3_common.h"
 #include "chain.h"
 #include "chain4_kloop.inc"
+#include "chain4_fused.inc"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -159,6 +160,19 @@ struct P2Cfg { static constexpr int rmax = RMAX, more = MORE, full = FULL, rows 
 #define C4_WL15 "a[124:127]"
 #define C4_CH15 "a120", "a121", "a122", "a123"
 #define C4_WCLOB15 "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127"
+#define C4_HIDDEN_VGPRS "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127"
+#define C4_GET_X0 "v_mov_b32 %0, v64\n\tv_mov_b32 %1, v65\n\tv_mov_b32 %2, v66\n\tv_mov_b32 %3, v67\n\tv_mov_b32 %4, v68\n\tv_mov_b32 %5, v69\n\tv_mov_b32 %6, v70\n\tv_mov_b32 %7, v71\n\tv_mov_b32 %8, v72\n\tv_mov_b32 %9, v73\n\tv_mov_b32 %10, v74\n\tv_mov_b32 %11, v75\n\tv_mov_b32 %12, v76\n\tv_mov_b32 %13, v77\n\tv_mov_b32 %14, v78\n\tv_mov_b32 %15, v79"
+#define C4_PUT_X0 "v_mov_b32 v64, %0\n\tv_mov_b32 v65, %1\n\tv_mov_b32 v66, %2\n\tv_mov_b32 v67, %3\n\tv_mov_b32 v68, %4\n\tv_mov_b32 v69, %5\n\tv_mov_b32 v70, %6\n\tv_mov_b32 v71, %7\n\tv_mov_b32 v72, %8\n\tv_mov_b32 v73, %9\n\tv_mov_b32 v74, %10\n\tv_mov_b32 v75, %11\n\tv_mov_b32 v76, %12\n\tv_mov_b32 v77, %13\n\tv_mov_b32 v78, %14\n\tv_mov_b32 v79, %15"
+#define C4_GET_X1 "v_mov_b32 %0, v80\n\tv_mov_b32 %1, v81\n\tv_mov_b32 %2, v82\n\tv_mov_b32 %3, v83\n\tv_mov_b32 %4, v84\n\tv_mov_b32 %5, v85\n\tv_mov_b32 %6, v86\n\tv_mov_b32 %7, v87\n\tv_mov_b32 %8, v88\n\tv_mov_b32 %9, v89\n\tv_mov_b32 %10, v90\n\tv_mov_b32 %11, v91\n\tv_mov_b32 %12, v92\n\tv_mov_b32 %13, v93\n\tv_mov_b32 %14, v94\n\tv_mov_b32 %15, v95"
+#define C4_PUT_X1 "v_mov_b32 v80, %0\n\tv_mov_b32 v81, %1\n\tv_mov_b32 v82, %2\n\tv_mov_b32 v83, %3\n\tv_mov_b32 v84, %4\n\tv_mov_b32 v85, %5\n\tv_mov_b32 v86, %6\n\tv_mov_b32 v87, %7\n\tv_mov_b32 v88, %8\n\tv_mov_b32 v89, %9\n\tv_mov_b32 v90, %10\n\tv_mov_b32 v91, %11\n\tv_mov_b32 v92, %12\n\tv_mov_b32 v93, %13\n\tv_mov_b32 v94, %14\n\tv_mov_b32 v95, %15"
+#define C4_GET_Y0 "v_mov_b32 %0, v96\n\tv_mov_b32 %1, v97\n\tv_mov_b32 %2, v98\n\tv_mov_b32 %3, v99\n\tv_mov_b32 %4, v100\n\tv_mov_b32 %5, v101\n\tv_mov_b32 %6, v102\n\tv_mov_b32 %7, v103\n\tv_mov_b32 %8, v104\n\tv_mov_b32 %9, v105\n\tv_mov_b32 %10, v106\n\tv_mov_b32 %11, v107\n\tv_mov_b32 %12, v108\n\tv_mov_b32 %13, v109\n\tv_mov_b32 %14, v110\n\tv_mov_b32 %15, v111"
+#define C4_PUT_Y0 "v_mov_b32 v96, %0\n\tv_mov_b32 v97, %1\n\tv_mov_b32 v98, %2\n\tv_mov_b32 v99, %3\n\tv_mov_b32 v100, %4\n\tv_mov_b32 v101, %5\n\tv_mov_b32 v102, %6\n\tv_mov_b32 v103, %7\n\tv_mov_b32 v104, %8\n\tv_mov_b32 v105, %9\n\tv_mov_b32 v106, %10\n\tv_mov_b32 v107, %11\n\tv_mov_b32 v108, %12\n\tv_mov_b32 v109, %13\n\tv_mov_b32 v110, %14\n\tv_mov_b32 v111, %15"
+#define C4_GET_Y1 "v_mov_b32 %0, v112\n\tv_mov_b32 %1, v113\n\tv_mov_b32 %2, v114\n\tv_mov_b32 %3, v115\n\tv_mov_b32 %4, v116\n\tv_mov_b32 %5, v117\n\tv_mov_b32 %6, v118\n\tv_mov_b32 %7, v119\n\tv_mov_b32 %8, v120\n\tv_mov_b32 %9, v121\n\tv_mov_b32 %10, v122\n\tv_mov_b32 %11, v123\n\tv_mov_b32 %12, v124\n\tv_mov_b32 %13, v125\n\tv_mov_b32 %14, v126\n\tv_mov_b32 %15, v127"
+#define C4_PUT_Y1 "v_mov_b32 v112, %0\n\tv_mov_b32 v113, %1\n\tv_mov_b32 v114, %2\n\tv_mov_b32 v115, %3\n\tv_mov_b32 v116, %4\n\tv_mov_b32 v117, %5\n\tv_mov_b32 v118, %6\n\tv_mov_b32 v119, %7\n\tv_mov_b32 v120, %8\n\tv_mov_b32 v121, %9\n\tv_mov_b32 v122, %10\n\tv_mov_b32 v123, %11\n\tv_mov_b32 v124, %12\n\tv_mov_b32 v125, %13\n\tv_mov_b32 v126, %14\n\tv_mov_b32 v127, %15"
+#define C4_ZERO_X "v_mov_b32 v64, 0\n\tv_mov_b32 v65, 0\n\tv_mov_b32 v66, 0\n\tv_mov_b32 v67, 0\n\tv_mov_b32 v68, 0\n\tv_mov_b32 v69, 0\n\tv_mov_b32 v70, 0\n\tv_mov_b32 v71, 0\n\tv_mov_b32 v72, 0\n\tv_mov_b32 v73, 0\n\tv_mov_b32 v74, 0\n\tv_mov_b32 v75, 0\n\tv_mov_b32 v76, 0\n\tv_mov_b32 v77, 0\n\tv_mov_b32 v78, 0\n\tv_mov_b32 v79, 0\n\tv_mov_b32 v80, 0\n\tv_mov_b32 v81, 0\n\tv_mov_b32 v82, 0\n\tv_mov_b32 v83, 0\n\tv_mov_b32 v84, 0\n\tv_mov_b32 v85, 0\n\tv_mov_b32 v86, 0\n\tv_mov_b32 v87, 0\n\tv_mov_b32 v88, 0\n\tv_mov_b32 v89, 0\n\tv_mov_b32 v90, 0\n\tv_mov_b32 v91, 0\n\tv_mov_b32 v92, 0\n\tv_mov_b32 v93, 0\n\tv_mov_b32 v94, 0\n\tv_mov_b32 v95, 0"
+#define C4_ZERO_Y "v_mov_b32 v96, 0\n\tv_mov_b32 v97, 0\n\tv_mov_b32 v98, 0\n\tv_mov_b32 v99, 0\n\tv_mov_b32 v100, 0\n\tv_mov_b32 v101, 0\n\tv_mov_b32 v102, 0\n\tv_mov_b32 v103, 0\n\tv_mov_b32 v104, 0\n\tv_mov_b32 v105, 0\n\tv_mov_b32 v106, 0\n\tv_mov_b32 v107, 0\n\tv_mov_b32 v108, 0\n\tv_mov_b32 v109, 0\n\tv_mov_b32 v110, 0\n\tv_mov_b32 v111, 0\n\tv_mov_b32 v112, 0\n\tv_mov_b32 v113, 0\n\tv_mov_b32 v114, 0\n\tv_mov_b32 v115, 0\n\tv_mov_b32 v116, 0\n\tv_mov_b32 v117, 0\n\tv_mov_b32 v118, 0\n\tv_mov_b32 v119, 0\n\tv_mov_b32 v120, 0\n\tv_mov_b32 v121, 0\n\tv_mov_b32 v122, 0\n\tv_mov_b32 v123, 0\n\tv_mov_b32 v124, 0\n\tv_mov_b32 v125, 0\n\tv_mov_b32 v126, 0\n\tv_mov_b32 v127, 0"
+#define C4_OUT16(t, o) "=v"(t[(o) + 0]), "=v"(t[(o) + 1]), "=v"(t[(o) + 2]), "=v"(t[(o) + 3]), "=v"(t[(o) + 4]), "=v"(t[(o) + 5]), "=v"(t[(o) + 6]), "=v"(t[(o) + 7]), "=v"(t[(o) + 8]), "=v"(t[(o) + 9]), "=v"(t[(o) + 10]), "=v"(t[(o) + 11]), "=v"(t[(o) + 12]), "=v"(t[(o) + 13]), "=v"(t[(o) + 14]), "=v"(t[(o) + 15])
+#define C4_IN16(t, o) "v"(t[(o) + 0]), "v"(t[(o) + 1]), "v"(t[(o) + 2]), "v"(t[(o) + 3]), "v"(t[(o) + 4]), "v"(t[(o) + 5]), "v"(t[(o) + 6]), "v"(t[(o) + 7]), "v"(t[(o) + 8]), "v"(t[(o) + 9]), "v"(t[(o) + 10]), "v"(t[(o) + 11]), "v"(t[(o) + 12]), "v"(t[(o) + 13]), "v"(t[(o) + 14]), "v"(t[(o) + 15])
 #define C4_CAT_(a, b) a##b
 #define C4_CAT(a, b) C4_CAT_(a, b)
 #define C4_OFF0 "0"
@@ -196,8 +210,14 @@ struct C4Plan {                                 // (one packed word per step: th
 #ifdef PAPR_C4_TRACE                                // cycle stamps of one workgroup: 8 waves x 256 stamps (scripts/probes/chain4_trace.py)
 __device__ long long g_chain4_trace[2048];
 #define C4_STAMP() do { asm volatile("" ::: "memory"); if (blockIdx.x == 100 && lane0 == 0 && trace_slot < 256) g_chain4_trace[wn * 256 + trace_slot++] = __builtin_readcyclecounter(); asm volatile("" ::: "memory"); } while (0)
+#ifdef PAPR_C4_TRACE_FINE                           // two more stamps per slot inside `pending`: P2 done | staging loads landed
+#define C4_STAMP2() C4_STAMP()
+#else
+#define C4_STAMP2() do {} while (0)
+#endif
 #else
 #define C4_STAMP() do {} while (0)
+#define C4_STAMP2() do {} while (0)
 #endif
 
 __device__ __forceinline__ long uniform64(long v) {       // a wave-uniform value the compiler keeps in scalar registers and does not move out of loops
@@ -208,8 +228,13 @@ __device__ __forceinline__ long uniform64(long v) {       // a wave-uniform valu
 
 // ONE: the reduced-precision mode (one f16 product per fp32 product, hi planes only; the counterpart of the reference's fp16
 // autocast, models/attn.py:248)
+// REGISTERS.  256 per lane: a[0:127] = the layer's weight fragments (by name, chain3.hip: why); v64-v127 = the two accumulator sets
+// (tile X: v[64:95], tile Y: v[96:127]), ALSO by name: as C++ variables they are 64 registers that live across everything, and every
+// statement with other needs made the register allocator move or spill whole 16-register tuples (770 spilled registers with the fused
+// slots in).  The compiler gets v0-v63 (amdgpu_num_vgpr) and never sees the rest: inline asm names them, the C++ row phases copy a
+// tile's 32 values in and out (acc_get / acc_put).
 template <bool DGRAD, bool ONE>
-__global__ __launch_bounds__(C4_THREADS, 2) void mlp_chain4_kernel(ChainArgs p, C4Plan plan, int iters, int generic_only) {
+__global__ __launch_bounds__(C4_THREADS, 2) __attribute__((amdgpu_num_vgpr(64))) void mlp_chain4_kernel(ChainArgs p, C4Plan plan, int iters, int generic_only, int fused_on, int prefetch_on) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane0 = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool k_first = wn < 4;                    // waves w and w + 4 share a SIMD
@@ -240,88 +265,51 @@ __global__ __launch_bounds__(C4_THREADS, 2) void mlp_chain4_kernel(ChainArgs p, 
         return reinterpret_cast<const char*>(w) + (size_t)(t * L.ksteps + kbeg) * 1024;
     };
 
-    // ---- multiply the tile in `planes` by step st (accumulators from zero or continued); with a next step sn each k-step's
-    // registers are refilled with that step's fragment as soon as the k-step is done
-    auto k_run = [&](const char* planes, C4Step st, bool refill, C4Step sn, f32x16 (&acc)[NI]) __attribute__((always_inline)) {
-        const ChainLayer& L = p.L[st.layer];
-        const int ksteps = st.kcnt;
-        const bool live = 32 * wn < L.N;
-        const char *nh = nullptr, *nl = nullptr;
-        int nks = 0;
-        if (refill) { const ChainLayer& Ln = p.L[sn.layer]; nh = frag_base(Ln, Ln.w_hi, sn.kbeg); nl = frag_base(Ln, Ln.w_lo, sn.kbeg); nks = sn.kcnt; }
-        const bool first = (st.flags & C4_FIRST) != 0;
-        C4_LANE();
-        const int arow = lane & 31, ax = arow & 15;
-        const unsigned ab = (unsigned)((arow / RB) * C4_BLK_BYTES + (arow % RB) * 512 + (((lane >> 5) ^ (ax & 1)) * 16));
-        const unsigned axr = (unsigned)((ax & ~1) * 16);
-        const unsigned w_lane = (unsigned)lane * 16u;   // (weight loads: a wave-uniform base + this lane offset)
-        // (this step's fragments were requested a slot ago and waited for in `pending` -- ahead of the row stores: a wait here would
-        // also wait for those, loads and stores share the counter)
-        if (live && ksteps == KS && first) {
-            // ---- the hot form: ONE asm statement for the whole k-loop (chain4_kloop.inc, scripts/gen_chain4_kloop.py)
-            const unsigned pb = (unsigned)(size_t)planes + ab;
-            unsigned ad[8];                         // LDS address of k-step j's fragments (k-step j + 8: + 256)
+    // ---- the accumulators: v64-v127, outside the compiler's view (see REGISTERS above)
+    asm volatile("" ::: C4_HIDDEN_VGPRS);            // (so that the kernel's register count covers them)
+    // a tile's 32 values into C++ variables and back (generic row phases; two statements of 16 operands each: an asm takes at most 30)
+    auto acc_get16 = [&](const int h, const int i, f32x16& a) __attribute__((always_inline)) {      // (h, i: constants after inlining)
+        float t[16];
+        if (h == 0 && i == 0) asm volatile(C4_GET_X0 : C4_OUT16(t, 0));
+        else if (h == 0) asm volatile(C4_GET_X1 : C4_OUT16(t, 0));
+        else if (i == 0) asm volatile(C4_GET_Y0 : C4_OUT16(t, 0));
+        else asm volatile(C4_GET_Y1 : C4_OUT16(t, 0));
 #pragma unroll
-            for (int j = 0; j < 8; ++j) ad[j] = pb + (((unsigned)j * 32u) ^ axr);
-            half8 f00, f01, f02, f03, f10, f11, f12, f13;       // fragment buffers (asm temporaries)
-#define C4_KLOOP_OPERANDS                                                                                                       \
-            [a0] "=&v"(acc[0]), [a1] "=&v"(acc[1]), [f00] "=&v"(f00), [f01] "=&v"(f01), [f02] "=&v"(f02), [f03] "=&v"(f03),         \
-            [f10] "=&v"(f10), [f11] "=&v"(f11), [f12] "=&v"(f12), [f13] "=&v"(f13)                                              \
-            : [ad0] "v"(ad[0]), [ad1] "v"(ad[1]), [ad2] "v"(ad[2]), [ad3] "v"(ad[3]), [ad4] "v"(ad[4]), [ad5] "v"(ad[5]),       \
-              [ad6] "v"(ad[6]), [ad7] "v"(ad[7]), [wv] "v"(w_lane), [bh0] "s"(nh), [bh1] "s"(nh + 4096), [bh2] "s"(nh + 8192),  \
-              [bh3] "s"(nh + 12288), [bl0] "s"(nl), [bl1] "s"(nl + 4096), [bl2] "s"(nl + 8192), [bl3] "s"(nl + 12288)
-            if (nks == KS) {
-                if constexpr (ONE) asm volatile(C4_KLOOP1_LD : C4_KLOOP_OPERANDS : C4_KLOOP_AGPRS, "memory");
-                else asm volatile(C4_KLOOP3_LD : C4_KLOOP_OPERANDS : C4_KLOOP_AGPRS, "memory");
-            } else {
-                if constexpr (ONE) asm volatile(C4_KLOOP1_NL : C4_KLOOP_OPERANDS : "memory");
-                else asm volatile(C4_KLOOP3_NL : C4_KLOOP_OPERANDS : "memory");
-                C4_WLOAD_ALL(nks, nh, nl);          // (a narrower next step: its fragments in a bunch)
-            }
-#undef C4_KLOOP_OPERANDS
-        } else {
-            // ---- any other width / a continued accumulation: the plain form (the compiler places the LDS reads and their waits)
-            if (first) {
-#pragma unroll
-                for (int i = 0; i < NI; ++i)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
-            }
-            half8 ah[2][NI], al[2][NI];
-            auto load_a = [&](int ks, half8 (&qh)[NI], half8 (&ql)[NI]) {
-                ks = ks < ksteps ? ks : ksteps - 1;
-                const unsigned o = ab + (((unsigned)ks * 32u) ^ axr);
-#pragma unroll
-                for (int i = 0; i < NI; ++i) {
-                    qh[i] = *reinterpret_cast<const half8*>(planes + i * 32768 + o);
-                    if constexpr (!ONE) ql[i] = *reinterpret_cast<const half8*>(planes + i * 32768 + o + C4_LO);
-                }
-            };
-            if (live) load_a(0, ah[0], al[0]);
-            // six matrix instructions of a k-step: hi.lo, lo.hi, hi.hi for both row tiles (the order of chain.hip per accumulator);
-            // then the registers of the k-step take the next step's fragment
-#define C4_KSTEP(ks, q)                                                                                                         \
-            if (live && (ks) < ksteps) {                                                                                        \
-                load_a((ks) + 1, ah[((ks) + 1) & 1], al[((ks) + 1) & 1]);                                                       \
-                if constexpr (ONE)                                                                                              \
-                    asm volatile("v_mfma_f32_32x32x16_f16 %0, " C4_CAT(C4_WH, ks) ", %2, %0\n\tv_mfma_f32_32x32x16_f16 %1, " C4_CAT(C4_WH, ks) ", %3, %1" \
-                                 : "+v"(acc[0]), "+v"(acc[1]) : "v"(ah[(ks) & 1][0]), "v"(ah[(ks) & 1][1]));                    \
-                else                                                                                                            \
-                asm volatile("v_mfma_f32_32x32x16_f16 %0, " C4_CAT(C4_WH, ks) ", %4, %0\n\tv_mfma_f32_32x32x16_f16 %1, " C4_CAT(C4_WH, ks) ", %5, %1\n\t" \
-                             "v_mfma_f32_32x32x16_f16 %0, " C4_CAT(C4_WL, ks) ", %2, %0\n\tv_mfma_f32_32x32x16_f16 %1, " C4_CAT(C4_WL, ks) ", %3, %1\n\t" \
-                             "v_mfma_f32_32x32x16_f16 %0, " C4_CAT(C4_WH, ks) ", %2, %0\n\tv_mfma_f32_32x32x16_f16 %1, " C4_CAT(C4_WH, ks) ", %3, %1"       \
-                             : "+v"(acc[0]), "+v"(acc[1])                                                                       \
-                             : "v"(ah[(ks) & 1][0]), "v"(ah[(ks) & 1][1]), "v"(al[(ks) & 1][0]), "v"(al[(ks) & 1][1]));        \
-            }                                                                                                                   \
-            C4_WLOAD_IF(ks, q, nks, nh, nl)
-            asm volatile("s_nop 1" ::: "memory");   // (the zeroed accumulators: VALU write -> matrix read)
-            C4_KSTEP(0, 0); C4_KSTEP(1, 1); C4_KSTEP(2, 2); C4_KSTEP(3, 3); C4_KSTEP(4, 0); C4_KSTEP(5, 1); C4_KSTEP(6, 2); C4_KSTEP(7, 3);
-            C4_KSTEP(8, 0); C4_KSTEP(9, 1); C4_KSTEP(10, 2); C4_KSTEP(11, 3); C4_KSTEP(12, 0); C4_KSTEP(13, 1); C4_KSTEP(14, 2); C4_KSTEP(15, 3);
-#undef C4_KSTEP
-            // the last results leave the matrix pipe 16 passes after issue; hipcc does not count wait states behind inline asm
-            asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]));
-        }
+        for (int e = 0; e < 16; ++e) a[e] = t[e];
     };
+    auto acc_put16 = [&](const int h, const int i, const f32x16& a) __attribute__((always_inline)) {
+        float t[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) t[e] = a[e];
+        if (h == 0 && i == 0) asm volatile(C4_PUT_X0 : : C4_IN16(t, 0) : "memory");
+        else if (h == 0) asm volatile(C4_PUT_X1 : : C4_IN16(t, 0) : "memory");
+        else if (i == 0) asm volatile(C4_PUT_Y0 : : C4_IN16(t, 0) : "memory");
+        else asm volatile(C4_PUT_Y1 : : C4_IN16(t, 0) : "memory");
+    };
+
+    // ---- multiply the tile in `planes` by a step (chain4_krun.inc): k_run_X for tile X, k_run_Y for tile Y
+#define C4_KRUN_NAME k_run_X
+#define C4_KL(x) x##_X
+#define C4_A0 "v[64:79]"
+#define C4_A1 "v[80:95]"
+#define C4_ZERO C4_ZERO_X
+#include "chain4_krun.inc"
+#undef C4_ZERO
+#undef C4_KRUN_NAME
+#undef C4_KL
+#undef C4_A0
+#undef C4_A1
+#define C4_KRUN_NAME k_run_Y
+#define C4_KL(x) x##_Y
+#define C4_A0 "v[96:111]"
+#define C4_A1 "v[112:127]"
+#define C4_ZERO C4_ZERO_Y
+#include "chain4_krun.inc"
+#undef C4_ZERO
+#undef C4_KRUN_NAME
+#undef C4_KL
+#undef C4_A0
+#undef C4_A1
 
     // ---- split a row held across the wave (lane: 4 columns) into the A planes: block wn, row u (staging)
     auto write_planes = [&](char* planes, unsigned wp, unsigned wq, int u, const float4& v, float sc, bool in_k, _Float16* gdst = nullptr) __attribute__((always_inline)) {
@@ -362,6 +350,7 @@ __global__ __launch_bounds__(C4_THREADS, 2) void mlp_chain4_kernel(ChainArgs p, 
             const float* rowp = p.A0 + (long)m * p.lda0;  // wave-uniform: scalar base + one lane offset
             v[q] = c < p.K0 ? *reinterpret_cast<const float4*>(rowp + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        if (!again) { asm volatile("s_waitcnt vmcnt(0)" :: "v"(v[7].x) : "memory"); }
         if (again) {
             // (with in_norm_stats the first staging wrote the standardised rows back: these ARE the rows the first layer multiplied)
             const float4 i0 = *reinterpret_cast<const float4*>(inv_tab + wn * RB), i1 = *reinterpret_cast<const float4*>(inv_tab + wn * RB + 4);
@@ -419,7 +408,7 @@ __global__ __launch_bounds__(C4_THREADS, 2) void mlp_chain4_kernel(ChainArgs p, 
     // ---- P1: first half of the row phase of layer l for tile h at rows m0, on the accumulators: bias / activation (forward) or
     // 1 / scale and the activation derivative (data-gradient), row stores, sign word, partial row maxima (or LayerNorm partials).
     // The post-activation values stay in `a` for P2.
-    auto p1_run = [&](f32x16 (&a)[NI], int h, long m0, int l, unsigned sw_in) __attribute__((always_inline)) {
+    auto p1_run = [&](const int h, long m0, int l, unsigned sw_in) __attribute__((always_inline)) {
         l = __builtin_amdgcn_readfirstlane(l);
         const int M32 = (int)p.M;
         int t0 = __builtin_amdgcn_readfirstlane((int)m0);
@@ -456,6 +445,8 @@ __global__ __launch_bounds__(C4_THREADS, 2) void mlp_chain4_kernel(ChainArgs p, 
                 const int rt = 32 * i + arow, m = t0 + rt;
                 const bool in_m = f_full || m < M32;
                 const float inv = inv_tab[rt];
+                f32x16 ai;                            // (one 32-row tile's values at a time: the compiler has 64 registers)
+                acc_get16(h, i, ai);
                 float lmax = 0.f;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -468,13 +459,13 @@ __global__ __launch_bounds__(C4_THREADS, 2) void mlp_chain4_kernel(ChainArgs p, 
                         const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
-                            const float pre = __builtin_fmaf(a[i][4 * g + c], inv, bb[c]);
+                            const float pre = __builtin_fmaf(ai[4 * g + c], inv, bb[c]);
                             y[c] = f_relu ? fmaxf(pre, 0.f) : fmaxf(pre, __builtin_fmaf(pre, slope, 0.f));
                         }
                     } else {
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
-                            const float gv = a[i][4 * g + c] * inv;
+                            const float gv = ai[4 * g + c] * inv;
                             if (f_bits) {
                                 const int bit = (int)(word << (16 * i + 4 * g + c));     // (bit 31 - n of the word = value n, first value in the top bit)
                                 if (f_relu) y[c] = __uint_as_float(__float_as_uint(gv) & (unsigned)(bit >> 31));
@@ -494,7 +485,7 @@ __global__ __launch_bounds__(C4_THREADS, 2) void mlp_chain4_kernel(ChainArgs p, 
 #endif
                     lmax = fmaxf(fmaxf(lmax, fabsf(y[0])), fmaxf(fabsf(y[1]), fmaxf(fabsf(y[2]), fabsf(y[3]))));
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) a[i][4 * g + c] = y[c];
+                    for (int c = 0; c < 4; ++c) ai[4 * g + c] = y[c];
                 }
                 if (!rt_norm) {
                     lmax = pair_max(lmax);
@@ -504,17 +495,18 @@ __global__ __launch_bounds__(C4_THREADS, 2) void mlp_chain4_kernel(ChainArgs p, 
                     // sums in a fixed order; P2 combines the waves
                     float s = 0.f;
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) s += (a[i][4 * g] + a[i][4 * g + 1]) + (a[i][4 * g + 2] + a[i][4 * g + 3]);
+                    for (int g = 0; g < 4; ++g) s += (ai[4 * g] + ai[4 * g + 1]) + (ai[4 * g + 2] + ai[4 * g + 3]);
                     const float mean_w = pair_sum(s) * (1.f / 32.f);
                     float q = 0.f;
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const float d0 = a[i][4 * g] - mean_w, d1 = a[i][4 * g + 1] - mean_w, d2 = a[i][4 * g + 2] - mean_w, d3 = a[i][4 * g + 3] - mean_w;
+                        const float d0 = ai[4 * g] - mean_w, d1 = ai[4 * g + 1] - mean_w, d2 = ai[4 * g + 2] - mean_w, d3 = ai[4 * g + 3] - mean_w;
                         q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
                     }
                     q = pair_sum(q);
                     if (hh == 0) nrm_all[(h * GW + wn) * C4_ROWS + rt] = make_float2(mean_w, q);
                 }
+                acc_put16(h, i, ai);
             }
             if (!DGRAD && f_bits && (f_full || t0 < M32)) L.sign_bits[(long)(t0 / C4_ROWS) * (GW * 64) + wn * 64 + lane] = word;
         };
@@ -545,7 +537,7 @@ __global__ __launch_bounds__(C4_THREADS, 2) void mlp_chain4_kernel(ChainArgs p, 
     // ---- P2: second half of the row phase (a slot later, behind the barrier): row maximum from the eight partial maxima, scale,
     // split of the values still in `a` into the tile's planes = the next layer's input; or the LayerNorm core's second half.
     // xmax: the next layer is a skip layer -- the scale must cover the run's input rows as well (their maxima: xmax_tab)
-    auto p2_run = [&](f32x16 (&a)[NI], int h, long m0, int l) __attribute__((always_inline)) {
+    auto p2_run = [&](const int h, long m0, int l) __attribute__((always_inline)) {
         l = __builtin_amdgcn_readfirstlane(l);
         const int M32 = (int)p.M;
         int t0 = __builtin_amdgcn_readfirstlane((int)m0);
@@ -580,11 +572,13 @@ __global__ __launch_bounds__(C4_THREADS, 2) void mlp_chain4_kernel(ChainArgs p, 
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 const int rt = 32 * i + arow;
+                f32x16 ai;
+                acc_get16(h, i, ai);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     char* dst = more ? planes + (rt >> 3) * C4_BLK_BYTES + (rt & 7) * 512 + hh * C4_LO + ((((unsigned)(4 * wn + g)) ^ (unsigned)(rt & 15)) * 16)
                                      : planes + wn * C4_BLK_BYTES + rt * 128 + ((((unsigned)(4 * hh + g)) ^ (unsigned)(rt & 7)) * 16);
-                    *reinterpret_cast<float4*>(dst) = make_float4(a[i][4 * g], a[i][4 * g + 1], a[i][4 * g + 2], a[i][4 * g + 3]);
+                    *reinterpret_cast<float4*>(dst) = make_float4(ai[4 * g], ai[4 * g + 1], ai[4 * g + 2], ai[4 * g + 3]);
                 }
             }
             const int q = lane >> 3, pc = lane & 7;     // store instruction s: row slot q, 16-byte piece pc of the row's 128 bytes
@@ -614,14 +608,16 @@ __global__ __launch_bounds__(C4_THREADS, 2) void mlp_chain4_kernel(ChainArgs p, 
                 m2 += 32.f * dm;
                 const float sigma = sqrtf(m2 / (float)(N - 1));
                 const float rinv = 1.0f / (sigma + p.norm_eps);
-                if (live && m < M32 && L.C != nullptr) {     // (direct stores: one layer per run, and a third copy of the staged path costs the kernel its registers)
+                if (live) {                           // the standardised values replace the tile's accumulators; store_rows takes them from there
+                    f32x16 ai;
+                    acc_get16(h, i, ai);
 #pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        *reinterpret_cast<float4*>(L.C + (long)m * L.ldc + cb + 4 * g) =
-                            make_float4((a[i][4 * g] - mean) * rinv, (a[i][4 * g + 1] - mean) * rinv, (a[i][4 * g + 2] - mean) * rinv, (a[i][4 * g + 3] - mean) * rinv);
+                    for (int e = 0; e < 16; ++e) ai[e] = (ai[e] - mean) * rinv;
+                    acc_put16(h, i, ai);
                 }
                 if (wn == 0 && hh == 0 && m < M32) { p.norm_stats[(long)m * 2] = rinv; p.norm_stats[(long)m * 2 + 1] = sigma; }
             }
+            if (L.C != nullptr) store_rows(false);      // (whole cache lines through the wave's block of the dead planes: last layer of the run)
             return;
         }
         auto rows = [&](auto cfg) {
@@ -641,6 +637,8 @@ __global__ __launch_bounds__(C4_THREADS, 2) void mlp_chain4_kernel(ChainArgs p, 
                                  fmaxf(fmaxf(pm[4 * C4_ROWS + rt], pm[5 * C4_ROWS + rt]), fmaxf(pm[6 * C4_ROWS + rt], pm[7 * C4_ROWS + rt])));
                 if (f_rmax && wn == 0 && hh == 0 && in_m) L.rowmax[m] = mx;
                 if (f_more) {
+                    f32x16 ai;
+                    acc_get16(h, i, ai);
                     if (Cfg::full != 1 && skip_next) mx = fmaxf(mx, xmax_all[h * C4_ROWS + rt]);
                     float inv;
                     const float sc = scale_from_max(__float_as_uint(mx), inv);
@@ -650,8 +648,8 @@ __global__ __launch_bounds__(C4_THREADS, 2) void mlp_chain4_kernel(ChainArgs p, 
                         const unsigned x = (unsigned)(rt & 15);
 #pragma unroll
                         for (int q = 0; q < 2; ++q) {           // the lane's two 16-byte chunks of the row
-                            const float4 v0 = make_float4(a[i][8 * q], a[i][8 * q + 1], a[i][8 * q + 2], a[i][8 * q + 3]);
-                            const float4 v1 = make_float4(a[i][8 * q + 4], a[i][8 * q + 5], a[i][8 * q + 6], a[i][8 * q + 7]);
+                            const float4 v0 = make_float4(ai[8 * q], ai[8 * q + 1], ai[8 * q + 2], ai[8 * q + 3]);
+                            const float4 v1 = make_float4(ai[8 * q + 4], ai[8 * q + 5], ai[8 * q + 6], ai[8 * q + 7]);
                             char* const dst = row + ((((unsigned)(cb >> 3) + q) ^ x) * 16);
                             if constexpr (ONE) {
                                 unsigned h0, h1, h2, h3;
@@ -711,15 +709,77 @@ __global__ __launch_bounds__(C4_THREADS, 2) void mlp_chain4_kernel(ChainArgs p, 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the first step's fragments
     lds_barrier();                                  // planes of the first X, the bias table
 
-    f32x16 accX[NI], accY[NI];
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) { accX[i][e] = 0.f; accY[i][e] = 0.f; }
 
-    // slot (h, si) of pair `it`: multiply tile h by step si [+ P1 of its layer]; what the OTHER tile still owes from the slot before
-    // (P2 of the layer it finished, the next tile's staging, or the re-staging of a skip layer's second segment)
-    auto slot = [&](f32x16 (&aT)[NI], f32x16 (&aU)[NI], const int h, int si, int it, long pr) __attribute__((always_inline)) {
+
+    // ---- the hot slot as ONE statement (chain4_fused.inc, generated by scripts/gen_chain4_fused.py -- the why and the how are there):
+    // the k-loop of tile T (step st: 16 k-steps from zero), P1 | s_barrier | P2 of tile U's layer pl, on the accumulators where they live
+    // (tile X = v[64:95], tile Y = v[96:127]): one flavour per tile.
+    // mode: 0 training forward, 1 inference, 2 data-gradient.
+#define C4F_INPUTS                                                                                                              \
+        [pbx] "v"(pbx), [wv] "v"(wv), [invad] "v"(invad), [biasad] "v"(biasad), [pmw] "v"(pmw), [pmr] "v"(pmr), [stw] "v"(stw),    \
+        [rdb] "v"(rdb), [gso] "v"(gso), [plw] "v"(plw), [sgn] "s"(sgn), [rmp] "s"(rmp), [crow0] "s"(crow0), [crow1] "s"(crow1),  \
+        [slope] "s"(slope), [c254] "s"(254), [pfb] "s"(pfb), [pfs] "s"(pfs)
+#define C4F_LD_INPUTS , [nhlo] "s"(nhlo), [nhhi] "s"(nhhi), [nllo] "s"(nllo), [nlhi] "s"(nlhi)
+#define C4F_RUN(NAME)                                                                                                           \
+        do {                                                                                                                    \
+            if (kc == 8) asm volatile(NAME##_Y_LD_K8 : [word] "+v"(word) : C4F_INPUTS C4F_LD_INPUTS : C4F_CLOBBERS, C4F_LD_CLOBBERS, C4F_AGPRS);   \
+            else if (kc == 10) asm volatile(NAME##_Y_LD_K10 : [word] "+v"(word) : C4F_INPUTS C4F_LD_INPUTS : C4F_CLOBBERS, C4F_LD_CLOBBERS, C4F_AGPRS);   \
+            else if (h == 0) asm volatile(NAME##_X_NL : [word] "+v"(word) : C4F_INPUTS : C4F_CLOBBERS);                         \
+            else if (ld) asm volatile(NAME##_Y_LD : [word] "+v"(word) : C4F_INPUTS C4F_LD_INPUTS : C4F_CLOBBERS, C4F_LD_CLOBBERS, C4F_AGPRS);  \
+            else asm volatile(NAME##_Y_NL : [word] "+v"(word) : C4F_INPUTS : C4F_CLOBBERS);                                     \
+        } while (0)
+    auto fused_slot = [&](const int h, const int kc, C4Step sn, bool refill, long pm0, int pl, unsigned& swU, int mode, long pf_m0) __attribute__((always_inline)) {
+        C4_LANE();
+        pl = __builtin_amdgcn_readfirstlane(pl);
+        const ChainLayer& LP = p.L[pl];
+        const int t0 = __builtin_amdgcn_readfirstlane((int)pm0);
+        const unsigned planesT = (unsigned)(size_t)(smem + h * C4_TILE_BYTES), planesU = (unsigned)(size_t)(smem + (1 - h) * C4_TILE_BYTES);
+        const int arow = lane & 31, hh = lane >> 5, ax = arow & 15, q = lane >> 3, pc = lane & 7;
+        const unsigned rowoff = (unsigned)((arow >> 3) * C4_BLK_BYTES + (arow & 7) * 512);
+        const unsigned pbx = (planesT + rowoff + (unsigned)((hh ^ (ax & 1)) * 16)) ^ (unsigned)((ax & ~1) * 16);
+        const unsigned wv = (unsigned)lane * 16u;
+        const unsigned invbase = (unsigned)(size_t)(inv_all + (1 - h) * C4_ROWS);
+        const unsigned invad = invbase + (unsigned)arow * 4u;
+        const unsigned biasad = (unsigned)(size_t)(bias_all + pl * 256 + 32 * wn + 16 * hh);
+        const unsigned pmr = (unsigned)(size_t)(pmax_all + (1 - h) * GW * C4_ROWS) + (unsigned)arow * 4u, pmw = pmr + (unsigned)wn * 256u;
+        const unsigned stw = planesU + rowoff + (unsigned)hh * C4_LO + (((unsigned)(4 * wn) ^ (unsigned)ax) << 4);
+        const unsigned rdb = planesU + (unsigned)((((q >> 1) & 1) + 2 * (q >> 2)) * C4_BLK_BYTES + (q & 1) * 2048 + (pc >> 2) * C4_LO) +
+                             ((unsigned)(4 * (wn ^ (q & 3)) + (pc & 3)) << 4);
+        const unsigned gso = (unsigned)((4 * (q & 3) + 16 * (q >> 2)) * 1024 + wn * 128 + pc * 16);
+        const unsigned plw = planesU + rowoff + (((unsigned)(4 * wn + 2 * hh) ^ (unsigned)ax) << 4);
+        const char* sgn = reinterpret_cast<const char*>(LP.sign_bits + (long)(t0 / C4_ROWS) * (GW * 64) + wn * 64);
+        const char* rmp = reinterpret_cast<const char*>(LP.rowmax + t0) - invbase;      // (the store's lane offset is the 1 / scale table's LDS address)
+        const char* crow0 = reinterpret_cast<const char*>(LP.C + (long)t0 * 256);
+        const char* crow1 = crow0 + 32768;
+        const float slope = LP.act == PAPR_ACT_LEAKY_RELU ? 0.2f : 0.f;
+        const bool relu = LP.act == PAPR_ACT_RELU;
+        const ChainLayer& Ln = p.L[sn.layer];
+        const char *nh = frag_base(Ln, Ln.w_hi, sn.kbeg), *nl = frag_base(Ln, Ln.w_lo, sn.kbeg);
+        const unsigned nhlo = (unsigned)(size_t)nh, nhhi = (unsigned)((size_t)nh >> 32), nllo = (unsigned)(size_t)nl, nlhi = (unsigned)((size_t)nl >> 32);
+        const bool ld = refill && sn.kcnt == KS;
+        // prefetch (see the generator): this wave's eight input rows of the tile at pf_m0, or nothing (pf_m0 < 0)
+        const char* pfb = reinterpret_cast<const char*>(p.A0 + (pf_m0 >= 0 ? pf_m0 + wn * RB : 0) * p.lda0);
+        const unsigned pfs = pf_m0 >= 0 ? (unsigned)p.lda0 * 4u : 0u;
+        unsigned word = swU;
+        // this step's fragments have landed: requested behind tile Y's k-loop of the step before, so tile X waits here -- and tile Y,
+        // a slot later, finds them waited for (a wait there would only wait for tile X's row stores: loads and stores share the counter)
+        if (h == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (DGRAD) {
+            if (relu) C4F_RUN(C4F_DGRAD_RELU); else C4F_RUN(C4F_DGRAD_LEAKY);
+        } else if (mode == 0) {
+            if (relu) C4F_RUN(C4F_FWD_RELU); else C4F_RUN(C4F_FWD_LEAKY);
+        } else {
+            if (relu) C4F_RUN(C4F_INF_RELU); else C4F_RUN(C4F_INF_LEAKY);
+        }
+        if (refill && !ld) { const int nks = sn.kcnt; const unsigned w_lane = wv; C4_WLOAD_ALL(nks, nh, nl); }     // (a narrower next step: its fragments in a bunch)
+    };
+
+    // slot (h, si) of pair `it`, tile T = h:   P1 of the OTHER tile U (the layer it finished multiplying a slot ago)  |  barrier  |
+    // multiply T by step si  ||  P2 of U (or the next tile's staging, or the re-staging of a skip layer's second segment)  |  barrier.
+    // Both halves of U's row phase sit a slot behind its k-loop, so that they can share the slot with T's matrix instructions: in the hot
+    // slots as ONE interleaved statement (fused_slot), elsewhere with the waves in two roles (waves 0-3 multiply first, waves 4-7 last).
+    unsigned swX = 0u, swY = 0u;                    // data-gradient: the sign word of the tile's pending P1, requested a slot ahead
+    auto slot = [&](unsigned& swT, unsigned& swU, const int h, int si, int it, long pr) __attribute__((always_inline)) {
         const long mX = 2 * pr * C4_ROWS, mY = mX + C4_ROWS;
         const long mT = h == 0 ? mX : mY;
         char* const planesT = smem + h * C4_TILE_BYTES;
@@ -736,31 +796,62 @@ __global__ __launch_bounds__(C4_THREADS, 2) void mlp_chain4_kernel(ChainArgs p, 
         if (h == 0 && si == 0) sm0 = mY;
         if (h == 1 && si + 1 == n_steps && it + 1 < iters) sm0 = mX + 2 * pstride * C4_ROWS;
         const C4Step sn = plan_step(si + 1 < n_steps ? si + 1 : 0);
-        unsigned sw = 0u;
-        if (DGRAD && (st.flags & C4_LAST) && p.L[st.layer].sign_bits != nullptr && mT < p.M)
-            sw = p.L[st.layer].sign_bits[(long)(mT / C4_ROWS) * (GW * 64) + wn * 64 + lane0];
+        const C4Step sp = plan_step(psi >= 0 ? psi : 0);
+        const bool p_rows = psi >= 0 && (sp.flags & C4_LAST) != 0;     // U owes a row phase
+        if (DGRAD) {                                // T's sign word for the next slot
+            swT = 0u;
+            if ((st.flags & C4_LAST) && p.L[st.layer].sign_bits != nullptr && mT < p.M)
+                swT = p.L[st.layer].sign_bits[(long)(mT / C4_ROWS) * (GW * 64) + wn * 64 + lane0];
+        }
+        // is this a hot slot?  T: a whole 256 x 256 step from zero; U: a middle layer (256 wide, a following layer that is no skip layer),
+        // its tile inside M, one of the three hot flag sets, rows of 256 floats; nothing to stage
+        int fmode = -1;
+        // (a short first layer -- 8 or 10 k-steps -- has fused forms for tile Y with the next step's 16 k-steps of fragments to request)
+        const bool k_hot = st.kcnt == KS || (h == 1 && (st.kcnt == 8 || st.kcnt == 10) && sn.kcnt == KS);
+        if (!ONE && fused_on && !generic_only && p_rows && sm0 < 0 && k_hot && (st.flags & C4_FIRST) && (st.flags & C4_LAST) && p.L[st.layer].N == 256) {
+            const ChainLayer& LP = p.L[sp.layer];
+            const bool mid = LP.N == 256 && sp.layer + 1 < n_layers && p.L[sp.layer + 1].k1steps == p.L[sp.layer + 1].ksteps && pm0 + C4_ROWS <= p.M;
+            const bool st_ = LP.C != nullptr, bi = LP.sign_bits != nullptr, rm = LP.rowmax != nullptr;
+            const bool act_ok = LP.act == PAPR_ACT_RELU || LP.act == PAPR_ACT_LEAKY_RELU;
+            if (mid && act_ok && st_ && bi && rm && LP.ldc == 256 && !LP.c_half) fmode = DGRAD ? 2 : 0;
+            else if (mid && act_ok && !DGRAD && !st_ && !bi && !rm) fmode = 1;
+        }
+        if (fmode >= 0) {
+            C4_STAMP();
+            // (the next pair's tile: staged two to four slots from now; a lane reads 16 bytes at 16 lane of each row, so the whole
+            // kilobyte behind a row's start must lie inside the array: one more tile of margin)
+            // (measured: the block costs its slot 3-4k cycles and the staging slots two to four slots later were not shorter for it -- they
+            // are bound by their own 600 instructions without matrix work beside them, not by the rows' arrival.  PAPR_C4_PREFETCH=1 to try.)
+            long pf_m0 = -1;
+            if (prefetch_on && si + 2 == n_steps && it + 1 < iters && mT + 2 * pstride * C4_ROWS + 3 * C4_ROWS <= p.M) pf_m0 = mT + 2 * pstride * C4_ROWS;
+            fused_slot(h, st.kcnt, sn, h == 1, pm0, sp.layer, swU, fmode, pf_m0);
+            C4_STAMP(); C4_STAMP(); C4_STAMP(); C4_STAMP(); C4_STAMP2(); C4_STAMP2();
+            lds_barrier();
+            return;
+        }
+        C4_STAMP();                                 // five stamps per slot: start | P1 done | barrier passed | first piece done | second piece done | (next start = barrier passed)
+#ifndef C4_X_NOP1
+        if (p_rows) p1_run(1 - h, pm0, sp.layer, swU);
+#endif
+        C4_STAMP();
+        if (p_rows) lds_barrier();                  // every wave's partial maxima of U are in LDS
+        C4_STAMP();
         auto pending = [&]() __attribute__((always_inline)) {
-            // the next k-loop's weight fragments (requested behind the last k-loop of tile Y, at least one P1 ago) have landed: waited for
-            // HERE, in front of this wave's row stores -- at the top of the k-loop the same wait sat behind them (1044 -> us per 4-layer run)
+            // the k-loop's weight fragments (requested behind the last k-loop of tile Y) have landed: waited for HERE, in front of this
+            // wave's row stores -- loads and stores share the counter
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (psi >= 0) {
-                const C4Step sp = plan_step(psi);
-                if (sp.flags & C4_LAST) p2_run(aU, 1 - h, pm0, sp.layer);
-                else { const C4Step sq = plan_step(psi + 1); stage(planesU, invU, xmaxU, pm0, true, sq.kcnt * 16); }
-            }
+            if (p_rows) p2_run(1 - h, pm0, sp.layer);
+            C4_STAMP2();
+            if (!p_rows && psi >= 0) { const C4Step sq = plan_step(psi + 1); stage(planesU, invU, xmaxU, pm0, true, sq.kcnt * 16); }
             if (sm0 >= 0) stage(planesU, invU, xmaxU, sm0, false, kpad0);
+            C4_STAMP2();
         };
-        C4_STAMP();                                 // five stamps per slot: start | rows-first P2 done | K done | P1 done | k-first P2 done | (next start = barrier passed)
 #ifndef C4_X_NOP2
         if (!k_first) pending();
 #endif
-        C4_STAMP();
 #ifndef C4_X_NOK
-        k_run(planesT, st, h == 1, sn, aT);
-#endif
-        C4_STAMP();
-#ifndef C4_X_NOP1
-        if (st.flags & C4_LAST) p1_run(aT, h, mT, st.layer, sw);
+        if (k_first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (h == 0) k_run_X(planesT, st, false, sn); else k_run_Y(planesT, st, true, sn);
 #endif
         C4_STAMP();
 #ifndef C4_X_NOP2
@@ -773,13 +864,19 @@ __global__ __launch_bounds__(C4_THREADS, 2) void mlp_chain4_kernel(ChainArgs p, 
     for (int it = 0; it < iters; ++it) {
 #pragma unroll 1
         for (int si = 0; si < n_steps; ++si) {
-            slot(accX, accY, 0, si, it, pair);
-            slot(accY, accX, 1, si, it, pair);
+            slot(swX, swY, 0, si, it, pair);
+            slot(swY, swX, 1, si, it, pair);
         }
         pair += pstride;
     }
-    // the last Y of this workgroup still owes the second half of its last layer's row phase
-    p2_run(accY, 1, 2 * (pair - pstride) * C4_ROWS + C4_ROWS, plan_step(n_steps - 1).layer);
+    // the last Y of this workgroup still owes its last layer's row phase
+    {
+        const long mYl = 2 * (pair - pstride) * C4_ROWS + C4_ROWS;
+        const int ll = plan_step(n_steps - 1).layer;
+        p1_run(1, mYl, ll, swY);
+        lds_barrier();
+        p2_run(1, mYl, ll);
+    }
 }
 
 }  // namespace
@@ -826,12 +923,14 @@ int papr_launch_chain4(const ChainArgs& a, bool dgrad, long long bytes, long lon
     const bool prof = papr_prof_on();
     if (prof) papr_prof_begin2(dgrad ? 10 : 9, a.M, a.n_layers, a.K0, bytes, flops, s);
     static const int generic_only = getenv("PAPR_C4_GENERIC") ? atoi(getenv("PAPR_C4_GENERIC")) : 0;      // (test switch: the hot instantiations off)
+    static const int fused_on = getenv("PAPR_C4_FUSED") ? atoi(getenv("PAPR_C4_FUSED")) : 1;            // (A/B switch: 0 = the two-role slots everywhere)
+    static const int prefetch_on = getenv("PAPR_C4_PREFETCH") ? atoi(getenv("PAPR_C4_PREFETCH")) : 0;   // (A/B switch: the next pair's input rows pulled towards the caches from inside a fused slot)
     if (a.one_product) {
-        if (dgrad) mlp_chain4_kernel<true, true><<<dim3(grid), dim3(C4_THREADS), C4_LDS_BYTES, s>>>(a, plan, iters, generic_only);
-        else mlp_chain4_kernel<false, true><<<dim3(grid), dim3(C4_THREADS), C4_LDS_BYTES, s>>>(a, plan, iters, generic_only);
+        if (dgrad) mlp_chain4_kernel<true, true><<<dim3(grid), dim3(C4_THREADS), C4_LDS_BYTES, s>>>(a, plan, iters, generic_only, fused_on, prefetch_on);
+        else mlp_chain4_kernel<false, true><<<dim3(grid), dim3(C4_THREADS), C4_LDS_BYTES, s>>>(a, plan, iters, generic_only, fused_on, prefetch_on);
     } else {
-        if (dgrad) mlp_chain4_kernel<true, false><<<dim3(grid), dim3(C4_THREADS), C4_LDS_BYTES, s>>>(a, plan, iters, generic_only);
-        else mlp_chain4_kernel<false, false><<<dim3(grid), dim3(C4_THREADS), C4_LDS_BYTES, s>>>(a, plan, iters, generic_only);
+        if (dgrad) mlp_chain4_kernel<true, false><<<dim3(grid), dim3(C4_THREADS), C4_LDS_BYTES, s>>>(a, plan, iters, generic_only, fused_on, prefetch_on);
+        else mlp_chain4_kernel<false, false><<<dim3(grid), dim3(C4_THREADS), C4_LDS_BYTES, s>>>(a, plan, iters, generic_only, fused_on, prefetch_on);
     }
     if (prof) papr_prof_end(s);
     PAPR_CHECK_LAUNCH("mlp_chain4");

@@ -1,0 +1,333 @@
+#!/usr/bin/env python3
+"""Generates papr_amd/csrc/chain4_fused.inc: the hot SLOT of chain4.hip as ONE inline-asm statement per variant -- the k-loop of
+tile T and BOTH halves of the row phase of the other tile U (P1 | s_barrier | P2), three instruction streams interleaved.
+
+Why: the two-role slots of chain4.hip (waves 0-3 multiply while waves 4-7 do row phases, then swap) cost 10k (inference) to
+13.5k (training) cycles per slot for 6.1k of matrix-pipe time (scripts/probes/chain4_trace.py): a wave's own k-loop (4k), P1 (2k)
+and P2 (2.5-5k) add up, and one SIMD issues about one instruction per four cycles whoever it belongs to.  A wave gets under its own
+sum only by issuing its vector / LDS / store instructions in the shadow of its own matrix instructions: behind every MFMA (32
+cycles of pipe, 64 with the SIMD partner's in between) come the k-loop's memory instruction and three or four instructions of
+the row phase.
+
+Streams (the arithmetic of chain4.hip's C++ row phases instruction for instruction: results are bit-identical, tests/test_hip_chain_variants.py)
+  K    sixteen k-steps of six MFMAs (hi.lo, lo.hi, hi.hi for two 32-row tiles, chain.hip's order per accumulator); A fragments in ONE
+       buffer, each register re-read for the next k-step right behind its last use; weights in a[0:127], refilled with the next
+       step's behind their last use (LD variants).
+  P1   on U's accumulators (still raw from the slot before): 1/scale and bias, activation, sign word (forward) or 1/scale and the
+       activation derivative from the sign word (data-gradient); partial row maxima -> LDS.
+  ---- s_barrier (every wave's partial maxima are in LDS)
+  P2   row maximum, power-of-two scale, 1/scale table; the rows through the wave's own piece of the dead planes to memory, whole
+       cache lines per instruction; split into hi / lo planes = the next layer's input.
+All LDS traffic goes through one in-order queue; every wait is computed by simulating that queue.
+
+Registers.  The accumulators live in v64-v127 outside the compiler's allocation (chain4.hip: tile X in v[64:95], tile Y in v[96:127]);
+the statement names them -- hence an X and a Y flavour of every variant.  Temporaries live in fixed registers named as clobbers
+(v28-v63); everything else that crosses the statement is an operand.
+
+  python scripts/gen_chain4_fused.py > papr_amd/csrc/chain4_fused.inc
+"""
+
+F = {"l0": "v[28:31]", "l1": "v[32:35]", "h0": "v[36:39]", "h1": "v[40:43]"}
+KA = "v44"                                      # k-loop address temporary
+AD, AD2 = "v45", "v46"                          # row-phase address temporaries
+G = ["v%d" % i for i in range(48, 64)]          # general temporaries (tuples start at even registers: gfx950 wants 64-bit alignment)
+GB = 48
+CLOB_V = ["v%d" % i for i in range(24, 64)]     # (the compiler has v0-v63: 40 temporaries + the statement's operands leave it ~12 across the statement)
+PFD = "v[24:27]"                                # where the prefetch loads land (never read)
+ACC = {"X": 64, "Y": 96}                        # the accumulators' registers (chain4.hip: REGISTERS)
+SNH, SNL = "s[90:91]", "s[92:93]"              # LD variants: running bases of the next step's hi / lo fragments (clobbers)
+
+
+def wh(ks): return "a[%d:%d]" % (8 * ks, 8 * ks + 3)
+def wl(ks): return "a[%d:%d]" % (8 * ks + 4, 8 * ks + 7)
+def vt(lo, n): return "v[%d:%d]" % (lo, lo + n - 1)
+
+
+class Item:
+    __slots__ = ("text", "lds", "need", "kind")
+
+    def __init__(self, text, lds=None, need=(), kind="valu"):
+        self.text, self.lds, self.need, self.kind = text, lds, tuple(need), kind
+
+
+def k_stream(acc_t, ld, kcnt=16):
+    """list of (mfma Item, [Items issued behind it]); acc_t = first register of T's accumulators"""
+    a0, a1 = vt(acc_t, 16), vt(acc_t + 16, 16)
+    off = {"l0": 4096, "l1": 36864, "h0": 0, "h1": 32768}
+
+    def rd(kind, ks):
+        return Item("ds_read_b128 %s, %s offset:%d" % (F[kind], KA if ks & 7 else "%[pbx]", off[kind] + (256 if ks >= 8 else 0)), lds=("f", kind, ks), kind="lds")
+
+    def addr(ks):
+        return [Item("v_xor_b32 %s, 0x%x, %%[pbx]" % (KA, 32 * (ks & 7)))] if ks & 7 else []
+
+    pro = [rd("l0", 0), rd("l1", 0), rd("h0", 0), rd("h1", 0)]
+    if ld:                                      # working copies of the next step's fragment bases (an asm operand has no sub-register syntax)
+        pro += [Item("s_mov_b32 s90, %[nhlo]", kind="salu"), Item("s_mov_b32 s91, %[nhhi]", kind="salu"),
+                Item("s_mov_b32 s92, %[nllo]", kind="salu"), Item("s_mov_b32 s93, %[nlhi]", kind="salu")]
+        if kcnt < 16:
+            # a short first layer (kcnt k-steps): the registers of the other k-steps are free from the start -- the next step's fragments for
+            # them are requested right here, from a second pair of running bases (s[94:97])
+            g0 = (kcnt >> 2) * 4096
+            pro += [Item("s_add_u32 s94, s90, 0x%x" % g0, kind="salu"), Item("s_addc_u32 s95, s91, 0", kind="salu"),
+                    Item("s_add_u32 s96, s92, 0x%x" % g0, kind="salu"), Item("s_addc_u32 s97, s93, 0", kind="salu")]
+            for ks in range(kcnt, 16):
+                pro.append(Item("global_load_dwordx4 %s, %%[wv], s[94:95] offset:%d" % (wh(ks), (ks & 3) * 1024), kind="vmem"))
+                pro.append(Item("global_load_dwordx4 %s, %%[wv], s[96:97] offset:%d" % (wl(ks), (ks & 3) * 1024), kind="vmem"))
+                if ks & 3 == 3 and ks < 15:
+                    pro += [Item("s_add_u32 s94, s94, 0x1000", kind="salu"), Item("s_addc_u32 s95, s95, 0", kind="salu"),
+                            Item("s_add_u32 s96, s96, 0x1000", kind="salu"), Item("s_addc_u32 s97, s97, 0", kind="salu")]
+    steps = []
+    for ks in range(kcnt):
+        nx = ks + 1 if ks < kcnt - 1 else None
+        first = ks == 0
+
+        def mf(acc, w, kind, init=False):
+            return Item("v_mfma_f32_32x32x16_f16 %s, %s, %s, %s" % (acc, w, F[kind], "0" if init else acc), need=[("f", kind, ks)], kind="mfma")
+        g = []
+        g.append((mf(a0, wh(ks), "l0", first), (addr(nx) + [rd("l0", nx)]) if nx is not None else []))
+        g.append((mf(a1, wh(ks), "l1", first), [rd("l1", nx)] if nx is not None else []))
+        g.append((mf(a0, wl(ks), "h0"), []))
+        post = []
+        if ld:
+            post.append(Item("global_load_dwordx4 %s, %%[wv], %s offset:%d" % (wl(ks), SNL, (ks & 3) * 1024), kind="vmem"))
+        g.append((mf(a1, wl(ks), "h1"), post))
+        g.append((mf(a0, wh(ks), "h0"), [rd("h0", nx)] if nx is not None else []))
+        post = [rd("h1", nx)] if nx is not None else []
+        if ld:
+            post.append(Item("global_load_dwordx4 %s, %%[wv], %s offset:%d" % (wh(ks), SNH, (ks & 3) * 1024), kind="vmem"))
+            if ks & 3 == 3 and ks < kcnt - 1:   # the bases move on by four k-steps
+                post += [Item("s_add_u32 s90, s90, 0x1000", kind="salu"), Item("s_addc_u32 s91, s91, 0", kind="salu"),
+                         Item("s_add_u32 s92, s92, 0x1000", kind="salu"), Item("s_addc_u32 s93, s93, 0", kind="salu")]
+        g.append((mf(a1, wh(ks), "h1"), post))
+        steps += g
+    return pro, steps
+
+
+def p1_stream(acc_u, mode, act):
+    """P1 on U's accumulators (first register acc_u).  mode: fwd (training forward), inf, dgrad; act: relu, leaky"""
+    it = []
+    B = G[0:8]
+    INV = [G[8], G[9]]
+    LM = [G[10], G[11]]
+    SWP, W, T1, T2 = G[12], [G[13], G[14]], G[15], G[13]       # (T2: data-gradient only, where no sign word is formed)
+    it.append(Item("ds_read_b32 %s, %%[invad]" % INV[0], lds=("inv", 0), kind="lds"))
+    it.append(Item("ds_read_b32 %s, %%[invad] offset:128" % INV[1], lds=("inv", 1), kind="lds"))
+    if mode == "fwd":
+        it += [Item("v_mov_b32 %s, 0" % W[0]), Item("v_mov_b32 %s, 0" % W[1])]
+    for gp in range(2):
+        if mode != "dgrad":
+            for j in range(2):
+                it.append(Item("ds_read_b128 %s, %%[biasad] offset:%d" % (vt(GB + 4 * j, 4), 32 * gp + 16 * j), lds=("b", gp, j), kind="lds"))
+        for i in range(2):
+            for gg in range(2):
+                g = 2 * gp + gg
+                regs = ["v%d" % (acc_u + 16 * i + 4 * g + c) for c in range(4)]
+                for c in range(4):
+                    a, n = regs[c], 16 * i + 4 * g + c
+                    if mode != "dgrad":
+                        it.append(Item("v_fma_f32 %s, %s, %s, %s" % (a, a, INV[i], B[4 * gg + c]), need=[("inv", i), ("b", gp, gg)]))
+                        if act == "relu":
+                            it.append(Item("v_max_f32 %s, 0, %s" % (a, a)))
+                        else:
+                            it.append(Item("v_fma_f32 %s, %s, %%[slope], 0" % (T1, a)))
+                            it.append(Item("v_max_f32 %s, %s, %s" % (a, a, T1)))
+                        if mode == "fwd":
+                            it.append(Item("v_cmp_lt_f32 vcc, 0, %s" % a))
+                            it.append(Item("v_addc_co_u32 %s, vcc, %s, %s, vcc" % (W[i], W[i], W[i])))
+                    else:
+                        it.append(Item("v_mul_f32 %s, %s, %s" % (a, a, INV[i]), need=[("inv", i)]))
+                        it.append(Item("v_bfe_i32 %s, %%[word], %d, 1" % (T1, 31 - n)))
+                        if act == "relu":
+                            it.append(Item("v_and_b32 %s, %s, %s" % (a, a, T1)))
+                        else:
+                            it.append(Item("v_mul_f32 %s, %%[slope], %s" % (T2, a)))
+                            it.append(Item("v_bfi_b32 %s, %s, %s, %s" % (a, T1, a, T2)))
+                first = gp == 0 and gg == 0
+                for c in (0, 2):
+                    it.append(Item("v_max3_f32 %s, |%s|, |%s|, %s" % (LM[i], regs[c], regs[c + 1], "0" if first and c == 0 else LM[i])))
+    for i in range(2):
+        it += [Item("v_mov_b32 %s, %s" % (SWP, LM[i])), Item("s_nop 1", kind="salu"),
+               Item("v_permlane32_swap_b32 %s, %s" % (LM[i], SWP)), Item("v_max_f32 %s, %s, %s" % (LM[i], LM[i], SWP)),
+               Item("ds_write_b32 %%[pmw], %s offset:%d" % (LM[i], 128 * i), lds=("pmw", i), kind="lds")]
+    if mode == "fwd":
+        it += [Item("v_lshl_or_b32 %%[word], %s, 16, %s" % (W[0], W[1])), Item("v_lshrrev_b32 %s, 2, %%[wv]" % T1),
+               Item("global_store_dword %s, %%[word], %%[sgn]" % T1, kind="vmem")]
+    return it
+
+
+def p2_stream(acc_u, mode):
+    it = []
+    PM = G[0:8]
+    MX, E, T = G[8], G[9], G[10]
+    SC, IN = [G[11], G[12]], [G[13], G[14]]
+    train = mode != "inf"
+    K140 = G[15]                                # (v_cndmask takes its constant from a register: a literal next to vcc is two constant-bus reads)
+    it.append(Item("v_mov_b32 %s, 0x8c" % K140))
+    for i in range(2):
+        src = "%[pmr]"
+        if i == 1:
+            it.append(Item("v_add_u32 %s, 128, %%[pmr]" % AD))
+            src = AD
+        for j in range(4):
+            it.append(Item("ds_read2st64_b32 %s, %s offset0:%d offset1:%d" % (vt(GB + 2 * j, 2), src, 2 * j, 2 * j + 1), lds=("pm", i, j), kind="lds"))
+        it.append(Item("v_max3_f32 %s, %s, %s, %s" % (MX, PM[0], PM[1], PM[2]), need=[("pm", i, 0), ("pm", i, 1)]))
+        it.append(Item("v_max3_f32 %s, %s, %s, %s" % (MX, MX, PM[3], PM[4]), need=[("pm", i, 2)]))
+        it.append(Item("v_max3_f32 %s, %s, %s, %s" % (MX, MX, PM[5], PM[6]), need=[("pm", i, 3)]))
+        it.append(Item("v_max_f32 %s, %s, %s" % (MX, MX, PM[7])))
+        if train:
+            it.append(Item("global_store_dword %%[invad], %s, %%[rmp] offset:%d" % (MX, 128 * i), kind="vmem"))      # (rmp: the row maxima's address minus the table's LDS offset)
+        # scale_from_max (chain4.hip): e = bits ? exponent : 140; scale = 2^(267 - e), 1/scale = 2^(e - 13), biased exponents clamped to [1, 254]
+        it += [Item("v_bfe_u32 %s, %s, 23, 8" % (E, MX)), Item("v_cmp_ne_u32 vcc, 0, %s" % MX), Item("v_cndmask_b32 %s, %s, %s, vcc" % (E, K140, E)),
+               Item("v_sub_u32 %s, 0x10b, %s" % (T, E)), Item("v_med3_i32 %s, %s, 1, %%[c254]" % (T, T)), Item("v_lshlrev_b32 %s, 23, %s" % (SC[i], T)),
+               Item("v_add_u32 %s, -13, %s" % (T, E)), Item("v_med3_i32 %s, %s, 1, %%[c254]" % (T, T)), Item("v_lshlrev_b32 %s, 23, %s" % (IN[i], T)),
+               Item("ds_write_b32 %%[invad], %s offset:%d" % (IN[i], 128 * i), lds=("invw", i), kind="lds")]
+    if train:
+        # ---- the rows: into the wave's own 128 bytes of every plane row (where its split goes afterwards) ...
+        for i in range(2):
+            for g in range(4):
+                dst = "%[stw]"
+                if g:
+                    it.append(Item("v_xor_b32 %s, %d, %%[stw]" % (AD, 16 * g)))
+                    dst = AD
+                it.append(Item("ds_write_b128 %s, %s offset:%d" % (dst, vt(acc_u + 16 * i + 4 * g, 4), 32768 * i), lds=("stw", i, g), kind="lds"))
+        # ... and back, eight lanes per row; row r = (sx & 3) + 4 (q & 3) + 16 (q >> 2) + 32 (sx >> 2) of the tile
+        R = [vt(GB, 4), vt(GB + 4, 4)]
+        for sx in range(8):
+            src = "%[rdb]"
+            if sx & 3:
+                it.append(Item("v_xor_b32 %s, 0x%x, %%[rdb]" % (AD2, 528 * (sx & 3))))
+                src = AD2
+            it.append(Item("ds_read_b128 %s, %s offset:%d" % (R[sx & 1], src, 32768 * (sx >> 2)), lds=("rb", sx), kind="lds"))
+            it.append(Item("global_store_dwordx4 %%[gso], %s, %%[crow%d] offset:%d" % (R[sx & 1], sx >> 2, 1024 * (sx & 3)), need=[("rb", sx)], kind="vmem"))
+    # ---- split into the planes
+    HS = [[["v%d" % (GB + 4 * s + j) for j in range(4)] for s in range(2)]] * 2      # [set][hi / lo][4] (one set: registers are scarce)
+    k = 0
+    for i in range(2):
+        for q in range(2):
+            H, L = HS[k & 1]
+            k += 1
+            regs = ["v%d" % (acc_u + 16 * i + 8 * q + e) for e in range(8)]
+            for j in range(4):
+                it.append(Item("v_fma_mixlo_f16 %s, %s, %s, 0" % (H[j], regs[2 * j], SC[i])))
+            for j in range(4):
+                it.append(Item("v_fma_mixhi_f16 %s, %s, %s, 0" % (H[j], regs[2 * j + 1], SC[i])))
+            for j in range(4):
+                it.append(Item("v_fma_mixlo_f16 %s, %s, %s, -%s op_sel_hi:[0,0,1]" % (L[j], regs[2 * j], SC[i], H[j])))
+            for j in range(4):
+                it.append(Item("v_fma_mixhi_f16 %s, %s, %s, -%s op_sel:[0,0,1] op_sel_hi:[0,0,1]" % (L[j], regs[2 * j + 1], SC[i], H[j])))
+            dst = "%[plw]"
+            if q:
+                it.append(Item("v_xor_b32 %s, 16, %%[plw]" % AD))
+                dst = AD
+            h0, l0 = int(H[0][1:]), int(L[0][1:])
+            it.append(Item("ds_write_b128 %s, %s offset:%d" % (dst, vt(h0, 4), 32768 * i), lds=("plh", i, q), kind="lds"))
+            it.append(Item("ds_write_b128 %s, %s offset:%d" % (dst, vt(l0, 4), 32768 * i + 4096), lds=("pll", i, q), kind="lds"))
+            it.append(Item("s_nop 1", kind="salu"))          # (a wide store's data registers must not be rewritten right behind it)
+    return it
+
+
+class Emit:
+    def __init__(self):
+        self.lines, self.queue, self.retired = [], [], 0
+
+    def put(self, item):
+        need = [t for t in item.need if t in self.queue[self.retired:]]
+        if need:
+            last = max(self.queue.index(t) for t in need)
+            after = len(self.queue) - 1 - last
+            self.lines.append("s_waitcnt lgkmcnt(%d)" % min(after, 15))
+            self.retired = max(self.retired, len(self.queue) - min(after, 15))
+        self.lines.append(item.text)
+        if item.lds is not None:
+            self.queue.append(item.lds)
+
+    def wait_for(self, tags):
+        self.put(Item("", need=tags))
+        self.lines.pop()
+
+
+def build(tile, mode, act, ld, kcnt=16):
+    acc_t, acc_u = (ACC["X"], ACC["Y"]) if tile == "X" else (ACC["Y"], ACC["X"])
+    pro, steps = k_stream(acc_t, ld, kcnt)
+    NM = 6 * kcnt                               # matrix instructions of the statement
+    p1, p2 = p1_stream(acc_u, mode, act), p2_stream(acc_u, mode)
+    e = Emit()
+    for x in pro:
+        e.put(x)
+    head = 8 if mode != "dgrad" else 2          # the row phase's first LDS reads ride in front of the first MFMA
+    for x in p1[:head]:
+        e.put(x)
+    p1 = p1[head:]
+    n1 = max(1, min(NM - 6, round(NM * (len(p1) + 6.0) / (len(p1) + len(p2) + 6))))      # MFMAs that carry P1
+    after_pf = []                               # memory instructions issued behind the prefetch block
+    put0 = e.put
+
+    def put(x):
+        put0(x)
+        if x.kind == "vmem":
+            after_pf.append(True)
+    e.put = put
+    for m, (mf, post) in enumerate(steps):
+        e.put(mf)
+        for x in post:
+            e.put(x)
+        if m == 5:
+            # ---- the input rows of the tile this workgroup stages a few slots from now (this wave's eight), pulled towards the caches:
+            # every CU stages at the same moment, 16 MB in one burst, and a staging slot took 23k cycles against 10k for a hot one
+            # (scripts/probes/chain4_trace.py).  Plain loads into four registers nobody reads; pfs = the rows' stride in bytes, 0 = not now.
+            e.lines += ["s_cmp_eq_u32 %[pfs], 0", "s_cbranch_scc1 .Lc4pf%=", "v_mov_b32 %s, %%[wv]" % AD2]
+            for q in range(8):
+                e.lines.append("global_load_dwordx4 %s, %s, %%[pfb]" % (PFD, AD2))
+                if q < 7:
+                    e.lines.append("v_add_u32 %s, %%[pfs], %s" % (AD2, AD2))
+            e.lines.append(".Lc4pf%=:")
+            after_pf = []
+        if m < n1:
+            left = n1 - m
+            take = -(-len(p1) // left)
+            for x in p1[:take]:
+                e.put(x)
+            p1 = p1[take:]
+            if m == n1 - 1:
+                assert not p1
+                e.wait_for([("pmw", 0), ("pmw", 1)])
+                e.lines.append("s_barrier")
+        else:
+            left = NM - m
+            take = -(-len(p2) // left)
+            for x in p2[:take]:
+                e.put(x)
+            p2 = p2[take:]
+    assert not p2
+    e.lines += ["s_nop 15", "s_nop 7"]          # the last results leave the matrix pipe 16 passes after issue
+    # the prefetch loads have landed (their registers belong to the compiler again behind the statement): everything older than the
+    # statement's own later memory instructions is complete (loads and stores retire in order)
+    younger = sum(1 for x in after_pf if x)
+    e.lines.append("s_waitcnt vmcnt(%d)" % min(younger, 63))
+    return e.lines
+
+
+def emit(name, lines):
+    print("#define %s \\" % name)
+    for i, l in enumerate(lines):
+        print('    "%s\\n\\t"%s' % (l, " \\" if i + 1 < len(lines) else ""))
+    print()
+
+
+if __name__ == "__main__":
+    print("// GENERATED by scripts/gen_chain4_fused.py -- do not edit.  The hot slots of chain4.hip, one asm statement each (see the script).")
+    total = {}
+    for mode in ("fwd", "inf", "dgrad"):
+        for act in ("relu", "leaky"):
+            for tile in ("X", "Y"):
+                for ld in ((0,) if tile == "X" else (0, 1)):
+                    lines = build(tile, mode, act, ld)
+                    emit("C4F_%s_%s_%s_%s" % (mode.upper(), act.upper(), tile, "LD" if ld else "NL"), lines)
+                    total[(mode, act, tile, ld)] = len(lines)
+            for kcnt in (8, 10):                # the run's first layer on tile Y (on tile X its slot also stages the next tile: no fused form)
+                emit("C4F_%s_%s_Y_LD_K%d" % (mode.upper(), act.upper(), kcnt), build("Y", mode, act, 1, kcnt))
+    print("#define C4F_CLOBBERS " + ", ".join('"%s"' % v for v in CLOB_V) + ', "vcc", "memory"')
+    print('#define C4F_LD_CLOBBERS "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97"')
+    print("#define C4F_AGPRS " + ", ".join('"a%d"' % i for i in range(128)))
+    print("// instructions per statement: " + ", ".join("%s_%s_%s_%s %d" % (k[0], k[1], k[2], "LD" if k[3] else "NL", v) for k, v in sorted(total.items())))

@@ -12,15 +12,16 @@ fragment and its use, and every wait is counted by hand.
   C4_KLOOP1(LD)  one product (h1): two MFMAs per k-step
   LD = 1: each k-step's weight registers are refilled with the next layer's fragment behind their last use.
 
-Operands (named): a0 a1 = the two accumulators (written, not read: their first products add to the constant 0); f00..f03 / f10..f13 = fragment buffers 0 / 1 (lo0 lo1 hi0 hi1; early-clobber
+Accumulators: v[64:95] (tile X flavour) / v[96:127] (tile Y), by name (written, not read: their first products add to the constant 0).  Operands (named): f00..f03 / f10..f13 = fragment buffers 0 / 1 (lo0 lo1 hi0 hi1; early-clobber
 temporaries); ad0..ad7 = LDS byte address of k-step j's hi0 fragment (k-step j + 8: + 256); wv = lane * 16; bh0..bh3 / bl0..bl3 =
 bases of the next layer's hi / lo fragments of k-steps 4 q .. 4 q + 3.   python scripts/gen_chain4_kloop.py > papr_amd/csrc/chain4_kloop.inc
 """
 
 def wh(ks): return "a[%d:%d]" % (8 * ks, 8 * ks + 3)
 def wl(ks): return "a[%d:%d]" % (8 * ks + 4, 8 * ks + 7)
+ACC = {"a0": "v[64:79]", "a1": "v[80:95]"}        # tile X; emit() rewrites them for tile Y (chain4.hip keeps the accumulators in v64-v127, outside the compiler's allocation)
 def mf(acc, w, x, first=False):  # (first: the accumulator's first product takes the constant 0 as its addend -- no zeroing beforehand)
-    return "v_mfma_f32_32x32x16_f16 %%[%s], %s, %%[%s], %s" % (acc, w, x, "0" if first else "%%[%s]" % acc)
+    return "v_mfma_f32_32x32x16_f16 %s, %s, %%[%s], %s" % (ACC[acc], w, x, "0" if first else ACC[acc])
 def rd(dst, ks, kind):          # fragment `kind` (l0 l1 h0 h1) of k-step ks
     off = {"l0": 4096, "l1": 36864, "h0": 0, "h1": 32768}[kind] + (256 if ks >= 8 else 0)
     return "ds_read_b128 %%[%s], %%[ad%d] offset:%d" % (dst, ks & 7, off)
@@ -79,10 +80,13 @@ def kloop1(ld):
     return t
 
 def emit(name, lines):
-    print("#define %s \\" % name)
-    for i, l in enumerate(lines):
-        print('    "%s\\n\\t"%s' % (l, " \\" if i + 1 < len(lines) else ""))
-    print()
+    for tile, sub in (("X", {}), ("Y", {"v[64:79]": "v[96:111]", "v[80:95]": "v[112:127]"})):
+        print("#define %s_%s \\" % (name, tile))
+        for i, l in enumerate(lines):
+            for a, b in sub.items():
+                l = l.replace(a, b)
+            print('    "%s\\n\\t"%s' % (l, " \\" if i + 1 < len(lines) else ""))
+        print()
 
 print("// GENERATED by scripts/gen_chain4_kloop.py -- do not edit.  The hot k-loops of chain4.hip, one asm statement each (see the script).")
 emit("C4_KLOOP3_LD", kloop3(True))

@@ -6,6 +6,7 @@ res = {}
 for v in ("3", "4"):
     out = "/tmp/c4diff_%s.pt" % v
     e = dict(os.environ, PAPR_CHAIN=v)
+    if v == "3": e.pop("PAPR_C4_FUSED", None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "chain_variants_worker.py"), out, M, n, act], env=e, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     res[v] = torch.load(out)

@@ -8,11 +8,12 @@ from papr_amd import ops, hip
 M = 512000
 mode = sys.argv[1] if len(sys.argv) > 1 else "inf"
 d = torch.device("cuda:0")
-n = 4
-spec = ops.MlpSpec("b", 256, dict(n_ff_layer=n, d_ff=256, d_ff_out=256, norm="none", ff_act="relu", ff_last_act="none"))
-ws = [(torch.randn(256, 256) * 0.1).to(d) for _ in range(n)]
+n = int(os.environ.get("LAYERS", "4"))
+d_in = int(os.environ.get("D_IN", "256"))
+spec = ops.MlpSpec("b", d_in, dict(n_ff_layer=n, d_ff=256, d_ff_out=256, norm="none", ff_act="relu", ff_last_act="none"))
+ws = [(torch.randn(256, spec.layers[i]["n_in"]) * 0.1).to(d) for i in range(n)]
 bs = [torch.zeros(256, device=d) for _ in range(n)]
-x = torch.randn(M, 256, device=d)
+x = torch.randn(M, spec.ld_in, device=d)
 gy = torch.randn(M, 256, device=d)
 scratch = [torch.empty((M, 256), device=d) for _ in range(2)]
 for _ in range(3):
@@ -23,8 +24,9 @@ torch.cuda.synchronize()
 buf = (ctypes.c_longlong * 2048)()
 hip.lib().papr_chain4_trace_read(buf)
 t = list(buf)
-names = ["P2 first", "K", "P1", "P2 last", "barrier"]
-tot = [0.0] * 5
+NS = int(os.environ.get("STAMPS", "5"))
+names = ["P1", "barrier", "first", "second", "end"] if NS == 5 else ["P1", "barrier", "A", "B", "C", "D", "end"]
+tot = [0.0] * NS
 cnt = 0
 s0, s1 = int(os.environ.get("S0", "4")), int(os.environ.get("S1", "12"))
 for sl in range(s0, s1):
@@ -32,9 +34,9 @@ for sl in range(s0, s1):
     print("  wave  " + "  ".join("%9s" % s for s in names) + "      total")
     for w in range(8):
         tt = t[w * 256: (w + 1) * 256]
-        i = 5 * sl
-        dts = [tt[i + j + 1] - tt[i + j] for j in range(5)]
+        i = NS * sl
+        dts = [tt[i + j + 1] - tt[i + j] for j in range(NS)]
         print("  %2d    " % w + "  ".join("%9d" % v for v in dts) + "  %9d" % sum(dts))
-        for j in range(5): tot[j] += dts[j]
+        for j in range(NS): tot[j] += dts[j]
         cnt += 1
 print("mean per wave and slot: " + "  ".join("%s %.0f" % (n_, v / cnt) for n_, v in zip(names, tot)) + "   slot %.0f" % (sum(tot) / cnt))

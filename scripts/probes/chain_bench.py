@@ -4,7 +4,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from papr_amd import ops, hip
-M, n = 512000, 4
+M, n = int(os.environ.get('BENCH_M', '512000')), 4
 d = torch.device("cuda:0")
 spec = ops.MlpSpec("b", 256, dict(n_ff_layer=n, d_ff=256, d_ff_out=256, norm="none", ff_act="relu", ff_last_act="none"))
 g = torch.Generator().manual_seed(0)
@@ -28,5 +28,5 @@ fw = [r[4] for r in recs if r[0] == 9]
 dg = [r[4] for r in recs if r[0] == 10]
 wg = [r[4] for r in recs if r[0] == 8]
 med = lambda v: sorted(v)[len(v) // 2] * 1e3 if v else float("nan")
-print("PAPR_CHAIN=%s  4-layer run, us: training forward %.0f  data-gradient %.0f  inference %.0f   (weight-gradient batch %.0f)" %
+print("M=%d " % M + "PAPR_CHAIN=%s  4-layer run, us: training forward %.0f  data-gradient %.0f  inference %.0f   (weight-gradient batch %.0f)" %
       (os.environ.get("PAPR_CHAIN", "2"), med(fw[0::2]), med(dg), med(fw[1::2]), med(wg)))

@@ -24,12 +24,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 VARIANTS = [("chain", {"PAPR_CHAIN": "1"}), ("chain3 two-role", {"PAPR_CHAIN": "3", "PAPR_C3_FUSED": "0"}), ("chain3", {"PAPR_CHAIN": "3", "PAPR_C3_FUSED": "1"}),
             ("chain3 again", {"PAPR_CHAIN": "3", "PAPR_C3_FUSED": "1"}), ("chain3 fused inference", {"PAPR_CHAIN": "3", "PAPR_C3_FUSED": "2"}),
             ("chain3 generic rows", {"PAPR_CHAIN": "3", "PAPR_C2_GENERIC": "1"}), ("chain2", {"PAPR_CHAIN": "2"}),
-            ("chain4", {"PAPR_CHAIN": "4"}), ("chain4 again", {"PAPR_CHAIN": "4"}), ("chain4 generic rows", {"PAPR_CHAIN": "4", "PAPR_C4_GENERIC": "1"})]
+            ("chain4", {"PAPR_CHAIN": "4"}), ("chain4 again", {"PAPR_CHAIN": "4"}), ("chain4 two-role", {"PAPR_CHAIN": "4", "PAPR_C4_FUSED": "0"}),
+            ("chain4 generic rows", {"PAPR_CHAIN": "4", "PAPR_C4_GENERIC": "1"})]
 
 
 def _run(tmp_path, name, env, M, n, act):
     out = tmp_path / (name.replace(" ", "_") + ".pt")
-    e = {k: v for k, v in os.environ.items() if k not in ("PAPR_CHAIN", "PAPR_C3_FUSED", "PAPR_C2_GENERIC", "PAPR_C4_GENERIC", "PAPR_GEMM_MODE")}
+    e = {k: v for k, v in os.environ.items() if k not in ("PAPR_CHAIN", "PAPR_C3_FUSED", "PAPR_C2_GENERIC", "PAPR_C4_GENERIC", "PAPR_C4_FUSED", "PAPR_GEMM_MODE")}
     e.update(env)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "chain_variants_worker.py"), str(out), str(M), str(n), act], env=e, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (name, r.stderr[-2000:])
