@@ -11,7 +11,7 @@ see papr_amd/data.py).  With N > 1 every rank renders its own patch (weak scalin
 averaged with one RCCL all-reduce inside PAPR.step().
 
 The JSON line also carries
-  roofline      the dominant kernel (default mode: mlp_chain3_kernel, the fused embedding-MLP runs, forward and
+  roofline      the dominant kernel (default mode: mlp_chain4_kernel, the fused embedding-MLP runs, forward and
                 data-gradient), timed live with HIP events on the launch stream during the timed steps; `frac` counts the
                 three f16 MFMA products of every fp32 product as work, `frac_algorithmic` only the fp32 flops
   roofline_knn  the ray -> k-nearest-points kernel against its logical HBM byte count (north_star)
@@ -238,7 +238,7 @@ def main():
                     "fp32_equivalent_tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0, "share_of_step_time": ms / (dt * 1e3)}
 
     def chain_line():
-        # fused layer runs (chain.hip): every fp32 product is three f16 MFMA products, and only the run's input, the
+        # fused layer runs (chain4.hip): every fp32 product is three f16 MFMA products, and only the run's input, the
         # saved activations / gradient rows and the masks cross HBM.  The matrix pipe is the nearer roof.
         rs = [r for r in recs if r[0] in (9, 10)]
         ms = sum(r[4] for r in rs)
@@ -246,7 +246,7 @@ def main():
         fl = float(sum(r[6] for r in rs))
         prods = 1.0 if args.gemm_mode == "h1" else 3.0        # f16 MFMA products issued per fp32 product
         ach = prods * fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        return ms, {"kernel": "mlp_chain3_kernel (fused embedding-MLP runs: forward and data-gradient, %s)" % ("one f16 product per fp32 product" if prods == 1.0 else "split-f16 MFMA, three products per fp32 product"),
+        return ms, {"kernel": "mlp_chain4_kernel (fused embedding-MLP runs: forward and data-gradient, %s)" % ("one f16 product per fp32 product" if prods == 1.0 else "split-f16 MFMA, three products per fp32 product"),
                     "bound": "mfma", "achieved": ach, "peak": F16_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / F16_MFMA_PEAK_TF,
                     "traffic": traffic_db.get("mlp_chain_bytes_per_launch"), "launches": len(rs),
                     "avg_launch_ms": ms / max(len(rs), 1), "algorithmic_gflop_per_launch": prods * fl / max(len(rs), 1) / 1e9,

@@ -531,7 +531,7 @@ static const int GEMM_MODE = [] {
     if (e && !strcmp(e, "h1")) return 5;
     return 4;
 }();
-// h1: h3, and the fused runs (chain3.hip) multiply one f16 product per fp32 product: the throughput mode that stands for the
+// h1: h3, and the fused runs (chain4.hip) multiply one f16 product per fp32 product: the throughput mode that stands for the
 // reference's fp16 autocast of the attention block (models/attn.py:248, `use_amp: true`); own tolerance in the tests.
 static const bool GEMM_ONE_PRODUCT_ENV = GEMM_MODE == 5;
 // The one-product arithmetic can also be asked for call by call (papr_mlp_precision: the host maps the reference's `use_amp: true`
@@ -849,7 +849,7 @@ struct TNH3Args {
                                                // scale_from_row_max() makes of its maximum (what the fused-run kernels of the h1 mode
                                                // store); ldg / ldx then count halfs
 };
-__device__ __forceinline__ float inv_scale_from_row_max(float m) {       // 1 / (the fused-run kernels' row scale), chain3.hip: scale_from_max
+__device__ __forceinline__ float inv_scale_from_row_max(float m) {       // 1 / (the fused-run kernels' row scale), chain4.hip: scale_from_max
     const unsigned bits = __float_as_uint(m);
     const int ea = bits ? (int)((bits >> 23) & 0xff) : 127 + 13;
     return pow2_from_biased(127 - 13 + (ea - 127));
@@ -1350,19 +1350,18 @@ static bool layer_rowmax_saved(const papr_layer* layers, int n_layers, int i) {
     return layer_on_h3(layers[i]);
 }
 
-// h1 mode, chain3.hip: the rows a fused run leaves for its weight-gradients are f16 (scaled per row, chain.h: c_half) instead
+// h1 mode: the rows a fused run leaves for its weight-gradients are f16 (scaled per row, chain.h: c_half) instead
 // of fp32 -- the weight-gradient kernel is HBM-bound, so half the bytes is half its time.  The buffers stay the caller's
 // fp32-sized ones: the f16 rows of a layer's output occupy the first half of outs[l] (row stride ld_out[l] halfs), and the f16
 // copy of the run's input rows the second half of the run's first output buffer; likewise the gradient-row slots of the
 // backward scratch.  Only the run's last output (forward) / the gradient that leaves the run (backward) remain fp32 rows.
 // PAPR_H1_ROWS=f32 keeps fp32 rows (A/B).
-static const bool H1_HALF_ROWS_OK = !(getenv("PAPR_H1_ROWS") && !strcmp(getenv("PAPR_H1_ROWS"), "f32")) &&
-                                    (!getenv("PAPR_CHAIN") || atoi(getenv("PAPR_CHAIN")) >= 3);
+static const bool H1_HALF_ROWS_OK = !(getenv("PAPR_H1_ROWS") && !strcmp(getenv("PAPR_H1_ROWS"), "f32"));
 #define H1_HALF_ROWS (H1_HALF_ROWS_OK && one_product_now())
 // forward run [b, e) of a training pass stores f16 rows (the backward pass asks the same question)
 static bool run_half_rows(const papr_layer* layers, int n_layers, int b, int e, const int32_t* ld_out, bool training) {
     if (!H1_HALF_ROWS || !training || e - b < 2) return false;
-    for (int l = 0; l < n_layers; ++l) if (layers[l].n_skip > 0) return false;          // (runs of such an MLP go to chain.hip)
+    for (int l = 0; l < n_layers; ++l) if (layers[l].n_skip > 0) return false;          // (the skip segment's weight gradient reads fp32 rows)
     const int k0pad = (layers[b].n_in + 31) / 32 * 32;
     if (k0pad > ld_out[b]) return false;                                                // the input copy must fit behind outs[b]'s rows
     for (int l = b; l < e - 1; ++l) if (ld_out[l] % 8 || layers[l].n_out % 32) return false;
@@ -1438,7 +1437,6 @@ extern "C" int papr_mlp_fwd(const papr_layer* layers, int n_layers, float* x, in
             }
             c.rowmax0 = saved ? saved + (size_t)i * M : nullptr;
             c.M = M; c.n_layers = e - i;
-            for (int l = 0; l < n_layers; ++l) c.legacy |= layers[l].n_skip > 0 ? 1 : 0;      // (sign-word layout: chain.h)
             c.one_product = GEMM_ONE_PRODUCT ? 1 : 0;
             const bool half_rows = run_half_rows(layers, n_layers, i, e, ld_out, saved != nullptr);
             if (half_rows) { c.a0_half = reinterpret_cast<_Float16*>(outs[i]) + (size_t)M * ld_out[i]; c.lda0_half = ld_out[i]; }
@@ -1464,7 +1462,7 @@ extern "C" int papr_mlp_fwd(const papr_layer* layers, int n_layers, float* x, in
                 c.norm_eps = out_norm->eps; c.norm_stats = out_norm->stats;      // standardised in the run's last row phase
                 norm_done = true;
             }
-            split.perm = papr_chain_version(c) == 4;
+            split.perm = 1;
             if (int err = chain_split_launch(split, e - i, s)) return err;
             if (int err = papr_launch_chain(c, false, bytes, flops, s)) return err;
             if (!saved) h3.swap();
@@ -1611,7 +1609,7 @@ extern "C" int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float*
             const int last = b == 0 ? (to_dx ? 0 : 1) : b;       // lowest layer whose data-gradient the launch computes
             ChainArgs c = {};
             c.A0 = g; c.lda0 = ldg; c.K0 = L.n_out; c.rowmax0 = runs.gmax[CHAIN_MAX_LAYERS];
-            c.M = M; c.legacy = any_skip ? 1 : 0; c.one_product = GEMM_ONE_PRODUCT ? 1 : 0;
+            c.M = M; c.one_product = GEMM_ONE_PRODUCT ? 1 : 0;
             // h1 mode: f16 rows (see run_half_rows).  x_half: what the forward run stored; g_half: this launch, if it has a layer
             // that is not its last (the copy of the top gradient rows goes behind that layer's rows)
             const bool x_half = run_half_rows(layers, n_layers, b, i + 1, ld_out, row_absmax != nullptr);
@@ -1646,7 +1644,7 @@ extern "C" int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float*
             }
             PAPR_REQUIRE(used <= H3_PLANE_HALFS, "papr_mlp_bwd: fused run needs %zu plane halfs", used);
             if (c.n_layers > 0) {
-                split.perm = papr_chain_version(c) == 4;
+                split.perm = 1;
                 if (int err = chain_split_launch(split, c.n_layers, s)) return err;
                 if (int err = papr_launch_chain(c, true, bytes, flops, s)) return err;
             }

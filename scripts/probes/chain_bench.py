@@ -1,5 +1,5 @@
 """Times of the fused-run launches alone: 4 x (512,000 x 256 x 256): training forward (all layers stored), data-gradient run,
-inference (last layer stored); from the library's own HIP-event records.   PAPR_CHAIN=1|2 selects the kernel."""
+inference (last layer stored); from the library's own HIP-event records.   PAPR_C4_FUSED=0: two-role slots only; PAPR_GEMM_MODE=h1: one-product mode; BENCH_M: rows."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -28,5 +28,5 @@ fw = [r[4] for r in recs if r[0] == 9]
 dg = [r[4] for r in recs if r[0] == 10]
 wg = [r[4] for r in recs if r[0] == 8]
 med = lambda v: sorted(v)[len(v) // 2] * 1e3 if v else float("nan")
-print("M=%d " % M + "PAPR_CHAIN=%s  4-layer run, us: training forward %.0f  data-gradient %.0f  inference %.0f   (weight-gradient batch %.0f)" %
-      (os.environ.get("PAPR_CHAIN", "2"), med(fw[0::2]), med(dg), med(fw[1::2]), med(wg)))
+print("M=%d " % M + "fused=%s mode=%s  4-layer run, us: training forward %.0f  data-gradient %.0f  inference %.0f   (weight-gradient batch %.0f)" %
+      (os.environ.get("PAPR_C4_FUSED", "1"), os.environ.get("PAPR_GEMM_MODE", "h3"), med(fw[0::2]), med(dg), med(fw[1::2]), med(wg)))

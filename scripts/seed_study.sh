@@ -1,7 +1,7 @@
 #!/bin/bash
 # Seed spread of the long training run: 21,500 steps of chair.yml on the procedural scene with prune / add live,
 # seeds 1..3, two arithmetic arms:
-#   r1arith : PAPR_CHAIN=1 PAPR_OWN_ADAM=0 PAPR_UNET_REST=0  (round-1 kernels: chain.hip, torch Adam, MIOpen for the U-Net's other layers)
+#   r1arith : PAPR_CHAIN=1 PAPR_OWN_ADAM=0 PAPR_UNET_REST=0  (round-1 kernels: chain.hip -- deleted later in round 3, this arm ran at commit 2b0e6d1 --, torch Adam, MIOpen for the U-Net's other layers)
 #   default : this tree's kernels
 # Run on the GPU box from the repo root:  bash scripts/seed_study.sh [steps] [seeds...]
 # One log per run under gpurun_out/seed_study/ (Eval / Pruned / Added lines only), summary table at the end.

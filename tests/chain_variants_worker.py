@@ -1,4 +1,4 @@
-"""One MLP through the fused-run kernels in a fresh process (the library reads PAPR_CHAIN / PAPR_C3_FUSED / PAPR_C2_GENERIC when it
+"""One MLP through the fused-run kernels in a fresh process (the library reads PAPR_C4_FUSED / PAPR_C4_GENERIC / PAPR_GEMM_MODE when it
 loads):   python tests/chain_variants_worker.py <out.pt> <M> <n_layers> <act>
 
 Training forward (every layer saved), data-gradient run with the saved sign words, the same without them, an inference pass;

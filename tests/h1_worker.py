@@ -1,4 +1,4 @@
-"""The reduced-precision mode of the fused MLP runs (PAPR_GEMM_MODE=h1: one f16 product per fp32 product, chain3.hip) in a
+"""The reduced-precision mode of the fused MLP runs (PAPR_GEMM_MODE=h1: one f16 product per fp32 product, chain4.hip) in a
 fresh process, because the library reads the mode when it loads:   python tests/h1_worker.py <case tag> <out.json>
 
 Renders the golden case and takes its gradients exactly like tests/test_hip_model.py does in the parity mode, and writes the

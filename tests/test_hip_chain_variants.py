@@ -1,16 +1,14 @@
-"""The fused-run kernels against each other, bit for bit.
+"""The forms of the fused-run kernel against each other, bit for bit.
 
-chain3.hip (default) carries hand-scheduled inline-asm k-loops and slots (chain3_kloop.inc, chain3_fused.inc: generated) whose
-correctness rests on hand-counted waits; chain.hip is round 1's kernel written in plain HIP C++ and pinned against the reference
-goldens by tests/test_hip_model.py.  Every arithmetic step is the same (MFMA order per accumulator, power-of-two row scales, split), so
-every saved activation, row maximum, weight / bias / input gradient and inference output must be IDENTICAL between
-  PAPR_CHAIN=1                  chain.hip
-  PAPR_CHAIN=3 PAPR_C3_FUSED=0  chain3.hip, two-role slots only (one-statement k-loops)
-  PAPR_CHAIN=3 PAPR_C3_FUSED=1  chain3.hip as shipped (training slots as fused statements)
-  PAPR_CHAIN=3 PAPR_C3_FUSED=2  ... and the inference slots too
-  PAPR_CHAIN=3 PAPR_C2_GENERIC=1  chain3.hip with the hot row-phase forms switched off
-  PAPR_CHAIN=2                  chain2.hip
-and from run to run (the races this file guards against showed up as run-to-run differences).  Sizes: a cloud-sized M with ragged last
+chain4.hip carries hand-scheduled inline-asm k-loops and whole slots (chain4_kloop.inc, chain4_fused.inc: generated) whose correctness rests
+on hand-counted waits and on registers the compiler does not know about; its two-role slots and its generic row phases are plain HIP C++
+(pinned against the reference goldens by tests/test_hip_model.py).  Every arithmetic step is the same (MFMA order per accumulator,
+power-of-two row scales, split), so every saved activation, row maximum, weight / bias / input gradient and inference output must be
+IDENTICAL between
+  (default)            hot slots as fused statements
+  PAPR_C4_FUSED=0      two-role slots everywhere (one-statement k-loops, C++ row phases with the flags as constants)
+  PAPR_C4_GENERIC=1    ... and the generic row phases (flags looked at at run time)
+and from run to run (the races this file guards against show up as run-to-run differences).  Sizes: a cloud-sized M with ragged last
 tiles and several workgroup iterations, and one below a tile; ReLU and LeakyReLU."""
 import os
 import subprocess
@@ -21,25 +19,19 @@ import torch
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-VARIANTS = [("chain", {"PAPR_CHAIN": "1"}), ("chain3 two-role", {"PAPR_CHAIN": "3", "PAPR_C3_FUSED": "0"}), ("chain3", {"PAPR_CHAIN": "3", "PAPR_C3_FUSED": "1"}),
-            ("chain3 again", {"PAPR_CHAIN": "3", "PAPR_C3_FUSED": "1"}), ("chain3 fused inference", {"PAPR_CHAIN": "3", "PAPR_C3_FUSED": "2"}),
-            ("chain3 generic rows", {"PAPR_CHAIN": "3", "PAPR_C2_GENERIC": "1"}), ("chain2", {"PAPR_CHAIN": "2"}),
-            ("chain4", {"PAPR_CHAIN": "4"}), ("chain4 again", {"PAPR_CHAIN": "4"}), ("chain4 two-role", {"PAPR_CHAIN": "4", "PAPR_C4_FUSED": "0"}),
-            ("chain4 generic rows", {"PAPR_CHAIN": "4", "PAPR_C4_GENERIC": "1"})]
+VARIANTS = [("generic rows", {"PAPR_C4_GENERIC": "1"}), ("two-role", {"PAPR_C4_FUSED": "0"}), ("fused", {}), ("fused again", {})]
 
 
 def _run(tmp_path, name, env, M, n, act):
     out = tmp_path / (name.replace(" ", "_") + ".pt")
-    e = {k: v for k, v in os.environ.items() if k not in ("PAPR_CHAIN", "PAPR_C3_FUSED", "PAPR_C2_GENERIC", "PAPR_C4_GENERIC", "PAPR_C4_FUSED", "PAPR_GEMM_MODE")}
+    e = {k: v for k, v in os.environ.items() if k not in ("PAPR_C4_GENERIC", "PAPR_C4_FUSED", "PAPR_GEMM_MODE")}
     e.update(env)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "chain_variants_worker.py"), str(out), str(M), str(n), act], env=e, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (name, r.stderr[-2000:])
     return torch.load(out)
 
 
-H1_VARIANTS = [("h1 two-role", {"PAPR_CHAIN": "3", "PAPR_C3_FUSED": "0", "PAPR_GEMM_MODE": "h1"}), ("h1", {"PAPR_CHAIN": "3", "PAPR_C3_FUSED": "1", "PAPR_GEMM_MODE": "h1"}),
-               ("h1 generic rows", {"PAPR_CHAIN": "3", "PAPR_C2_GENERIC": "1", "PAPR_GEMM_MODE": "h1"}),
-               ("h1 chain4", {"PAPR_CHAIN": "4", "PAPR_GEMM_MODE": "h1"}), ("h1 chain4 generic rows", {"PAPR_CHAIN": "4", "PAPR_C4_GENERIC": "1", "PAPR_GEMM_MODE": "h1"})]
+H1_VARIANTS = [("h1 generic rows", {"PAPR_C4_GENERIC": "1", "PAPR_GEMM_MODE": "h1"}), ("h1", {"PAPR_GEMM_MODE": "h1"}), ("h1 again", {"PAPR_GEMM_MODE": "h1"})]
 
 
 def _flat(res):
@@ -62,11 +54,11 @@ def test_fused_run_kernels_agree_bit_for_bit(tmp_path, M, n, act):
         for (k, a), (_, b) in zip(_flat(ref), _flat(res)):
             assert a.shape == b.shape, (name, k)
             same = torch.equal(a, b)
-            assert same, "%s: %s differs from chain.hip in %d of %d elements (max |diff| %g)" % (name, k, int((a != b).sum()), a.numel(), float((a - b).abs().max()))
+            assert same, "%s: %s differs from the generic form in %d of %d elements (max |diff| %g)" % (name, k, int((a != b).sum()), a.numel(), float((a - b).abs().max()))
 
 
 def test_one_product_mode_forms_agree_bit_for_bit(tmp_path):
-    """The same for the reduced-precision mode (PAPR_GEMM_MODE=h1): its two-role slots, its fused slots and its generic row phases."""
+    """The same for the reduced-precision mode (PAPR_GEMM_MODE=h1: two-role slots; hot and generic row phases)."""
     ref = None
     for name, env in H1_VARIANTS:
         res = _run(tmp_path, name, env, 40000, 5, "relu")

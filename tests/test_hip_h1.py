@@ -3,7 +3,7 @@
 The reference's counterpart is `use_amp: true`: ProximityAttention.forward under fp16 autocast (models/attn.py:248), whose Linear
 layers multiply fp16 operands -- 11-bit mantissas, ~1e-3 relative per product.  h1 keeps fp32 accumulation and fp32 rows where a run
 of layers begins and ends, multiplies ONE f16 product per fp32 product with the power-of-two row scales of the parity mode
-(chain3.hip, ONE), and leaves the rows its weight gradients read as f16 (the hi planes it multiplied; PAPR_H1_ROWS=f32: fp32 rows).
+(chain4.hip, ONE), and leaves the rows its weight gradients read as f16 (the hi planes it multiplied; PAPR_H1_ROWS=f32: fp32 rows).
 Its bar, stated here (measured: 1.3e-4 / 1.7e-3): RGB / fused features within 2e-3 of the fp32 reference's (values of order 1), the
 loss within 1 %, every gradient tensor finite with an rms error below 1 % of the tensor's largest reference entry.  The parity
 mode's own bars (1e-4 / 2e-4) are in tests/test_hip_model.py; bench.py reports this mode as a second line, never as `value`."""
@@ -27,16 +27,16 @@ def _run(tag, out, **extra):
 
 def test_h1_f16_rows_and_fp32_rows_both_meet_the_bar_and_differ(tmp_path):
     """The rows between a fused run and its weight gradients: f16 (default) and fp32 (PAPR_H1_ROWS=f32) are two computations -- different
-    bits in the weight gradients -- that both stay inside the mode's tolerance, with the two-role slots (PAPR_C3_FUSED=0) as well."""
+    bits in the weight gradients -- that both stay inside the mode's tolerance, with the generic row phases (PAPR_C4_GENERIC=1) as well."""
     half = _run("chair1k", tmp_path / "a.json")
     full = _run("chair1k", tmp_path / "b.json", PAPR_H1_ROWS="f32")
-    half2 = _run("chair1k", tmp_path / "c.json", PAPR_C3_FUSED="0")
+    half2 = _run("chair1k", tmp_path / "c.json", PAPR_C4_GENERIC="1")
     for res in (half, full, half2):
         assert res["rgb"] <= 2e-3
         for name, e in res["grads"].items():
             assert e["finite"] and e["rms_rel"] <= 1e-2, (name, e)
     assert half["digest"] != full["digest"], "same weight gradients with f16 and fp32 rows: the f16-row path did not run"
-    assert half["digest"] == half2["digest"], "fused and two-role slots store different f16 rows"
+    assert half["digest"] == half2["digest"], "hot and generic row phases store different f16 rows"
     assert abs(half["digest"] - full["digest"]) <= 2e-3 * abs(full["digest"])
 
 
