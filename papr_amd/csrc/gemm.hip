@@ -1595,8 +1595,14 @@ extern "C" int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float*
             if (int e = gemm_tn(gi, ldgi, L.n_out, in, ld_in, L.n_in, M, d_weight[i], L.ldw, d_bias[i], workspace, s)) return e;
         }
         if (L.n_skip > 0) {
-            if (int e = tnq.flush()) return e;
-            if (int e = gemm_tn(gi, ldgi, L.n_out, x, ldx, L.n_skip, M, d_weight[i] + L.skip_col, L.ldw, nullptr, workspace, s)) return e;
+            // the skip segment [previous output | x]: dW[:, skip_col ..) = G^T x -- split-f16 like the first segment when the forward
+            // run left the maxima of the x rows (row_absmax[0 .. M): a fused run that starts at layer 0), fp32 MFMA otherwise
+            if (h3w && L.n_skip <= SLAB && layer_rowmax_saved(layers, n_layers, 0)) {
+                if (int e = tnq.push(gi, ldgi, L.n_out, x, ldx, L.n_skip, M, gmax_i, row_absmax, d_weight[i] + L.skip_col, L.ldw, nullptr)) return e;
+            } else {
+                if (int e = tnq.flush()) return e;
+                if (int e = gemm_tn(gi, ldgi, L.n_out, x, ldx, L.n_skip, M, d_weight[i] + L.skip_col, L.ldw, nullptr, workspace, s)) return e;
+            }
         }
         return 0;
     };
