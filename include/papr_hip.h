@@ -10,8 +10,9 @@
  *   - plain device pointers + sizes, fp32 row-major, int32 indices; no torch / C++ types.
  *   - every call enqueues work on `stream` (a hipStream_t passed as void*) and returns
  *     immediately; 0 = ok, non-zero = error (text via papr_last_error()).
- *   - no internal allocation, no global state: scratch is passed in by the caller; the
- *     *_workspace_bytes helpers say how much.
+ *   - no internal allocation, no settings kept between calls: scratch is passed in by the caller (the
+ *     *_workspace_bytes helpers say how much), modes are arguments.  Process-wide by design: the optional
+ *     profiler switch (papr_profile_enable) and the last-error text.
  *   - "ld" arguments are row strides in floats and must be multiples of 4 (16-byte rows).
  */
 #ifndef PAPR_HIP_H
@@ -165,7 +166,7 @@ typedef struct {
  * workspace: papr_mlp_fwd_workspace_bytes(M) bytes (per-row operand scales and the pre-split weight of
  * the split-f16 GEMM; see gemm.hip).  Arithmetic: fp32 in, fp32 out; wide layers multiply on the f16
  * matrix pipe with every fp32 operand split into two halves (22 mantissa bits, fp32 accumulation) unless
- * the environment variable PAPR_GEMM_MODE=f32 selects fp32 MFMA everywhere.
+ * `mode` says otherwise (PAPR_MLP_* below).
  * row_absmax: NULL (inference: nothing is kept for a backward pass, and only outs[n_layers-1] is defined
  * afterwards), or papr_mlp_saved_floats(n_layers, M) floats of state for papr_mlp_bwd: max_k |input row m
  * of layer i| at [i*M + m] for every layer that ran on a split-f16 kernel (other entries undefined),
@@ -184,19 +185,22 @@ typedef struct {
     float* stats;       /* (M, 2) */
 } papr_row_norm;
 
-/* Arithmetic of the papr_mlp_fwd / papr_mlp_bwd calls that follow ON THIS THREAD: 0 = the library's mode (PAPR_GEMM_MODE, default
- * the fp32-parity split products), 1 = one f16 product per fp32 product with f16 rows between a fused run and its weight
- * gradients (the `h1` mode) -- the counterpart of the reference running its attention block under fp16 autocast when the YAML
- * says `use_amp: true` (models/attn.py:248).  A backward call must use the setting of its forward call.  Returns the previous
- * setting.  (Takes effect on top of the default mode only.) */
-int papr_mlp_precision(int32_t one_product);
+/* `mode` of papr_mlp_fwd / papr_mlp_bwd / papr_mlp_bwd_needs_weight_t: which arithmetic and which kernels carry the call.  An argument of
+ * every call (ABI 16; before: a thread-local precision setting plus an environment variable read when the library loaded) --
+ * the library keeps nothing between calls.  A backward call must name the mode of its forward call.
+ *   PAPR_MLP_H3      fp32-parity default: wide layers as split-f16 products (hi.hi + hi.lo + lo.hi, fp32 accumulate), runs of layers fused
+ *   PAPR_MLP_H1      one f16 product per fp32 product in the fused runs, f16 rows between a run and its weight gradients: the counterpart
+ *                    of the reference running its attention block under fp16 autocast (`use_amp: true`, models/attn.py:248)
+ *   PAPR_MLP_F32     exact fp32 MFMA everywhere;  PAPR_MLP_FWD / _DGRAD / _LAYERS: A/B steps between F32 and H3 (split-f16 forward only /
+ *                    + data-gradient / + weight gradient, one launch per layer) */
+enum { PAPR_MLP_H3 = 0, PAPR_MLP_H1 = 1, PAPR_MLP_F32 = 2, PAPR_MLP_FWD = 3, PAPR_MLP_DGRAD = 4, PAPR_MLP_LAYERS = 5 };
 size_t papr_mlp_fwd_workspace_bytes(int64_t M);
 /* in_norm (optional): the same LayerNorm core in FRONT of layer 0 (FeedForward.innorm) over the first in_norm->width
  * columns of x.  x is then overwritten with its standardised rows (papr_mlp_bwd and papr_rownorm_bwd read them),
  * except in inference (row_absmax == NULL) inside a fused run without skip layers, where nobody reads x again. */
 int papr_mlp_fwd(const papr_layer* layers, int n_layers, float* x, int ldx, int64_t M,
                  float* const* outs, const int32_t* ld_out, float* row_absmax, const papr_row_norm* in_norm,
-                 const papr_row_norm* out_norm, void* workspace, papr_stream_t stream);
+                 const papr_row_norm* out_norm, void* workspace, int32_t mode, papr_stream_t stream);
 
 /* Backward.  d_out: gradient w.r.t. the last layer's output (M, ld_out[n-1]); it is consumed
  * (overwritten).  scratch0/scratch1: two (M, max width) buffers.  d_weight[i] (n_out, ldw) and
@@ -206,11 +210,11 @@ int papr_mlp_fwd(const papr_layer* layers, int n_layers, float* x, int ldx, int6
 size_t papr_mlp_bwd_workspace_bytes(int64_t M);
 /* 1 if papr_mlp_bwd will read layers[i].weight_t for some layer (weight_t itself is not inspected), 0 if every
  * data-gradient runs inside a fused launch, which reads the transpose out of `weight` in place. */
-int papr_mlp_bwd_needs_weight_t(const papr_layer* layers, int n_layers, int need_dx);
+int papr_mlp_bwd_needs_weight_t(const papr_layer* layers, int n_layers, int need_dx, int32_t mode);
 int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float* x, int ldx, int64_t M,
                  float* const* outs, const int32_t* ld_out, const float* row_absmax, float* d_out,
                  float* scratch0, float* scratch1, int ld_scratch, float* const* d_weight,
-                 float* const* d_bias, float* d_x, void* workspace, papr_stream_t stream);
+                 float* const* d_bias, float* d_x, void* workspace, int32_t mode, papr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * K4  attention tail        replaces attention("scaled-dot") + score_act (models/attn.py:217-225)

@@ -522,25 +522,23 @@ static const int NT_VARIANT = getenv("PAPR_NT_VARIANT") ? atoi(getenv("PAPR_NT_V
 // within 2e-3, bitwise chunk invariance, reference loss trajectory within 5e-6).  The one measurable
 // difference: after the reference's three Adam steps the point positions agree to 5e-5 in f32 mode and to
 // 1e-4 in the split modes (22-bit operands; Adam divides by |g| for near-zero gradients).
-static const int GEMM_MODE = [] {
-    const char* e = getenv("PAPR_GEMM_MODE");
-    if (e && !strcmp(e, "f32")) return 0;
-    if (e && !strcmp(e, "fwd")) return 1;
-    if (e && !strcmp(e, "dgrad")) return 2;
-    if (e && !strcmp(e, "layers")) return 3;
-    if (e && !strcmp(e, "h1")) return 5;
-    return 4;
-}();
-// h1: h3, and the fused runs (chain4.hip) multiply one f16 product per fp32 product: the throughput mode that stands for the
-// reference's fp16 autocast of the attention block (models/attn.py:248, `use_amp: true`); own tolerance in the tests.
-static const bool GEMM_ONE_PRODUCT_ENV = GEMM_MODE == 5;
-// The one-product arithmetic can also be asked for call by call (papr_mlp_precision: the host maps the reference's `use_amp: true`
-// to it) -- on top of the default mode only, so that the A/B modes stay what they say.  Thread-local: set by
-// the caller right before papr_mlp_fwd / papr_mlp_bwd.
-static thread_local int t_one_product = 0;
-static inline bool one_product_now() { return GEMM_ONE_PRODUCT_ENV || (t_one_product != 0 && GEMM_MODE == 4); }
-#define GEMM_ONE_PRODUCT one_product_now()
-static const bool GEMM_H3_FWD = GEMM_MODE >= 1, GEMM_H3 = GEMM_MODE >= 2, GEMM_H3_WGRAD = GEMM_MODE >= 3, GEMM_CHAIN = GEMM_MODE >= 4;
+// The mode is an ARGUMENT of papr_mlp_fwd / papr_mlp_bwd / papr_mlp_bwd_needs_weight_t (include/papr_hip.h: PAPR_MLP_*): the library reads no
+// environment variable for it and keeps no setting between calls.  Inside a call it sits in a thread-local context so that the helpers
+// below need not all carry it; the entry points set it from their argument first thing.
+//   h1 (PAPR_MLP_H1): h3, and the fused runs (chain4.hip) multiply one f16 product per fp32 product: the throughput mode that stands for
+//   the reference's fp16 autocast of the attention block (models/attn.py:248, `use_amp: true`); own tolerance in the tests.
+static thread_local int t_mode = 4;            // 0 f32, 1 fwd, 2 dgrad, 3 layers, 4 h3, 5 h1
+static inline int mode_from_arg(int32_t m) {
+    switch (m) { case PAPR_MLP_F32: return 0; case PAPR_MLP_FWD: return 1; case PAPR_MLP_DGRAD: return 2; case PAPR_MLP_LAYERS: return 3;
+                 case PAPR_MLP_H1: return 5; default: return 4; }
+}
+#define GEMM_MODE t_mode
+#define GEMM_ONE_PRODUCT (t_mode == 5)
+#define GEMM_H3_FWD (t_mode >= 1)
+#define GEMM_H3 (t_mode >= 2)
+#define GEMM_H3_WGRAD (t_mode >= 3)
+#define GEMM_CHAIN (t_mode >= 4)
+static inline bool one_product_now() { return t_mode == 5; }
 
 // Caller-provided scratch of the split-f16 mode, carved from the workspace argument of papr_mlp_fwd / _bwd:
 // two per-row max|.| arrays (rows of the layer input / of its output, swapped after every layer) and the
@@ -1302,12 +1300,6 @@ __global__ __launch_bounds__(256) void act_grad_kernel(float* g, long ldg, const
 
 constexpr size_t TN_SLAB_BYTES = (size_t)TN_BATCH * TN_JOB_FLOATS * sizeof(float);      // partial tiles of a batch of weight-gradients
 
-extern "C" int papr_mlp_precision(int32_t one_product) {
-    const int prev = t_one_product;
-    t_one_product = one_product ? 1 : 0;
-    return prev;
-}
-
 extern "C" size_t papr_mlp_fwd_workspace_bytes(int64_t M) { return H3Scratch::bytes(M); }
 extern "C" size_t papr_mlp_saved_floats(int32_t n_layers, int64_t M) { return (size_t)n_layers * (M + CHAIN_SIGN_WORDS * chain_sign_rows(M)); }
 
@@ -1409,7 +1401,8 @@ static int chain_split_launch(const SplitBatch& b, int n, hipStream_t s) {
 
 extern "C" int papr_mlp_fwd(const papr_layer* layers, int n_layers, float* x, int ldx, int64_t M,
                             float* const* outs, const int32_t* ld_out, float* row_absmax, const papr_row_norm* in_norm,
-                            const papr_row_norm* out_norm, void* workspace, papr_stream_t stream) {
+                            const papr_row_norm* out_norm, void* workspace, int32_t mode, papr_stream_t stream) {
+    t_mode = mode_from_arg(mode);
     PAPR_REQUIRE(layers && x && outs && ld_out && n_layers >= 1, "papr_mlp_fwd: bad arguments");
     hipStream_t s = as_stream(stream);
     bool have_amax = false;                 // split-f16 mode: row maxima of the current layer's input are in h3.in()
@@ -1518,10 +1511,11 @@ struct BwdRunScratch {
         for (int i = 0; i < CHAIN_MAX_LAYERS; ++i) { g[i] = q; q += (size_t)M * G_LD; }
         for (int i = 0; i <= CHAIN_MAX_LAYERS; ++i) { gmax[i] = q; q += M; }
     }
-    static size_t bytes(long M) { return GEMM_CHAIN ? ((size_t)CHAIN_MAX_LAYERS * M * G_LD + (size_t)(CHAIN_MAX_LAYERS + 1) * M + 4) * sizeof(float) : 0; }
+    static size_t bytes(long M) { return ((size_t)CHAIN_MAX_LAYERS * M * G_LD + (size_t)(CHAIN_MAX_LAYERS + 1) * M + 4) * sizeof(float); }
 };
 
-extern "C" int papr_mlp_bwd_needs_weight_t(const papr_layer* layers, int n_layers, int need_dx) {
+extern "C" int papr_mlp_bwd_needs_weight_t(const papr_layer* layers, int n_layers, int need_dx, int32_t mode) {
+    t_mode = mode_from_arg(mode);
     if (!layers || n_layers < 1) return 1;
     bool any_skip = false;
     for (int i = 0; i < n_layers; ++i) any_skip |= layers[i].n_skip > 0;
@@ -1540,7 +1534,8 @@ extern "C" size_t papr_mlp_bwd_workspace_bytes(int64_t M) { return TN_SLAB_BYTES
 extern "C" int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float* x, int ldx, int64_t M,
                             float* const* outs, const int32_t* ld_out, const float* row_absmax, float* d_out,
                             float* scratch0, float* scratch1, int ld_scratch, float* const* d_weight,
-                            float* const* d_bias, float* d_x, void* workspace, papr_stream_t stream) {
+                            float* const* d_bias, float* d_x, void* workspace, int32_t mode, papr_stream_t stream) {
+    t_mode = mode_from_arg(mode);
     PAPR_REQUIRE(layers && x && outs && ld_out && d_out && d_weight && d_bias && workspace && n_layers >= 1,
                  "papr_mlp_bwd: bad arguments");
     PAPR_REQUIRE(n_layers == 1 || (scratch0 && scratch1), "papr_mlp_bwd: scratch buffers required");

@@ -13,7 +13,9 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PAPR_HIP_LIB", os.path.join(_PKG, "libpapr_hip.so"))   # override: instrumented builds (scripts/probes)
 
 ACT = {"none": 0, "relu": 1, "leakyrelu": 2}
-EXPECTED_ABI = 15          # papr_abi_version() of the library these argtypes were written for
+EXPECTED_ABI = 16
+# `mode` argument of papr_mlp_fwd / papr_mlp_bwd (include/papr_hip.h: PAPR_MLP_*)
+MLP_MODES = {"h3": 0, "h1": 1, "f32": 2, "fwd": 3, "dgrad": 4, "layers": 5}          # papr_abi_version() of the library these argtypes were written for
 
 EXPORTS = [
     "papr_abi_version", "papr_last_error", "papr_ray_knn_workspace_bytes", "papr_ray_knn",
@@ -21,7 +23,7 @@ EXPORTS = [
     "papr_segment_reduce", "papr_group_pairs_workspace_bytes", "papr_group_pairs", "papr_points_knn",
     "papr_rownorm_fwd", "papr_rownorm_bwd", "papr_ln_fold_fwd", "papr_ln_fold_bwd", "papr_mlp_fwd_workspace_bytes", "papr_mlp_bwd_workspace_bytes", "papr_mlp_saved_floats", "papr_mlp_bwd_needs_weight_t", "papr_mlp_fwd",
     "papr_mlp_bwd",
-    "papr_attn_tail_fwd", "papr_attn_tail_bwd", "papr_conv3x3_weight_halfs", "papr_conv3x3_workspace_bytes", "papr_conv3x3_fwd", "papr_conv3x3_wgrad_workspace_bytes", "papr_conv3x3_wgrad", "papr_maxpool2_fwd", "papr_maxpool2_bwd", "papr_upconv2x2_fwd", "papr_upconv2x2_dgrad", "papr_upconv2x2_wgrad_workspace_bytes", "papr_upconv2x2_wgrad", "papr_conv1x1_fwd", "papr_conv1x1_bwd_workspace_bytes", "papr_conv1x1_bwd", "papr_adam_step", "papr_mlp_precision", "papr_composite_fwd", "papr_composite_bwd_workspace_bytes", "papr_composite_bwd", "papr_profile_enable", "papr_profile_collect",
+    "papr_attn_tail_fwd", "papr_attn_tail_bwd", "papr_conv3x3_weight_halfs", "papr_conv3x3_workspace_bytes", "papr_conv3x3_fwd", "papr_conv3x3_wgrad_workspace_bytes", "papr_conv3x3_wgrad", "papr_maxpool2_fwd", "papr_maxpool2_bwd", "papr_upconv2x2_fwd", "papr_upconv2x2_dgrad", "papr_upconv2x2_wgrad_workspace_bytes", "papr_upconv2x2_wgrad", "papr_conv1x1_fwd", "papr_conv1x1_bwd_workspace_bytes", "papr_conv1x1_bwd", "papr_adam_step", "papr_composite_fwd", "papr_composite_bwd_workspace_bytes", "papr_composite_bwd", "papr_profile_enable", "papr_profile_collect",
 ]
 
 
@@ -109,7 +111,6 @@ def lib():
     L.papr_conv1x1_bwd_workspace_bytes.argtypes = [i64, i32, i32]
     L.papr_conv1x1_bwd.argtypes = [vp, vp, i64, i32, vp, i32, vp, vp, vp, vp, vp]
     L.papr_adam_step.argtypes = [vp, i32, vp, i32, vp]
-    L.papr_mlp_precision.argtypes = [i32]
     L.papr_composite_fwd.argtypes = [vp, vp, i32, i32, vp, i64, i32, i32, vp, vp]
     L.papr_composite_bwd_workspace_bytes.restype = C.c_size_t
     L.papr_composite_bwd_workspace_bytes.argtypes = [i64]
@@ -120,12 +121,12 @@ def lib():
     L.papr_mlp_fwd_workspace_bytes.argtypes = [i64]
     L.papr_mlp_bwd_workspace_bytes.restype = C.c_size_t
     L.papr_mlp_bwd_workspace_bytes.argtypes = [i64]
-    L.papr_mlp_bwd_needs_weight_t.argtypes = [C.POINTER(Layer), i32, i32]
+    L.papr_mlp_bwd_needs_weight_t.argtypes = [C.POINTER(Layer), i32, i32, i32]
     L.papr_mlp_saved_floats.restype = C.c_size_t
     L.papr_mlp_saved_floats.argtypes = [i32, i64]
-    L.papr_mlp_fwd.argtypes = [C.POINTER(Layer), i32, vp, i32, i64, C.POINTER(vp), C.POINTER(C.c_int32), vp, C.POINTER(RowNorm), C.POINTER(RowNorm), vp, vp]
+    L.papr_mlp_fwd.argtypes = [C.POINTER(Layer), i32, vp, i32, i64, C.POINTER(vp), C.POINTER(C.c_int32), vp, C.POINTER(RowNorm), C.POINTER(RowNorm), vp, i32, vp]
     L.papr_mlp_bwd.argtypes = [C.POINTER(Layer), i32, vp, i32, i64, C.POINTER(vp), C.POINTER(C.c_int32), vp, vp, vp, vp,
-                               i32, C.POINTER(vp), C.POINTER(vp), vp, vp, vp]
+                               i32, C.POINTER(vp), C.POINTER(vp), vp, vp, i32, vp]
     L.papr_attn_tail_fwd.argtypes = [C.POINTER(TailDesc), vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp]
     L.papr_attn_tail_bwd.argtypes = [C.POINTER(TailDesc), vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.papr_profile_enable.argtypes = [i32]

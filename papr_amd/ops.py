@@ -18,6 +18,17 @@ import torch.nn.functional as F
 from . import hip
 
 
+def mlp_mode(one_product):
+    """The `mode` argument of papr_mlp_fwd / papr_mlp_bwd (include/papr_hip.h: PAPR_MLP_*) for one call.  The library itself reads no
+    environment: PAPR_GEMM_MODE (h3 default | h1 | layers | dgrad | fwd | f32: A/B and benchmark switch) is THIS module's, and a
+    `use_amp: true` model asks for the one-product arithmetic call by call (on top of the default mode only, so that the A/B modes
+    stay what they say)."""
+    name = os.environ.get("PAPR_GEMM_MODE", "h3")
+    if name == "h3" and one_product:
+        name = "h1"
+    return hip.MLP_MODES[name]
+
+
 def _pad4(n):
     return (n + 3) // 4 * 4
 
@@ -30,7 +41,7 @@ class MlpSpec:
     """Static description of one embedding MLP (reference models/mlp.py:12-45 as configured by
     models/attn.py:152-163)."""
 
-    one_product = False        # True: this MLP's library calls run in the one-product (h1) arithmetic (papr_mlp_precision)
+    one_product = False        # True: this MLP's library calls run in the one-product (h1) arithmetic (mode argument PAPR_MLP_H1)
 
     def __init__(self, name, d_in, ecfg):
         self.name = name
@@ -418,10 +429,9 @@ def mlp_forward(spec, ws, bs, x, M, keep=True, out_norm=None, in_norm=None):
     if out_norm is not None:
         outs.norm_stats = torch.empty((M, 2), device=dev, dtype=torch.float32)
         norm = C.byref(hip.RowNorm(out_norm[1], out_norm[0], outs.norm_stats.data_ptr()))
-    hip.lib().papr_mlp_precision(1 if spec.one_product else 0)
     hip.check(hip.lib().papr_mlp_fwd(tab, spec.n_layer, hip.ptr(x), x.shape[1], M, hip.ptr_array(outs),
                                      hip.i32_array(spec.ld_out), hip.ptr(outs.row_absmax), inorm, norm,
-                                     hip.ptr(_workspace(dev, "fwd", M)), hip.stream_ptr()), "papr_mlp_fwd")
+                                     hip.ptr(_workspace(dev, "fwd", M)), mlp_mode(spec.one_product), hip.stream_ptr()), "papr_mlp_fwd")
     return outs
 
 
@@ -442,18 +452,17 @@ def mlp_backward(spec, ws, bs, x, M, outs, d_out, scratch, need_dx):
     """Returns (d_ws, d_bs, d_x or None).  d_out is consumed."""
     dev = x.device
     tab = _layer_table(spec, ws, bs)
-    if hip.lib().papr_mlp_bwd_needs_weight_t(tab, spec.n_layer, 1 if need_dx else 0):     # (fused runs read W^T in place)
+    if hip.lib().papr_mlp_bwd_needs_weight_t(tab, spec.n_layer, 1 if need_dx else 0, mlp_mode(spec.one_product)):     # (fused runs read W^T in place)
         wts = [w.t().contiguous() for w in ws]
         tab = _layer_table(spec, ws, bs, wts)
     d_ws = [torch.empty_like(w) for w in ws]
     d_bs = [torch.empty_like(b) for b in bs]
     d_x = torch.empty_like(x) if need_dx else None
-    hip.lib().papr_mlp_precision(1 if spec.one_product else 0)          # (the setting of this chain's forward call)
     hip.check(hip.lib().papr_mlp_bwd(tab, spec.n_layer, hip.ptr(x), x.shape[1], M, hip.ptr_array(outs),
                                      hip.i32_array(spec.ld_out), hip.ptr(getattr(outs, "row_absmax", None)),
                                      hip.ptr(d_out), hip.ptr(scratch[0]), hip.ptr(scratch[1]),
                                      scratch[0].shape[1], hip.ptr_array(d_ws), hip.ptr_array(d_bs), hip.ptr(d_x),
-                                     hip.ptr(_workspace(dev, "bwd", M)), hip.stream_ptr()), "papr_mlp_bwd")
+                                     hip.ptr(_workspace(dev, "bwd", M)), mlp_mode(spec.one_product), hip.stream_ptr()), "papr_mlp_bwd")
     return d_ws, d_bs, d_x
 
 
@@ -505,9 +514,8 @@ def linear_rows(x, w):
     t = tab[0]
     t.weight, t.weight_t, t.bias = w.data_ptr(), None, None
     t.n_in, t.n_out, t.ldw, t.ldwt, t.n_skip, t.skip_col, t.act = x.shape[1], n_out, w.shape[1], 0, 0, 0, 0
-    hip.lib().papr_mlp_precision(0)
     hip.check(hip.lib().papr_mlp_fwd(tab, 1, hip.ptr(x), x.shape[1], M, hip.ptr_array([out]), hip.i32_array([n_out]),
-                                     None, None, None, hip.ptr(_workspace(x.device, "fwd", M)), hip.stream_ptr()), "papr_mlp_fwd")
+                                     None, None, None, hip.ptr(_workspace(x.device, "fwd", M)), mlp_mode(False), hip.stream_ptr()), "papr_mlp_fwd")
     return out
 
 

@@ -392,7 +392,7 @@ def test_use_amp_true_as_shipped_three_steps_and_scaler_behaviour():
 
 
 def test_use_amp_selects_the_one_product_arithmetic_call_by_call():
-    """`use_amp: true` maps the embedding MLPs to the library's one-product arithmetic (papr_mlp_precision; the reference runs its
+    """`use_amp: true` maps the embedding MLPs to the library's one-product arithmetic (the `mode` argument of papr_mlp_fwd / papr_mlp_bwd; the reference runs its
     attention block under fp16 autocast then, models/attn.py:248).  Two models in ONE process, one with the flag and one without,
     interleaved: each keeps its own arithmetic forward and backward -- the fp32 one stays bit-identical to a run without the other,
     the AMP one stays within the h1 tolerance of it (tests/test_hip_h1.py) and is not bit-identical."""
