@@ -29,6 +29,7 @@
 // the k-th distance are unordered in the reference (topk sorted=False); here the first one met in
 // the (fixed) stream order is kept, so results are reproducible run to run.
 #include "papr_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -101,6 +102,18 @@ __device__ __forceinline__ float ray_dist2(const RayK& c, float px, float py, fl
     return __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
 }
 
+// The same quantity with contracted arithmetic: 13 VALU operations instead of 22.  NOT used for the selection itself -- only as a
+// conservative filter in front of it: a point whose cheap distance lies more than 1/64 above the current k-th distance cannot beat
+// it in exact arithmetic either (the two evaluations differ by rounding only: relative 1e-7 x |v| / |D|, i.e. below 1e-4 for any
+// point near the threshold in scenes of this scale), so the exact, reference-ordered evaluation runs only for the few batches that hold
+// such a point (a few percent once the threshold has settled).  Round 2's profile had the kernel bound by exactly these VALU operations.
+__device__ __forceinline__ float ray_dist2_fast(const RayK& c, float px, float py, float pz) {
+    const float vx = px - c.ox, vy = py - c.oy, vz = pz - c.oz;
+    const float tt = __builtin_fmaf(vz, c.dz, __builtin_fmaf(vy, c.dy, vx * c.dx)) * c.rcp;
+    const float ex = __builtin_fmaf(-c.dx, tt, vx), ey = __builtin_fmaf(-c.dy, tt, vy), ez = __builtin_fmaf(-c.dz, tt, vz);
+    return __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
+}
+
 constexpr unsigned INF_BITS = 0x7f800000u;
 
 // One ray's k-set: lanes < k hold (distance bits, point index), unordered; lanes >= k hold 0 bits.
@@ -108,11 +121,15 @@ struct KSet {
     unsigned bits;   // per lane
     int idx;         // per lane
     unsigned thr;    // uniform: largest member = current k-th smallest
+    unsigned thr_hi; // uniform: thr x (1 + 1/64): what the cheap distance is tested against
     int tl;          // uniform: a lane holding it
     __device__ __forceinline__ void refresh() {
         thr = wave_umax(bits);
+        thr_hi = __float_as_uint(__uint_as_float(thr) * 1.015625f);
         tl = __builtin_ctzll(__ballot(bits == thr));
     }
+    // does any lane hold a point that may enter the set? (cheap distances)
+    __device__ __forceinline__ bool may_enter(float d2_fast) const { return __ballot(__float_as_uint(d2_fast) < thr_hi) != 0; }
     // offer the candidates flagged in d2 < thr; DEDUP skips points that are already members (seeded sets)
     template <bool DEDUP>
     __device__ __forceinline__ void offer(float d2, int pidx, int lane) {
@@ -158,7 +175,7 @@ __global__ __launch_bounds__(256) void ray_knn_kernel(const float4* __restrict__
         rk[t].dy = p[4]; rk[t].dz = p[5]; rk[t].den = p[6]; rk[t].rcp = p[7];
     }
     KSet ks[T];
-    ks[0].bits = lane < k ? INF_BITS : 0u; ks[0].idx = -1; ks[0].thr = INF_BITS; ks[0].tl = 0;
+    ks[0].bits = lane < k ? INF_BITS : 0u; ks[0].idx = -1; ks[0].thr = INF_BITS; ks[0].thr_hi = INF_BITS; ks[0].tl = 0;
 
     // ---- phase A: ray 0 against every point
     for (int base = 0; base < P; base += 64 * PPL) {
@@ -167,8 +184,10 @@ __global__ __launch_bounds__(256) void ray_knn_kernel(const float4* __restrict__
             int pi = base + q * 64 + lane;
             bool ok = pi < P;
             float4 v = stream[ok ? pi : P - 1];
-            float d2 = ray_dist2(rk[0], v.x, v.y, v.z);
-            ks[0].template offer<false>(ok ? d2 : INFINITY, __float_as_int(v.w), lane);
+            if (ks[0].may_enter(ok ? ray_dist2_fast(rk[0], v.x, v.y, v.z) : INFINITY)) {
+                float d2 = ray_dist2(rk[0], v.x, v.y, v.z);
+                ks[0].template offer<false>(ok ? d2 : INFINITY, __float_as_int(v.w), lane);
+            }
         }
     }
     // ---- seed rays 1..T-1 with ray 0's neighbours
@@ -199,8 +218,10 @@ __global__ __launch_bounds__(256) void ray_knn_kernel(const float4* __restrict__
         for (int t = 1; t < T; ++t) {
 #pragma unroll
             for (int q = 0; q < PPL; ++q) {
-                float d2 = ray_dist2(rk[t], px[q], py[q], pz[q]);
-                ks[t].template offer<true>(ok[q] ? d2 : INFINITY, pidx[q], lane);
+                if (ks[t].may_enter(ok[q] ? ray_dist2_fast(rk[t], px[q], py[q], pz[q]) : INFINITY)) {
+                    float d2 = ray_dist2(rk[t], px[q], py[q], pz[q]);
+                    ks[t].template offer<true>(ok[q] ? d2 : INFINITY, pidx[q], lane);
+                }
             }
         }
     }
@@ -250,11 +271,29 @@ extern "C" int papr_ray_knn(const float* points, int64_t P, const float* rays_o,
     PAPR_CHECK_LAUNCH("pack_rays");
     scatter_points_kernel<<<dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s>>>(points, (int)P, P > 1 ? coprime_stride(P) : 0, pstream);
     PAPR_CHECK_LAUNCH("scatter_points");
-    constexpr int T = 8, PPL = 4;
-    long tiles = (R + T - 1) / T;
+    // Rays per wave T: a tile costs ~(1.8 + T - 1) ray passes over the cloud (its first ray starts cold, the others are seeded), and the
+    // launch takes as long as the SIMD with the most tiles: ceil(tiles / SIMDs) of them.  With T = 8 a 160 x 160 patch is 3,200 tiles on
+    // 1,024 SIMDs -- 4 on some, 3.125 on average, a quarter of the machine idle at the end (round 2); T = 5 makes it exactly 5 each.
+    constexpr int PPL = 4;
+    static int n_simd = 0;
+    if (!n_simd) { int dev = 0, cu = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev); n_simd = 4 * (cu > 0 ? cu : 256); }
+    static const int t_env = getenv("PAPR_KNN_T") ? atoi(getenv("PAPR_KNN_T")) : 0;      // (A/B switch)
+    int T = 8;
+    double best = 1e300;
+    for (int t : {4, 5, 6, 8}) {
+        const long tl = (R + t - 1) / t;
+        const double cost = (double)((tl + n_simd - 1) / n_simd) * (0.8 + t);
+        if (cost < best - 1e-9) { best = cost; T = t; }
+    }
+    if (t_env == 4 || t_env == 5 || t_env == 6 || t_env == 8) T = t_env;
+    const long tiles = (R + T - 1) / T;
+    const dim3 grid((unsigned)((tiles + 3) / 4)), block(256);
     const bool prof = papr_prof_on();
     if (prof) papr_prof_begin(5, R, (int)P, k, s);
-    ray_knn_kernel<T, PPL><<<dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, s>>>(pstream, points, (int)P, rec, R, k, out_idx, out_dist);
+    if (T == 4) ray_knn_kernel<4, PPL><<<grid, block, 0, s>>>(pstream, points, (int)P, rec, R, k, out_idx, out_dist);
+    else if (T == 5) ray_knn_kernel<5, PPL><<<grid, block, 0, s>>>(pstream, points, (int)P, rec, R, k, out_idx, out_dist);
+    else if (T == 6) ray_knn_kernel<6, PPL><<<grid, block, 0, s>>>(pstream, points, (int)P, rec, R, k, out_idx, out_dist);
+    else ray_knn_kernel<8, PPL><<<grid, block, 0, s>>>(pstream, points, (int)P, rec, R, k, out_idx, out_dist);
     if (prof) papr_prof_end(s);
     PAPR_CHECK_LAUNCH("ray_knn");
     return 0;
