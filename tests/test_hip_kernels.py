@@ -614,14 +614,17 @@ def test_conv1x1_forward_and_gradients_match_torch(B, H, W, c_in, c_out):
 
 
 @pytest.mark.parametrize("hw", [(40, 40), (24, 36)])
-def test_small_unet_on_own_kernels_matches_torch_module(hw):
+@pytest.mark.parametrize("use_amp", [False, True])
+def test_small_unet_on_own_kernels_matches_torch_module(hw, use_amp):
     """The whole SmallUNet (reference models/unet.py:182-258) on this library's kernels against the same module run by torch
     in float64 on the CPU: output and every parameter / input gradient; and no layer of the device run may go through
-    aten / MIOpen convolution or pooling (profiler check of the launched kernels)."""
+    aten / MIOpen convolution or pooling (profiler check of the launched kernels).  use_amp (what every shipped scene file sets;
+    the reference autocasts the module to fp16 there, models/unet.py:212): the same kernels, the same bars -- the head is not handed
+    to torch autocast + MIOpen."""
     import copy
     from papr_amd.unet import SmallUNet
     torch.manual_seed(3)
-    net = SmallUNet(32, 3)
+    net = SmallUNet(32, 3, use_amp=use_amp)
     x = torch.randn(1, 32, *hw)
     gy = torch.randn(1, 3, *hw) * 1e-2
     ref = copy.deepcopy(net).double()

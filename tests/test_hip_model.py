@@ -341,8 +341,8 @@ def test_full_size_chair_step_properties():
 
 def test_use_amp_true_as_shipped_three_steps_and_scaler_behaviour():
     """The reference's SHIPPED default is `use_amp: true` (configs/default.yml:6-7): GradScaler live (models/model.py:24-26,
-    train.py:174-177), the U-Net under fp16 autocast (models/unet.py:212), the attention block under autocast
-    (models/attn.py:248).  Three train steps of the G7 case with the flag left on: finite, the loss trajectory within 1e-3 of
+    train.py:174-177), the U-Net under fp16 autocast (models/unet.py:212; here: on the library's own split-f16 kernels, papr_amd/unet.py),
+    the attention block under autocast (models/attn.py:248; here: the one-product arithmetic).  Three train steps of the G7 case with the flag left on: finite, the loss trajectory within 1e-3 of
     the reference's fp32 trajectory (fp16 rounding of the render head; the reference's own AMP run differs from its fp32 run
     by the same order), the scale stays at its initial 65536 while gradients are finite, and a step whose gradients overflow
     is skipped (parameters untouched, scale halved) exactly as torch's GradScaler prescribes."""
