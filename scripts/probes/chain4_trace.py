@@ -25,7 +25,7 @@ buf = (ctypes.c_longlong * 2048)()
 hip.lib().papr_chain4_trace_read(buf)
 t = list(buf)
 NS = int(os.environ.get("STAMPS", "5"))
-names = ["P1", "barrier", "first", "second", "end"] if NS == 5 else ["P1", "barrier", "A", "B", "C", "D", "end"]
+names = (["decide", "operands", "statement", "barrier", "loop"] if os.environ.get("HOT") else ["P1", "barrier", "first", "second", "end"]) if NS == 5 else ["P1", "barrier", "A", "B", "C", "D", "end"]
 tot = [0.0] * NS
 cnt = 0
 s0, s1 = int(os.environ.get("S0", "4")), int(os.environ.get("S1", "12"))

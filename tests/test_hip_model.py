@@ -310,11 +310,8 @@ def test_full_size_chair_step_properties():
 
     tgt = torch.rand(1, 160, 160, 3, generator=g).cuda()
 
-    class FirstThree(torch.nn.Module):       # the U-Net runs on MIOpen, whose transposed convolutions are not run-to-run deterministic:
-        def forward(self, x, gamma=None, beta=None):      # a fixed head takes its place for the bit-exact part
-            return x[:, :3]
-    m.renderer = FirstThree()
-
+    # (the U-Net head is in: every layer runs on the library's own kernels, whose reductions -- taps, pixel chunks, bias sums -- run in a
+    # fixed order, and whose split-f16 scales are powers of two taken from the tensors)
     def grads(scale):
         for p in m.parameters():
             p.grad = None
@@ -327,7 +324,7 @@ def test_full_size_chair_step_properties():
     out2, g2 = grads(1.0)
     assert torch.equal(out1, out2)
     mine = list(g1)
-    assert len(mine) > 40
+    assert len(mine) > 40 and any(n.startswith("renderer.") for n in mine)
     per_point = ("points", "pc_feats", "points_influ_scores")       # segment sums that straddle a 128-pair chunk meet through atomics
     close = lambda a, b: torch.all((a - b).abs() <= 2e-6 * b.abs().max())
     _, g3 = grads(2.0)
