@@ -104,6 +104,45 @@ def k_stream(acc_t, ld, kcnt=16):
     return pro, steps
 
 
+def k_stream_one(acc_t, ld, kcnt=16):
+    """the same for the one-product mode (h1): two MFMAs per k-step (hi.hi for the two 32-row tiles), hi fragments only -- in TWO buffers
+    (the lo fragments' registers are free), each re-read for k-step ks + 2 right behind its use; hi weights only."""
+    a0, a1 = vt(acc_t, 16), vt(acc_t + 16, 16)
+    buf = [(F["h0"], F["h1"]), (F["l0"], F["l1"])]
+    KB = [KA, AD2]                              # one address temporary per buffer (AD2: the row phases of this mode do not need it)
+
+    def rd(j, ks):
+        b = ks & 1
+        return Item("ds_read_b128 %s, %s offset:%d" % (buf[b][j], KB[b] if ks & 7 else "%[pbx]", (32768 if j else 0) + (256 if ks >= 8 else 0)), lds=("f", j, ks), kind="lds")
+
+    def addr(ks):
+        return [Item("v_xor_b32 %s, 0x%x, %%[pbx]" % (KB[ks & 1], 32 * (ks & 7)))] if ks & 7 else []
+
+    pro = [rd(0, 0), rd(1, 0)] + (addr(1) + [rd(0, 1), rd(1, 1)] if kcnt > 1 else [])
+    if ld:
+        pro += [Item("s_mov_b32 s90, %[nhlo]", kind="salu"), Item("s_mov_b32 s91, %[nhhi]", kind="salu")]
+        if kcnt < 16:
+            pro += [Item("s_add_u32 s94, s90, 0x%x" % ((kcnt >> 2) * 4096), kind="salu"), Item("s_addc_u32 s95, s91, 0", kind="salu")]
+            for ks in range(kcnt, 16):
+                pro.append(Item("global_load_dwordx4 %s, %%[wv], s[94:95] offset:%d" % (wh(ks), (ks & 3) * 1024), kind="vmem"))
+                if ks & 3 == 3 and ks < 15:
+                    pro += [Item("s_add_u32 s94, s94, 0x1000", kind="salu"), Item("s_addc_u32 s95, s95, 0", kind="salu")]
+    steps = []
+    for ks in range(kcnt):
+        nx = ks + 2 if ks + 2 < kcnt else None
+        b = ks & 1
+        m0 = Item("v_mfma_f32_32x32x16_f16 %s, %s, %s, %s" % (a0, wh(ks), buf[b][0], "0" if ks == 0 else a0), need=[("f", 0, ks)], kind="mfma")
+        m1 = Item("v_mfma_f32_32x32x16_f16 %s, %s, %s, %s" % (a1, wh(ks), buf[b][1], "0" if ks == 0 else a1), need=[("f", 1, ks)], kind="mfma")
+        steps.append((m0, (addr(nx) + [rd(0, nx)]) if nx is not None else []))
+        post = [rd(1, nx)] if nx is not None else []
+        if ld:
+            post.append(Item("global_load_dwordx4 %s, %%[wv], %s offset:%d" % (wh(ks), SNH, (ks & 3) * 1024), kind="vmem"))
+            if ks & 3 == 3 and ks < kcnt - 1:
+                post += [Item("s_add_u32 s90, s90, 0x1000", kind="salu"), Item("s_addc_u32 s91, s91, 0", kind="salu")]
+        steps.append((m1, post))
+    return pro, steps
+
+
 def p1_stream(acc_u, mode, act):
     """P1 on U's accumulators (first register acc_u).  mode: fwd (training forward), inf, dgrad; act: relu, leaky"""
     it = []
@@ -156,7 +195,7 @@ def p1_stream(acc_u, mode, act):
     return it
 
 
-def p2_stream(acc_u, mode):
+def p2_stream(acc_u, mode, one=False):
     it = []
     PM = G[0:8]
     MX, E, T = G[8], G[9], G[10]
@@ -182,6 +221,33 @@ def p2_stream(acc_u, mode):
                Item("v_sub_u32 %s, 0x10b, %s" % (T, E)), Item("v_med3_i32 %s, %s, 1, %%[c254]" % (T, T)), Item("v_lshlrev_b32 %s, 23, %s" % (SC[i], T)),
                Item("v_add_u32 %s, -13, %s" % (T, E)), Item("v_med3_i32 %s, %s, 1, %%[c254]" % (T, T)), Item("v_lshlrev_b32 %s, 23, %s" % (IN[i], T)),
                Item("ds_write_b32 %%[invad], %s offset:%d" % (IN[i], 128 * i), lds=("invw", i), kind="lds")]
+    if one:
+        # ---- one-product mode: hi planes only; the f16 rows the weight gradient reads (ChainLayer::c_half) ARE the hi plane's bytes (each row
+        # times its power-of-two scale): written to the planes, read back sixteen rows per instruction (four lanes per row's 64 bytes), stored
+        H = ["v%d" % (GB + j) for j in range(4)]
+        for i in range(2):
+            for q in range(2):
+                regs = ["v%d" % (acc_u + 16 * i + 8 * q + e) for e in range(8)]
+                for j in range(4):
+                    it.append(Item("v_fma_mixlo_f16 %s, %s, %s, 0" % (H[j], regs[2 * j], SC[i])))
+                for j in range(4):
+                    it.append(Item("v_fma_mixhi_f16 %s, %s, %s, 0" % (H[j], regs[2 * j + 1], SC[i])))
+                dst = "%[plw]"
+                if q:
+                    it.append(Item("v_xor_b32 %s, 16, %%[plw]" % AD))
+                    dst = AD
+                it.append(Item("ds_write_b128 %s, %s offset:%d" % (dst, vt(GB, 4), 32768 * i), lds=("plh", i, q), kind="lds"))
+                it.append(Item("s_nop 1", kind="salu"))
+        if train:
+            R = [vt(GB, 4), vt(GB + 4, 4)]          # (the split is done: its registers are free)
+            for sx in range(4):
+                src = "%[rdb]"
+                if sx:
+                    it.append(Item("v_xor_b32 %s, 0x%x, %%[rdb]" % (AD, 528 * sx)))
+                    src = AD
+                it.append(Item("ds_read_b128 %s, %s" % (R[sx & 1], src), lds=("rb", sx), kind="lds"))
+                it.append(Item("global_store_dwordx4 %%[gso], %s, %%[crow0] offset:%d" % (R[sx & 1], 512 * sx), need=[("rb", sx)], kind="vmem"))
+        return it
     if train:
         # ---- the rows: into the wave's own 128 bytes of every plane row (where its split goes afterwards) ...
         for i in range(2):
@@ -247,11 +313,11 @@ class Emit:
         self.lines.pop()
 
 
-def build(tile, mode, act, ld, kcnt=16):
+def build(tile, mode, act, ld, kcnt=16, one=False):
     acc_t, acc_u = (ACC["X"], ACC["Y"]) if tile == "X" else (ACC["Y"], ACC["X"])
-    pro, steps = k_stream(acc_t, ld, kcnt)
-    NM = 6 * kcnt                               # matrix instructions of the statement
-    p1, p2 = p1_stream(acc_u, mode, act), p2_stream(acc_u, mode)
+    pro, steps = k_stream_one(acc_t, ld, kcnt) if one else k_stream(acc_t, ld, kcnt)
+    NM = len(steps)                             # matrix instructions of the statement
+    p1, p2 = p1_stream(acc_u, mode, act), p2_stream(acc_u, mode, one)
     e = Emit()
     for x in pro:
         e.put(x)
@@ -272,7 +338,7 @@ def build(tile, mode, act, ld, kcnt=16):
         e.put(mf)
         for x in post:
             e.put(x)
-        if m == 5:
+        if m == 5 and not one:
             # ---- the input rows of the tile this workgroup stages a few slots from now (this wave's eight), pulled towards the caches:
             # every CU stages at the same moment, 16 MB in one burst, and a staging slot took 23k cycles against 10k for a hot one
             # (scripts/probes/chain4_trace.py).  Plain loads into four registers nobody reads; pfs = the rows' stride in bytes, 0 = not now.
@@ -327,6 +393,12 @@ if __name__ == "__main__":
                     total[(mode, act, tile, ld)] = len(lines)
             for kcnt in (8, 10):                # the run's first layer on tile Y (on tile X its slot also stages the next tile: no fused form)
                 emit("C4F_%s_%s_Y_LD_K%d" % (mode.upper(), act.upper(), kcnt), build("Y", mode, act, 1, kcnt))
+            # one-product mode (h1)
+            for tile in ("X", "Y"):
+                for ld in ((0,) if tile == "X" else (0, 1)):
+                    emit("C4F1_%s_%s_%s_%s" % (mode.upper(), act.upper(), tile, "LD" if ld else "NL"), build(tile, mode, act, ld, 16, True))
+            for kcnt in (8, 10):
+                emit("C4F1_%s_%s_Y_LD_K%d" % (mode.upper(), act.upper(), kcnt), build("Y", mode, act, 1, kcnt, True))
     print("#define C4F_CLOBBERS " + ", ".join('"%s"' % v for v in CLOB_V) + ', "vcc", "memory"')
     print('#define C4F_LD_CLOBBERS "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97"')
     print("#define C4F_AGPRS " + ", ".join('"a%d"' % i for i in range(128)))
