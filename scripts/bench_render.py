@@ -28,3 +28,8 @@ for _ in range(n):
     rgb = render_full(m, rayo, rayd, c2w, chunk, chunk)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
 print("render 800x800, P=%d, chunk %dx%d: %.1f ms/image, %.2f M rays/s" % (P, chunk, chunk, dt * 1e3, 0.64 / dt))
+if len(sys.argv) > 3:       # a JSON record for profiles/
+    import json
+    json.dump({"workload": "configs/nerfsyn/lego.yml (value MLP with skip layer 5, LeakyReLU), P=%d points, one 800x800 view = 640,000 rays through PAPR.evaluate in "
+                           "%dx%d chunks + SmallUNet + compositing (reference test_step loop, test.py:59-104); fp32 parity mode; data resident" % (P, chunk, chunk),
+               "ms_per_image": dt * 1e3, "rays_per_s": 0.64e6 / dt, "images_timed": n, "warmup_images": 2}, open(sys.argv[3], "w"), indent=1)
