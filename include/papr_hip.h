@@ -133,6 +133,10 @@ int papr_rownorm_fwd(const float* x, int64_t rows, int width, int ld, float eps,
                      papr_stream_t stream);
 int papr_rownorm_bwd(const float* dy, const float* y, const float* stats, int64_t rows, int width, int ld,
                      float eps, float* dx, papr_stream_t stream);
+/* dots[m] = rows[m] . dot_rows[m / rows_per_dot] over `width` columns, m < M: the stand-alone form of papr_row_norm.dots (what
+ * papr_mlp_fwd runs when the last layer is not inside a fused run). */
+int papr_row_dots(const float* rows, int64_t M, int width, int ld, const float* dot_rows, int ld_dot, int rows_per_dot,
+                  float* dots, papr_stream_t stream);
 
 /* The affine part of that LayerNorm, y = a_2 * xh + b_2 (models/attn.py:42), folded into the Linear layer behind it:
  *   W (a_2 * xh + b_2) + c  =  (W * a_2) xh + (W b_2 + c).
@@ -183,6 +187,14 @@ typedef struct {
     float eps;
     int32_t width;      /* logical row width (= n_out of the last layer) */
     float* stats;       /* (M, 2) */
+    /* out_norm only, optional (dots != NULL; ABI 17): dots[m] = y_m . dot_rows[m / rows_per_dot] over `width` columns -- the attention
+     * scores' dot products (models/attn.py:219-221, with dot_rows = W_k^T (W_q Q + b_q) of the ray that owns row m) taken where the
+     * standardised key rows are produced.  In inference (row_absmax == NULL) outs[n_layers-1] is then UNDEFINED afterwards: a fused run
+     * never writes the (R*k, d_model) key embedding (papr_attn_tail_fwd: precomputed_dots).  Ignored for in_norm. */
+    const float* dot_rows;  /* (ceil(M / rows_per_dot), ld_dot) */
+    int32_t ld_dot;         /* floats, a multiple of 4 */
+    int32_t rows_per_dot;
+    float* dots;            /* (M) */
 } papr_row_norm;
 
 /* `mode` of papr_mlp_fwd / papr_mlp_bwd / papr_mlp_bwd_needs_weight_t: which arithmetic and which kernels carry the call.  An argument of
@@ -235,6 +247,8 @@ typedef struct {
     int32_t normalize;
     float bkg_score;
     int32_t scale_dim;      /* scores are divided by sqrt(scale_dim) (the reference's d_model); 0 -> d_model */
+    int32_t precomputed_dots;   /* papr_attn_tail_fwd only (ABI 17): 1 = kp holds the R*k dot products qp . kp_j already
+                                 * (papr_row_norm.dots of the key MLP's call); qp is not read */
 } papr_tail_desc;
 
 int papr_attn_tail_fwd(const papr_tail_desc* d, const float* kp, const float* qp, const float* score_bias,

@@ -41,6 +41,9 @@ struct ChainArgs {
     int in_norm_writeback;                // memory as well (training: the backward pass reads them; runs with a skip layer)
     float norm_eps;                       // forward: with norm_stats, the LAST layer's rows are standardised (LayerNorm core,
     float* norm_stats;                    // papr_row_norm in papr_hip.h) before they are stored; (M, 2) = 1/(std+eps), std
+    const float* dot_rows; long ld_dot;   // with norm_stats and dots: dots[m] = (standardised row m) . dot_rows[m / rows_per_dot] -- the
+    int rows_per_dot;                     // attention scores' dot products straight from the last row phase (the last layer's C may then
+    float* dots;                          // be null: inference never writes the key embedding); (M) floats
     ChainLayer L[CHAIN_MAX_LAYERS];
 };
 

@@ -1408,6 +1408,10 @@ extern "C" int papr_mlp_fwd(const papr_layer* layers, int n_layers, float* x, in
     bool have_amax = false;                 // split-f16 mode: row maxima of the current layer's input are in h3.in()
     bool norm_done = false;
     PAPR_REQUIRE(!out_norm || (out_norm->stats && out_norm->width >= 2), "papr_mlp_fwd: out_norm needs stats and a width");
+    const bool want_dots = out_norm && out_norm->dots;
+    PAPR_REQUIRE(!want_dots || (out_norm->dot_rows && out_norm->rows_per_dot >= 1 && out_norm->ld_dot % 4 == 0 && out_norm->ld_dot >= out_norm->width),
+                 "papr_mlp_fwd: out_norm->dots needs dot_rows with 16-byte rows of at least `width` floats and rows_per_dot >= 1");
+    bool dots_done = false;
     PAPR_REQUIRE(!in_norm || (in_norm->stats && in_norm->width >= 2 && in_norm->width <= ldx), "papr_mlp_fwd: in_norm needs stats and a width <= ldx");
     if (in_norm && !(chain_run_end(layers, n_layers, 0, true) >= 2))      // not staged by a fused run: one pass over x first
         if (int e = papr_rownorm_fwd(x, M, in_norm->width, ldx, in_norm->eps, x, in_norm->stats, stream)) return e;
@@ -1454,6 +1458,12 @@ extern "C" int papr_mlp_fwd(const papr_layer* layers, int n_layers, float* x, in
             if (out_norm && e == n_layers && layers[e - 1].act == PAPR_ACT_NONE && out_norm->width == layers[e - 1].n_out) {
                 c.norm_eps = out_norm->eps; c.norm_stats = out_norm->stats;      // standardised in the run's last row phase
                 norm_done = true;
+                if (want_dots) {                    // ... and multiplied with its ray's row there; inference: the rows themselves stay on the chip
+                    c.dot_rows = out_norm->dot_rows; c.ld_dot = out_norm->ld_dot; c.rows_per_dot = out_norm->rows_per_dot; c.dots = out_norm->dots;
+                    dots_done = true;
+                    if (!saved) { bytes -= 4LL * M * layers[e - 1].n_out; c.L[e - 1 - i].C = nullptr; }
+                    bytes += 4LL * M + 4LL * ((M + c.rows_per_dot - 1) / c.rows_per_dot) * layers[e - 1].n_out;
+                }
             }
             split.perm = 1;
             if (int err = chain_split_launch(split, e - i, s)) return err;
@@ -1494,8 +1504,11 @@ extern "C" int papr_mlp_fwd(const papr_layer* layers, int n_layers, float* x, in
         if (int e = gemm_nt(a, s)) return e;
     }
     if (out_norm && !norm_done)             // not inside a fused run: one more pass over the rows
-        return papr_rownorm_fwd(outs[n_layers - 1], M, out_norm->width, ld_out[n_layers - 1], out_norm->eps, outs[n_layers - 1],
-                                out_norm->stats, stream);
+        if (int e = papr_rownorm_fwd(outs[n_layers - 1], M, out_norm->width, ld_out[n_layers - 1], out_norm->eps, outs[n_layers - 1],
+                                     out_norm->stats, stream)) return e;
+    if (want_dots && !dots_done)
+        return papr_row_dots(outs[n_layers - 1], M, out_norm->width, ld_out[n_layers - 1], out_norm->dot_rows, out_norm->ld_dot,
+                             out_norm->rows_per_dot, out_norm->dots, stream);
     return 0;
 }
 

@@ -102,6 +102,9 @@ __global__ __launch_bounds__(256) void tail_fwd_kernel(papr_tail_desc d, const f
     const float inv_sqrt_d = 1.0f / sqrtf((float)(d.scale_dim > 0 ? d.scale_dim : d.d_model));
     const float* q = qp + r * d.ld_qp;
     float my_score = 0.f;
+    if (d.precomputed_dots) {
+        if (lane < k) my_score = kp[r * k + lane];
+    } else {
     // TG key rows per round: their 1 KB loads are in flight together (one row at a time is a chain of load latencies;
     // 1 row: 202 us, 4: 178 us, 10: 175 us per 25,600 x 20 x 256 launch)
     constexpr int TG = 4;
@@ -125,6 +128,7 @@ __global__ __launch_bounds__(256) void tail_fwd_kernel(papr_tail_desc d, const f
             const float dot = wave_sum(part[u]);
             if (lane == j0 + u) my_score = dot;          // (j0 + u >= k repeats row k-1 into a lane that is masked below)
         }
+    }
     }
     if (score_bias) my_score += score_bias[r];
     float z = -INFINITY;
@@ -342,6 +346,31 @@ extern "C" int papr_rownorm_fwd(const float* x, int64_t rows, int width, int ld,
     return 0;
 }
 
+// dots[m] = rows[m] . dot_rows[m / rows_per_dot]: one wave per row (the stand-alone form of what a fused run's last row phase does)
+__global__ __launch_bounds__(256) void row_dots_kernel(const float* __restrict__ rows, long M, int width, int ld,
+                                                       const float* __restrict__ dot_rows, int ld_dot, int rows_per_dot,
+                                                       float* __restrict__ dots) {
+    const int lane = threadIdx.x & 63;
+    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const float* a = rows + m * ld;
+    const float* g = dot_rows + (m / rows_per_dot) * ld_dot;
+    float part = 0.f;
+    for (int c = lane; c < width; c += 64) part = fmaf(a[c], g[c], part);
+    part = wave_sum(part);
+    if (lane == 0) dots[m] = part;
+}
+
+extern "C" int papr_row_dots(const float* rows, int64_t M, int width, int ld, const float* dot_rows, int ld_dot,
+                             int rows_per_dot, float* dots, papr_stream_t stream) {
+    PAPR_REQUIRE(rows && dot_rows && dots, "papr_row_dots: null pointer");
+    PAPR_REQUIRE(width >= 1 && ld >= width && ld_dot >= width && rows_per_dot >= 1, "papr_row_dots: width %d / ld %d / ld_dot %d / rows_per_dot %d", width, ld, ld_dot, rows_per_dot);
+    if (M <= 0) return 0;
+    row_dots_kernel<<<dim3((unsigned)((M + 3) / 4)), dim3(256), 0, as_stream(stream)>>>(rows, M, width, ld, dot_rows, ld_dot, rows_per_dot, dots);
+    PAPR_CHECK_LAUNCH("row_dots");
+    return 0;
+}
+
 extern "C" int papr_rownorm_bwd(const float* dy, const float* y, const float* stats, int64_t rows, int width, int ld,
                                 float eps, float* dx, papr_stream_t stream) {
     (void)eps;
@@ -367,7 +396,7 @@ extern "C" int papr_attn_tail_fwd(const papr_tail_desc* d, const float* kp, cons
                                   const float* v, const float* influ, const int32_t* idx, int64_t R, float* scores, float* attn,
                                   float* fused, papr_stream_t stream) {
     if (int e = check_tail(d, "papr_attn_tail_fwd")) return e;
-    PAPR_REQUIRE(kp && qp && v && influ && idx && scores && attn && fused, "papr_attn_tail_fwd: null pointer");
+    PAPR_REQUIRE(kp && (qp || d->precomputed_dots) && v && influ && idx && scores && attn && fused, "papr_attn_tail_fwd: null pointer");
     if (R <= 0) return 0;
     tail_fwd_kernel<<<dim3((unsigned)((R + 3) / 4)), dim3(256), 0, as_stream(stream)>>>(*d, kp, qp, v, score_bias, influ, idx, R, scores, attn, fused);
     PAPR_CHECK_LAUNCH("tail_fwd");

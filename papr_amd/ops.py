@@ -406,13 +406,16 @@ class LayerOutputs(list):
     row_absmax = None
     norm_stats = None
     in_stats = None
+    dots = None
 
 
-def mlp_forward(spec, ws, bs, x, M, keep=True, out_norm=None, in_norm=None):
+def mlp_forward(spec, ws, bs, x, M, keep=True, out_norm=None, in_norm=None, dot_rows=None, rows_per_dot=1):
     """Run the chain; returns the list of layer outputs (all kept, or two ping-pong buffers).
     out_norm = (width, eps): the last output comes back row-standardised (LayerNorm core), outs.norm_stats holds
     the (M, 2) statistics papr_rownorm_bwd needs.  in_norm = (width, eps): x is standardised first (outs.in_stats; x itself
-    is overwritten, except in inference inside a fused run, where nobody reads it again)."""
+    is overwritten, except in inference inside a fused run, where nobody reads it again).
+    dot_rows (with out_norm): outs.dots (M,) = standardised row m . dot_rows[m // rows_per_dot]; without `keep` the last output
+    itself is then undefined (a fused run does not write it)."""
     dev = x.device
     outs = LayerOutputs()
     if keep:
@@ -428,7 +431,11 @@ def mlp_forward(spec, ws, bs, x, M, keep=True, out_norm=None, in_norm=None):
         inorm = C.byref(hip.RowNorm(in_norm[1], in_norm[0], outs.in_stats.data_ptr()))
     if out_norm is not None:
         outs.norm_stats = torch.empty((M, 2), device=dev, dtype=torch.float32)
-        norm = C.byref(hip.RowNorm(out_norm[1], out_norm[0], outs.norm_stats.data_ptr()))
+        rn = hip.RowNorm(out_norm[1], out_norm[0], outs.norm_stats.data_ptr())
+        if dot_rows is not None:
+            outs.dots = torch.empty(M, device=dev, dtype=torch.float32)
+            rn.dot_rows, rn.ld_dot, rn.rows_per_dot, rn.dots = dot_rows.data_ptr(), dot_rows.stride(0), rows_per_dot, outs.dots.data_ptr()
+        norm = C.byref(rn)
     hip.check(hip.lib().papr_mlp_fwd(tab, spec.n_layer, hip.ptr(x), x.shape[1], M, hip.ptr_array(outs),
                                      hip.i32_array(spec.ld_out), hip.ptr(outs.row_absmax), inorm, norm,
                                      hip.ptr(_workspace(dev, "fwd", M)), mlp_mode(spec.one_product), hip.stream_ptr()), "papr_mlp_fwd")
@@ -436,6 +443,7 @@ def mlp_forward(spec, ws, bs, x, M, keep=True, out_norm=None, in_norm=None):
 
 
 _ws_cache = {}
+_SCORES_IN_RUN = os.environ.get("PAPR_SCORES_IN_RUN", "1") != "0"
 
 
 def _workspace(dev, kind, M):
@@ -706,25 +714,30 @@ class _RenderFn(torch.autograd.Function):
         eps = plan.eps
         # (the LayerNorm cores in front of and behind the key / query MLPs ride in the fused runs: rows are standardised
         # while they are staged, and again in the last row phase)
-        k_outs = mlp_forward(plan.key, kw, kb, key_in, M, keep, (plan.key.d_out, eps) if plan.kq_norm else None,
-                             (plan.key_w, eps) if plan.kq_norm else None)
         q_outs = mlp_forward(plan.qry, qw, qb, qry_in, R, keep, (plan.qry.d_out, eps) if plan.kq_norm else None,
                              (plan.qry_w, eps) if plan.kq_norm else None)
-        K, Q = k_outs[-1], q_outs[-1]
-        kst, qst, kst2, qst2 = k_outs.in_stats, q_outs.in_stats, k_outs.norm_stats, q_outs.norm_stats
+        Q = q_outs[-1]
         # score_j = (W_q Q + b_q).(W_k K_j + b_k) = K_j.(W_k^T q') + b_k.q'  with q' = W_q Q + b_q: the R*k-row w_k
         # product of the reference (models/attn.py:217) becomes two R-row products (plain library GEMMs)
         qp = mlp_forward(plan.wq, wqw, wqb, Q, R, True)[0]
         w_aug = torch.cat([wkw[0].t(), wkb[0][None, :], wkb[0].new_zeros((3, wkb[0].shape[0]))], 0).contiguous()
         g = linear_rows(qp, w_aug)                           # (R, key.d_out + 4): [W_k^T q' | b_k.q' | 0 0 0]
         c0 = g[:, plan.key.d_out].contiguous()               # (R,)
+        # inference: the dot products K_j.g are taken in the key run's last row phase, the (R*k, d_model) key embedding is never
+        # written (1 KB per pair out and back in again otherwise); PAPR_SCORES_IN_RUN=0 for the A/B
+        in_run = (not keep) and plan.kq_norm and _SCORES_IN_RUN
+        k_outs = mlp_forward(plan.key, kw, kb, key_in, M, keep, (plan.key.d_out, eps) if plan.kq_norm else None,
+                             (plan.key_w, eps) if plan.kq_norm else None, dot_rows=g if in_run else None, rows_per_dot=k)
+        K = k_outs[-1]
+        kst, qst, kst2, qst2 = k_outs.in_stats, q_outs.in_stats, k_outs.norm_stats, q_outs.norm_stats
         v_outs = mlp_forward(plan.val, vw, vb, val_in, M, keep)
         V = v_outs[-1]
         td = plan.tail_desc(k)
+        td.precomputed_dots = int(in_run)
         scores = torch.empty((R, k), device=dev, dtype=torch.float32)
         attn = torch.empty((R, k + 1), device=dev, dtype=torch.float32)
         fused = torch.empty((R, plan.C), device=dev, dtype=torch.float32)
-        hip.check(lib.papr_attn_tail_fwd(C.byref(td), hip.ptr(K), hip.ptr(g), hip.ptr(c0), hip.ptr(V), hip.ptr(influ), hip.ptr(idx), R,
+        hip.check(lib.papr_attn_tail_fwd(C.byref(td), hip.ptr(k_outs.dots if in_run else K), hip.ptr(g), hip.ptr(c0), hip.ptr(V), hip.ptr(influ), hip.ptr(idx), R,
                                          hip.ptr(scores), hip.ptr(attn), hip.ptr(fused), hip.stream_ptr()), "papr_attn_tail_fwd")
         ctx.plan, ctx.rpi, ctx.n = plan, rays_per_image, (n_k, n_q, n_v)
         ctx.mark_non_differentiable(sel)

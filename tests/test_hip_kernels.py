@@ -392,6 +392,45 @@ def test_mlp_forward_backward_vs_torch(M, d_in, width, d_out, n, act, skips):
     np.testing.assert_allclose(d_x2.cpu().numpy(), d_x.cpu().numpy(), rtol=0, atol=3e-5 * sx)
 
 
+@pytest.mark.parametrize("R,k,d_in,width,d_out,n", [(1234, 20, 117, 256, 256, 5), (61, 7, 39, 256, 64, 3), (300, 20, 27, 64, 32, 2), (5, 63, 117, 256, 256, 5)])
+def test_row_dots_from_the_last_row_phase(R, k, d_in, width, d_out, n):
+    """papr_row_norm.dots: the score dot products leave the fused key run instead of the key embedding (inference), and equal what
+    the standardised rows give when they are written and multiplied afterwards (papr_row_dots, torch).  The (300, .., 64, 32) chain is
+    too narrow for a fused run: there the library's own fallback (rows, then papr_row_dots) answers."""
+    from papr_amd import hip, ops
+    import ctypes as C
+    gen = torch.Generator().manual_seed(R)
+    M = R * k
+    ecfg = dict(n_ff_layer=n, d_ff=width, d_ff_out=d_out, norm="none", ff_act="relu", ff_last_act="none", skip_layers=[])
+    spec = ops.MlpSpec("t", d_in, ecfg)
+    d = dev()
+    ws = [((torch.rand(d_out if i == n - 1 else width, d_in if i == 0 else width, generator=gen) * 2 - 1) * 0.15).to(d) for i in range(n)]
+    bs = [((torch.rand(d_out if i == n - 1 else width, generator=gen) * 2 - 1) * 0.1).to(d) for i in range(n)]
+    ew, eb = ops.prepare_mlp_weights(spec, ws, bs)
+    xp = torch.zeros(M, spec.ld_in); xp[:, :d_in] = torch.randn(M, d_in, generator=gen)
+    g = torch.zeros(R, d_out + 4); g[:, :d_out] = torch.randn(R, d_out, generator=gen)
+    gd = g.to(d)
+    eps = 1e-6
+    plain = ops.mlp_forward(spec, ew, eb, xp.to(d), M, keep=False, out_norm=(d_out, eps))
+    rows = plain[-1].clone()
+    want = (rows[:, :d_out].double().view(R, k, d_out) * gd[:, None, :d_out].double()).sum(-1).view(-1)
+    tol = 2e-6 * float((rows[:, :d_out].double().norm(dim=1).max() * gd.double().norm(dim=1).max()))
+    own = torch.empty(M, device=d)
+    hip.check(hip.lib().papr_row_dots(hip.ptr(rows), M, d_out, rows.stride(0), hip.ptr(gd), gd.stride(0), k, hip.ptr(own), hip.stream_ptr()), "papr_row_dots")
+    np.testing.assert_allclose(own.cpu().numpy(), want.cpu().numpy(), rtol=0, atol=tol)
+    inf = ops.mlp_forward(spec, ew, eb, xp.to(d), M, keep=False, out_norm=(d_out, eps), dot_rows=gd, rows_per_dot=k)
+    np.testing.assert_allclose(inf.dots.cpu().numpy(), want.cpu().numpy(), rtol=0, atol=tol)
+    assert torch.equal(inf.norm_stats, plain.norm_stats)
+    # training form: rows AND dots; the rows are the ones a call without dots writes, the dots the inference call's
+    kept = ops.mlp_forward(spec, ew, eb, xp.to(d), M, keep=True, out_norm=(d_out, eps), dot_rows=gd, rows_per_dot=k)
+    assert torch.equal(kept[-1], rows) and torch.equal(kept.dots, inf.dots)
+    # every row stands alone: a chunk of the rows gives the same bits
+    M2 = (R // 2) * k
+    if M2:
+        part = ops.mlp_forward(spec, ew, eb, xp[:M2].to(d), M2, keep=False, out_norm=(d_out, eps), dot_rows=gd, rows_per_dot=k)
+        assert torch.equal(part.dots, inf.dots[:M2])
+
+
 # ------------------------------------------------------------------------------------------- K4
 @pytest.mark.parametrize("R,k,d_model,Cc,act,normalize", [(300, 20, 256, 32, "relu", True), (65, 12, 64, 3, "relu", True),
                                                           (17, 1, 256, 32, "none", False), (40, 63, 128, 32, "leakyrelu", True)])

@@ -169,7 +169,17 @@ def test_chunked_evaluate_is_chunk_invariant_and_matches_oracle_at_10k_points():
                 f, _ = m.evaluate(ro_d, rd_d[:, h0:h0 + 7, w0:w0 + 9].contiguous(), c2w_d)
                 parts[:, h0:h0 + 7, w0:w0 + 9] = f
         out = O.render(st, cfg, ro, rd, want_rgb=False)
+        # inference takes the scores' dot products in the key run's last row phase; the other route (key embedding written, read
+        # back by the attention tail) must paint the same picture
+        from papr_amd import ops
+        ops._SCORES_IN_RUN = False
+        try:
+            full_b, attn_b = m.evaluate(ro_d, rd_d, c2w_d)
+        finally:
+            ops._SCORES_IN_RUN = True
     assert torch.equal(parts, full)
+    np.testing.assert_allclose(full_b.cpu().numpy(), full.cpu().numpy(), rtol=0, atol=1e-5)
+    np.testing.assert_allclose(attn_b.cpu().numpy(), attn_full.cpu().numpy(), rtol=0, atol=1e-5)
     assert np.array_equal(np.sort(m.select_k_ind.cpu().numpy()[0, -3:, -2:], -1),
                           np.sort(out["idx"].numpy()[0, 21:, 18:], -1))
     np.testing.assert_allclose(full.squeeze(-2).cpu().numpy(), out["fused"].numpy(), rtol=0, atol=RGB_TOL)
