@@ -723,9 +723,10 @@ class _RenderFn(torch.autograd.Function):
         w_aug = torch.cat([wkw[0].t(), wkb[0][None, :], wkb[0].new_zeros((3, wkb[0].shape[0]))], 0).contiguous()
         g = linear_rows(qp, w_aug)                           # (R, key.d_out + 4): [W_k^T q' | b_k.q' | 0 0 0]
         c0 = g[:, plan.key.d_out].contiguous()               # (R,)
-        # inference: the dot products K_j.g are taken in the key run's last row phase, the (R*k, d_model) key embedding is never
-        # written (1 KB per pair out and back in again otherwise); PAPR_SCORES_IN_RUN=0 for the A/B
-        in_run = (not keep) and plan.kq_norm and _SCORES_IN_RUN
+        # the dot products K_j.g are taken in the key run's last row phase: in inference the (R*k, d_model) key embedding is never written
+        # (1 KB per pair out and back in again otherwise), in training the attention tail does not read it back (the backward pass does);
+        # PAPR_SCORES_IN_RUN=0 for the A/B
+        in_run = plan.kq_norm and _SCORES_IN_RUN
         k_outs = mlp_forward(plan.key, kw, kb, key_in, M, keep, (plan.key.d_out, eps) if plan.kq_norm else None,
                              (plan.key_w, eps) if plan.kq_norm else None, dot_rows=g if in_run else None, rows_per_dot=k)
         K = k_outs[-1]
