@@ -299,11 +299,12 @@ def main():
         "roofline_wgrad_h3": wg if wg_ms > 0 and dominant is not wg else None,
         "roofline_mlp_chain": ch if ch_ms > 0 and dominant is not ch else None,
         "roofline_conv3x3": conv_line(),
-        "roofline_knn": {"kernel": "ray_knn_kernel<8,4>", "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+        "roofline_knn": {"kernel": "ray_knn_blocks_kernel (P >= 2,048: binned cloud, bounding spheres; the three binning kernels, ~18 us, are not in avg_launch_ms)", "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
                          "achieved": knn_bytes / (knn_ms * 1e-3) / 1e9 if knn_ms > 0 else 0.0,
                          "frac": knn_bytes / (knn_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if knn_ms > 0 else 0.0,
                          "avg_launch_ms": knn_ms, "logical_bytes_per_launch": knn_bytes,
-                         "note": "logical bytes (12P+12+4k per ray); the cloud is L2-resident so physical HBM traffic is far lower"},
+                         "note": "logical bytes (12P+12+4k per ray: what an every-point-against-every-ray search reads); the spatial form looks at ~20 % "
+                                 "of the points and the cloud is L2-resident, so physical HBM traffic is far lower; the kernel is bound by instruction issue"},
     }
     if os.environ.get("PAPR_BENCH_LAUNCHES"):           # per-shape launch table of the timed steps, on stderr
         tab = {}

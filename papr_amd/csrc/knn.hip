@@ -3,6 +3,10 @@
 // Replaces PAPR._calculate_global_distances (reference models/model.py:258-283), which materialises
 // five R x P fp32 tensors and runs torch.topk over them.  Here nothing of size R x P ever exists.
 //
+// Two forms.  Clouds of 2,048 points and more: the SPATIAL form further down (ray_knn_blocks_kernel: the cloud binned and cut into blocks
+// of 64 points with bounding spheres, a ray walks only the blocks that can hold a nearer point; 197 -> 158 us at P = 10,000, 448 -> 235 us
+// at 30,000, per 25,600 rays, binning included).  Smaller clouds, and PAPR_KNN_BLOCKS=0: every point against every ray, described here.
+//
 // Work decomposition (wave64, one wave = one tile of T rays against ALL points):
 //   * the 64 lanes of a wave each hold PPL points of the current batch in VGPRs (coalesced 16-byte
 //     loads of a {x,y,z,index} stream); the batch is reused for all T rays of the tile, so the point
@@ -30,6 +34,7 @@
 // the (fixed) stream order is kept, so results are reproducible run to run.
 #include "papr_common.h"
 #include <stdlib.h>
+#include <algorithm>
 
 namespace {
 
@@ -39,8 +44,9 @@ typedef __attribute__((address_space(4))) const float cfloat;
 __global__ __launch_bounds__(256) void pack_rays_kernel(const float* __restrict__ rays_o,
                                                         const float* __restrict__ rays_d, long R,
                                                         long rays_per_image, float eps,
-                                                        float* __restrict__ rec) {
+                                                        float* __restrict__ rec, unsigned* __restrict__ zero, int n_zero) {
     long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (long i = r; i < n_zero; i += (long)gridDim.x * blockDim.x) zero[i] = 0u;      // (the binning's cell counters and cursors)
     if (r >= R) return;
     long n = r / rays_per_image;
     float dx = rays_d[r * 3 + 0], dy = rays_d[r * 3 + 1], dz = rays_d[r * 3 + 2];
@@ -243,6 +249,308 @@ __global__ __launch_bounds__(256) void ray_knn_kernel(const float4* __restrict__
     }
 }
 
+// ================================================================================================
+// The spatial form (P >= KNN_BLOCKS_MIN_P): the cloud is binned on a 16^3 grid over its bounding box, laid out in Morton order of
+// the cells and cut into blocks of 64 consecutive points with a bounding sphere each (three small kernels per launch:
+// the points move every training step; knn_count / knn_place / knn_bounds).  A ray then tests the SPHERES first -- 64 blocks per instruction, one per lane -- and only
+// walks the blocks that can still hold a point nearer than its current k-th distance: ~17 of 156 blocks at P = 10,000, ~23 of 469
+// at 30,000, instead of every point.  Exact all the same: a block is skipped only if  dist(centre, line) - radius - slack  is not
+// below the k-th distance, where the slack covers the rounding of both evaluations; the points of a visited block get the
+// reference-ordered distance (ray_dist2) as before.
+//
+// A wave owns a run of T consecutive rays (neighbouring pixels) and works through them one after the other; ray i + 1 starts from
+// ray i's neighbour set (exact distances recomputed), so only the first ray of a run starts cold -- and that one walks the blocks
+// its line pierces first, which brings the k-th distance down before the rest is looked at.
+//
+// Ties: the set is the k smallest by (distance, index) -- a total order, so the result does not depend on the order in which the
+// points are met (the binning places the points of a cell with LDS atomics, in no particular order) nor on the seed.
+
+constexpr int KNN_CELLS = 16;                   // per axis
+
+__device__ __forceinline__ unsigned spread4(unsigned v) { return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4) | ((v & 8u) << 6); }
+
+__device__ __forceinline__ float shfl_xor_f(float v, int m) { return __shfl_xor(v, m, 64); }
+
+constexpr int KNN_NCELL = KNN_CELLS * KNN_CELLS * KNN_CELLS;
+constexpr int KNN_SAMPLE = 1024;
+
+// The grid's box: the bounding box of a fixed sample of 1,024 points, found by every workgroup for itself (12 KB out of L2, the same
+// reduction everywhere, so every workgroup of every kernel lands on the same bits).  Points outside it are clamped into the border
+// cells -- the grid only has to group neighbours, the spheres are taken from the points themselves.
+struct CellGrid {
+    float org[3], inv[3];
+    __device__ __forceinline__ unsigned cell_of(float x, float y, float z) const {
+        const unsigned cx = (unsigned)fminf(fmaxf((x - org[0]) * inv[0], 0.f), (float)(KNN_CELLS - 1));      // (NaN -> 0)
+        const unsigned cy = (unsigned)fminf(fmaxf((y - org[1]) * inv[1], 0.f), (float)(KNN_CELLS - 1));
+        const unsigned cz = (unsigned)fminf(fmaxf((z - org[2]) * inv[2], 0.f), (float)(KNN_CELLS - 1));
+        return spread4(cx) | (spread4(cy) << 1) | (spread4(cz) << 2);
+    }
+};
+
+// (1,024 threads)
+__device__ __forceinline__ CellGrid sample_grid(const float* __restrict__ points, int P, float (*red)[16], float* bb) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long step = P > KNN_SAMPLE ? P / KNN_SAMPLE : 1;
+    const long i = (long)tid * step;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    if (i < P) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { const float v = points[i * 3 + a]; lo[a] = fminf(lo[a], v); hi[a] = fmaxf(hi[a], v); }      // (a NaN drops out)
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { lo[a] = fminf(lo[a], shfl_xor_f(lo[a], m)); hi[a] = fmaxf(hi[a], shfl_xor_f(hi[a], m)); }
+        if (lane == 0) { red[a][wave] = lo[a]; red[3 + a][wave] = hi[a]; }
+    }
+    __syncthreads();
+    if (tid < 6) {
+        float v = red[tid][0];
+        for (int w = 1; w < 16; ++w) v = tid < 3 ? fminf(v, red[tid][w]) : fmaxf(v, red[tid][w]);
+        bb[tid] = v;
+    }
+    __syncthreads();
+    CellGrid g;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        g.org[a] = bb[a];
+        const float ext = bb[3 + a] - bb[a];
+        g.inv[a] = ext > 0.f && ext < INFINITY ? (float)KNN_CELLS / ext : 0.f;
+        if (!(g.org[a] > -INFINITY && g.org[a] < INFINITY)) { g.org[a] = 0.f; g.inv[a] = 0.f; }
+    }
+    return g;
+}
+
+// points per cell (counts[] zeroed by pack_rays_kernel)
+__global__ __launch_bounds__(1024) void knn_count_kernel(const float* __restrict__ points, int P, unsigned* __restrict__ counts) {
+    __shared__ float red[6][16];
+    __shared__ float bb[6];
+    const CellGrid g = sample_grid(points, P, red, bb);
+    const long i = (long)blockIdx.x * 1024 + threadIdx.x;
+    if (i < P) atomicAdd(&counts[g.cell_of(points[i * 3], points[i * 3 + 1], points[i * 3 + 2])], 1u);
+}
+
+// every point to its place in the Morton-ordered stream: offset of its cell (prefix over the counts, redone per workgroup: 4,096 values) + a
+// ticket from the cell's cursor (cursors[] zeroed by pack_rays_kernel).  The order inside a cell is whatever the atomics give.
+__global__ __launch_bounds__(1024) void knn_place_kernel(const float* __restrict__ points, int P, const unsigned* __restrict__ counts,
+                                                         unsigned* __restrict__ cursors, float4* __restrict__ stream) {
+    __shared__ float red[6][16];
+    __shared__ float bb[6];
+    __shared__ unsigned off[KNN_NCELL];
+    __shared__ unsigned wtot[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const CellGrid g = sample_grid(points, P, red, bb);
+    {
+        const unsigned c0 = counts[4 * tid], c1 = counts[4 * tid + 1], c2 = counts[4 * tid + 2], c3 = counts[4 * tid + 3];
+        const unsigned mine = c0 + c1 + c2 + c3;
+        unsigned incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const unsigned o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();
+        unsigned base = 0;
+        for (int w = 0; w < wave; ++w) base += wtot[w];
+        const unsigned ex = base + incl - mine;
+        off[4 * tid] = ex; off[4 * tid + 1] = ex + c0; off[4 * tid + 2] = ex + c0 + c1; off[4 * tid + 3] = ex + c0 + c1 + c2;
+    }
+    __syncthreads();
+    const long i = (long)blockIdx.x * 1024 + tid;
+    if (i < P) {
+        const float x = points[i * 3], y = points[i * 3 + 1], z = points[i * 3 + 2];
+        const unsigned c = g.cell_of(x, y, z);
+        const unsigned pos = off[c] + atomicAdd(&cursors[c], 1u);
+        stream[pos] = make_float4(x, y, z, __int_as_float((int)i));
+    }
+    const long nb64 = ((long)P + 63) / 64 * 64;
+    if (i >= P && i < nb64) stream[i] = make_float4(points[0], points[1], points[2], __int_as_float(-1));     // (padding, masked by its position)
+}
+
+// one wave per block of 64 stream positions: bounding sphere (centre of the block's box, largest distance to it, rounded outwards)
+__global__ __launch_bounds__(256) void knn_bounds_kernel(const float4* __restrict__ stream, int P, int nblk, float4* __restrict__ blk) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= nblk) return;
+    const int pi = b * 64 + lane;
+    const float4 v = stream[pi < P ? pi : b * 64];
+    float l[3] = {v.x, v.y, v.z}, h[3] = {v.x, v.y, v.z};
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { l[a] = fminf(l[a], shfl_xor_f(l[a], m)); h[a] = fmaxf(h[a], shfl_xor_f(h[a], m)); }
+    const float cx = 0.5f * (l[0] + h[0]), cy = 0.5f * (l[1] + h[1]), cz = 0.5f * (l[2] + h[2]);
+    const float dx = v.x - cx, dy = v.y - cy, dz = v.z - cz;
+    float d2 = dx * dx + dy * dy + dz * dz;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) d2 = fmaxf(d2, shfl_xor_f(d2, m));
+    // (NaN / infinite coordinates: an infinite radius -- the block is always visited and the exact evaluation decides; fmaxf drops a NaN, so test the sum too)
+    float r = sqrtf(d2) * 1.000002f + 1e-30f;
+    const float chk = (l[0] + h[0]) + (l[1] + h[1]) + (l[2] + h[2]);
+    float any_nan = (v.x == v.x && v.y == v.y && v.z == v.z) ? 0.f : 1.f;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) any_nan = fmaxf(any_nan, shfl_xor_f(any_nan, m));
+    const bool bad = !(r < INFINITY) || !(chk == chk) || !(chk > -INFINITY && chk < INFINITY) || any_nan != 0.f;
+    if (lane == 0) blk[b] = bad ? make_float4(0.f, 0.f, 0.f, INFINITY) : make_float4(cx, cy, cz, r);
+}
+
+// One ray's k-set under the total order (distance bits, index), kept SORTED across lanes 0 .. k-1 (ascending; entries that are not
+// filled yet are (inf, -1) and count as the largest): the k-th distance is lane k-1's, an insertion is one whole-wave shift by a lane
+// (DPP wave_shr:1) behind the candidate's place -- no maximum to look for again, no ranking at the end.
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, 0xf, 0xf, false); }
+
+struct KSetT {
+    unsigned bits;   // per lane
+    int idx;         // per lane; -1 = not filled yet (counts as the largest index)
+    unsigned thr;    // uniform: distance bits of the largest member
+    unsigned thr_idx;// uniform: its index
+    int k;
+#ifdef KNN_DEBUG_VISITS
+    int n_ins = 0, n_off = 0;
+#endif
+    __device__ __forceinline__ void refresh() {
+        thr = (unsigned)__builtin_amdgcn_readlane((int)bits, k - 1);
+        thr_idx = (unsigned)__builtin_amdgcn_readlane(idx, k - 1);
+    }
+    // lanes < k hold k entries in any order -> ascending (k rounds of rank counting, one forward permute)
+    __device__ __forceinline__ void sort(int lane) {
+        int rank = 0;
+        for (int j = 0; j < k; ++j) {
+            const unsigned bj = (unsigned)__builtin_amdgcn_readlane((int)bits, j);
+            const unsigned ij = (unsigned)__builtin_amdgcn_readlane(idx, j);
+            rank += (bj < bits || (bj == bits && ij < (unsigned)idx)) ? 1 : 0;
+        }
+        const int to = (lane < k ? rank : lane) * 4;
+        bits = (unsigned)__builtin_amdgcn_ds_permute(to, (int)bits);
+        idx = __builtin_amdgcn_ds_permute(to, idx);
+        refresh();
+    }
+    // DEDUP: the set was started from a neighbour ray's members, which the stream brings up again
+    // (tried: the members' stream positions kept in the set and masked out of a block's candidates up front -- a ballot per visited block
+    // and a third register to shift per insertion cost what the twenty short trips through the loop cost: 158 -> 166 us)
+    template <bool DEDUP>
+    __device__ __forceinline__ void offer(bool ok, float d2, int pidx, int lane) {
+        unsigned long long m = __ballot(ok && __float_as_uint(d2) <= thr);
+        while (m) {
+            const int src = __builtin_ctzll(m);
+            m &= m - 1;
+            const unsigned cb = (unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(d2), src);
+            const int ci = __builtin_amdgcn_readlane(pidx, src);
+#ifdef KNN_DEBUG_VISITS
+            ++n_off;
+#endif
+            if (cb < thr || (cb == thr && (unsigned)ci < thr_idx)) {
+                if (DEDUP && __ballot(idx == ci) != 0) continue;
+#ifdef KNN_DEBUG_VISITS
+                ++n_ins;
+#endif
+                // the members below the candidate stay, the others move up a lane, the last one leaves
+                const int at = __builtin_popcountll(__ballot(lane < k && (bits < cb || (bits == cb && (unsigned)idx < (unsigned)ci))));
+                const unsigned sb = (unsigned)dpp_mov<0x138>((int)bits, (int)bits);
+                const int si = dpp_mov<0x138>(idx, idx);
+                const bool up = lane > at && lane < k;
+                bits = lane == at ? cb : (up ? sb : bits);
+                idx = lane == at ? ci : (up ? si : idx);
+                refresh();
+            }
+        }
+    }
+};
+
+// lower bound (squared) of the reference distance of any point inside the sphere B to the ray, 0 if the line may touch the sphere.
+// The reference's D = v - d (v.d)/(d.d + eps) is never shorter than the perpendicular, so the perpendicular with the true 1/|d|^2 is
+// a valid bound; slack: the rounding of this evaluation and of ray_dist2 (a few eps |v| each) and of the radius.
+__device__ __forceinline__ float block_need2(const RayK& c, float rcp_true, float4 B) {
+    const float vx = B.x - c.ox, vy = B.y - c.oy, vz = B.z - c.oz;
+    const float tt = __builtin_fmaf(vz, c.dz, __builtin_fmaf(vy, c.dy, vx * c.dx)) * rcp_true;
+    const float ex = __builtin_fmaf(-c.dx, tt, vx), ey = __builtin_fmaf(-c.dy, tt, vy), ez = __builtin_fmaf(-c.dz, tt, vz);
+    const float dl = __builtin_sqrtf(__builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex)));
+    const float slack = 4e-6f * ((fabsf(vx) + fabsf(vy)) + (fabsf(vz) + B.w));
+    const float need = (dl - B.w) - slack;
+    return need > 0.f ? need * need * 0.999999f : 0.f;       // (NaN -> 0: visit)
+}
+
+__global__ __launch_bounds__(256) void ray_knn_blocks_kernel(const float4* __restrict__ stream, const float4* __restrict__ blk, int nblk,
+                                                             const float* __restrict__ points, int P, const float* rec, long R, int k, int T,
+                                                             int* __restrict__ out_idx, float* __restrict__ out_dist) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long tile = (long)blockIdx.x * 4 + wave;
+    const long r0 = tile * T;
+    if (r0 >= R) return;
+    cfloat* crec = (cfloat*)rec;
+    KSetT ks;
+    ks.k = k;
+#ifdef KNN_DEBUG_VISITS
+    int dbg_visits = 0;
+#endif
+    ks.bits = lane < k ? INF_BITS : 0u; ks.idx = -1; ks.thr = INF_BITS; ks.thr_idx = 0xffffffffu;
+#pragma unroll 1
+    for (int t = 0; t < T; ++t) {
+        const long r = r0 + t;
+        if (r >= R) break;
+        RayK rk;
+        {
+            cfloat* q = crec + r * 8;
+            rk.ox = q[0]; rk.oy = q[1]; rk.oz = q[2]; rk.dx = q[3]; rk.dy = q[4]; rk.dz = q[5]; rk.den = q[6]; rk.rcp = q[7];
+        }
+        const float dd = __builtin_fmaf(rk.dz, rk.dz, __builtin_fmaf(rk.dy, rk.dy, rk.dx * rk.dx));
+        const float rcp_true = dd > 0.f ? 1.0f / dd : 0.f;
+        const bool cold = t == 0;
+        if (!cold) {                                // the previous ray's neighbours, at this ray's distances
+            const int pi = lane < k ? ks.idx : 0;
+            const float d2 = ray_dist2(rk, points[pi * 3 + 0], points[pi * 3 + 1], points[pi * 3 + 2]);
+            ks.bits = lane < k ? __float_as_uint(d2) : 0u;
+            ks.sort(lane);
+        }
+        // pass 0 (cold start only): the blocks the line pierces; pass 1: every block that can still hold a nearer point.  The next
+        // block's points are requested before the current one's are looked at.
+        for (int pass = cold ? 0 : 1; pass < 2; ++pass) {
+            float4 B = blk[lane < nblk ? lane : nblk - 1];
+            for (int c0 = 0; c0 < nblk; c0 += 64) {
+                const float need2 = c0 + lane < nblk ? block_need2(rk, rcp_true, B) : INFINITY;
+                if (c0 + 64 < nblk) B = blk[c0 + 64 + lane < nblk ? c0 + 64 + lane : nblk - 1];
+                unsigned long long m;
+                if (pass == 0) m = __ballot(need2 == 0.f);
+                else m = __ballot(need2 < __uint_as_float(ks.thr) && !(cold && need2 == 0.f));
+                // the walk is bound by the latency of the blocks' loads (five waves per SIMD, each waiting for its one block): take the chunk's
+                // blocks eight at a time -- eight loads in flight, then the eight evaluations; a block whose bound the k-th distance has passed
+                // in the meantime costs its load only
+                constexpr int D = 8;
+                while (m) {
+                    int ss[D];
+                    float4 vv[D];
+#pragma unroll
+                    for (int u = 0; u < D; ++u) {
+                        ss[u] = m ? __builtin_ctzll(m) : -1;
+                        m &= m - 1;                 // (0 stays 0)
+                        if (ss[u] >= 0) vv[u] = stream[(c0 + ss[u]) * 64 + lane];       // (the stream is padded to whole blocks)
+                    }
+#pragma unroll
+                    for (int u = 0; u < D; ++u) {
+                        if (ss[u] < 0) break;
+                        if (pass == 1 && !(read_lane(need2, ss[u]) < __uint_as_float(ks.thr))) continue;
+#ifdef KNN_DEBUG_VISITS
+                        ++dbg_visits;
+#endif
+                        const int pi = (c0 + ss[u]) * 64 + lane;
+                        const float d2 = ray_dist2(rk, vv[u].x, vv[u].y, vv[u].z);
+                        if (cold) ks.template offer<false>(pi < P, d2, __float_as_int(vv[u].w), lane);
+                        else ks.template offer<true>(pi < P, d2, __float_as_int(vv[u].w), lane);
+                    }
+                }
+            }
+        }
+        if (lane < k) {                             // (the set is ascending in (distance, index))
+            out_idx[r * k + lane] = ks.idx;
+            if (out_dist) out_dist[r * k + lane] = sqrtf(__uint_as_float(ks.bits));
+        }
+#ifdef KNN_DEBUG_VISITS
+        if (out_dist && lane == 0) { out_dist[r * k + 0] = (float)dbg_visits; out_dist[r * k + 1] = (float)ks.n_ins; out_dist[r * k + 2] = (float)ks.n_off; }
+        dbg_visits = 0; ks.n_ins = 0; ks.n_off = 0;
+#endif
+    }
+}
+
 int coprime_stride(long n) {
     long mul = (long)(n * 0.6180339887) | 1;
     auto gcd = [](long a, long b) { while (b) { long t = a % b; a = b; b = t; } return a; };
@@ -252,8 +560,11 @@ int coprime_stride(long n) {
 
 }  // namespace
 
+constexpr int64_t KNN_BLOCKS_MIN_P = 2048;      // below: every point against every ray (nothing to skip in a dozen blocks)
+
 extern "C" size_t papr_ray_knn_workspace_bytes(int64_t R, int64_t P) {
-    return (size_t)R * 8 * sizeof(float) + (size_t)P * 4 * sizeof(float);
+    // ray records | point stream, padded to whole 64-point blocks | one bounding sphere per block | cell counters and cursors
+    return (size_t)R * 8 * sizeof(float) + (size_t)(P + 64) * 4 * sizeof(float) + (size_t)(P / 64 + 2) * 4 * sizeof(float) + (size_t)2 * KNN_NCELL * sizeof(unsigned);
 }
 
 extern "C" int papr_ray_knn(const float* points, int64_t P, const float* rays_o, const float* rays_d,
@@ -267,17 +578,47 @@ extern "C" int papr_ray_knn(const float* points, int64_t P, const float* rays_o,
     hipStream_t s = as_stream(stream);
     float* rec = static_cast<float*>(workspace);
     float4* pstream = reinterpret_cast<float4*>(rec + (size_t)R * 8);
-    pack_rays_kernel<<<dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s>>>(rays_o, rays_d, R, rays_per_image, eps, rec);
+    float4* blk = pstream + (size_t)(P + 64);
+    unsigned* counts = reinterpret_cast<unsigned*>(blk + (size_t)(P / 64 + 2));
+    pack_rays_kernel<<<dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s>>>(rays_o, rays_d, R, rays_per_image, eps, rec, counts, 2 * KNN_NCELL);
     PAPR_CHECK_LAUNCH("pack_rays");
+    static int n_simd = 0;
+    if (!n_simd) { int dev = 0, cu = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev); n_simd = 4 * (cu > 0 ? cu : 256); }
+    static const int t_env = getenv("PAPR_KNN_T") ? atoi(getenv("PAPR_KNN_T")) : 0;      // (A/B switch)
+    static const int blocks_env = getenv("PAPR_KNN_BLOCKS") ? atoi(getenv("PAPR_KNN_BLOCKS")) : 1;      // (A/B switch: 0 = every point against every ray)
+    if (blocks_env && P >= KNN_BLOCKS_MIN_P && k < 64) {
+        const int nblk = (int)((P + 63) / 64);
+        const unsigned pg = (unsigned)(((long)nblk * 64 + 1023) / 1024);
+        knn_count_kernel<<<dim3(pg), dim3(1024), 0, s>>>(points, (int)P, counts);
+        knn_place_kernel<<<dim3(pg), dim3(1024), 0, s>>>(points, (int)P, counts, counts + KNN_NCELL, pstream);
+        knn_bounds_kernel<<<dim3((unsigned)((nblk + 3) / 4)), dim3(256), 0, s>>>(pstream, (int)P, nblk, blk);
+        PAPR_CHECK_LAUNCH("knn_bin_points");
+        // rays per wave.  The kernel is bound by instruction issue (3.5k instructions per ray, SQ_INSTS_*): a run costs its cold first ray
+        // (~2.8 warm rays' worth) + T - 1 warm ones, and the launch takes as long as the SIMD with the most runs; but with fewer than four
+        // waves per SIMD the loads' latency shows (T = 25, one run per SIMD: 396 us against 158), so T stays <= R / (4 SIMDs).
+        int T = 2;
+        double best = 1e300;
+        const int t_max = (int)std::max<long>(2, std::min<long>(16, R / (4L * n_simd)));
+        for (int t = 2; t <= t_max; ++t) {
+            const long tl = (R + t - 1) / t;
+            const double cost = (double)((tl + n_simd - 1) / n_simd) * (1.8 + t);
+            if (cost < best - 1e-9) { best = cost; T = t; }
+        }
+        if (t_env >= 1 && t_env <= 64) T = t_env;
+        const long tiles = (R + T - 1) / T;
+        const bool prof = papr_prof_on();
+        if (prof) papr_prof_begin(5, R, (int)P, k, s);
+        ray_knn_blocks_kernel<<<dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, s>>>(pstream, blk, nblk, points, (int)P, rec, R, k, T, out_idx, out_dist);
+        if (prof) papr_prof_end(s);
+        PAPR_CHECK_LAUNCH("ray_knn_blocks");
+        return 0;
+    }
     scatter_points_kernel<<<dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s>>>(points, (int)P, P > 1 ? coprime_stride(P) : 0, pstream);
     PAPR_CHECK_LAUNCH("scatter_points");
     // Rays per wave T: a tile costs ~(1.8 + T - 1) ray passes over the cloud (its first ray starts cold, the others are seeded), and the
     // launch takes as long as the SIMD with the most tiles: ceil(tiles / SIMDs) of them.  With T = 8 a 160 x 160 patch is 3,200 tiles on
     // 1,024 SIMDs -- 4 on some, 3.125 on average, a quarter of the machine idle at the end (round 2); T = 5 makes it exactly 5 each.
     constexpr int PPL = 4;
-    static int n_simd = 0;
-    if (!n_simd) { int dev = 0, cu = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev); n_simd = 4 * (cu > 0 ? cu : 256); }
-    static const int t_env = getenv("PAPR_KNN_T") ? atoi(getenv("PAPR_KNN_T")) : 0;      // (A/B switch)
     int T = 8;
     double best = 1e300;
     for (int t : {4, 5, 6, 8}) {

@@ -81,7 +81,7 @@ def case_rays(tag):
 
 def grad_check(got, ref, name=""):
     """Gradient parity bar.  e = |got - ref| / max |ref| over the tensor:
-      * rms(e) <= 2e-4 and e <= 1e-3 for all but 0.1 % of the elements (measured on every golden case: rms 1e-8 ... 1.2e-4, typical
+      * rms(e) <= 1.5e-4 and e <= 1e-3 for all but 0.1 % of the elements (measured on every golden case: rms 1e-8 ... 1.2e-4, typical
         maximum 1e-6 ... 7e-4: fp32 sums of 5,120 - 512,000 terms in another order, 22-bit split-f16 operands);
       * the remaining elements <= 1e-2: isolated outliers -- a ReLU / LeakyReLU pre-activation within rounding of zero takes the
         other branch of the derivative than in the reference's own fp32 evaluation, which changes ONE pair's gradient row by
@@ -92,5 +92,5 @@ def grad_check(got, ref, name=""):
     scale = max(np.abs(ref).max(), 1e-30)
     e = np.abs(got - ref) / scale
     rms, frac, worst = float(np.sqrt((e ** 2).mean())), float((e > 1e-3).mean()), float(e.max())
-    assert rms <= 2e-4 and frac <= 1e-3 and worst <= 1e-2, (name, rms, frac, worst)
+    assert rms <= 1.5e-4 and frac <= 1e-3 and worst <= 1e-2, (name, rms, frac, worst)
     return worst

@@ -99,6 +99,33 @@ def test_knn_duplicate_points_exact_ties():
     assert torch.all(idx[:, 1:][same] > idx[:, :-1][same])
 
 
+def test_knn_block_path_total_order_and_determinism():
+    """P >= 2,048 runs the spatial form (binned cloud, bounding spheres): exact duplicates across blocks, a run-to-run identical
+    answer although the binning places points with atomics, and -- a cloud of ONE repeated point -- the k smallest indices, because
+    the set is the k smallest by (distance, index)."""
+    pts = uniform_points(3000, 12.0, seed=11)
+    pts = torch.cat([pts, pts[:700]])            # exact duplicates, far apart in index
+    ro, rd, _ = synth_rays(1, 9, 9, seed=4)
+    idx, dist = _knn(pts, ro, rd, 10)
+    idx2, dist2 = _knn(pts, ro, rd, 10)
+    assert torch.equal(idx, idx2) and torch.equal(dist, dist2)
+    feat = O.ray_point_distance(pts, ro, rd, 1e-6).reshape(-1, pts.shape[0])
+    kth = feat.topk(10, largest=False).values.max(-1).values
+    np.testing.assert_allclose(dist.max(-1).values.numpy(), kth.numpy(), rtol=2e-6)
+    same = dist[:, 1:] == dist[:, :-1]
+    assert torch.all(idx[:, 1:][same] > idx[:, :-1][same])
+    # a duplicated pair is two members of the same distance: both or the lower index, never only the higher one
+    lowdup = idx[(idx >= 3000)] - 3000
+    for r in range(idx.shape[0]):
+        members = set(idx[r].tolist())
+        for j in members:
+            if j >= 3000:
+                assert j - 3000 in members, (r, j)
+    one = torch.tensor([[0.3, -0.2, 0.1]]).repeat(2500, 1)
+    idx, dist = _knn(one, ro, rd, 7)
+    assert torch.equal(idx, torch.arange(7, dtype=idx.dtype).expand_as(idx))
+
+
 def test_knn_rejects_bad_k():
     from papr_amd import ops
     pts = uniform_points(100, 1.0, seed=0).to(dev())
