@@ -44,9 +44,11 @@ typedef __attribute__((address_space(4))) const float cfloat;
 __global__ __launch_bounds__(256) void pack_rays_kernel(const float* __restrict__ rays_o,
                                                         const float* __restrict__ rays_d, long R,
                                                         long rays_per_image, float eps,
-                                                        float* __restrict__ rec, unsigned* __restrict__ zero, int n_zero) {
+                                                        float* __restrict__ rec, unsigned* __restrict__ zero, int n_zero,
+                                                        float4* __restrict__ pad, long n_pad) {
     long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    for (long i = r; i < n_zero; i += (long)gridDim.x * blockDim.x) zero[i] = 0u;      // (the binning's cell counters and cursors)
+    for (long i = r; i < n_zero; i += (long)gridDim.x * blockDim.x) zero[i] = 0u;      // (the binning's cell counters, cursors, block count)
+    for (long i = r; i < n_pad; i += (long)gridDim.x * blockDim.x) pad[i] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));      // (stream places no point takes)
     if (r >= R) return;
     long n = r / rays_per_image;
     float dx = rays_d[r * 3 + 0], dy = rays_d[r * 3 + 1], dz = rays_d[r * 3 + 2];
@@ -330,48 +332,69 @@ __global__ __launch_bounds__(1024) void knn_count_kernel(const float* __restrict
     if (i < P) atomicAdd(&counts[g.cell_of(points[i * 3], points[i * 3 + 1], points[i * 3 + 2])], 1u);
 }
 
-// every point to its place in the Morton-ordered stream: offset of its cell (prefix over the counts, redone per workgroup: 4,096 values) + a
-// ticket from the cell's cursor (cursors[] zeroed by pack_rays_kernel).  The order inside a cell is whatever the atomics give.
+// every point to its place in the Morton-ordered stream: offset of its cell + a ticket from the cell's cursor (cursors[] zeroed by
+// pack_rays_kernel; the order inside a cell is whatever the atomics give).  Blocks are ALIGNED: the cells sharing the first `bits` bits
+// of the Morton key form a group, every group starts at a multiple of 64 (the gap is padding, pre-filled by pack_rays_kernel), so no
+// block straddles two groups -- cut every 64 points regardless, a tenth of the blocks spanned a jump of the curve with spheres
+// half the scene wide, and every ray visited them (visited blocks per ray 32 -> 19 at P = 10,000, 55 -> 21 at 30,000; bits is chosen
+// so that a group holds ~64 points).  The offsets (two prefix sums over 4,096 values) are redone by every workgroup.
 __global__ __launch_bounds__(1024) void knn_place_kernel(const float* __restrict__ points, int P, const unsigned* __restrict__ counts,
-                                                         unsigned* __restrict__ cursors, float4* __restrict__ stream) {
+                                                         unsigned* __restrict__ cursors, float4* __restrict__ stream, int bits,
+                                                         unsigned* __restrict__ nblk_out) {
     __shared__ float red[6][16];
     __shared__ float bb[6];
-    __shared__ unsigned off[KNN_NCELL];
+    __shared__ unsigned ex[KNN_NCELL];      // points in front of a cell
+    __shared__ unsigned gb[KNN_NCELL];      // padded start of a group
     __shared__ unsigned wtot[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const CellGrid g = sample_grid(points, P, red, bb);
-    {
-        const unsigned c0 = counts[4 * tid], c1 = counts[4 * tid + 1], c2 = counts[4 * tid + 2], c3 = counts[4 * tid + 3];
+    // exclusive prefix over 4,096 values, four per thread: a wave scan, the sixteen wave totals
+    auto scan4 = [&](unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned* out) {
         const unsigned mine = c0 + c1 + c2 + c3;
         unsigned incl = mine;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const unsigned o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+        __syncthreads();                            // (wtot free again)
         if (lane == 63) wtot[wave] = incl;
         __syncthreads();
         unsigned base = 0;
         for (int w = 0; w < wave; ++w) base += wtot[w];
-        const unsigned ex = base + incl - mine;
-        off[4 * tid] = ex; off[4 * tid + 1] = ex + c0; off[4 * tid + 2] = ex + c0 + c1; off[4 * tid + 3] = ex + c0 + c1 + c2;
+        const unsigned e = base + incl - mine;
+        out[4 * tid] = e; out[4 * tid + 1] = e + c0; out[4 * tid + 2] = e + c0 + c1; out[4 * tid + 3] = e + c0 + c1 + c2;
+        __syncthreads();
+    };
+    scan4(counts[4 * tid], counts[4 * tid + 1], counts[4 * tid + 2], counts[4 * tid + 3], ex);
+    const int shift = 12 - bits, G = 1 << bits;
+    unsigned sz[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int gi = 4 * tid + u;
+        unsigned n = 0;
+        if (gi < G) {
+            const int c_end = (gi + 1) << shift;
+            n = (c_end < KNN_NCELL ? ex[c_end] : (unsigned)P) - ex[gi << shift];
+        }
+        sz[u] = (n + 63u) & ~63u;
     }
-    __syncthreads();
+    scan4(sz[0], sz[1], sz[2], sz[3], gb);
+    if (blockIdx.x == 0 && tid == 1023) *nblk_out = (gb[KNN_NCELL - 1] + sz[3]) / 64u;      // (groups beyond G are empty)
     const long i = (long)blockIdx.x * 1024 + tid;
     if (i < P) {
         const float x = points[i * 3], y = points[i * 3 + 1], z = points[i * 3 + 2];
         const unsigned c = g.cell_of(x, y, z);
-        const unsigned pos = off[c] + atomicAdd(&cursors[c], 1u);
+        const unsigned gi = c >> shift;
+        const unsigned pos = gb[gi] + (ex[c] - ex[gi << shift]) + atomicAdd(&cursors[c], 1u);
         stream[pos] = make_float4(x, y, z, __int_as_float((int)i));
     }
-    const long nb64 = ((long)P + 63) / 64 * 64;
-    if (i >= P && i < nb64) stream[i] = make_float4(points[0], points[1], points[2], __int_as_float(-1));     // (padding, masked by its position)
 }
 
 // one wave per block of 64 stream positions: bounding sphere (centre of the block's box, largest distance to it, rounded outwards)
-__global__ __launch_bounds__(256) void knn_bounds_kernel(const float4* __restrict__ stream, int P, int nblk, float4* __restrict__ blk) {
+__global__ __launch_bounds__(256) void knn_bounds_kernel(const float4* __restrict__ stream, const unsigned* __restrict__ nblk_p, float4* __restrict__ blk) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= nblk) return;
-    const int pi = b * 64 + lane;
-    const float4 v = stream[pi < P ? pi : b * 64];
+    if (b >= (int)*nblk_p) return;
+    float4 v = stream[b * 64 + lane];
+    if (__float_as_int(v.w) < 0) v = stream[b * 64];       // (padding; a block's first place always holds a point)
     float l[3] = {v.x, v.y, v.z}, h[3] = {v.x, v.y, v.z};
 #pragma unroll
     for (int a = 0; a < 3; ++a)
@@ -469,9 +492,10 @@ __device__ __forceinline__ float block_need2(const RayK& c, float rcp_true, floa
     return need > 0.f ? need * need * 0.999999f : 0.f;       // (NaN -> 0: visit)
 }
 
-__global__ __launch_bounds__(256) void ray_knn_blocks_kernel(const float4* __restrict__ stream, const float4* __restrict__ blk, int nblk,
+__global__ __launch_bounds__(256) void ray_knn_blocks_kernel(const float4* __restrict__ stream, const float4* __restrict__ blk, const unsigned* nblk_p,
                                                              const float* __restrict__ points, int P, const float* rec, long R, int k, int T,
                                                              int* __restrict__ out_idx, float* __restrict__ out_dist) {
+    const int nblk = __builtin_amdgcn_readfirstlane((int)*nblk_p);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const long tile = (long)blockIdx.x * 4 + wave;
@@ -532,10 +556,10 @@ __global__ __launch_bounds__(256) void ray_knn_blocks_kernel(const float4* __res
 #ifdef KNN_DEBUG_VISITS
                         ++dbg_visits;
 #endif
-                        const int pi = (c0 + ss[u]) * 64 + lane;
                         const float d2 = ray_dist2(rk, vv[u].x, vv[u].y, vv[u].z);
-                        if (cold) ks.template offer<false>(pi < P, d2, __float_as_int(vv[u].w), lane);
-                        else ks.template offer<true>(pi < P, d2, __float_as_int(vv[u].w), lane);
+                        const int pidx = __float_as_int(vv[u].w);       // (< 0: padding)
+                        if (cold) ks.template offer<false>(pidx >= 0, d2, pidx, lane);
+                        else ks.template offer<true>(pidx >= 0, d2, pidx, lane);
                     }
                 }
             }
@@ -562,9 +586,19 @@ int coprime_stride(long n) {
 
 constexpr int64_t KNN_BLOCKS_MIN_P = 2048;      // below: every point against every ray (nothing to skip in a dozen blocks)
 
+// Morton prefix bits of a group: ~64 points per group
+static int knn_group_bits(int64_t P) {
+    int bits = 3;
+    while (bits < 12 && (double)P / (double)(1 << bits) > 90.5) ++bits;       // (64 sqrt 2)
+    return bits;
+}
+// places of the aligned stream: every group may end with up to 63 places of padding
+static int64_t knn_stream_places(int64_t P) { return (P + 63 * ((int64_t)1 << knn_group_bits(P)) + 127) / 64 * 64; }
+
 extern "C" size_t papr_ray_knn_workspace_bytes(int64_t R, int64_t P) {
     // ray records | point stream, padded to whole 64-point blocks | one bounding sphere per block | cell counters and cursors
-    return (size_t)R * 8 * sizeof(float) + (size_t)(P + 64) * 4 * sizeof(float) + (size_t)(P / 64 + 2) * 4 * sizeof(float) + (size_t)2 * KNN_NCELL * sizeof(unsigned);
+    return (size_t)R * 8 * sizeof(float) + (size_t)knn_stream_places(P) * 4 * sizeof(float) + (size_t)(knn_stream_places(P) / 64) * 4 * sizeof(float) +
+           (size_t)(2 * KNN_NCELL + 4) * sizeof(unsigned);
 }
 
 extern "C" int papr_ray_knn(const float* points, int64_t P, const float* rays_o, const float* rays_d,
@@ -578,20 +612,23 @@ extern "C" int papr_ray_knn(const float* points, int64_t P, const float* rays_o,
     hipStream_t s = as_stream(stream);
     float* rec = static_cast<float*>(workspace);
     float4* pstream = reinterpret_cast<float4*>(rec + (size_t)R * 8);
-    float4* blk = pstream + (size_t)(P + 64);
-    unsigned* counts = reinterpret_cast<unsigned*>(blk + (size_t)(P / 64 + 2));
-    pack_rays_kernel<<<dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s>>>(rays_o, rays_d, R, rays_per_image, eps, rec, counts, 2 * KNN_NCELL);
+    static const int blocks_env = getenv("PAPR_KNN_BLOCKS") ? atoi(getenv("PAPR_KNN_BLOCKS")) : 1;      // (A/B switch: 0 = every point against every ray)
+    const bool spatial = blocks_env && P >= KNN_BLOCKS_MIN_P && k < 64;
+    const int64_t places = knn_stream_places(P);
+    float4* blk = pstream + (size_t)places;
+    unsigned* counts = reinterpret_cast<unsigned*>(blk + (size_t)(places / 64));
+    pack_rays_kernel<<<dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s>>>(rays_o, rays_d, R, rays_per_image, eps, rec, counts, spatial ? 2 * KNN_NCELL + 4 : 0,
+                                                                             pstream, spatial ? places : 0);
     PAPR_CHECK_LAUNCH("pack_rays");
     static int n_simd = 0;
     if (!n_simd) { int dev = 0, cu = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev); n_simd = 4 * (cu > 0 ? cu : 256); }
     static const int t_env = getenv("PAPR_KNN_T") ? atoi(getenv("PAPR_KNN_T")) : 0;      // (A/B switch)
-    static const int blocks_env = getenv("PAPR_KNN_BLOCKS") ? atoi(getenv("PAPR_KNN_BLOCKS")) : 1;      // (A/B switch: 0 = every point against every ray)
-    if (blocks_env && P >= KNN_BLOCKS_MIN_P && k < 64) {
-        const int nblk = (int)((P + 63) / 64);
-        const unsigned pg = (unsigned)(((long)nblk * 64 + 1023) / 1024);
+    if (spatial) {
+        const unsigned pg = (unsigned)((P + 1023) / 1024);
+        unsigned* nblk_p = counts + 2 * KNN_NCELL;
         knn_count_kernel<<<dim3(pg), dim3(1024), 0, s>>>(points, (int)P, counts);
-        knn_place_kernel<<<dim3(pg), dim3(1024), 0, s>>>(points, (int)P, counts, counts + KNN_NCELL, pstream);
-        knn_bounds_kernel<<<dim3((unsigned)((nblk + 3) / 4)), dim3(256), 0, s>>>(pstream, (int)P, nblk, blk);
+        knn_place_kernel<<<dim3(pg), dim3(1024), 0, s>>>(points, (int)P, counts, counts + KNN_NCELL, pstream, knn_group_bits(P), nblk_p);
+        knn_bounds_kernel<<<dim3((unsigned)((places / 64 + 3) / 4)), dim3(256), 0, s>>>(pstream, nblk_p, blk);
         PAPR_CHECK_LAUNCH("knn_bin_points");
         // rays per wave.  The kernel is bound by instruction issue (3.5k instructions per ray, SQ_INSTS_*): a run costs its cold first ray
         // (~2.8 warm rays' worth) + T - 1 warm ones, and the launch takes as long as the SIMD with the most runs; but with fewer than four
@@ -608,7 +645,7 @@ extern "C" int papr_ray_knn(const float* points, int64_t P, const float* rays_o,
         const long tiles = (R + T - 1) / T;
         const bool prof = papr_prof_on();
         if (prof) papr_prof_begin(5, R, (int)P, k, s);
-        ray_knn_blocks_kernel<<<dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, s>>>(pstream, blk, nblk, points, (int)P, rec, R, k, T, out_idx, out_dist);
+        ray_knn_blocks_kernel<<<dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, s>>>(pstream, blk, nblk_p, points, (int)P, rec, R, k, T, out_idx, out_dist);
         if (prof) papr_prof_end(s);
         PAPR_CHECK_LAUNCH("ray_knn_blocks");
         return 0;
