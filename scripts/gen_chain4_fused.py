@@ -27,13 +27,18 @@ the statement names them -- hence an X and a Y flavour of every variant.  Tempor
   python scripts/gen_chain4_fused.py > papr_amd/csrc/chain4_fused.inc
 """
 
+import os
+ABLATE = os.environ.get("C4F_ABLATE", "")      # timing experiments (scripts/probes/c4_variant.sh with -DC4_FUSED_INC=...)
+
 F = {"l0": "v[28:31]", "l1": "v[32:35]", "h0": "v[36:39]", "h1": "v[40:43]"}
 KA = "v44"                                      # k-loop address temporary
 AD, AD2 = "v45", "v46"                          # row-phase address temporaries
+ADW = "v47"                                     # this wave's place in the partial-maxima table
 G = ["v%d" % i for i in range(48, 64)]          # general temporaries (tuples start at even registers: gfx950 wants 64-bit alignment)
 GB = 48
-CLOB_V = ["v%d" % i for i in range(24, 64)]     # (the compiler has v0-v63: 40 temporaries + the statement's operands leave it ~12 across the statement)
-PFD = "v[24:27]"                                # where the prefetch loads land (never read)
+CLOB_V = ["v%d" % i for i in range(28, 64)]     # (the compiler has v0-v63: 36 temporaries + the statement's operands leave it ~16 across the statement;
+                                                # with v24-v27 taken as well -- a prefetch experiment's landing registers -- one operand was spilled and every hot slot
+                                                # began with its reload from scratch and a vmcnt(0) wait behind the previous slot's row stores)
 ACC = {"X": 64, "Y": 96}                        # the accumulators' registers (chain4.hip: REGISTERS)
 SNH, SNL = "s[90:91]", "s[92:93]"              # LD variants: running bases of the next step's hi / lo fragments (clobbers)
 
@@ -143,9 +148,18 @@ def k_stream_one(acc_t, ld, kcnt=16):
     return pro, steps
 
 
+def pm_delta(acc_u):
+    """LDS bytes from tile U's 1 / scale table to its partial-maxima table (chain4.hip: C4_OFF_INV / C4_OFF_PMAX; inv_all [2][64] floats,
+    pmax_all [2][8][64] floats): both are indexed by the lane's row, so the statement takes ONE address operand (invad) and reaches the
+    other table through the instructions' offset fields -- two vector operands fewer for the compiler to keep across the statement."""
+    u = 0 if acc_u == ACC["X"] else 1
+    return 512 + u * (8 * 64 * 4 - 64 * 4)
+
+
 def p1_stream(acc_u, mode, act):
     """P1 on U's accumulators (first register acc_u).  mode: fwd (training forward), inf, dgrad; act: relu, leaky"""
     it = []
+    PMD = pm_delta(acc_u)
     B = G[0:8]
     INV = [G[8], G[9]]
     LM = [G[10], G[11]]
@@ -185,10 +199,11 @@ def p1_stream(acc_u, mode, act):
                 first = gp == 0 and gg == 0
                 for c in (0, 2):
                     it.append(Item("v_max3_f32 %s, |%s|, |%s|, %s" % (LM[i], regs[c], regs[c + 1], "0" if first and c == 0 else LM[i])))
+    it.append(Item("v_add_u32 %s, %%[wn256], %%[invad]" % ADW))      # (this wave's slice of the partial-maxima table: 256 bytes per wave)
     for i in range(2):
         it += [Item("v_mov_b32 %s, %s" % (SWP, LM[i])), Item("s_nop 1", kind="salu"),
                Item("v_permlane32_swap_b32 %s, %s" % (LM[i], SWP)), Item("v_max_f32 %s, %s, %s" % (LM[i], LM[i], SWP)),
-               Item("ds_write_b32 %%[pmw], %s offset:%d" % (LM[i], 128 * i), lds=("pmw", i), kind="lds")]
+               Item("ds_write_b32 %s, %s offset:%d" % (ADW, LM[i], PMD + 128 * i), lds=("pmw", i), kind="lds")]
     if mode == "fwd":
         it += [Item("v_lshl_or_b32 %%[word], %s, 16, %s" % (W[0], W[1])), Item("v_lshrrev_b32 %s, 2, %%[wv]" % T1),
                Item("global_store_dword %s, %%[word], %%[sgn]" % T1, kind="vmem")]
@@ -203,13 +218,15 @@ def p2_stream(acc_u, mode, one=False):
     train = mode != "inf"
     K140 = G[15]                                # (v_cndmask takes its constant from a register: a literal next to vcc is two constant-bus reads)
     it.append(Item("v_mov_b32 %s, 0x8c" % K140))
+    PMD = pm_delta(acc_u)
+    assert PMD % 256 == 0
     for i in range(2):
-        src = "%[pmr]"
+        src = "%[invad]"
         if i == 1:
-            it.append(Item("v_add_u32 %s, 128, %%[pmr]" % AD))
+            it.append(Item("v_add_u32 %s, 128, %%[invad]" % AD))
             src = AD
         for j in range(4):
-            it.append(Item("ds_read2st64_b32 %s, %s offset0:%d offset1:%d" % (vt(GB + 2 * j, 2), src, 2 * j, 2 * j + 1), lds=("pm", i, j), kind="lds"))
+            it.append(Item("ds_read2st64_b32 %s, %s offset0:%d offset1:%d" % (vt(GB + 2 * j, 2), src, PMD // 256 + 2 * j, PMD // 256 + 2 * j + 1), lds=("pm", i, j), kind="lds"))
         it.append(Item("v_max3_f32 %s, %s, %s, %s" % (MX, PM[0], PM[1], PM[2]), need=[("pm", i, 0), ("pm", i, 1)]))
         it.append(Item("v_max3_f32 %s, %s, %s, %s" % (MX, MX, PM[3], PM[4]), need=[("pm", i, 2)]))
         it.append(Item("v_max3_f32 %s, %s, %s, %s" % (MX, MX, PM[5], PM[6]), need=[("pm", i, 3)]))
@@ -318,6 +335,12 @@ def build(tile, mode, act, ld, kcnt=16, one=False):
     pro, steps = k_stream_one(acc_t, ld, kcnt) if one else k_stream(acc_t, ld, kcnt)
     NM = len(steps)                             # matrix instructions of the statement
     p1, p2 = p1_stream(acc_u, mode, act), p2_stream(acc_u, mode, one)
+    if ABLATE == "K":                           # (timing experiment, results wrong: the k-loop alone)
+        p1, p2 = [], []
+    elif ABLATE == "KP1":
+        p2 = []
+    elif ABLATE == "KP2":
+        p1 = []
     e = Emit()
     for x in pro:
         e.put(x)
@@ -326,29 +349,10 @@ def build(tile, mode, act, ld, kcnt=16, one=False):
         e.put(x)
     p1 = p1[head:]
     n1 = max(1, min(NM - 6, round(NM * (len(p1) + 6.0) / (len(p1) + len(p2) + 6))))      # MFMAs that carry P1
-    after_pf = []                               # memory instructions issued behind the prefetch block
-    put0 = e.put
-
-    def put(x):
-        put0(x)
-        if x.kind == "vmem":
-            after_pf.append(True)
-    e.put = put
     for m, (mf, post) in enumerate(steps):
         e.put(mf)
         for x in post:
             e.put(x)
-        if m == 5 and not one:
-            # ---- the input rows of the tile this workgroup stages a few slots from now (this wave's eight), pulled towards the caches:
-            # every CU stages at the same moment, 16 MB in one burst, and a staging slot took 23k cycles against 10k for a hot one
-            # (scripts/probes/chain4_trace.py).  Plain loads into four registers nobody reads; pfs = the rows' stride in bytes, 0 = not now.
-            e.lines += ["s_cmp_eq_u32 %[pfs], 0", "s_cbranch_scc1 .Lc4pf%=", "v_mov_b32 %s, %%[wv]" % AD2]
-            for q in range(8):
-                e.lines.append("global_load_dwordx4 %s, %s, %%[pfb]" % (PFD, AD2))
-                if q < 7:
-                    e.lines.append("v_add_u32 %s, %%[pfs], %s" % (AD2, AD2))
-            e.lines.append(".Lc4pf%=:")
-            after_pf = []
         if m < n1:
             left = n1 - m
             take = -(-len(p1) // left)
@@ -367,10 +371,6 @@ def build(tile, mode, act, ld, kcnt=16, one=False):
             p2 = p2[take:]
     assert not p2
     e.lines += ["s_nop 15", "s_nop 7"]          # the last results leave the matrix pipe 16 passes after issue
-    # the prefetch loads have landed (their registers belong to the compiler again behind the statement): everything older than the
-    # statement's own later memory instructions is complete (loads and stores retire in order)
-    younger = sum(1 for x in after_pf if x)
-    e.lines.append("s_waitcnt vmcnt(%d)" % min(younger, 63))
     return e.lines
 
 

@@ -29,6 +29,15 @@ names = (["decide", "operands", "statement", "barrier", "loop"] if os.environ.ge
 tot = [0.0] * NS
 cnt = 0
 s0, s1 = int(os.environ.get("S0", "4")), int(os.environ.get("S1", "12"))
+if os.environ.get("SUMMARY"):                     # one line per slot: the slot's length seen by waves 0 and 4, and its pieces for wave 0
+    for sl in range(s0, s1):
+        row = []
+        for w in (0, 4):
+            tt = t[w * 256: (w + 1) * 256]
+            row.append(tt[NS * (sl + 1)] - tt[NS * sl])
+        tt = t[0:256]
+        print("slot %2d (tile %s): %6d %6d cycles   wave 0 pieces: %s" % (sl, "XY"[sl & 1], row[0], row[1], " ".join("%6d" % (tt[NS * sl + j + 1] - tt[NS * sl + j]) for j in range(NS))))
+    sys.exit(0)
 for sl in range(s0, s1):
     print("slot %d (tile %s)" % (sl, "XY"[sl & 1]))
     print("  wave  " + "  ".join("%9s" % s for s in names) + "      total")
