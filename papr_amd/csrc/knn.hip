@@ -30,8 +30,8 @@
 // Arithmetic follows the reference formulation operation by operation (no FMA contraction, IEEE
 // division, torch.norm's fma chain) so that near-tie neighbours resolve the same way:
 // v = p - o; t = (v.d)/(d.d+eps); D = v - d t; select on |D|^2 (sqrt is monotone).  Exact ties at
-// the k-th distance are unordered in the reference (topk sorted=False); here the first one met in
-// the (fixed) stream order is kept, so results are reproducible run to run.
+// the k-th distance are unordered in the reference (topk sorted=False); this form keeps the first one met
+// in the (fixed) stream order, the spatial form the smallest indices: reproducible run to run either way.
 #include "papr_common.h"
 #include <stdlib.h>
 #include <algorithm>
