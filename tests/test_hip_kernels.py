@@ -419,7 +419,9 @@ def test_mlp_forward_backward_vs_torch(M, d_in, width, d_out, n, act, skips):
     np.testing.assert_allclose(d_x2.cpu().numpy(), d_x.cpu().numpy(), rtol=0, atol=3e-5 * sx)
 
 
-@pytest.mark.parametrize("R,k,d_in,width,d_out,n", [(1234, 20, 117, 256, 256, 5), (61, 7, 39, 256, 64, 3), (300, 20, 27, 64, 32, 2), (5, 63, 117, 256, 256, 5)])
+# (4000 x 20 rows: workgroups carry more than one pair of tiles, so the staging slots with the early request of the next rows run too)
+@pytest.mark.parametrize("R,k,d_in,width,d_out,n", [(1234, 20, 117, 256, 256, 5), (61, 7, 39, 256, 64, 3), (300, 20, 27, 64, 32, 2), (5, 63, 117, 256, 256, 5),
+                                                    (4000, 20, 117, 256, 256, 5)])
 def test_row_dots_from_the_last_row_phase(R, k, d_in, width, d_out, n):
     """papr_row_norm.dots: the score dot products leave the fused key run instead of the key embedding (inference), and equal what
     the standardised rows give when they are written and multiplied afterwards (papr_row_dots, torch).  The (300, .., 64, 32) chain is

@@ -186,6 +186,45 @@ def test_chunked_evaluate_is_chunk_invariant_and_matches_oracle_at_10k_points():
     np.testing.assert_allclose(attn_full.squeeze(-1).cpu().numpy(), out["attn"].numpy(), rtol=0, atol=RGB_TOL)
 
 
+def test_evaluate_of_a_multi_tile_chunk_matches_oracle():
+    """64 x 64 rays x 20 neighbours = 81,920 pair rows: every workgroup of the fused runs carries several pairs of tiles (the unit tests'
+    other sizes fit one pair per workgroup), i.e. the staging slots between pairs -- next rows requested early, last layers' row phases,
+    the score dot products -- are compared with the oracle here."""
+    from papr_amd import get_model
+    from papr_amd.config import deep_merge
+    cfg = deep_merge(case_cfg("chair1k"), {"geoms": {"points": {"init_num": 10000}}})
+    pts = uniform_points(10000, 12.0, seed=6)
+    torch.manual_seed(1); np.random.seed(1)
+    m = get_model(cfg, device="cpu")
+    formula_fill(m.state_dict())
+    with torch.no_grad():
+        m.points.copy_(pts)
+    st = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m = m.to("cuda")
+    ro, rd, c2w = synth_rays(1, 64, 64, seed=8)
+    ro_d, rd_d, c2w_d = cuda(ro, rd, c2w)
+    with torch.no_grad():
+        full, attn_full = m.evaluate(ro_d, rd_d, c2w_d)
+    out = O.render(st, cfg, ro, rd, want_rgb=False)
+    np.testing.assert_allclose(full.squeeze(-2).cpu().numpy(), out["fused"].numpy(), rtol=0, atol=RGB_TOL)
+    np.testing.assert_allclose(attn_full.squeeze(-1).cpu().numpy(), out["attn"].numpy(), rtol=0, atol=RGB_TOL)
+    # the training form of the same rows (every layer saved, row stores in every slot) and its gradients against the oracle's autograd
+    ws = torch.linspace(0.5, 1.5, out["fused"].shape[-1])
+    fused_t, attn_t, _, _ = m._render(ro_d, rd_d)
+    np.testing.assert_allclose(fused_t.detach().cpu().numpy().reshape(out["fused"].shape), out["fused"].numpy(), rtol=0, atol=RGB_TOL)
+    (fused_t * ws.to("cuda")).sum().backward()
+    sto = {k: v.detach().clone() for k, v in st.items()}
+    names = ["points", "points_influ_scores", "pc_feats", "proximity_attn.attention_layer.w_q.bias"]
+    names = [n for n in names if n in sto]
+    for n in names:
+        sto[n].requires_grad_(True)
+    o2 = O.render(sto, cfg, ro, rd, idx=out["idx"], want_rgb=False)
+    (o2["fused"] * ws).sum().backward()
+    params = dict(m.named_parameters())
+    for n in names:
+        grad_check(params[n].grad.cpu().numpy(), sto[n].grad.numpy(), n)
+
+
 def test_select_all_points_when_k_exceeds_cloud():
     from papr_amd import get_model
     from papr_amd.config import deep_merge
