@@ -92,7 +92,7 @@ int papr_build_features_bwd(const papr_feature_desc* d, const float* points, con
 
 /* Same backward, but instead of atomics it writes one gradient row {dx,dy,dz,0} per pair into
  * d_pair_points (R*k,4); the per-point feature columns stay in d_val / d_key.  Feed both to
- * papr_segment_reduce for a balanced, nearly atomic-free scatter (replaces the
+ * papr_segment_reduce for a balanced, atomic-free scatter (replaces the
  * index_put_(accumulate=True) backward of the three gathers, models/model.py:330,435,509). */
 int papr_build_features_bwd_pairs(const papr_feature_desc* d, const float* points, const float* rays_o,
                                   const float* rays_d, int64_t R, int64_t rays_per_image, const int32_t* idx,
@@ -102,9 +102,10 @@ int papr_build_features_bwd_pairs(const papr_feature_desc* d, const float* point
  * the point of each entry; seg (P+1) int64: group bounds.  d_points[p] += sum of pair_points rows,
  * d_influ[p] += sum of pair_influ, d_feats[p][c] += sum of rows[pair][col0 + c] (c < ncols <= 128) over
  * point p's group.  Any of the three inputs may be NULL.  accumulate = 0: the outputs must be zeroed by the
- * caller (groups that straddle the kernel's fixed-size chunks are completed with atomic adds; the other rows
- * are overwritten); accumulate = 1: every sum is ADDED to what the outputs hold (a second pass: point features
- * that feed both the key and the value branch, use_ink + use_inv). */
+ * caller (points nobody selected are not written); accumulate = 1: every sum is ADDED to what the outputs hold
+ * (a second pass: point features that feed both the key and the value branch, use_ink + use_inv).
+ * No atomics (ABI 18): a group inside one 128-entry chunk is summed there, a group that spans several chunks from
+ * the chunks' shares in chunk order -- the same bits on every run.  workspace: papr_segment_reduce_workspace_bytes(M). */
 /* ------------------------------------------------------------------------------------
  * K6  point -> k nearest points of the cloud      replaces the two scipy KDTree queries of add_points_knn
  *                                                  (models/utils.py:27-29 `tree.query(points, k=sample_k)`, :59 `tree.query(query, k=k+1)`).
@@ -123,9 +124,11 @@ size_t papr_group_pairs_workspace_bytes(int64_t M, int64_t P);
 int papr_group_pairs(const int32_t* idx, int64_t M, int64_t P, int64_t* order, int32_t* sorted_pts, int64_t* seg,
                      void* workspace, size_t workspace_bytes, papr_stream_t stream);
 
+size_t papr_segment_reduce_workspace_bytes(int64_t M);
 int papr_segment_reduce(const int64_t* order, const int32_t* sorted_pts, const int64_t* seg, int64_t M, int64_t P,
                         const float* pair_points, const float* pair_influ, const float* rows, int ld, int col0,
-                        int ncols, float* d_points, float* d_influ, float* d_feats, int accumulate, papr_stream_t stream);
+                        int ncols, float* d_points, float* d_influ, float* d_feats, int accumulate, void* workspace,
+                        papr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Row standardisation  y = (x - mean) / (std_unbiased + eps)      (the non-affine core of the

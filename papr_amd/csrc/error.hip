@@ -13,7 +13,7 @@ void papr_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* papr_last_error(void) { return g_err; }
-extern "C" int papr_abi_version(void) { return 17; }
+extern "C" int papr_abi_version(void) { return 18; }
 
 // ---- optional launch timing (diagnostics only; see papr_profile_enable in papr_hip.h) ----------
 namespace {

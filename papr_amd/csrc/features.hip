@@ -265,17 +265,19 @@ __global__ __launch_bounds__(256) void feats_scatter_kernel(const float* __restr
 // per chunk (a wave-per-point split is hopelessly unbalanced: a few points are selected by thousands
 // of rays).  Lanes span the feature columns, lanes 0-2 also carry xyz and lane 3 the influence term.
 // A group that lies inside one chunk is stored directly; a group that straddles chunks is finished
-// with atomic adds (a few per chunk instead of 67 per pair).  Outputs must be zeroed by the caller.
+// by a second small kernel that adds the chunks' shares in chunk order (no atomics: bit-reproducible).  Outputs must be zeroed by the caller.
 constexpr int SEG_CH = 128;
+constexpr int SEG_PW = 4 + 128;                   // floats of one parked share: point gradient (3) + influence (1) + up to 128 feature columns
 
 __global__ __launch_bounds__(256) void segment_reduce_kernel(const long* __restrict__ order, const int* __restrict__ sorted_pts,
                                                              const long* __restrict__ seg, long M,
                                                              const float* __restrict__ pair_points, const float* __restrict__ pair_influ,
                                                              const float* __restrict__ rows, int ld, int col0, int ncols,
                                                              float* __restrict__ d_points, float* __restrict__ d_influ,
-                                                             float* __restrict__ d_feats, int accumulate) {
+                                                             float* __restrict__ d_feats, int accumulate, float* __restrict__ partial) {
     const int lane = threadIdx.x & 63;
-    const long e0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * SEG_CH;
+    const long chunk = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long e0 = chunk * SEG_CH;
     if (e0 >= M) return;
     const int n = (int)(M - e0 < SEG_CH ? M - e0 : SEG_CH);
     // this chunk's entries: lane holds entries lane and lane+64
@@ -300,10 +302,13 @@ __global__ __launch_bounds__(256) void segment_reduce_kernel(const long* __restr
             if (c0_ok) d_feats[(long)p * ncols + lane] = acc0;
             if (c1_ok) d_feats[(long)p * ncols + lane + 64] = acc1;
         } else {
-            if (pair_points && lane < 3) unsafeAtomicAdd(d_points + p * 3 + lane, small);
-            if (pair_influ && lane == 3) unsafeAtomicAdd(d_influ + p, small);
-            if (c0_ok) unsafeAtomicAdd(d_feats + (long)p * ncols + lane, acc0);
-            if (c1_ok) unsafeAtomicAdd(d_feats + (long)p * ncols + lane + 64, acc1);
+            // the group goes on in a neighbouring chunk: this chunk's share is parked (slot 0: the group came in from the chunk before, slot 1: it
+            // starts here and runs on) and segment_finish_kernel adds the shares in chunk order -- with atomic adds three or more shares of a
+            // popular point arrived in any order and training was not bit-reproducible from run to run
+            float* const ps = partial + (chunk * 2 + (seg[p] < e0 ? 0 : 1)) * SEG_PW;
+            if (lane < 4) ps[lane] = small;
+            ps[4 + lane] = acc0;
+            ps[4 + 64 + lane] = acc1;
         }
         small = acc0 = acc1 = 0.f;
     };
@@ -330,6 +335,37 @@ __global__ __launch_bounds__(256) void segment_reduce_kernel(const long* __restr
         }
     }
     flush(cur);
+}
+
+// one wave per point whose group of pairs spans several chunks: the chunks' parked shares, added in chunk order
+__global__ __launch_bounds__(256) void segment_finish_kernel(const long* __restrict__ seg, long P, int has_points, int has_influ, int ncols,
+                                                             float* __restrict__ d_points, float* __restrict__ d_influ,
+                                                             float* __restrict__ d_feats, int accumulate, const float* __restrict__ partial) {
+    const int lane = threadIdx.x & 63;
+    const long p = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= P) return;
+    const long a = seg[p], b = seg[p + 1];
+    if (b <= a) return;
+    const long c0 = a / SEG_CH, c1 = (b - 1) / SEG_CH;
+    if (c0 == c1) return;                           // (wholly inside one chunk: segment_reduce_kernel wrote it)
+    float small = 0.f, acc0 = 0.f, acc1 = 0.f;
+    for (long c = c0; c <= c1; ++c) {
+        const float* ps = partial + (c * 2 + (a < c * SEG_CH ? 0 : 1)) * SEG_PW;
+        if (lane < 4) small += ps[lane];
+        acc0 += ps[4 + lane];
+        acc1 += ps[4 + 64 + lane];
+    }
+    const bool c0_ok = ncols > 0 && lane < ncols, c1_ok = ncols > 0 && lane + 64 < ncols;
+    if (accumulate) {
+        if (has_points && lane < 3) small += d_points[p * 3 + lane];
+        if (has_influ && lane == 3) small += d_influ[p];
+        if (c0_ok) acc0 += d_feats[p * ncols + lane];
+        if (c1_ok) acc1 += d_feats[p * ncols + lane + 64];
+    }
+    if (has_points && lane < 3) d_points[p * 3 + lane] = small;
+    if (has_influ && lane == 3) d_influ[p] = small;
+    if (c0_ok) d_feats[p * ncols + lane] = acc0;
+    if (c1_ok) d_feats[p * ncols + lane + 64] = acc1;
 }
 
 // LDS row pitch of the per-wave staging buffer: the widest encoding block, made odd
@@ -446,10 +482,15 @@ extern "C" int papr_build_features_bwd_pairs(const papr_feature_desc* d, const f
     return 0;
 }
 
+extern "C" size_t papr_segment_reduce_workspace_bytes(int64_t M) {
+    return (size_t)((M + SEG_CH - 1) / SEG_CH) * 2 * SEG_PW * sizeof(float);
+}
+
 extern "C" int papr_segment_reduce(const int64_t* order, const int32_t* sorted_pts, const int64_t* seg, int64_t M, int64_t P,
                                    const float* pair_points, const float* pair_influ, const float* rows, int ld, int col0,
-                                   int ncols, float* d_points, float* d_influ, float* d_feats, int accumulate, papr_stream_t stream) {
-    PAPR_REQUIRE(order && sorted_pts && seg, "papr_segment_reduce: null index arrays");
+                                   int ncols, float* d_points, float* d_influ, float* d_feats, int accumulate, void* workspace,
+                                   papr_stream_t stream) {
+    PAPR_REQUIRE(order && sorted_pts && seg && workspace, "papr_segment_reduce: null index arrays / workspace");
     PAPR_REQUIRE(M < ((int64_t)1 << 31), "papr_segment_reduce: more than 2^31 pairs");
     PAPR_REQUIRE(!rows || (d_feats && ncols >= 1 && ncols <= 128), "papr_segment_reduce: 1 <= ncols <= 128 and d_feats required");
     PAPR_REQUIRE(!pair_points || d_points, "papr_segment_reduce: d_points required");
@@ -458,7 +499,11 @@ extern "C" int papr_segment_reduce(const int64_t* order, const int32_t* sorted_p
     const long chunks = (M + SEG_CH - 1) / SEG_CH;
     segment_reduce_kernel<<<dim3((unsigned)((chunks + 3) / 4)), dim3(256), 0, as_stream(stream)>>>(
         reinterpret_cast<const long*>(order), sorted_pts, reinterpret_cast<const long*>(seg), M, pair_points, pair_influ, rows, ld,
-        col0, ncols, d_points, d_influ, d_feats, accumulate);
+        col0, ncols, d_points, d_influ, d_feats, accumulate, static_cast<float*>(workspace));
     PAPR_CHECK_LAUNCH("segment_reduce");
+    segment_finish_kernel<<<dim3((unsigned)((P + 3) / 4)), dim3(256), 0, as_stream(stream)>>>(
+        reinterpret_cast<const long*>(seg), P, pair_points ? 1 : 0, pair_influ ? 1 : 0, rows ? ncols : 0, d_points, d_influ, d_feats, accumulate,
+        static_cast<const float*>(workspace));
+    PAPR_CHECK_LAUNCH("segment_finish");
     return 0;
 }

@@ -828,13 +828,14 @@ class _RenderFn(torch.autograd.Function):
                 rows, ld, col0 = d_val, d_val.shape[1], plan.val_w - fdim
             else:
                 rows, ld, col0 = d_key, d_key.shape[1], plan.key_w - fdim
+        seg_ws = torch.empty(lib.papr_segment_reduce_workspace_bytes(M) // 4, device=dev, dtype=torch.float32)
         hip.check(lib.papr_segment_reduce(hip.ptr(s["order"]), hip.ptr(s["sorted_pts"]), hip.ptr(s["seg"]), M, s["P"], hip.ptr(pair_pts), hip.ptr(pair_influ),
                                           hip.ptr(rows), ld, col0, fdim if rows is not None else 0, hip.ptr(d_points), hip.ptr(d_influ),
-                                          hip.ptr(d_feats), 0, hip.stream_ptr()), "papr_segment_reduce")
+                                          hip.ptr(d_feats), 0, hip.ptr(seg_ws), hip.stream_ptr()), "papr_segment_reduce")
         if need_geo and plan.fdesc.val_has_feats and plan.fdesc.key_has_feats:      # features feed both branches
             hip.check(lib.papr_segment_reduce(hip.ptr(s["order"]), hip.ptr(s["sorted_pts"]), hip.ptr(s["seg"]), M, s["P"], None, None,
                                               hip.ptr(d_key), d_key.shape[1], plan.key_w - fdim, fdim, None, None, hip.ptr(d_feats),
-                                              1, hip.stream_ptr()), "papr_segment_reduce")
+                                              1, hip.ptr(seg_ws), hip.stream_ptr()), "papr_segment_reduce")
         ctx.saved = None
         grads_wb = d_kw + d_kb + d_wk + d_wkb + d_qw + d_qb + d_wq + d_wqb + d_vw + d_vb
         return (None, None, None, None, None, None, d_points, d_feats, d_influ, None, None, None) + tuple(grads_wb)

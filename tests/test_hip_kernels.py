@@ -264,9 +264,16 @@ def test_segment_reduce_matches_index_put_accumulate(P, M, hot):
     d_p, d_i, d_f = torch.zeros(P, 3, device=d), torch.zeros(P, 1, device=d), torch.zeros(P, nc, device=d)
     a = [hip.ptr(order), hip.ptr(sorted_pts), hip.ptr(seg), M, P]
     pp_d, pi_d, rows_d = pair_pts.to(d), pair_influ.to(d), rows.to(d)          # (kept alive: hip.ptr holds no reference)
+    ws = torch.empty(hip.lib().papr_segment_reduce_workspace_bytes(M) // 4, device=d)
     hip.check(hip.lib().papr_segment_reduce(*a, hip.ptr(pp_d), hip.ptr(pi_d), hip.ptr(rows_d), ld, col0, nc,
-                                            hip.ptr(d_p), hip.ptr(d_i), hip.ptr(d_f), 0, hip.stream_ptr()), "papr_segment_reduce")
+                                            hip.ptr(d_p), hip.ptr(d_i), hip.ptr(d_f), 0, hip.ptr(ws), hip.stream_ptr()), "papr_segment_reduce")
     torch.cuda.synchronize()
+    # no atomics: a second run gives the same bits (a popular point's group spans dozens of chunks)
+    e_p, e_i, e_f = torch.zeros(P, 3, device=d), torch.zeros(P, 1, device=d), torch.zeros(P, nc, device=d)
+    hip.check(hip.lib().papr_segment_reduce(*a, hip.ptr(pp_d), hip.ptr(pi_d), hip.ptr(rows_d), ld, col0, nc,
+                                            hip.ptr(e_p), hip.ptr(e_i), hip.ptr(e_f), 0, hip.ptr(ws), hip.stream_ptr()), "papr_segment_reduce")
+    torch.cuda.synchronize()
+    assert torch.equal(e_p, d_p) and torch.equal(e_i, d_i) and torch.equal(e_f, d_f)
     big = lambda w: 4e-6 * w.abs().max().item() + 1e-7          # fp32 sums of up to `hot` terms in another order
     np.testing.assert_allclose(d_p.cpu().double().numpy(), want_p.numpy(), rtol=0, atol=big(want_p))
     np.testing.assert_allclose(d_i.cpu()[:, 0].double().numpy(), want_i.numpy(), rtol=0, atol=big(want_i))
@@ -278,7 +285,7 @@ def test_segment_reduce_matches_index_put_accumulate(P, M, hot):
     want_f2 = want_f + torch.zeros(P, nc, dtype=torch.float64).index_put_((flat.long(),), rows2[:, 56:56 + nc].double(), accumulate=True)
     rows2_d = rows2.to(d)
     hip.check(hip.lib().papr_segment_reduce(*a, None, None, hip.ptr(rows2_d), 120, 56, nc, None, None, hip.ptr(d_f), 1,
-                                            hip.stream_ptr()), "papr_segment_reduce")
+                                            hip.ptr(ws), hip.stream_ptr()), "papr_segment_reduce")
     torch.cuda.synchronize()
     np.testing.assert_allclose(d_f.cpu().double().numpy(), want_f2.numpy(), rtol=0, atol=big(want_f2))
 
@@ -312,8 +319,9 @@ def test_features_backward_pairs_plus_segment_reduce_is_the_product_path():
                                                       hip.ptr(idx_d), hip.ptr(gk_d), hip.ptr(gv_d), hip.ptr(pair_pts), hip.stream_ptr()), "bwd_pairs")
     order, sorted_pts, seg = _segment_inputs(idx_d.view(-1), P)
     d_pts, d_f = torch.zeros((P, 3), device=d), torch.zeros((P, 64), device=d)
+    ws = torch.empty(hip.lib().papr_segment_reduce_workspace_bytes(M) // 4, device=d)
     hip.check(hip.lib().papr_segment_reduce(hip.ptr(order), hip.ptr(sorted_pts), hip.ptr(seg), M, P, hip.ptr(pair_pts), None, hip.ptr(gv_d),
-                                            gv_d.shape[1], plan.val_w - 64, 64, hip.ptr(d_pts), None, hip.ptr(d_f), 0, hip.stream_ptr()), "segment_reduce")
+                                            gv_d.shape[1], plan.val_w - 64, 64, hip.ptr(d_pts), None, hip.ptr(d_f), 0, hip.ptr(ws), hip.stream_ptr()), "segment_reduce")
     torch.cuda.synchronize()
     ref, fref = st["points"].grad, st["pc_feats"].grad
     np.testing.assert_allclose(d_pts.cpu().numpy(), ref.numpy(), rtol=0, atol=2e-4 * ref.abs().max().item())
