@@ -38,10 +38,10 @@ const char* papr_last_error(void);
  * points (P,3); rays_o (N,3); rays_d (R,3) with R = N * rays_per_image; ray r belongs to image
  * r / rays_per_image.  Distance = | v - d (v.d)/(d.d+eps) |, v = p - o, d used as given.
  * out_idx (R,k) int32, ascending in (distance, point index); out_dist (R,k) or NULL.  When several
- * points tie exactly at the k-th distance (the reference's topk(sorted=False) is unordered there): clouds of
- * 2,048 points and more (binned per call, bounding spheres of 64-point blocks, k < 64) keep the ones with the
- * smallest indices -- the set is the k smallest by (distance, index); smaller clouds keep the first ones met in
- * a fixed order.  Reproducible run to run either way.
+ * points tie exactly at the k-th distance (the reference's topk(sorted=False) is unordered there) the ones with
+ * the smallest indices are kept: the set is the k smallest by (distance, index), whichever form runs -- clouds of
+ * 2,048 points and more are binned per call (bounding spheres of 64-point blocks, k < 64), smaller ones are
+ * searched point by point.
  * Requires 1 <= k <= 64 and k <= P.  workspace: papr_ray_knn_workspace_bytes(R, P) bytes, contents irrelevant
  * on entry (ray records, the binned copy of the cloud, block bounds, cell counters: all rebuilt by every call).
  */

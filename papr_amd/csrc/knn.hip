@@ -30,8 +30,9 @@
 // Arithmetic follows the reference formulation operation by operation (no FMA contraction, IEEE
 // division, torch.norm's fma chain) so that near-tie neighbours resolve the same way:
 // v = p - o; t = (v.d)/(d.d+eps); D = v - d t; select on |D|^2 (sqrt is monotone).  Exact ties at
-// the k-th distance are unordered in the reference (topk sorted=False); this form keeps the first one met
-// in the (fixed) stream order, the spatial form the smallest indices: reproducible run to run either way.
+// the k-th distance are unordered in the reference (topk sorted=False); both forms keep the smallest
+// indices (the set is the k smallest by (distance, index)), so they agree bit for bit -- a training run is the
+// same with either (scripts/probes/knn_forms_train.sh).
 #include "papr_common.h"
 #include <stdlib.h>
 #include <algorithm>
@@ -122,32 +123,43 @@ __device__ __forceinline__ float ray_dist2_fast(const RayK& c, float px, float p
     return __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
 }
 
-constexpr unsigned INF_BITS = 0x7f800000u;
 
 // One ray's k-set: lanes < k hold (distance bits, point index), unordered; lanes >= k hold 0 bits.
+constexpr unsigned INF_BITS = 0x7f800000u;
+
 struct KSet {
     unsigned bits;   // per lane
-    int idx;         // per lane
+    int idx;         // per lane (-1: not filled yet -- counts as the largest index)
     unsigned thr;    // uniform: largest member = current k-th smallest
+    unsigned thr_idx;// uniform: its index
     unsigned thr_hi; // uniform: thr x (1 + 1/64): what the cheap distance is tested against
-    int tl;          // uniform: a lane holding it
+    int tl;          // uniform: the lane holding it
+    unsigned long long kmask;       // uniform: lanes 0 .. k-1
+    // the set is the k smallest by (distance bits, index) -- the same total order as the spatial form's, so that both forms give the same answer at
+    // exact ties of the k-th distance as well (and a training run the same bits with either)
     __device__ __forceinline__ void refresh() {
         thr = wave_umax(bits);
+        unsigned long long mm = __ballot(bits == thr) & kmask;
+        if (mm & (mm - 1)) {                        // several members at the largest distance: the one with the largest index goes first
+            const unsigned mi = wave_umax(bits == thr ? (unsigned)idx : 0u);
+            mm = __ballot(bits == thr && (unsigned)idx == mi) & kmask;
+        }
+        tl = __builtin_ctzll(mm);
+        thr_idx = (unsigned)__builtin_amdgcn_readlane(idx, tl);
         thr_hi = __float_as_uint(__uint_as_float(thr) * 1.015625f);
-        tl = __builtin_ctzll(__ballot(bits == thr));
     }
     // does any lane hold a point that may enter the set? (cheap distances)
     __device__ __forceinline__ bool may_enter(float d2_fast) const { return __ballot(__float_as_uint(d2_fast) < thr_hi) != 0; }
-    // offer the candidates flagged in d2 < thr; DEDUP skips points that are already members (seeded sets)
+    // offer the candidates; DEDUP skips points that are already members (seeded sets).  (An infinite d2 marks a lane without a point.)
     template <bool DEDUP>
     __device__ __forceinline__ void offer(float d2, int pidx, int lane) {
-        unsigned long long m = __ballot(__float_as_uint(d2) < thr);
+        unsigned long long m = __ballot(__float_as_uint(d2) <= thr && __float_as_uint(d2) < INF_BITS);
         while (m) {
             int src = __builtin_ctzll(m);
             m &= m - 1;
             unsigned cb = (unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(d2), src);
-            if (cb < thr) {
-                int ci = __builtin_amdgcn_readlane(pidx, src);
+            int ci = __builtin_amdgcn_readlane(pidx, src);
+            if (cb < thr || (cb == thr && (unsigned)ci < thr_idx)) {
                 if (DEDUP && __ballot(idx == ci) != 0) continue;
                 bool here = lane == tl;
                 bits = here ? cb : bits;
@@ -183,7 +195,10 @@ __global__ __launch_bounds__(256) void ray_knn_kernel(const float4* __restrict__
         rk[t].dy = p[4]; rk[t].dz = p[5]; rk[t].den = p[6]; rk[t].rcp = p[7];
     }
     KSet ks[T];
-    ks[0].bits = lane < k ? INF_BITS : 0u; ks[0].idx = -1; ks[0].thr = INF_BITS; ks[0].thr_hi = INF_BITS; ks[0].tl = 0;
+    const unsigned long long kmask = k >= 64 ? ~0ull : (1ull << k) - 1ull;
+#pragma unroll
+    for (int t = 0; t < T; ++t) ks[t].kmask = kmask;
+    ks[0].bits = lane < k ? INF_BITS : 0u; ks[0].idx = -1; ks[0].thr = INF_BITS; ks[0].thr_idx = 0xffffffffu; ks[0].thr_hi = INF_BITS; ks[0].tl = 0;
 
     // ---- phase A: ray 0 against every point
     for (int base = 0; base < P; base += 64 * PPL) {

@@ -97,6 +97,12 @@ def test_knn_duplicate_points_exact_ties():
     # the output is ascending in (distance, index)
     same = dist[:, 1:] == dist[:, :-1]
     assert torch.all(idx[:, 1:][same] > idx[:, :-1][same])
+    # the set is the k smallest by (distance, index) in this form too: of a duplicated pair never only the higher index
+    for r in range(idx.shape[0]):
+        members = set(idx[r].tolist())
+        for j in members:
+            if j >= 500:
+                assert j - 500 in members, (r, j)
 
 
 def test_knn_block_path_total_order_and_determinism():
