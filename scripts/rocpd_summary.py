@@ -5,7 +5,7 @@ rocprofv3 7.2 writes `*_results.db` by default; this turns its `kernels` view in
 `--stats` prints, so the summary can be committed under profiles/ as plain text.
 usage: python scripts/rocpd_summary.py gpurun_out/prof1/r01_results.db [min_start_fraction | last:N[:marker]]
 
-`last:N` keeps the dispatches from the N-th last launch of the marker kernel (default ray_knn_kernel, the first
+`last:N` keeps the dispatches from the N-th last launch of the marker kernel (default ray_knn -- either form of the kernel --, the first
 kernel of every step) onwards, i.e. the last N steps: warm-up steps (MIOpen's solver search runs seconds of
 naive convolutions there) stay out of the table.
 """
@@ -25,7 +25,7 @@ def main(path, skip="0"):
     t0, t1 = rows[0][1], rows[-1][2]
     if skip.startswith("last:"):
         parts = skip.split(":")
-        n, marker = int(parts[1]), (parts[2] if len(parts) > 2 else "ray_knn_kernel")
+        n, marker = int(parts[1]), (parts[2] if len(parts) > 2 else "ray_knn")
         marks = [s for name, s, e in rows if marker in name]
         cut = marks[-n] if len(marks) >= n else t0
         print("# last %d steps (from the %d-th last %s launch): %.3f ms of wall time" % (n, n, marker, (t1 - cut) / 1e6))
