@@ -271,6 +271,18 @@ def test_c_abi_library_exports_every_declared_symbol():
     assert lib.papr_mlp_fwd_workspace_bytes(1000) >= 2 * 1000 * 4 + 2 * 512 * 704 * 2
 
 
+def test_generated_kernel_sources_are_current():
+    """chain4_kloop.inc / chain4_fused.inc are what their generators print (a stale include would still build -- and run another kernel
+    than the scripts describe)."""
+    import subprocess
+    import sys as _sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for script, inc in (("gen_chain4_kloop.py", "chain4_kloop.inc"), ("gen_chain4_fused.py", "chain4_fused.inc")):
+        env = {k: v for k, v in os.environ.items() if not k.startswith("C4F_")}          # (the generators' experiment switches)
+        out = subprocess.run([_sys.executable, os.path.join(root, "scripts", script)], capture_output=True, text=True, env=env, check=True).stdout
+        assert out == open(os.path.join(root, "papr_amd", "csrc", inc)).read(), "%s is not what scripts/%s prints" % (inc, script)
+
+
 def test_mlp_generator_surface():
     """The per-pixel MLP render head (reference models/renderer.py:6-17) keeps the reference's parameter names, refuses
     what the kernels cannot do, and -- like the rest of the path -- has no CPU fallback."""
