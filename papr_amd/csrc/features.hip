@@ -71,12 +71,18 @@ __device__ __forceinline__ RayGeom load_ray(const float* __restrict__ rays_o, co
 __device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // buf[r][c], r < 64, c < w  ->  dst[(m0 + r) * ld + c0 + c]
+// (four floats per store instruction: the block's place in a row is only 4-byte aligned, which a global dwordx4 store accepts)
+typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 __device__ __forceinline__ void wave_flush(const float* buf, int pitch, int w, float* __restrict__ dst, long ld, int c0, long m0, long M) {
-    const int lane = threadIdx.x & 63, total = 64 * w;
-    const float inv_w = 1.0f / (float)w;
+    const int lane = threadIdx.x & 63, wq = (w + 3) >> 2, total = 64 * wq;
+    const float inv_wq = 1.0f / (float)wq;
     for (int e = lane; e < total; e += 64) {
-        const int r = (int)(((float)e + 0.5f) * inv_w), c = e - r * w;
-        if (m0 + r < M) dst[(m0 + r) * ld + c0 + c] = buf[r * pitch + c];
+        const int r = (int)(((float)e + 0.5f) * inv_wq), c = 4 * (e - r * wq);
+        if (m0 + r >= M) continue;
+        const float* b = buf + r * pitch + c;
+        float* d = dst + (m0 + r) * ld + c0 + c;
+        if (c + 3 < w) *reinterpret_cast<f32x4_a4*>(d) = f32x4_a4{b[0], b[1], b[2], b[3]};
+        else for (int j = 0; c + j < w; ++j) d[j] = b[j];
     }
 }
 // src[(m0 + r) * ld + c0 + c]  ->  buf[r][c]   (rows beyond M read row M-1)
