@@ -53,6 +53,10 @@ def parse():
     ap.add_argument("--psnr-steps", type=int, default=3000,
                     help="N = 1 only: after the timed region, train.py runs this many steps of the same scene file from seed 1 on the procedural scene "
                          "(a child process) and its last evaluation PSNR goes into the JSON line as psnr_after_steps (BASELINE's metric is rays/s + test PSNR); 0 = skip")
+    ap.add_argument("--profile-steps", type=int, default=-1,
+                    help="steps of the second, instrumented pass behind the timed region (HIP events around every library launch: the roofline records); "
+                         "-1 = as many as --steps, 0 = none (no roofline objects)")
+    ap.add_argument("--no-shipped-line", action="store_true", help="skip as_shipped_amp (a child process with --amp: the scene file's own use_amp: true)")
     ap.add_argument("--amp", action="store_true",
                     help="run with the scene file's own `use_amp: true` (the reference trains its attention block and U-Net under fp16 autocast then; "
                          "here: GradScaler on, embedding MLPs in the one-product mode, U-Net on the own split-f16 kernels); default is the fp32 "
@@ -127,7 +131,7 @@ def psnr_after_steps(args):
 
 def main():
     args = parse()
-    os.environ["PAPR_GEMM_MODE"] = args.gemm_mode       # read by libpapr_hip.so when it loads
+    os.environ["PAPR_GEMM_MODE"] = args.gemm_mode       # read by papr_amd/ops.py (mlp_mode) at every call: the `mode` argument of papr_mlp_fwd / _bwd
     from papr_amd import dist as pdist, get_model, get_loss, hip
     from papr_amd.data import SyntheticRayData
     world = pdist.init_from_env("cuda")
@@ -167,35 +171,50 @@ def main():
     P = model.points.shape[0]
 
     def barrier():
-        if world > 1:
+        if torch.distributed.is_initialized():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
         train_step(model, loss_fn, pool[i % len(pool)], i)
+    # ---- the timed region: exactly `steps` steps of the product as it ships, no instrumentation ----
     barrier()
-    hip.profile_enable(True)
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = train_step(model, loss_fn, pool[i % len(pool)], args.warmup + i)
     barrier()
     dt = time.perf_counter() - t0
-    hip.profile_enable(False)
-    recs = hip.profile_collect()
-    if world > 1:
+    final_loss = float(loss.detach())
+    # ---- a second pass for the roofline records: the library brackets every launch with a HIP event pair on the launch stream ----
+    prof_steps = args.steps if args.profile_steps < 0 else args.profile_steps
+    recs, dt_prof = [], 0.0
+    if prof_steps > 0:
+        hip.profile_enable(True)
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(prof_steps):
+            train_step(model, loss_fn, pool[i % len(pool)], args.warmup + args.steps + i)
+        barrier()
+        dt_prof = time.perf_counter() - t1
+        hip.profile_enable(False)
+        recs = hip.profile_collect()
+    if torch.distributed.is_initialized():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
     if rank != 0:
         return
 
     # ---- roofline of the dominant kernel, from the HIP-event records of the timed steps ---------
     plan = model.plan
     true_k = {plan.key.ld_in: plan.key_w, plan.val.ld_in: plan.val_w, plan.qry.ld_in: plan.qry_w}
-    traffic_db = {}
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath) and args.gemm_mode != "h1":      # (the counter passes were run in the parity mode; h1 moves f16 rows: traffic null)
-        traffic_db = json.load(open(tpath))
+    traffic_all = json.load(open(tpath)) if os.path.exists(tpath) else {}
+    # (the counter passes were run in the parity mode; the one-product modes move f16 rows: traffic null there)
+    traffic_db = traffic_all if (args.gemm_mode != "h1" and not args.amp) else {}
+    dt_prof = max(dt_prof, 1e-9)
 
     def mfma_line(kernel, ids, key):
         rs = [r for r in recs if r[0] in ids]
@@ -205,7 +224,7 @@ def main():
         return ms, {"kernel": kernel, "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                     "frac": ach / FP32_MFMA_PEAK_TF, "traffic": traffic_db.get(key), "launches": len(rs),
                     "avg_launch_ms": ms / max(len(rs), 1), "algorithmic_gflop_per_launch": fl / max(len(rs), 1) / 1e9,
-                    "share_of_step_time": ms / (dt * 1e3)}
+                    "share_of_step_time": ms / (dt_prof * 1e3)}
 
     def h3_line():
         # split-f16 GEMM: 3 f16 MFMAs per fp32 product make the layer HBM-bound.  Algorithmic bytes per launch:
@@ -220,7 +239,7 @@ def main():
                     "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                     "traffic": traffic_db.get("gemm_nt_h3_bytes_per_launch"), "launches": len(rs),
                     "avg_launch_ms": ms / max(len(rs), 1), "algorithmic_bytes_per_launch": by / max(len(rs), 1),
-                    "fp32_equivalent_tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0, "share_of_step_time": ms / (dt * 1e3)}
+                    "fp32_equivalent_tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0, "share_of_step_time": ms / (dt_prof * 1e3)}
 
     def wgrad_h3_line():
         # split-f16 weight gradient: G (M x N) and X (M x K) are read once, the 256 per-CU partial tiles are
@@ -236,7 +255,7 @@ def main():
                     "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                     "traffic": traffic_db.get("gemm_tn_h3_bytes_per_launch"), "launches": len(rs),
                     "avg_launch_ms": ms / max(len(rs), 1), "algorithmic_bytes_per_launch": by / max(len(rs), 1),
-                    "fp32_equivalent_tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0, "share_of_step_time": ms / (dt * 1e3)}
+                    "fp32_equivalent_tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0, "share_of_step_time": ms / (dt_prof * 1e3)}
 
     def chain_line():
         # fused layer runs (chain4.hip): every fp32 product is three f16 MFMA products, and only the run's input, the
@@ -245,19 +264,18 @@ def main():
         ms = sum(r[4] for r in rs)
         by = float(sum(r[5] for r in rs))
         fl = float(sum(r[6] for r in rs))
-        prods = 1.0 if args.gemm_mode == "h1" else 3.0        # f16 MFMA products issued per fp32 product
-        ach = prods * fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        prods = 1.0 if (args.gemm_mode == "h1" or args.amp) else 3.0        # f16 MFMA products issued per fp32 product
+        tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0          # fp32-equivalent (algorithmic) TFLOP/s
         return ms, {"kernel": "mlp_chain4_kernel (fused embedding-MLP runs: forward and data-gradient, %s)" % ("one f16 product per fp32 product" if prods == 1.0 else "split-f16 MFMA, three products per fp32 product"),
-                    "bound": "mfma", "achieved": ach, "peak": F16_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / F16_MFMA_PEAK_TF,
+                    "bound": "mfma", "achieved": tf, "peak": F16_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf / F16_MFMA_PEAK_TF,
                     "traffic": traffic_db.get("mlp_chain_bytes_per_launch"), "launches": len(rs),
-                    "avg_launch_ms": ms / max(len(rs), 1), "algorithmic_gflop_per_launch": prods * fl / max(len(rs), 1) / 1e9,
-                    "note": "achieved / frac count the f16 MFMA products issued per fp32 product (parity mode: hi.hi + hi.lo + lo.hi) as work, padded input widths; "
-                            "frac_algorithmic = fp32-equivalent flops / f16 dense peak",
-                    "frac_algorithmic": fl / (ms * 1e-3) / 1e12 / F16_MFMA_PEAK_TF if ms > 0 else 0.0,
-                    "fp32_equivalent_tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
+                    "avg_launch_ms": ms / max(len(rs), 1), "algorithmic_gflop_per_launch": fl / max(len(rs), 1) / 1e9,
+                    "note": "achieved / frac = ALGORITHMIC flops (2 M N K of every layer, true input widths 117 / 142 / 39) over the launch time, against the dense f16 MFMA peak; "
+                            "frac_issued counts the f16 MFMA products the kernel issues per fp32 product (parity mode: hi.hi + hi.lo + lo.hi = 3) = matrix-pipe utilisation",
+                    "frac_issued": prods * tf / F16_MFMA_PEAK_TF, "issued_tflops": prods * tf, "products_per_fp32_product": prods,
                     "algorithmic_bytes_per_launch": by / max(len(rs), 1),
                     "hbm_gbs": by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0, "hbm_frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else 0.0,
-                    "share_of_step_time": ms / (dt * 1e3)}
+                    "share_of_step_time": ms / (dt_prof * 1e3)}
 
     def conv_line():
         # 3x3 layers of the U-Net head (conv.hip): forward / data-gradient (11) and weight-gradient (12) launches incl. their
@@ -270,7 +288,7 @@ def main():
         return {"kernel": "conv3x3_h3_kernel + conv3x3_wgrad_h3_kernel (U-Net 3x3 layers, split-f16 implicit GEMM)", "bound": "mfma",
                 "achieved": 3.0 * fl / (ms * 1e-3) / 1e12, "peak": F16_MFMA_PEAK_TF, "unit": "TFLOP/s",
                 "frac": 3.0 * fl / (ms * 1e-3) / 1e12 / F16_MFMA_PEAK_TF, "traffic": None, "launches": len(rs),
-                "avg_launch_ms": ms / len(rs), "fp32_equivalent_tflops": fl / (ms * 1e-3) / 1e12, "share_of_step_time": ms / (dt * 1e3)}
+                "avg_launch_ms": ms / len(rs), "fp32_equivalent_tflops": fl / (ms * 1e-3) / 1e12, "share_of_step_time": ms / (dt_prof * 1e3)}
 
     nt_ms, nt_line = mfma_line("gemm_nt_kernel<128,256,2,2> (embedding-MLP forward + data-gradient GEMMs, fp32 MFMA)", (0,),
                                "gemm_nt_128x256_bytes_per_launch")
@@ -279,9 +297,30 @@ def main():
     wg_ms, wg = wgrad_h3_line()
     ch_ms, ch = chain_line()
     dominant = max(((nt_ms, nt_line), (tn_ms, tn_line), (h3_ms, h3), (wg_ms, wg), (ch_ms, ch)), key=lambda t: t[0])[1]
-    knn = [r for r in recs if r[0] == 5]
-    knn_ms = sum(r[4] for r in knn) / max(len(knn), 1)
-    knn_bytes = R * (12.0 * P + 12 + 4 * k)
+    def knn_line():
+        # north_star asks for "the fraction of the kNN HBM roofline".  The binned form reads ~8 % of the cloud per ray and the cloud (120 KB at
+        # P = 10,000) is cache-resident, so the HBM roofline does not bind this kernel: the line carries the PHYSICAL fetch rate from the counter
+        # pass and the instruction count that does bind it, and the logical rate (what an every-point search would have to move) without a fraction.
+        knn = [r for r in recs if r[0] == 5]
+        knn_ms = sum(r[4] for r in knn) / max(len(knn), 1)
+        knn_bytes = R * (12.0 * P + 12 + 4 * k)
+        fetch_kb = traffic_all.get("ray_knn_fetch_kb_raw_P%d" % P)
+        insts = traffic_all.get("ray_knn_wave_insts_per_launch_P%d" % P)
+        phys = 2.0 * 1024.0 * fetch_kb if fetch_kb else None                 # (FETCH_SIZE doubled: the guide's gfx950 correction)
+        return {"kernel": "ray_knn_blocks_kernel (P >= 2,048: binned cloud, bounding spheres; the three binning kernels, ~18 us, are not in avg_launch_ms)",
+                "bound": "issue", "unit": "GB/s", "peak": HBM_PEAK_GBS, "avg_launch_ms": knn_ms,
+                "achieved": phys / (knn_ms * 1e-3) / 1e9 if phys and knn_ms > 0 else None,
+                "frac": phys / (knn_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if phys and knn_ms > 0 else None,
+                "physical_fetch_bytes_per_launch": phys,
+                "physical_fetch_gbs": phys / (knn_ms * 1e-3) / 1e9 if phys and knn_ms > 0 else None,
+                "wave_insts_per_ray": insts / R if insts else None,
+                "logical_bytes_per_launch": knn_bytes, "logical_gbs": knn_bytes / (knn_ms * 1e-3) / 1e9 if knn_ms > 0 else 0.0,
+                "rays_per_s_kernel_alone": R / (knn_ms * 1e-3) if knn_ms > 0 else 0.0,
+                "note": "achieved / frac = PHYSICAL HBM-side fetch (rocprofv3 FETCH_SIZE x 2 of the counter pass, profiles/traffic.json) over the live launch time: far "
+                        "below the HBM roof because the cloud is cache-resident and the walk touches ~19 of 247 blocks per ray; the kernel is bound by "
+                        "instruction issue (wave_insts_per_ray = SQ_INSTS_VALU + SALU + LDS + VMEM of the counter pass / rays).  logical_gbs = (12 P + 12 + 4 k) "
+                        "bytes per ray (SURVEY section 8d: what an every-point search reads) over the same time; it exceeds the HBM peak because those bytes are never moved"}
+
     out = {
         "metric": "train rays/sec, nerf_synthetic/%s (PAPR), fp32 in/out, GEMM mode '%s'" % (os.path.splitext(os.path.basename(args.scene))[0], args.gemm_mode),
         "value": world * R * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -292,20 +331,15 @@ def main():
                                "U-Net head, MSE loss (LPIPS weight 0: VGG weights unavailable offline), use_amp=%s; "
                                "points_influ_scores drawn U(0,1) (seed 5) instead of the untrained all-zero init so that the attention scores are not all zero"
                                % (P, H, W, R, k, "true (GradScaler, one-product embedding MLPs; the U-Net stays on the own kernels)" if args.amp else "false"),
-                   "global_batch_rays": world * R, "parallelism": "dp%d" % world, "gemm_mode": args.gemm_mode, "final_loss": float(loss.detach())},
-        "roofline": dominant,
+                   "global_batch_rays": world * R, "parallelism": "dp%d" % world, "gemm_mode": args.gemm_mode, "final_loss": final_loss},
+        "roofline": dominant if recs else None,
         "roofline_gemm_nt_fp32": nt_line if nt_ms > 0 and dominant is not nt_line else None,
         "roofline_gemm_nt_h3": h3 if h3_ms > 0 and dominant is not h3 else None,
         "roofline_wgrad": tn_line if tn_ms > 0 and dominant is not tn_line else None,
         "roofline_wgrad_h3": wg if wg_ms > 0 and dominant is not wg else None,
         "roofline_mlp_chain": ch if ch_ms > 0 and dominant is not ch else None,
         "roofline_conv3x3": conv_line(),
-        "roofline_knn": {"kernel": "ray_knn_blocks_kernel (P >= 2,048: binned cloud, bounding spheres; the three binning kernels, ~18 us, are not in avg_launch_ms)", "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
-                         "achieved": knn_bytes / (knn_ms * 1e-3) / 1e9 if knn_ms > 0 else 0.0,
-                         "frac": knn_bytes / (knn_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if knn_ms > 0 else 0.0,
-                         "avg_launch_ms": knn_ms, "logical_bytes_per_launch": knn_bytes,
-                         "note": "logical bytes (12P+12+4k per ray: what an every-point-against-every-ray search reads); the spatial form looks at ~20 % "
-                                 "of the points and the cloud is L2-resident, so physical HBM traffic is far lower; the kernel is bound by instruction issue"},
+        "roofline_knn": knn_line(),
     }
     if os.environ.get("PAPR_BENCH_LAUNCHES"):           # per-shape launch table of the timed steps, on stderr
         tab = {}
@@ -314,27 +348,50 @@ def main():
             c[0] += 1; c[1] += r[4]
         for key in sorted(tab, key=lambda t: -tab[t][1]):
             n, ms = tab[key]
-            print("kernel %2d  M=%-8d N=%-5d K=%-5d  %4d launches  %.3f ms each  %.3f ms/step" % (*key, n, ms / n, ms / args.steps), file=sys.stderr)
+            print("kernel %2d  M=%-8d N=%-5d K=%-5d  %4d launches  %.3f ms each  %.3f ms/step" % (*key, n, ms / n, ms / max(prof_steps, 1)), file=sys.stderr)
     if args.gemm_mode == "h1":
         out["dtype"] = "f32 rows, fused MLP runs multiply one f16 product per fp32 product (fp32 accumulate): the reduced-precision throughput mode"
-    if world == 1 and args.gemm_mode == "h3" and not args.no_amp_line:
-        # second line: the reduced-precision throughput mode (the library reads the mode when it loads: a child process)
+    def child_line(extra):
+        """A second measurement of this script in a fresh process (the mode is fixed when the first model is built); the headline line never depends on it."""
         import subprocess
-        cmd = [sys.executable, os.path.abspath(__file__), "--gemm-mode", "h1", "--no-cpu-baseline", "--steps", str(args.steps), "--warmup", str(args.warmup),
-               "--scene", args.scene, "--points", str(args.points)] + (["--amp"] if args.amp else [])
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        cmd = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-amp-line", "--no-shipped-line", "--psnr-steps", "0", "--steps", str(args.steps),
+               "--warmup", str(args.warmup), "--scene", args.scene, "--points", str(args.points)] + extra
         try:
-            j = json.loads(r.stdout.strip().splitlines()[-1])
-            out["throughput_mode_h1"] = {"value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "final_loss": j["config"]["final_loss"],
-                                         "note": "PAPR_GEMM_MODE=h1: one f16 product per fp32 product in the fused embedding-MLP runs (the counterpart of the reference's "
-                                                 "fp16 autocast of the attention block, models/attn.py:248); tolerance in tests/test_hip_h1.py; NOT the headline `value`",
-                                         "roofline_mlp_chain": j.get("roofline") if "mlp_chain" in (j.get("roofline") or {}).get("kernel", "") else j.get("roofline_mlp_chain")}
-        except Exception as e:      # the headline line must not depend on the second one
-            out["throughput_mode_h1"] = {"error": "%s: %s" % (type(e).__name__, (r.stderr or "")[-300:])}
-    if world == 1 and args.psnr_steps > 0 and args.gemm_mode == "h3":
-        out["psnr_after_steps"] = psnr_after_steps(args)
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+            return json.loads(r.stdout.strip().splitlines()[-1])
+        except Exception as e:
+            return {"error": "%s: %s" % (type(e).__name__, str(e)[-300:])}
+
+    def chain_of(j):
+        return j.get("roofline") if "mlp_chain" in (j.get("roofline") or {}).get("kernel", "") else j.get("roofline_mlp_chain")
+
+    main_line = world == 1 and args.gemm_mode == "h3" and not args.amp
+    if main_line and not args.no_shipped_line:
+        # BASELINE configs[1] verbatim: configs/nerfsyn/chair.yml as shipped has use_amp: true
+        j = child_line(["--amp"])
+        out["as_shipped_amp"] = j if "error" in j else {
+            "value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "final_loss": j["config"]["final_loss"], "dtype": j["dtype"],
+            "workload": j["config"]["workload"], "roofline_mlp_chain": chain_of(j),
+            "note": "the scene file's own `use_amp: true` (the reference then runs its attention block and U-Net under fp16 autocast, models/attn.py:248, "
+                    "models/unet.py:212): GradScaler on, embedding MLPs one f16 product per fp32 product, U-Net on the own split-f16 kernels.  Tolerance against the "
+                    "fp32 pin only (tests/test_hip_model.py: the reference's own AMP output cannot be produced without CUDA); NOT the headline `value`, which is the "
+                    "fp32 parity mode the 1e-4 bar is stated for"}
+    if main_line and not args.no_amp_line:
+        j = child_line(["--gemm-mode", "h1"])
+        out["throughput_mode_h1"] = j if "error" in j else {
+            "value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "final_loss": j["config"]["final_loss"],
+            "note": "PAPR_GEMM_MODE=h1: one f16 product per fp32 product in the fused embedding-MLP runs, GradScaler off; tolerance in tests/test_hip_h1.py; NOT the headline `value`",
+            "roofline_mlp_chain": chain_of(j)}
+    if main_line and args.psnr_steps > 0:
+        try:
+            out["psnr_after_steps"] = psnr_after_steps(args)
+        except Exception as e:
+            out["psnr_after_steps"] = {"error": "%s: %s" % (type(e).__name__, str(e)[-300:])}
     if not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(cfg, init_state, args.cpu_rays, args.cpu_steps)
+        try:
+            out["cpu_baseline"] = cpu_baseline(cfg, init_state, args.cpu_rays, args.cpu_steps)
+        except Exception as e:
+            out["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, str(e)[-300:])}
     print(json.dumps(out))
 
 

@@ -14,10 +14,16 @@ import torch
 import torch.distributed as td
 
 
+def launched():
+    """True under a launcher (torch.distributed.run exports RANK, WORLD_SIZE and MASTER_ADDR for every rank it starts, one rank included)."""
+    return all(k in os.environ for k in ("RANK", "WORLD_SIZE", "MASTER_ADDR"))
+
+
 def init_from_env(device=None):
-    """Initialise the default process group when launched by torch.distributed.run (WORLD_SIZE > 1)."""
+    """Initialise the default process group when started by torch.distributed.run -- with ONE rank as well, so that a
+    `--nproc-per-node 1` launch walks the same code as an 8-rank one (a plain `python bench.py` forms no group).  Returns the world size."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1 or td.is_initialized():
+    if td.is_initialized() or not launched():
         return world
     use_gpu = torch.cuda.is_available() and (device is None or torch.device(device).type == "cuda")
     # PAPR_DIST_BACKEND=gloo: several ranks on ONE device (tests on a 1-GPU box: RCCL refuses two ranks per GPU); the
@@ -42,6 +48,14 @@ def init_from_env(device=None):
 
 def world_size():
     return td.get_world_size() if td.is_available() and td.is_initialized() else 1
+
+
+def active():
+    """Do the collectives run?  With more than one rank, always.  PAPR_DIST_SINGLE=1 keeps them on in a one-rank group as well (every
+    collective is then the identity): the way a 1-GPU box executes the RCCL calls of this module (tests/test_hip_rccl.py)."""
+    if not (td.is_available() and td.is_initialized()):
+        return False
+    return td.get_world_size() > 1 or os.environ.get("PAPR_DIST_SINGLE", "0") == "1"
 
 
 def rank():
@@ -70,18 +84,38 @@ def _broadcast(t, src):
         td.broadcast(t, src=src)
 
 
+def _dense(t):
+    """Every element of t's memory span is an element of t, once (contiguous in SOME dimension order)."""
+    n, expect = t.numel(), 1
+    if n == 0:
+        return True
+    for size, stride in sorted(((sz, st) for sz, st in zip(t.size(), t.stride()) if sz != 1), key=lambda x: x[1]):
+        if stride != expect:
+            return False
+        expect *= size
+    return expect == n
+
+
 def average_gradients(params):
     """One flat bucket: g <- mean over ranks of g, for every parameter that has a gradient.
 
     Parameters whose gradient is None on this rank (e.g. no ray touched them) contribute zeros, so
     all ranks always reduce the same layout."""
-    ws = world_size()
-    if ws == 1:
+    if not active():
         return 0
+    ws = world_size()
     params = [p for p in params if p.requires_grad]
     if not params:
         return 0
-    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
+    # the bucket holds every gradient in the MEMORY order of its parameter (the U-Net's channels-last weights included: autograd's
+    # layout contract gives p.grad the strides of p), so that a view of the bucket with p's strides IS the averaged gradient
+    def in_memory_order(p):
+        g = p.grad if p.grad is not None else torch.zeros_like(p, memory_format=torch.preserve_format)
+        if g.stride() != p.stride():
+            g = torch.empty_like(p, memory_format=torch.preserve_format).copy_(g)
+        return g.as_strided((g.numel(),), (1,)) if _dense(g) else g.contiguous().reshape(-1)
+
+    flat = torch.cat([in_memory_order(p) for p in params])
     if td.get_backend() == "nccl":                   # RCCL averages in the collective; gloo has no AVG
         td.all_reduce(flat, op=td.ReduceOp.AVG)
     else:
@@ -89,13 +123,13 @@ def average_gradients(params):
         flat.div_(ws)
     # the averaged gradients stay where they are: every p.grad becomes a view of the bucket (67 copy-back launches per step
     # otherwise; the optimizers' zero_grad drops the views before the next backward pass)
-    # (a parameter in another memory format -- the U-Net's channels-last weights -- gets a gradient with ITS strides, as
-    # autograd's layout contract has it: the fused / foreach optimizers walk parameter and gradient memory side by side)
     off = 0
     for p in params:
         n = p.numel()
-        g = flat[off:off + n].view_as(p)
-        p.grad = g if g.stride() == p.stride() else torch.empty_like(p).copy_(g)
+        if _dense(p):
+            p.grad = flat.as_strided(p.size(), p.stride(), off)
+        else:
+            p.grad = torch.empty_like(p).copy_(flat[off:off + n].view_as(p))
         off += n
     return flat.numel()
 
@@ -104,7 +138,7 @@ def broadcast_point_cloud(tensors, src=0):
     """Broadcast a list of per-point tensors whose first dimension may differ across ranks.
 
     Returns new tensors (same dtype/device as the inputs) holding rank `src`'s values."""
-    if world_size() == 1:
+    if not active():
         return tensors
     dev = tensors[0].device
     n = torch.tensor([tensors[0].shape[0]], device=dev, dtype=torch.int64)
@@ -119,7 +153,7 @@ def broadcast_point_cloud(tensors, src=0):
 
 
 def broadcast_module_state(module, src=0):
-    if world_size() == 1:
+    if not active():
         return
     for t in list(module.parameters()) + list(module.buffers()):
         _broadcast(t.data, src)

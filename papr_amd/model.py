@@ -249,7 +249,7 @@ class PAPR(nn.Module):
                 opt.zero_grad()
 
     def step(self, step=-1):
-        if pdist.world_size() > 1:
+        if pdist.active():
             pdist.average_gradients([p for o in self.optimizers.values() if o is not None
                                      for g in o.param_groups for p in g["params"]])
         opts = [opt for opt in self.optimizers.values() if opt is not None]
@@ -281,7 +281,7 @@ class PAPR(nn.Module):
             self.pc_feats = nn.Parameter(feats.to(dev), requires_grad=self.pc_feats.requires_grad)
 
     def _sync_points(self):
-        if pdist.world_size() > 1:
+        if pdist.active():
             tensors = [self.points.data, self.points_influ_scores.data] + ([self.pc_feats.data] if self.use_pc_feats else [])
             out = pdist.broadcast_point_cloud(tensors)
             self._replace_points(out[0], out[1], out[2] if self.use_pc_feats else None)

@@ -395,8 +395,102 @@ def g13_ref_checkpoint():
         print("wrote g13_ref_ckpt/%s %.1f KB" % (f, os.path.getsize(os.path.join(out_dir, f)) / 1024))
 
 
+# ----------------------------------------------------------------------------------- G14
+G14_COMB = ["mean", "random", "random-softmax", "weighted", "duplicate"]
+G14_SAMPLE = ["random", "top-knn-std", "top-knn-mean", "top-knn-max", "top-knn-min", "influ-scores-max", "influ-scores-min"]
+
+
+def g14_cloud(P, seed):
+    """Seeded cloud: uniform points, a lattice patch (equal neighbour distances: ties in the site ranking) and a few exact duplicates."""
+    g = torch.Generator().manual_seed(seed)
+    pts = (torch.rand((P, 3), generator=g) * 2 - 1) * 12.0
+    n_lat = min(64, P // 4)
+    lat = torch.stack(torch.meshgrid(*[torch.arange(4.0)] * 3, indexing="ij"), -1).reshape(-1, 3)[:n_lat] * 1.5 - 3.0
+    pts[:n_lat] = lat
+    if P >= 40:
+        pts[P - 5:] = pts[20:25]                                   # five duplicated points
+    influ = torch.rand((P, 1), generator=g)
+    feats = torch.randn((P, 8), generator=g)
+    return pts.float(), influ.float(), feats.float()
+
+
+def g14_grow():
+    """The reference's growth / pruning procedures (models/utils.py:9-109 add_points_knn; models/model.py:335-394 PAPR.prune_points / add_points) under
+    fixed numpy seeds: every (comb_type, sample_type) pair, the `N <= add_num` branches, and the model-level calls incl. the `max_points` guard."""
+    from models.utils import add_points_knn
+    out = {}
+    pts, influ, feats = g14_cloud(600, 14)
+    out["cloud/points"], out["cloud/influ"], out["cloud/feats"] = npf(pts), npf(influ), npf(feats)
+    case = 0
+    for comb in G14_COMB:
+        for samp in G14_SAMPLE:
+            np.random.seed(1400 + case)
+            nc, n, ni, nf = add_points_knn(pts.clone(), influ.clone(), add_num=37, k=3, comb_type=comb, sample_type=samp, sample_k=10, point_features=feats.clone())
+            tag = "pair/%s/%s" % (comb, samp)
+            out[tag + "/coords"], out[tag + "/influ"], out[tag + "/feats"] = np.asarray(nc, dtype=np.float32), np.asarray(ni, dtype=np.float32), np.asarray(nf, dtype=np.float32)
+            out[tag + "/seed_n"] = np.array([1400 + case, n])
+            assert n == 37
+            case += 1
+    # the config's own pair at other k / sample_k, and without features
+    np.random.seed(1450)
+    nc, n, ni, nf = add_points_knn(pts.clone(), influ.clone(), add_num=50, k=5, comb_type="random", sample_type="top-knn-std", sample_k=6, point_features=None)
+    out["k5/coords"], out["k5/influ"] = np.asarray(nc, dtype=np.float32), np.asarray(ni, dtype=np.float32)
+    assert nf is None
+    # N <= add_num: random comb types draw sites with replacement, the others take every point once
+    spts, sinflu, sfeats = g14_cloud(20, 15)
+    out["small/points"], out["small/influ"], out["small/feats"] = npf(spts), npf(sinflu), npf(sfeats)
+    for i, comb in enumerate(G14_COMB):
+        np.random.seed(1460 + i)
+        nc, n, ni, nf = add_points_knn(spts.clone(), sinflu.clone(), add_num=30, k=3, comb_type=comb, sample_type="top-knn-std", sample_k=10, point_features=sfeats.clone())
+        tag = "small/%s" % comb
+        out[tag + "/coords"], out[tag + "/influ"], out[tag + "/feats"] = np.asarray(nc, dtype=np.float32), np.asarray(ni, dtype=np.float32), np.asarray(nf, dtype=np.float32)
+        out[tag + "/seed_n"] = np.array([1460 + i, n])
+    # model level: PAPR.prune_points (both prune types) and PAPR.add_points (default config pair; with and without the `max_points` guard).
+    # The initial state is the seeded construction itself (setup_seed(1); the build reproduces that stream bit for bit, test_initialisation_...),
+    # so only the influence scores set here, the per-point results and -- for the 64-wide features -- a float64 row checksum plus the NEW rows are stored.
+    rowsum = lambda t: t.detach().double().sum(1).numpy()
+    for ptype, tag in (("<", "lt"), (">", "gt")):
+        cfg = load_cfg("nerfsyn/chair.yml", geoms={"points": {"init_num": 1000}}, training={"prune_type": ptype})
+        setup_seed(1)
+        model = get_model(DictAsMember(copy.deepcopy(cfg)), "cpu")
+        with torch.no_grad():
+            model.points_influ_scores.copy_(torch.rand((1000, 1), generator=torch.Generator().manual_seed(16)))
+            model.points_influ_scores[::7] = 0.0                     # never-selected points keep exactly 0.0: `0 > 0` is false, they go
+        if tag == "lt":
+            out["model/influ0"] = npf(model.points_influ_scores)
+            out["model/points0_sum"], out["model/feats0_rowsum"] = npf(model.points).astype(np.float64).sum(0), rowsum(model.pc_feats)
+        n_drop = model.prune_points(0.3)
+        out["model/%s/n_drop" % tag] = np.array(int(n_drop))
+        out["model/%s/points" % tag], out["model/%s/influ" % tag], out["model/%s/feats_rowsum" % tag] = npf(model.points), npf(model.points_influ_scores), rowsum(model.pc_feats)
+        if tag == "lt":
+            P1 = model.points.shape[0]
+            np.random.seed(1470)
+            n_add = model.add_points(100)
+            out["model/add/n"] = np.array(int(n_add))
+            out["model/add/points"], out["model/add/influ"] = npf(model.points), npf(model.points_influ_scores)
+            out["model/add/feats_rowsum"], out["model/add/new_feats"] = rowsum(model.pc_feats), npf(model.pc_feats[P1:])
+            assert model.points.shape[0] == P1 + 100
+    for tag, max_points in (("cap", 650), ("full", 500)):
+        cfg = load_cfg("nerfsyn/chair.yml", geoms={"points": {"init_num": 600}}, max_points=max_points)
+        setup_seed(1)
+        model = get_model(DictAsMember(copy.deepcopy(cfg)), "cpu")
+        with torch.no_grad():
+            model.points_influ_scores.copy_(torch.rand((600, 1), generator=torch.Generator().manual_seed(17)))
+        out["model/%s/influ0" % tag] = npf(model.points_influ_scores)
+        np.random.seed(1480)
+        n_add = model.add_points(100)
+        out["model/%s/n" % tag] = np.array(int(n_add))
+        out["model/%s/points" % tag], out["model/%s/influ" % tag] = npf(model.points), npf(model.points_influ_scores)
+        out["model/%s/feats_rowsum" % tag], out["model/%s/new_feats" % tag] = rowsum(model.pc_feats), npf(model.pc_feats[600:])
+        print("max_points", max_points, "->", int(n_add), tuple(model.points.shape))
+    save("g14_grow.npz", **out)
+
+
 if __name__ == "__main__":
     small = {"geoms": {"points": {"init_num": 1000}}}
+    if "--round4" in sys.argv:
+        g14_grow()
+        sys.exit(0)
     if "--round3" in sys.argv:
         g13_ref_checkpoint()
         sys.exit(0)

@@ -139,3 +139,45 @@ def test_two_rank_average_equals_reference_two_image_batch(tmp_path):
         want = g9[ref]
         assert torch.equal(r0[key], r1[key])
         np.testing.assert_allclose(r0[key].numpy(), want, rtol=0, atol=1e-5 * np.abs(want).max() + 1e-9, err_msg=key)
+
+
+# ---------------------------------------------------------------------------------------------
+_ONE_RANK = r'''
+import os, sys, torch
+sys.path.insert(0, %r)
+import torch.distributed as td
+from papr_amd import dist as pdist
+assert pdist.launched() and not td.is_initialized()
+assert pdist.init_from_env("cpu") == 1 and td.is_initialized() and td.get_backend() == "gloo" and td.get_world_size() == 1
+assert pdist.active() == (os.environ.get("PAPR_DIST_SINGLE") == "1")
+g = torch.Generator().manual_seed(0)
+ps = [torch.nn.Parameter(torch.randn(s, generator=g)) for s in [(7, 3), (7, 1), (8, 4, 3, 3), (5,)]]
+ps[2].data = ps[2].data.contiguous(memory_format=torch.channels_last)
+for p in ps:
+    p.grad = torch.randn(p.shape, generator=g).contiguous(memory_format=torch.channels_last if p.dim() == 4 else torch.contiguous_format)
+ps[1].grad = None
+before = [None if p.grad is None else p.grad.clone() for p in ps]
+n = pdist.average_gradients(ps)
+if pdist.active():
+    assert n == sum(p.numel() for p in ps)
+    base = ps[0].grad.untyped_storage().data_ptr()
+    for p, b in zip(ps, before):
+        assert p.grad.untyped_storage().data_ptr() == base and p.grad.stride() == p.stride()
+        assert torch.equal(p.grad, b if b is not None else torch.zeros_like(p))
+    out = pdist.broadcast_point_cloud([ps[0].data, ps[1].data])
+    assert torch.equal(out[0], ps[0].data) and out[0] is not ps[0].data
+else:
+    assert n == 0 and ps[1].grad is None
+td.destroy_process_group()
+print("ok")
+'''
+
+
+@pytest.mark.parametrize("single", ["1", "0"])
+def test_a_one_rank_launch_forms_a_group_and_runs_the_collectives_only_on_request(single):
+    """`torch.distributed.run --nproc-per-node 1` exports RANK / WORLD_SIZE = 1 / MASTER_*: init_from_env forms the group (gloo here, RCCL
+    on a GPU: tests/test_hip_rccl.py); the collectives run in it with PAPR_DIST_SINGLE=1 and are short-cut without."""
+    import subprocess
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), PAPR_DIST_SINGLE=single)
+    r = subprocess.run([sys.executable, "-c", _ONE_RANK % ROOT], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout + r.stderr)[-3000:]

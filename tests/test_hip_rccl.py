@@ -1,0 +1,66 @@
+"""The RCCL branch of papr_amd/dist.py on the one GPU a test box has (BASELINE.json configs[4]).
+
+RCCL refuses two ranks per device, so the N > 1 arithmetic is covered by tests/test_hip_dp.py (gloo, two ranks on one GPU) and
+tests/test_dp_gloo.py (CPU).  What those cannot reach is the transport the metric names: `init_process_group("nccl", device_id=...)`,
+`all_reduce(ReduceOp.AVG)` on the device bucket, device `broadcast`, and bench.py started by `torch.distributed.run`.  Here a ONE-rank
+RCCL group runs all of it (PAPR_DIST_SINGLE=1 keeps papr_amd.dist from short-cutting a world of one), in fresh child processes."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_one_rank_rccl_group_runs_every_collective_of_the_dp_path(tmp_path):
+    out = os.path.join(str(tmp_path), "rccl.json")
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               PAPR_DIST_SINGLE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("PAPR_DIST_BACKEND", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_worker.py"), out], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+    res = json.load(open(out))
+    assert res["backend"] == "nccl" and res["lib"].endswith("libpapr_hip.so")
+    assert res["pruned"] == 667 and res["added"] == 20 and res["points"] == 353
+
+
+def _bench(extra_env, launcher, port=None):
+    cmd = [sys.executable]
+    if launcher:
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port)]
+    cmd += [os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--profile-steps", "0", "--no-amp-line", "--no-shipped-line",
+            "--psnr-steps", "0", "--no-cpu-baseline"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "PAPR_DIST_BACKEND"):
+        env.pop(k, None)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_under_the_launcher_prints_the_same_line_as_the_plain_launch():
+    """`python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1 ...` -- the driver's N > 1 command line with N = 1: the launcher
+    starts before any GPU call, bench.py forms the RCCL group, averages the gradient bucket every step (PAPR_DIST_SINGLE=1), takes the MAX of
+    the ranks' times with an all-reduce and prints ONE line.  Same training trajectory as the plain launch; step time within the box's noise."""
+    plain = _bench({}, launcher=False)
+    dp = _bench({"PAPR_DIST_SINGLE": "1"}, launcher=True, port=_free_port())
+    assert plain["n_gpus"] == 1 and dp["n_gpus"] == 1 and dp["config"]["parallelism"] == "dp1"
+    assert dp["config"]["final_loss"] == plain["config"]["final_loss"]           # AVG over one rank is the identity: same bits
+    assert dp["value"] == pytest.approx(25600 * 6 / (dp["ms_per_step"] * 6e-3), rel=1e-6)
+    # one flat 21.9 MB bucket (a cat and an all-reduce) per step on top of a ~12 ms step
+    assert dp["ms_per_step"] <= 1.15 * plain["ms_per_step"] + 0.3, (dp["ms_per_step"], plain["ms_per_step"])

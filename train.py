@@ -174,8 +174,11 @@ def main():
                 torch.save(torch.tensor(eval_psnrs), os.path.join(log_dir, "eval_psnrs.pth"))
                 if step % 50000 == 0:
                     torch.save(model.state_dict(), os.path.join(log_dir, "model_%d.pth" % step))
-            if world > 1:
+            if pdist.active():
                 torch.distributed.barrier()
+    if torch.distributed.is_initialized():
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
     return eval_psnrs
 
 
