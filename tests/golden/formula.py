@@ -97,3 +97,47 @@ def write_t2_fixture(base, H=40, W=64, n_train=3, n_test=2, seed=3):
         img[:4, :5] = 255                                                   # pure white pixels: zeroed when white_bg is false
         Image.fromarray(img).save(os.path.join(base, "rgb", name + ".png"))
         np.savetxt(os.path.join(base, "pose", name + ".txt"), cams[i] @ flip)   # stored in OpenCV convention
+
+
+def write_blender_fixture(base, res=40, n_train=12, n_test=3, seed=5):
+    """A nerf_synthetic-format scene (dataset/load_nerfsyn.py): transforms_{train,test}.json + RGBA PNGs of two shaded spheres on a transparent
+    background, ray-traced in numpy from orbit cameras with the dataset's field of view.  Deterministic: the golden generator and the tests
+    write the same bytes."""
+    import json
+    import os
+    import numpy as np
+    from PIL import Image
+    from papr_amd.data import CAMERA_ANGLE_X, make_cameras
+    cams = make_cameras(n_train + n_test, seed=seed, coord_scale=1.0).numpy().astype(np.float64)
+    focal = 0.5 * res / np.tan(0.5 * CAMERA_ANGLE_X)
+    px = (np.arange(res) + 0.5 - res / 2.0) / focal
+    x, y = np.meshgrid(px, -px)
+    dirs = np.stack([x, y, -np.ones_like(x)], -1)
+    spheres = [(np.array([0.0, 0.0, 0.0]), 0.9, np.array([0.85, 0.35, 0.2])), (np.array([0.7, -0.5, 0.6]), 0.45, np.array([0.2, 0.5, 0.9]))]
+    light = np.array([0.4, 0.3, 0.85]) / np.linalg.norm([0.4, 0.3, 0.85])
+    for split, lo, hi in (("train", 0, n_train), ("test", n_train, n_train + n_test)):
+        os.makedirs(os.path.join(base, split), exist_ok=True)
+        frames = []
+        for i in range(lo, hi):
+            c2w = cams[i]
+            d = dirs @ c2w[:3, :3].T
+            d = d / np.linalg.norm(d, axis=-1, keepdims=True)
+            o = c2w[:3, 3]
+            rgba = np.zeros((res, res, 4))
+            depth = np.full((res, res), np.inf)
+            for c, r, col in spheres:
+                oc = o - c
+                b = (d * oc).sum(-1)
+                disc = b * b - (oc @ oc - r * r)
+                t = -b - np.sqrt(np.maximum(disc, 0.0))
+                hit = (disc > 0) & (t > 0) & (t < depth)
+                n = (o + d * t[..., None] - c) / r
+                shade = 0.25 + 0.75 * np.maximum((n * light).sum(-1), 0.0)
+                rgba[hit, :3] = (col * shade[..., None])[hit]
+                rgba[hit, 3] = 1.0
+                depth = np.where(hit, t, depth)
+            name = "r_%d" % (i - lo)
+            Image.fromarray(np.round(rgba * 255).astype(np.uint8), "RGBA").save(os.path.join(base, split, name + ".png"))
+            frames.append({"file_path": "./%s/%s" % (split, name), "transform_matrix": [[float(v) for v in row] for row in c2w]})
+        with open(os.path.join(base, "transforms_%s.json" % split), "w") as f:
+            json.dump({"camera_angle_x": CAMERA_ANGLE_X, "frames": frames}, f)

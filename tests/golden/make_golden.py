@@ -40,7 +40,7 @@ from models.utils import posenc as ref_posenc  # noqa: E402
 from models.attn import LayerNorm as RefLayerNorm  # noqa: E402
 import train as ref_train  # noqa: E402
 
-from formula import formula_fill, synth_rays, uniform_points, write_t2_fixture  # noqa: E402
+from formula import formula_fill, synth_rays, uniform_points, write_t2_fixture, write_blender_fixture  # noqa: E402
 
 torch.set_num_threads(8)
 
@@ -400,14 +400,15 @@ G14_COMB = ["mean", "random", "random-softmax", "weighted", "duplicate"]
 G14_SAMPLE = ["random", "top-knn-std", "top-knn-mean", "top-knn-max", "top-knn-min", "influ-scores-max", "influ-scores-min"]
 
 
-def g14_cloud(P, seed):
-    """Seeded cloud: uniform points, a lattice patch (equal neighbour distances: ties in the site ranking) and a few exact duplicates."""
+def g14_cloud(P, seed, ties=False):
+    """Seeded cloud of uniform points; ties: plus a lattice patch (equal neighbour distances: ties in the site ranking AND in the neighbour
+    order, which scipy's KDTree resolves by its traversal) and a few exact duplicates."""
     g = torch.Generator().manual_seed(seed)
     pts = (torch.rand((P, 3), generator=g) * 2 - 1) * 12.0
-    n_lat = min(64, P // 4)
-    lat = torch.stack(torch.meshgrid(*[torch.arange(4.0)] * 3, indexing="ij"), -1).reshape(-1, 3)[:n_lat] * 1.5 - 3.0
-    pts[:n_lat] = lat
-    if P >= 40:
+    if ties:
+        n_lat = min(64, P // 4)
+        lat = torch.stack(torch.meshgrid(*[torch.arange(4.0)] * 3, indexing="ij"), -1).reshape(-1, 3)[:n_lat] * 1.5 - 3.0
+        pts[:n_lat] = lat
         pts[P - 5:] = pts[20:25]                                   # five duplicated points
     influ = torch.rand((P, 1), generator=g)
     feats = torch.randn((P, 8), generator=g)
@@ -431,6 +432,16 @@ def g14_grow():
             out[tag + "/seed_n"] = np.array([1400 + case, n])
             assert n == 37
             case += 1
+    # a cloud with exact ties (lattice patch, duplicated points): the host procedure uses the same KDTree as the reference and must follow it
+    # through them; a brute-force search cannot promise the KDTree's order among equal distances, so the device test stays on the cloud above
+    tpts, tinflu, tfeats = g14_cloud(600, 14, ties=True)
+    out["ties/points"], out["ties/influ"], out["ties/feats"] = npf(tpts), npf(tinflu), npf(tfeats)
+    for i, (comb, samp) in enumerate((("mean", "top-knn-max"), ("random", "top-knn-min"), ("weighted", "top-knn-std"), ("random-softmax", "random"))):
+        np.random.seed(1490 + i)
+        nc, n, ni, nf = add_points_knn(tpts.clone(), tinflu.clone(), add_num=37, k=3, comb_type=comb, sample_type=samp, sample_k=10, point_features=tfeats.clone())
+        tag = "ties/%s/%s" % (comb, samp)
+        out[tag + "/coords"], out[tag + "/influ"], out[tag + "/feats"] = np.asarray(nc, dtype=np.float32), np.asarray(ni, dtype=np.float32), np.asarray(nf, dtype=np.float32)
+        out[tag + "/seed_n"] = np.array([1490 + i, n])
     # the config's own pair at other k / sample_k, and without features
     np.random.seed(1450)
     nc, n, ni, nf = add_points_knn(pts.clone(), influ.clone(), add_num=50, k=5, comb_type="random", sample_type="top-knn-std", sample_k=6, point_features=None)
@@ -456,6 +467,8 @@ def g14_grow():
         with torch.no_grad():
             model.points_influ_scores.copy_(torch.rand((1000, 1), generator=torch.Generator().manual_seed(16)))
             model.points_influ_scores[::7] = 0.0                     # never-selected points keep exactly 0.0: `0 > 0` is false, they go
+            # the 10 x 10 x 10 initial lattice is all ties; a trained cloud has none: seeded jitter (the device search cannot follow the KDTree's tie order)
+            model.points.add_(0.3 * torch.randn((1000, 3), generator=torch.Generator().manual_seed(18)))
         if tag == "lt":
             out["model/influ0"] = npf(model.points_influ_scores)
             out["model/points0_sum"], out["model/feats0_rowsum"] = npf(model.points).astype(np.float64).sum(0), rowsum(model.pc_feats)
@@ -476,6 +489,7 @@ def g14_grow():
         model = get_model(DictAsMember(copy.deepcopy(cfg)), "cpu")
         with torch.no_grad():
             model.points_influ_scores.copy_(torch.rand((600, 1), generator=torch.Generator().manual_seed(17)))
+            model.points.add_(0.3 * torch.randn((600, 3), generator=torch.Generator().manual_seed(19)))
         out["model/%s/influ0" % tag] = npf(model.points_influ_scores)
         np.random.seed(1480)
         n_add = model.add_points(100)
@@ -486,10 +500,102 @@ def g14_grow():
     save("g14_grow.npz", **out)
 
 
+# ----------------------------------------------------------------------------------- G15
+G15_OVER = {
+    "seed": 4, "geoms": {"points": {"init_num": 1000}},
+    "dataset": {"patches": {"height": 16, "width": 16}},
+    "eval": {"step": 100, "img_idx": 1, "max_height": 20, "max_width": 20, "save_fig": False},
+    # 360 steps with everything the long schedule has: warm-up (60 steps), pruning every 60 steps from step 120, growth every 120 from 240;
+    # lr_factor 0.3: at full rate this tiny problem overshoots behind the warm-up (eval PSNR 13 -> 8 dB), at 0.3 it improves monotonically
+    "training": {"steps": 360, "prune_steps": 60, "prune_start": 120, "prune_stop": 330, "prune_thresh": 0.0,
+                 "add_steps": 120, "add_start": 240, "add_stop": 360, "add_num": 80,
+                 "lr": {"lr_factor": 0.3, "attn": {"warmup": 60}, "points_influ_scores": {"warmup": 60}, "feats": {"warmup": 60}, "generator": {"warmup": 60}}},
+}
+
+
+def g15_run(threads):
+    """One run of the reference's loop; returns the per-step / per-event record."""
+    import tempfile
+    torch.set_num_threads(threads)
+    with tempfile.TemporaryDirectory() as tmp:
+        scene = os.path.join(tmp, "scene") + "/"
+        write_blender_fixture(scene)
+        over = copy.deepcopy(G15_OVER)
+        over["dataset"]["path"] = scene
+        over["eval"]["dataset"] = {"path": scene}
+        over["save_dir"] = os.path.join(tmp, "exp")
+        over["index"] = "g15"
+        cfg = load_cfg("nerfsyn/chair.yml", **over)
+        ecfg = copy.deepcopy(cfg)
+        ecfg["dataset"].update(ecfg["eval"]["dataset"])            # (train.py:351-353)
+        args, eargs = DictAsMember(copy.deepcopy(cfg)), DictAsMember(ecfg)
+        os.makedirs(os.path.join(cfg["save_dir"], cfg["index"]), exist_ok=True)
+        from dataset import get_dataset as ref_get_dataset
+        setup_seed(cfg["seed"])
+        model = get_model(args, "cpu")                              # main(): train.py:302-307
+        dataset = ref_get_dataset(args.dataset, mode="train")
+        eval_dataset = ref_get_dataset(eargs.dataset, mode="test")
+        rec = {"loss": [], "img": [], "P": [], "influ_pos": [], "tgt_sum": []}
+        orig_step = ref_train.train_step
+
+        def spy(step, model, device, dataset, batch, loss_fn, a):   # per-step record around the reference's own train_step
+            rec["img"].append(int(batch[0][0]))
+            rec["tgt_sum"].append(float(batch[2].double().sum()))     # which crop: the checksum of the target patch
+            rec["P"].append(int(model.points.shape[0]))
+            out = orig_step(step, model, device, dataset, batch, loss_fn, a)
+            rec["loss"].append(float(out[0]))
+            rec["influ_pos"].append(int((model.points_influ_scores > 0).sum()))
+            return out
+        ref_train.train_step = spy
+        ev_log = []                                                 # (step, kind 0 = prune / 1 = add, count, points after)
+        for kind, name in ((0, "prune_points"), (1, "add_points")):
+            def wrap(fn, kind):
+                def call(*a, **k):
+                    n = fn(*a, **k)
+                    ev_log.append((len(rec["loss"]), kind, int(n), int(model.points.shape[0])))
+                    return n
+                return call
+            setattr(model, name, wrap(getattr(model, name), kind))
+        losses = [[], [], []]
+        try:
+            ref_train.train_and_eval(0, model, "cpu", dataset, eval_dataset, losses, args)
+        finally:
+            ref_train.train_step = orig_step
+        sd = model.state_dict()
+        print("threads", threads, "events (step, prune 0 / add 1, count, points after):", ev_log)
+        print("eval psnrs:", losses[2], "train-loss averages:", losses[0])
+        return dict(loss=np.array(rec["loss"]), tgt_sum=np.array(rec["tgt_sum"]), img=np.array(rec["img"], dtype=np.int32), P=np.array(rec["P"], dtype=np.int32),
+                    influ_pos=np.array(rec["influ_pos"], dtype=np.int32), events=np.array(ev_log, dtype=np.int32),
+                    eval_psnrs=np.array(losses[2]), eval_losses=np.array(losses[1]), train_loss_avgs=np.array(losses[0]),
+                    points_final=npf(sd["points"]), influ_final=npf(sd["points_influ_scores"]),
+                    attn_lr=np.array(model.attn_lr), pts_lr=np.array(model.pts_lr))
+
+
+def g15_dynamics():
+    """The reference's own training loop -- train.train_and_eval (train.py:182-300) with its DataLoader, train_step, prune / add schedule,
+    init_optimizers(step) re-creation and eval_step -- on CPU for 360 steps of a tiny nerf_synthetic-format directory (formula.write_blender_fixture).
+    Run twice with different thread counts (torch's CPU reductions change their summation order with it): run `a` is the pin, `b` shows how far
+    the REFERENCE drifts from itself over these steps -- the yardstick for the band the build is held to."""
+    a, b = g15_run(8), g15_run(3)
+    assert np.array_equal(a["img"], b["img"]) and np.array_equal(a["tgt_sum"], b["tgt_sum"])
+    out = {"a/" + k: v for k, v in a.items()}
+    out.update({"b/" + k: v for k, v in b.items() if k not in ("img", "tgt_sum", "points_final", "influ_final")})
+    save("g15_dynamics.npz", cfg_json=np.array(json.dumps(G15_OVER)), **out)
+
+
 if __name__ == "__main__":
     small = {"geoms": {"points": {"init_num": 1000}}}
-    if "--round4" in sys.argv:
+    if "--g14" in sys.argv:
         g14_grow()
+        sys.exit(0)
+    if "--g15" in sys.argv:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+        g15_dynamics()
+        sys.exit(0)
+    if "--round4" in sys.argv:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+        g14_grow()
+        g15_dynamics()
         sys.exit(0)
     if "--round3" in sys.argv:
         g13_ref_checkpoint()

@@ -57,27 +57,29 @@ def test_get_rays_on_device_within_one_ulp_of_reference():
 
 
 def test_patch_offsets_follow_the_reference_numpy_draws(tmp_path):
-    """extract_patches draws (start row, start column) per patch from numpy; a scene with seed 7 draws the same crops the
-    reference draws under np.random.seed(7) -- and never touches the global stream (add_points owns that one)."""
+    """extract_patches draws (start row, start column) per patch from numpy.  own_stream (data parallelism): a scene with seed 7 draws the crops the
+    reference draws under np.random.seed(7) and never touches the global stream (add_points owns that one); one process: the crops come from
+    the GLOBAL stream, like the reference's."""
     from papr_amd.dataset import _ImageScene
     g = golden("g10_rays.npz")
     for tag, ph in (("blender", 160), ("t2", 180)):
         H, W, fx, fy, scale = g[tag + "/cam"]
-        sc = _ImageScene()
         H, W = int(H), int(W)
         ids = np.tile(np.arange(H * W, dtype=np.float32).reshape(1, H, W, 1), (2, 1, 1, 3))      # pixel id as colour: reveals the crop
-        sc._finish(ids, np.tile(np.eye(4, dtype=np.float32), (2, 1, 1)), fx, fy,
-                   {"coord_scale": 1.0, "patches": {"height": ph, "width": ph}}, "cpu", seed=7)
-        np.random.seed(123)
-        state = np.random.get_state()[1].copy()
-        got = []
-        for i in range(2):
-            for j in range(2):
-                tgt = sc.patch(i)[0]
-                first = int(tgt[0, 0, 0, 0])
-                got.append([first // W, first % W])
-        assert np.array_equal(np.array(got).reshape(2, 2, 2), g[tag + "/patch_hw"])
-        assert np.array_equal(np.random.get_state()[1], state)
+        for own in (True, False):
+            sc = _ImageScene()
+            sc._finish(ids, np.tile(np.eye(4, dtype=np.float32), (2, 1, 1)), fx, fy,
+                       {"coord_scale": 1.0, "patches": {"height": ph, "width": ph}}, "cpu", seed=7, own_stream=own)
+            np.random.seed(123 if own else 7)
+            state = np.random.get_state()[1].copy()
+            got = []
+            for i in range(2):
+                for j in range(2):
+                    tgt = sc.patch(i)[0]
+                    first = int(tgt[0, 0, 0, 0])
+                    got.append([first // W, first % W])
+            assert np.array_equal(np.array(got).reshape(2, 2, 2), g[tag + "/patch_hw"])
+            assert np.array_equal(np.random.get_state()[1], state) == own
 
 
 def test_tanks_and_temples_reader_matches_reference_dataset(tmp_path):
@@ -124,7 +126,7 @@ def test_ranks_draw_different_patches_from_a_blender_directory(tmp_path):
     dcfg = {"type": "synthetic", "path": base, "factor": 1, "white_bg": True, "coord_scale": 10.0, "patches": {"height": 8, "width": 8}}
     np.random.seed(11)
     state = np.random.get_state()[1].copy()
-    r0, r1, r0_again = (get_dataset(dcfg, "train", "cpu", seed=s) for s in (5, 6, 5))
+    r0, r1, r0_again = (get_dataset(dcfg, "train", "cpu", seed=s, own_stream=True) for s in (5, 6, 5))
     assert type(r0).__name__ == "BlenderScene" and r0.images.shape == (5, 24, 24, 3)
     a = [r0.patch() for _ in range(6)]
     b = [r1.patch() for _ in range(6)]

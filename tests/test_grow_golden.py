@@ -43,6 +43,16 @@ def _check_pairs(grow, dev):
             _close(nc, g[tag + "/coords"], tag + "/coords", atol)
             _close(ni, g[tag + "/influ"], tag + "/influ", atol)
             _close(nf, g[tag + "/feats"], tag + "/feats", atol)
+    if dev == "cpu":        # exact ties (lattice patch, duplicated points): the host procedure follows the reference's KDTree through them
+        tpts, tinflu, tfeats = _cloud(g, "ties", dev)
+        for comb, samp in (("mean", "top-knn-max"), ("random", "top-knn-min"), ("weighted", "top-knn-std"), ("random-softmax", "random")):
+            tag = "ties/%s/%s" % (comb, samp)
+            seed, n = (int(v) for v in g[tag + "/seed_n"])
+            np.random.seed(seed)
+            nc, n_new, ni, nf = grow(tpts, tinflu, 37, 3, comb_type=comb, sample_type=samp, sample_k=10, feats=tfeats)
+            _close(nc, g[tag + "/coords"], tag + "/coords", ATOL.get(comb, 0.0))
+            _close(ni, g[tag + "/influ"], tag + "/influ", ATOL.get(comb, 0.0))
+            _close(nf, g[tag + "/feats"], tag + "/feats", ATOL.get(comb, 0.0))
     np.random.seed(1450)
     nc, n_new, ni, nf = grow(pts, influ, 50, 5, comb_type="random", sample_type="top-knn-std", sample_k=6, feats=None)
     assert n_new == 50 and nf is None
@@ -94,11 +104,12 @@ def _check_model_level(dev):
     tol = 0.0 if dev == "cpu" else 1e-6
     for ptype, tag in (("<", "lt"), (">", "gt")):
         m = _model(1000, dev, training={"prune_type": ptype})
-        # the seeded construction is the reference's (same RNG stream): the stored checksums of ITS initial state agree
-        assert np.array_equal(m.points.detach().double().sum(0).cpu().numpy(), g["model/points0_sum"])
         assert np.array_equal(_rowsum(m.pc_feats), g["model/feats0_rowsum"])
         with torch.no_grad():
             m.points_influ_scores.copy_(torch.from_numpy(g["model/influ0"]))
+            m.points.add_((0.3 * torch.randn((1000, 3), generator=torch.Generator().manual_seed(18))).to(dev))      # (no lattice ties: see make_golden.g14_grow)
+        # the seeded construction is the reference's (same RNG stream): the stored checksums of ITS state agree
+        assert np.array_equal(m.points.detach().cpu().double().sum(0).numpy(), g["model/points0_sum"])
         m.clear_optimizer(); m.clear_scheduler()
         n_drop = int(m.prune_points(0.3))
         assert n_drop == int(g["model/%s/n_drop" % tag])
@@ -121,6 +132,7 @@ def _check_model_level(dev):
         m = _model(600, dev, max_points=max_points)
         with torch.no_grad():
             m.points_influ_scores.copy_(torch.from_numpy(g["model/%s/influ0" % tag]))
+            m.points.add_((0.3 * torch.randn((600, 3), generator=torch.Generator().manual_seed(19))).to(dev))
         np.random.seed(1480)
         n_add = int(m.add_points(100))
         assert n_add == int(g["model/%s/n" % tag]) == (50 if tag == "cap" else 0)

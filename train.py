@@ -26,6 +26,8 @@ def parse_args():
     ap.add_argument("--opt", type=str, default="", help="Option file path")
     ap.add_argument("--resume", type=int, default=0, help="Resume training")
     ap.add_argument("--steps", type=int, default=-1, help="override training.steps (smoke runs)")
+    ap.add_argument("--log-steps", type=str, default="", help="diagnostics: write every step's loss / image index / point count and every prune / add event to this .npz "
+                                                             "(reads the loss back every step: not for timing runs)")
     ap.add_argument("--set", nargs="*", default=[], help="extra overrides, e.g. use_amp=false training.losses.lpips=0")
     return ap.parse_args()
 
@@ -111,7 +113,7 @@ def main():
     setup_seed(args.seed)
     model = get_model(args, dev).to(dev)
     pdist.broadcast_module_state(model)
-    dataset = get_dataset(cfg["dataset"], "train", dev, seed=args.seed + rank)
+    dataset = get_dataset(cfg["dataset"], "train", dev, seed=args.seed + rank, own_stream=world > 1)
     eval_set = get_dataset(eargs["dataset"], "test", dev, seed=args.seed)
     loss_fn = get_loss(cfg["training"]["losses"]).to(dev)
     start = 0
@@ -135,12 +137,18 @@ def main():
     T = args.training
     step, pruned, t0, run_loss = start, False, time.time(), 0.0
     print("Start step:", start, "Total steps:", T.steps)
+    slog = {"loss": [], "P": [], "events": [], "img": [], "tgt_sum": []} if (cli.log_steps and rank == 0) else None
     while step < T.steps:
+        # (the reference's `for batch in trainloader` has the step's batch in hand BEFORE the prune / add block runs, train.py:205-250: the crop is
+        # drawn from the global numpy stream ahead of add_points' draws)
+        batch = sample_batch(dataset, cfg["dataset"]["batch_size"])
         if T.prune_steps > 0 and T.prune_start <= step < T.prune_stop and step % T.prune_steps == 0:
             thr = T.prune_thresh_list[bisect.bisect_left(T.prune_steps_list, step)] if len(T.prune_steps_list) > 0 else T.prune_thresh
             n = reinit(model, step, lambda: model.prune_points(thr))
             pruned = True
             print("Step %d: Pruned %d points" % (step, n))
+            if slog is not None:
+                slog["events"].append((step, 0, int(n), int(model.points.shape[0])))
         add_now = None
         if pruned and len(T.add_steps_list) > 0:
             if step in T.add_steps_list:
@@ -153,8 +161,16 @@ def main():
                 n = reinit(model, step, lambda: model.add_points(add_now if len(T.add_steps_list) == 0 else capped))
                 model.added_points = True
                 print("Step %d: Added %d points" % (step, n))
-        loss = train_step(step, model, sample_batch(dataset, cfg["dataset"]["batch_size"]), loss_fn, args)
+                if slog is not None:
+                    slog["events"].append((step, 1, int(n), int(model.points.shape[0])))
+        if slog is not None:
+            slog["P"].append(int(model.points.shape[0]))
+        loss = train_step(step, model, batch, loss_fn, args)
         step += 1
+        if slog is not None:
+            slog["loss"].append(loss.item())
+            slog["img"].append(getattr(dataset, "last_indices", [-1])[0])
+            slog["tgt_sum"].append(float(batch[0].double().sum()))
         if step % 200 == 0 and rank == 0:
             l = loss.item()
             print("Train step:", step, "loss:", l, "attn_lr:", model.attn_lr, "pts_lr:", model.pts_lr, "scale:",
@@ -176,6 +192,10 @@ def main():
                     torch.save(model.state_dict(), os.path.join(log_dir, "model_%d.pth" % step))
             if pdist.active():
                 torch.distributed.barrier()
+    if slog is not None:
+        np.savez(cli.log_steps, loss=np.array(slog["loss"]), img=np.array(slog["img"], dtype=np.int32), tgt_sum=np.array(slog["tgt_sum"]), P=np.array(slog["P"], dtype=np.int32), events=np.array(slog["events"], dtype=np.int32).reshape(-1, 4),
+                 eval_psnrs=np.array(eval_psnrs), eval_losses=np.array(eval_losses), points_final=model.points.detach().cpu().numpy(),
+                 influ_final=model.points_influ_scores.detach().cpu().numpy(), attn_lr=np.array(model.attn_lr), pts_lr=np.array(model.pts_lr))
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
