@@ -11,8 +11,10 @@
  *   - every call enqueues work on `stream` (a hipStream_t passed as void*) and returns
  *     immediately; 0 = ok, non-zero = error (text via papr_last_error()).
  *   - no internal allocation, no settings kept between calls: scratch is passed in by the caller (the
- *     *_workspace_bytes helpers say how much), modes are arguments.  Process-wide by design: the optional
- *     profiler switch (papr_profile_enable) and the last-error text.
+ *     *_workspace_bytes helpers say how much), modes are arguments, and the library reads NO environment variable.
+ *     Process-wide by design, and only through explicit calls: the optional profiler switch (papr_profile_enable),
+ *     the last-error text, and the A/B switches of papr_set_switch (defaults = the product; none changes a result).
+ *     Device facts (compute-unit count, kernel attributes) are cached per device id.
  *   - "ld" arguments are row strides in floats and must be multiples of 4 (16-byte rows).
  */
 #ifndef PAPR_HIP_H
@@ -210,8 +212,11 @@ typedef struct {
  *   PAPR_MLP_H1      one f16 product per fp32 product in the fused runs, f16 rows between a run and its weight gradients: the counterpart
  *                    of the reference running its attention block under fp16 autocast (`use_amp: true`, models/attn.py:248)
  *   PAPR_MLP_F32     exact fp32 MFMA everywhere;  PAPR_MLP_FWD / _DGRAD / _LAYERS: A/B steps between F32 and H3 (split-f16 forward only /
- *                    + data-gradient / + weight gradient, one launch per layer) */
-enum { PAPR_MLP_H3 = 0, PAPR_MLP_H1 = 1, PAPR_MLP_F32 = 2, PAPR_MLP_FWD = 3, PAPR_MLP_DGRAD = 4, PAPR_MLP_LAYERS = 5 };
+ *                    + data-gradient / + weight gradient, one launch per layer)
+ *   PAPR_MLP_H1_F32ROWS  H1 with fp32 rows between a run and its weight gradients (ABI 19; before: PAPR_H1_ROWS=f32 in the environment): another
+ *                    computation than H1 -- other bits in the weight gradients, inside the same tolerance
+ * An unknown value is an error. */
+enum { PAPR_MLP_H3 = 0, PAPR_MLP_H1 = 1, PAPR_MLP_F32 = 2, PAPR_MLP_FWD = 3, PAPR_MLP_DGRAD = 4, PAPR_MLP_LAYERS = 5, PAPR_MLP_H1_F32ROWS = 6 };
 size_t papr_mlp_fwd_workspace_bytes(int64_t M);
 /* in_norm (optional): the same LayerNorm core in FRONT of layer 0 (FeedForward.innorm) over the first in_norm->width
  * columns of x.  x is then overwritten with its standardised rows (papr_mlp_bwd and papr_rownorm_bwd read them),
@@ -379,6 +384,21 @@ typedef struct {
 } papr_profile_record;
 
 int papr_profile_enable(int on);
+
+/* Process-wide A/B and test switches (ABI 19; before: environment variables read by the library at first use).  Every value of every
+ * switch gives BIT-IDENTICAL results (tests/test_hip_chain_variants.py, scripts/probes/knn_ab.py); they choose between forms of a kernel.
+ * The defaults are what ships; papr_amd/hip.py forwards the historical PAPR_C4_* / PAPR_KNN_* environment names to these calls.
+ *   PAPR_SW_C4_GENERIC  (0)    1: the fused-run kernel's specialised row-phase instantiations off
+ *   PAPR_SW_C4_FUSED    (1)    0: its hot slots as two-role C++ slots instead of one generated statement
+ *   PAPR_SW_C4_EARLY    (3)    bit 0 / bit 1: early request of the next tile's rows in forward / data-gradient staging slots
+ *   PAPR_SW_KNN_BLOCKS  (1)    0: every point against every ray instead of the binned cloud
+ *   PAPR_SW_KNN_T       (0)    rays per wave of the binned form, 0 = chosen from R
+ *   PAPR_SW_WGRAD_WGS   (600)  workgroups the 3x3 weight-gradient aims for
+ *   PAPR_SW_NT_VARIANT  (0)    tiling of the fp32-MFMA layer GEMM (1, 2: double-buffered; 3: four waves per SIMD) */
+enum { PAPR_SW_C4_GENERIC = 0, PAPR_SW_C4_FUSED = 1, PAPR_SW_C4_EARLY = 2, PAPR_SW_KNN_BLOCKS = 3, PAPR_SW_KNN_T = 4, PAPR_SW_WGRAD_WGS = 5,
+       PAPR_SW_NT_VARIANT = 6, PAPR_SW_COUNT = 7 };
+int papr_set_switch(int32_t which, int32_t value);
+int32_t papr_get_switch(int32_t which);
 /* Waits for the recorded events, writes up to `cap` records (oldest first), clears the log and
  * returns the number of records that were pending. */
 int papr_profile_collect(papr_profile_record* out, int cap);

@@ -68,6 +68,24 @@ def _compiler_agpr_uses(asm):
     return n
 
 
+def _register_metadata_ok(asm, kernel_substr="mlp_chain4_kernel"):
+    """chain4.hip's by-name registers are only safe while the code object SAYS it owns them: every kernel descriptor must allocate the full unified
+    file with the AGPR bank at 128 (`.amdhsa_accum_offset 128`: v0-v127 | a0-a127) and the metadata must count 256 VGPRs / 128 AGPRs.  A compiler that
+    stopped counting the empty-asm clobbers of v64-v127 would shrink these and alias the accumulators with the weights."""
+    offs = re.findall(r"\.amdhsa_accum_offset\s+(\d+)", asm)
+    frees = re.findall(r"\.amdhsa_next_free_vgpr\s+(\d+)", asm)
+    blocks = re.findall(r"- \.agpr_count:\s+(\d+)(?:(?!- \.agpr_count:).)*?\.name:\s+(\S+)(?:(?!- \.agpr_count:).)*?\.vgpr_count:\s+(\d+)", asm, re.S)
+    kernels = [(int(a), name, int(v)) for a, name, v in blocks if kernel_substr in name]
+    problems = []
+    if not offs or any(int(o) != 128 for o in offs):
+        problems.append("amdhsa_accum_offset %s (want 128 everywhere)" % sorted(set(offs)))
+    if not frees or any(int(f) != 256 for f in frees):
+        problems.append("amdhsa_next_free_vgpr %s (want 256)" % sorted(set(frees)))
+    if len(kernels) < 4 or any(a != 128 or v != 256 for a, _, v in kernels):
+        problems.append("metadata agpr_count / vgpr_count %s (want 128 / 256 for the four kernels)" % [(a, v) for a, _, v in kernels])
+    return problems
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -100,6 +118,11 @@ def build_library(force=False, verbose=True):
             if src in HIDDEN_VGPRS and _compiler_hidden_vgpr_uses(asm):
                 os.remove(os.path.join(objdir, src.replace(".hip", ".o")))
                 raise RuntimeError("%s: compiler-generated code touches v64-v127, where the kernel keeps its accumulators by name" % src)
+            if src in HIDDEN_VGPRS:
+                bad = _register_metadata_ok(asm)
+                if bad:
+                    os.remove(os.path.join(objdir, src.replace(".hip", ".o")))
+                    raise RuntimeError("%s: register metadata does not cover the by-name registers: %s" % (src, "; ".join(bad)))
             n = _compiler_agpr_uses(asm)
             if n:
                 os.remove(os.path.join(objdir, src.replace(".hip", ".o")))

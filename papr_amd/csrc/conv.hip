@@ -469,11 +469,8 @@ extern "C" int papr_conv3x3_fwd(const float* x, int32_t B, int32_t H, int32_t W,
     a.bias = bias; a.out = out; a.N = c_out; a.relu = relu; a.xmax_bits = xmax;
     a.splits = conv_splits(M, c_in, c_out);
     a.partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + 256 + papr_conv3x3_weight_halfs(c_out, c_in) * sizeof(_Float16));
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (papr_first_on_device(PAPR_ONCE_CONV))
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_h3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CV_LDS_BYTES);
-        attr_set = true;
-    }
     const bool prof = papr_prof_on();
     if (prof) papr_prof_begin2(11, M, c_out, (int)K, 4LL * M * (c_in + c_out), 2LL * M * c_out * K, s);
     conv3x3_h3_kernel<<<dim3((unsigned)((M + CV_BM - 1) / CV_BM), (unsigned)(n_pad / CV_BN), (unsigned)a.splits), dim3(256), CV_LDS_BYTES, s>>>(a);
@@ -491,7 +488,7 @@ extern "C" int papr_conv3x3_fwd(const float* x, int32_t B, int32_t H, int32_t W,
 // pixels per workgroup of the weight-gradient launch: enough chunks for ~600 workgroups, at least 8 slabs each
 static long wgrad_px_per_chunk(long M, int c_in, int c_out) {
     const long tiles = (long)((c_out + 127) / 128) * ((c_in + 127) / 128) * 9;
-    static const long target = getenv("PAPR_WGRAD_WGS") ? atol(getenv("PAPR_WGRAD_WGS")) : 600;
+    const long target = papr_switch(PAPR_SW_WGRAD_WGS) > 0 ? papr_switch(PAPR_SW_WGRAD_WGS) : 600;
     long chunks = (target + tiles - 1) / tiles;
     long px = (M + chunks - 1) / chunks;
     px = (px + 31) / 32 * 32;
@@ -530,11 +527,9 @@ extern "C" int papr_conv3x3_wgrad(const float* d_out, const float* x, int32_t B,
     a.partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + 256);
     a.partial_b = d_bias ? a.partial + (size_t)chunks * c_out * 9 * c_in : nullptr;
     a.px_per_chunk = px;
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (papr_first_on_device(PAPR_ONCE_CONV_WGRAD)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_h3_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CV_LDS_BYTES);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_h3_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CV_LDS_BYTES);
-        attr_set = true;
     }
     const int ct = c_in <= 32 ? 32 : 128;
     const int tiles = ((c_out + 127) / 128) * ((c_in + ct - 1) / ct);

@@ -13,7 +13,43 @@ void papr_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* papr_last_error(void) { return g_err; }
-extern "C" int papr_abi_version(void) { return 18; }
+extern "C" int papr_abi_version(void) { return 19; }
+
+// ---- process-wide switches and per-device caches ------------------------------------------------
+#include <atomic>
+namespace {
+std::atomic<int32_t> g_switch[PAPR_SW_COUNT] = {{0}, {1}, {3}, {1}, {0}, {600}, {0}};        // defaults = the product (papr_hip.h: PAPR_SW_*)
+constexpr int MAX_DEVICES = 64;
+std::atomic<int> g_cu[MAX_DEVICES];
+std::atomic<unsigned> g_once[MAX_DEVICES];
+int current_device() { int dev = 0; (void)hipGetDevice(&dev); return dev >= 0 && dev < MAX_DEVICES ? dev : 0; }
+}  // namespace
+
+int papr_switch(int which) { return which >= 0 && which < PAPR_SW_COUNT ? g_switch[which].load(std::memory_order_relaxed) : 0; }
+
+extern "C" int papr_set_switch(int32_t which, int32_t value) {
+    PAPR_REQUIRE(which >= 0 && which < PAPR_SW_COUNT, "papr_set_switch: unknown switch %d", which);
+    g_switch[which].store(value, std::memory_order_relaxed);
+    return 0;
+}
+
+extern "C" int32_t papr_get_switch(int32_t which) { return papr_switch(which); }
+
+int papr_cu_count() {
+    const int dev = current_device();
+    int n = g_cu[dev].load(std::memory_order_relaxed);
+    if (n <= 0) {
+        (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        if (n <= 0) n = 256;
+        g_cu[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
+
+bool papr_first_on_device(int slot) {
+    const unsigned bit = 1u << slot;
+    return !(g_once[current_device()].fetch_or(bit, std::memory_order_relaxed) & bit);
+}
 
 // ---- optional launch timing (diagnostics only; see papr_profile_enable in papr_hip.h) ----------
 namespace {

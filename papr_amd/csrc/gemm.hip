@@ -507,8 +507,7 @@ int launch_nt(const NTArgs& a, hipStream_t s) {
 // 8 waves x (64x64) beats 4 waves x (128x64) on the 128x256 tile: 586 vs 628 us per 512000x256x256
 // layer (4 waves per SIMD hide the slab hand-over and the epilogue better).  PAPR_NT_WAVES4 keeps the
 // old shape reachable for A/B runs.
-static const bool NT_WAVES4 = getenv("PAPR_NT_WAVES4") != nullptr;
-static const int NT_VARIANT = getenv("PAPR_NT_VARIANT") ? atoi(getenv("PAPR_NT_VARIANT")) : 0;   // A/B switch
+#define NT_VARIANT papr_switch(PAPR_SW_NT_VARIANT)          // A/B switch: 1 / 2 = double-buffered tilings, 3 = four waves per SIMD
 
 // Which wide GEMMs run on the split-f16 kernels.  PAPR_GEMM_MODE = h3 (default) | layers | dgrad | fwd | f32.
 //   h3   : everything below, and runs of consecutive layers fused into one kernel (chain.hip).
@@ -528,9 +527,12 @@ static const int NT_VARIANT = getenv("PAPR_NT_VARIANT") ? atoi(getenv("PAPR_NT_V
 //   h1 (PAPR_MLP_H1): h3, and the fused runs (chain4.hip) multiply one f16 product per fp32 product: the throughput mode that stands for
 //   the reference's fp16 autocast of the attention block (models/attn.py:248, `use_amp: true`); own tolerance in the tests.
 static thread_local int t_mode = 4;            // 0 f32, 1 fwd, 2 dgrad, 3 layers, 4 h3, 5 h1
-static inline int mode_from_arg(int32_t m) {
-    switch (m) { case PAPR_MLP_F32: return 0; case PAPR_MLP_FWD: return 1; case PAPR_MLP_DGRAD: return 2; case PAPR_MLP_LAYERS: return 3;
-                 case PAPR_MLP_H1: return 5; default: return 4; }
+static thread_local bool t_h1_f32_rows = false;
+static inline bool mode_from_arg(int32_t m) {  // false: not a mode of papr_hip.h
+    t_h1_f32_rows = m == PAPR_MLP_H1_F32ROWS;
+    switch (m) { case PAPR_MLP_F32: t_mode = 0; return true; case PAPR_MLP_FWD: t_mode = 1; return true; case PAPR_MLP_DGRAD: t_mode = 2; return true;
+                 case PAPR_MLP_LAYERS: t_mode = 3; return true; case PAPR_MLP_H3: t_mode = 4; return true;
+                 case PAPR_MLP_H1: case PAPR_MLP_H1_F32ROWS: t_mode = 5; return true; default: return false; }
 }
 #define GEMM_MODE t_mode
 #define GEMM_ONE_PRODUCT (t_mode == 5)
@@ -585,15 +587,11 @@ __global__ __launch_bounds__(256) void split_weight_kernel(const float* __restri
 int launch_nt_h3(const NTArgs& a, _Float16* planes, hipStream_t s) {
     constexpr int BM = 128, BN = 256;
     const int tiles_m = (int)((a.M + BM - 1) / BM);
-    static int n_cu = 0;
-    if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu <= 0) n_cu = 256; }
+    const int n_cu = papr_cu_count();
     dim3 grid((unsigned)(tiles_m < n_cu ? tiles_m : n_cu), (unsigned)((a.N + BN - 1) / BN));   // one persistent workgroup per CU
     size_t lds = (size_t)2 * 2 * BM * 40 * sizeof(_Float16) + (size_t)8 * 32 * 36 * sizeof(float) + (size_t)4 * BM * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (papr_first_on_device(PAPR_ONCE_NT_H3))
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_h3_kernel<BM, BN, 2, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
     // pre-split the weight once per launch (64k-180k elements): the hot loop then copies f16 planes verbatim
     const int ncols = a.A2 ? a.wcol2 + a.K2 : a.K1;
     const int pitch = (ncols + 31) / 32 * 32, rows_pad = (a.N + BN - 1) / BN * BN;
@@ -620,7 +618,7 @@ int gemm_nt(const NTArgs& a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0) return 0;
     if (a.N > 128) {
         if (a.amax_in) return launch_nt_h3(a, a.planes, s);
-        if (NT_WAVES4) return launch_nt<128, 256, 4, 2>(a, s);
+        if (NT_VARIANT == 3) return launch_nt<128, 256, 4, 2>(a, s);
         if (NT_VARIANT == 1) return launch_nt<128, 256, 2, 2, 16, true>(a, s);
         if (NT_VARIANT == 2) return launch_nt<128, 256, 2, 2, 32, true>(a, s);
         return launch_nt<128, 256, 2, 2>(a, s);
@@ -1238,8 +1236,7 @@ struct TNH3Queue {
         if (batch.n == TN_BATCH || (batch.n > 0 && (job_full != full || g_half != half)))
             if (int e = flush()) return e;
         full = job_full; half = g_half;
-        static int n_cu = 0;
-        if (!n_cu) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); if (n_cu <= 0 || n_cu > MAX_SLICES) n_cu = MAX_SLICES; }
+        const int n_cu = papr_cu_count() > MAX_SLICES ? MAX_SLICES : papr_cu_count();
         long stages = (M + TN_ROWS - 1) / TN_ROWS;
         int S = (int)(stages < n_cu ? stages : n_cu);                   // one workgroup per CU streams one slice
         long rows_per_slice = ((stages + S - 1) / S) * TN_ROWS;
@@ -1257,15 +1254,13 @@ struct TNH3Queue {
     }
     int flush() {
         if (batch.n == 0) return 0;
-        static bool attr_set = false;
-        if (!attr_set) {
+        if (papr_first_on_device(PAPR_ONCE_TN_H3)) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_h3_kernel<true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T3_LDS_BYTES);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_h3_kernel<false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T3_LDS_BYTES);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_h3_kernel<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T3_LDS_BYTES);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_h3_kernel<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T3_LDS_BYTES);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_h3_kernel<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T3_LDS_BYTES);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_h3_kernel<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T3_LDS_BYTES);
-            attr_set = true;
         }
         const bool prof = papr_prof_on();
         if (prof) papr_prof_begin2(8, batch.job[0].M, batch.n, 0, bytes, flops, s);
@@ -1347,9 +1342,8 @@ static bool layer_rowmax_saved(const papr_layer* layers, int n_layers, int i) {
 // fp32-sized ones: the f16 rows of a layer's output occupy the first half of outs[l] (row stride ld_out[l] halfs), and the f16
 // copy of the run's input rows the second half of the run's first output buffer; likewise the gradient-row slots of the
 // backward scratch.  Only the run's last output (forward) / the gradient that leaves the run (backward) remain fp32 rows.
-// PAPR_H1_ROWS=f32 keeps fp32 rows (A/B).
-static const bool H1_HALF_ROWS_OK = !(getenv("PAPR_H1_ROWS") && !strcmp(getenv("PAPR_H1_ROWS"), "f32"));
-#define H1_HALF_ROWS (H1_HALF_ROWS_OK && one_product_now())
+// mode PAPR_MLP_H1_F32ROWS keeps fp32 rows (a different computation: other bits in the weight gradients; A/B).
+#define H1_HALF_ROWS (!t_h1_f32_rows && one_product_now())
 // forward run [b, e) of a training pass stores f16 rows (the backward pass asks the same question)
 static bool run_half_rows(const papr_layer* layers, int n_layers, int b, int e, const int32_t* ld_out, bool training) {
     if (!H1_HALF_ROWS || !training || e - b < 2) return false;
@@ -1402,7 +1396,7 @@ static int chain_split_launch(const SplitBatch& b, int n, hipStream_t s) {
 extern "C" int papr_mlp_fwd(const papr_layer* layers, int n_layers, float* x, int ldx, int64_t M,
                             float* const* outs, const int32_t* ld_out, float* row_absmax, const papr_row_norm* in_norm,
                             const papr_row_norm* out_norm, void* workspace, int32_t mode, papr_stream_t stream) {
-    t_mode = mode_from_arg(mode);
+    PAPR_REQUIRE(mode_from_arg(mode), "papr_mlp_fwd: unknown mode %d", mode);
     PAPR_REQUIRE(layers && x && outs && ld_out && n_layers >= 1, "papr_mlp_fwd: bad arguments");
     hipStream_t s = as_stream(stream);
     bool have_amax = false;                 // split-f16 mode: row maxima of the current layer's input are in h3.in()
@@ -1528,8 +1522,7 @@ struct BwdRunScratch {
 };
 
 extern "C" int papr_mlp_bwd_needs_weight_t(const papr_layer* layers, int n_layers, int need_dx, int32_t mode) {
-    t_mode = mode_from_arg(mode);
-    if (!layers || n_layers < 1) return 1;
+    if (!mode_from_arg(mode) || !layers || n_layers < 1) return 1;
     bool any_skip = false;
     for (int i = 0; i < n_layers; ++i) any_skip |= layers[i].n_skip > 0;
     if (any_skip) return 1;                         // (skip layers and the accumulating layer-0 data-gradient read weight_t)
@@ -1548,7 +1541,7 @@ extern "C" int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float*
                             float* const* outs, const int32_t* ld_out, const float* row_absmax, float* d_out,
                             float* scratch0, float* scratch1, int ld_scratch, float* const* d_weight,
                             float* const* d_bias, float* d_x, void* workspace, int32_t mode, papr_stream_t stream) {
-    t_mode = mode_from_arg(mode);
+    PAPR_REQUIRE(mode_from_arg(mode), "papr_mlp_bwd: unknown mode %d", mode);
     PAPR_REQUIRE(layers && x && outs && ld_out && d_out && d_weight && d_bias && workspace && n_layers >= 1,
                  "papr_mlp_bwd: bad arguments");
     PAPR_REQUIRE(n_layers == 1 || (scratch0 && scratch1), "papr_mlp_bwd: scratch buffers required");

@@ -111,16 +111,21 @@ __device__ __forceinline__ float ray_dist2(const RayK& c, float px, float py, fl
     return __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
 }
 
-// The same quantity with contracted arithmetic: 13 VALU operations instead of 22.  NOT used for the selection itself -- only as a
-// conservative filter in front of it: a point whose cheap distance lies more than 1/64 above the current k-th distance cannot beat
-// it in exact arithmetic either (the two evaluations differ by rounding only: relative 1e-7 x |v| / |D|, i.e. below 1e-4 for any
-// point near the threshold in scenes of this scale), so the exact, reference-ordered evaluation runs only for the few batches that hold
-// such a point (a few percent once the threshold has settled).  Round 2's profile had the kernel bound by exactly these VALU operations.
+// A LOWER BOUND of the same quantity with contracted arithmetic: 17 VALU operations instead of 22.  NOT used for the selection itself -- only as a
+// conservative filter in front of it.  The two evaluations differ by rounding only: |d2_fast - d2| <= c eps |v| |D| + (c eps |v|)^2 with c ~ 4
+// (the error of e = v - d t is ~ eps |v| per component).  Relative to d2 = |D|^2 that is c eps |v| / |D|: below 1/64 unless |D| < 1.5e-5 |v|, and
+// there the absolute difference is below 4e-12 |v|^2.  So a point with exact d2 <= thr always has
+//     max(d2_fast - 2^-30 |v|^2, 0) <= thr (1 + 1/64):
+// the relative slack covers every point further than 1.5e-5 |v| from the ray, the absolute term (250x the bound) the ones closer -- coincident
+// and on-ray points (duplicates after add_points), thr == 0 included (the test is <=).  The exact, reference-ordered evaluation runs only for the
+// few batches that hold such a point (a few percent once the threshold has settled).
 __device__ __forceinline__ float ray_dist2_fast(const RayK& c, float px, float py, float pz) {
     const float vx = px - c.ox, vy = py - c.oy, vz = pz - c.oz;
     const float tt = __builtin_fmaf(vz, c.dz, __builtin_fmaf(vy, c.dy, vx * c.dx)) * c.rcp;
     const float ex = __builtin_fmaf(-c.dx, tt, vx), ey = __builtin_fmaf(-c.dy, tt, vy), ez = __builtin_fmaf(-c.dz, tt, vz);
-    return __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
+    const float d2 = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
+    const float vv = __builtin_fmaf(vz, vz, __builtin_fmaf(vy, vy, vx * vx));
+    return fmaxf(__builtin_fmaf(-0x1p-30f, vv, d2), 0.f);
 }
 
 
@@ -132,7 +137,7 @@ struct KSet {
     int idx;         // per lane (-1: not filled yet -- counts as the largest index)
     unsigned thr;    // uniform: largest member = current k-th smallest
     unsigned thr_idx;// uniform: its index
-    unsigned thr_hi; // uniform: thr x (1 + 1/64): what the cheap distance is tested against
+    unsigned thr_hi; // uniform: thr x (1 + 1/64): what the cheap lower bound of the distance is tested against (<=)
     int tl;          // uniform: the lane holding it
     unsigned long long kmask;       // uniform: lanes 0 .. k-1
     // the set is the k smallest by (distance bits, index) -- the same total order as the spatial form's, so that both forms give the same answer at
@@ -149,7 +154,7 @@ struct KSet {
         thr_hi = __float_as_uint(__uint_as_float(thr) * 1.015625f);
     }
     // does any lane hold a point that may enter the set? (cheap distances)
-    __device__ __forceinline__ bool may_enter(float d2_fast) const { return __ballot(__float_as_uint(d2_fast) < thr_hi) != 0; }
+    __device__ __forceinline__ bool may_enter(float d2_fast) const { return __ballot(__float_as_uint(d2_fast) <= thr_hi) != 0; }
     // offer the candidates; DEDUP skips points that are already members (seeded sets).  (An infinite d2 marks a lane without a point.)
     template <bool DEDUP>
     __device__ __forceinline__ void offer(float d2, int pidx, int lane) {
@@ -627,7 +632,7 @@ extern "C" int papr_ray_knn(const float* points, int64_t P, const float* rays_o,
     hipStream_t s = as_stream(stream);
     float* rec = static_cast<float*>(workspace);
     float4* pstream = reinterpret_cast<float4*>(rec + (size_t)R * 8);
-    static const int blocks_env = getenv("PAPR_KNN_BLOCKS") ? atoi(getenv("PAPR_KNN_BLOCKS")) : 1;      // (A/B switch: 0 = every point against every ray)
+    const int blocks_env = papr_switch(PAPR_SW_KNN_BLOCKS);      // (A/B switch: 0 = every point against every ray)
     const bool spatial = blocks_env && P >= KNN_BLOCKS_MIN_P && k < 64;
     const int64_t places = knn_stream_places(P);
     float4* blk = pstream + (size_t)places;
@@ -635,9 +640,8 @@ extern "C" int papr_ray_knn(const float* points, int64_t P, const float* rays_o,
     pack_rays_kernel<<<dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s>>>(rays_o, rays_d, R, rays_per_image, eps, rec, counts, spatial ? 2 * KNN_NCELL + 4 : 0,
                                                                              pstream, spatial ? places : 0);
     PAPR_CHECK_LAUNCH("pack_rays");
-    static int n_simd = 0;
-    if (!n_simd) { int dev = 0, cu = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev); n_simd = 4 * (cu > 0 ? cu : 256); }
-    static const int t_env = getenv("PAPR_KNN_T") ? atoi(getenv("PAPR_KNN_T")) : 0;      // (A/B switch)
+    const int n_simd = 4 * papr_cu_count();
+    const int t_env = papr_switch(PAPR_SW_KNN_T);      // (A/B switch)
     if (spatial) {
         const unsigned pg = (unsigned)((P + 1023) / 1024);
         unsigned* nblk_p = counts + 2 * KNN_NCELL;

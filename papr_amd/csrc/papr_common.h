@@ -10,6 +10,11 @@ bool papr_prof_on();
 void papr_prof_begin(int kernel, long M, int N, int K, hipStream_t s);
 void papr_prof_begin2(int kernel, long M, int N, int K, long long bytes, long long flops, hipStream_t s);
 void papr_prof_end(hipStream_t s);
+// process-wide A/B switches (papr_set_switch in papr_hip.h; the library reads no environment) and per-device facts
+int papr_switch(int which);
+int papr_cu_count();                       // compute units of the CURRENT device (cached per device id)
+bool papr_first_on_device(int slot);       // true once per (current device, slot): hipFuncSetAttribute calls of a launcher
+enum { PAPR_ONCE_CHAIN4 = 0, PAPR_ONCE_NT_H3, PAPR_ONCE_TN_H3, PAPR_ONCE_CONV, PAPR_ONCE_CONV_WGRAD, PAPR_ONCE_SLOTS };
 
 #define PAPR_REQUIRE(cond, ...)                \
     do {                                       \

@@ -13,9 +13,12 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PAPR_HIP_LIB", os.path.join(_PKG, "libpapr_hip.so"))   # override: instrumented builds (scripts/probes)
 
 ACT = {"none": 0, "relu": 1, "leakyrelu": 2}
-EXPECTED_ABI = 18
+EXPECTED_ABI = 19
 # `mode` argument of papr_mlp_fwd / papr_mlp_bwd (include/papr_hip.h: PAPR_MLP_*)
-MLP_MODES = {"h3": 0, "h1": 1, "f32": 2, "fwd": 3, "dgrad": 4, "layers": 5}          # papr_abi_version() of the library these argtypes were written for
+MLP_MODES = {"h3": 0, "h1": 1, "f32": 2, "fwd": 3, "dgrad": 4, "layers": 5, "h1_f32rows": 6}
+# process-wide A/B switches of the library (papr_set_switch; PAPR_SW_* in include/papr_hip.h).  The library itself reads no environment:
+# lib() forwards these historical variable names once, when it loads the library (scripts/probes, tests/test_hip_chain_variants.py)
+SWITCHES = {"PAPR_C4_GENERIC": 0, "PAPR_C4_FUSED": 1, "PAPR_C4_EARLY": 2, "PAPR_KNN_BLOCKS": 3, "PAPR_KNN_T": 4, "PAPR_WGRAD_WGS": 5, "PAPR_NT_VARIANT": 6}
 
 EXPORTS = [
     "papr_abi_version", "papr_last_error", "papr_ray_knn_workspace_bytes", "papr_ray_knn",
@@ -23,7 +26,7 @@ EXPORTS = [
     "papr_segment_reduce_workspace_bytes", "papr_segment_reduce", "papr_group_pairs_workspace_bytes", "papr_group_pairs", "papr_points_knn",
     "papr_rownorm_fwd", "papr_rownorm_bwd", "papr_row_dots", "papr_ln_fold_fwd", "papr_ln_fold_bwd", "papr_mlp_fwd_workspace_bytes", "papr_mlp_bwd_workspace_bytes", "papr_mlp_saved_floats", "papr_mlp_bwd_needs_weight_t", "papr_mlp_fwd",
     "papr_mlp_bwd",
-    "papr_attn_tail_fwd", "papr_attn_tail_bwd", "papr_conv3x3_weight_halfs", "papr_conv3x3_workspace_bytes", "papr_conv3x3_fwd", "papr_conv3x3_wgrad_workspace_bytes", "papr_conv3x3_wgrad", "papr_maxpool2_fwd", "papr_maxpool2_bwd", "papr_upconv2x2_fwd", "papr_upconv2x2_dgrad", "papr_upconv2x2_wgrad_workspace_bytes", "papr_upconv2x2_wgrad", "papr_conv1x1_fwd", "papr_conv1x1_bwd_workspace_bytes", "papr_conv1x1_bwd", "papr_adam_step", "papr_composite_fwd", "papr_composite_bwd_workspace_bytes", "papr_composite_bwd", "papr_profile_enable", "papr_profile_collect",
+    "papr_attn_tail_fwd", "papr_attn_tail_bwd", "papr_conv3x3_weight_halfs", "papr_conv3x3_workspace_bytes", "papr_conv3x3_fwd", "papr_conv3x3_wgrad_workspace_bytes", "papr_conv3x3_wgrad", "papr_maxpool2_fwd", "papr_maxpool2_bwd", "papr_upconv2x2_fwd", "papr_upconv2x2_dgrad", "papr_upconv2x2_wgrad_workspace_bytes", "papr_upconv2x2_wgrad", "papr_conv1x1_fwd", "papr_conv1x1_bwd_workspace_bytes", "papr_conv1x1_bwd", "papr_adam_step", "papr_composite_fwd", "papr_composite_bwd_workspace_bytes", "papr_composite_bwd", "papr_profile_enable", "papr_profile_collect", "papr_set_switch", "papr_get_switch",
 ]
 
 
@@ -135,11 +138,25 @@ def lib():
     L.papr_attn_tail_bwd.argtypes = [C.POINTER(TailDesc), vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.papr_profile_enable.argtypes = [i32]
     L.papr_profile_collect.argtypes = [C.POINTER(ProfileRecord), i32]
+    L.papr_set_switch.argtypes = [i32, i32]
+    L.papr_get_switch.argtypes = [i32]
     for name in EXPORTS:
         getattr(L, name)  # every declared entry point must resolve
     _check_single_hip_runtime()
+    for env, which in SWITCHES.items():
+        if os.environ.get(env, "") != "":
+            if L.papr_set_switch(which, int(os.environ[env])) != 0:
+                raise RuntimeError("papr_amd: papr_set_switch(%s) failed: %s" % (env, L.papr_last_error().decode()))
     _lib = L
     return L
+
+
+def set_switch(name, value):
+    """Set a process-wide A/B switch of the library by its historical environment name (SWITCHES); returns the previous value."""
+    L = lib()
+    old = L.papr_get_switch(SWITCHES[name])
+    check(L.papr_set_switch(SWITCHES[name], int(value)), "papr_set_switch")
+    return old
 
 
 def _check_single_hip_runtime():

@@ -101,7 +101,19 @@ class ProximityAttentionParams(nn.Module):
         self.attention_layer = _AttentionLayerParams(acfg["embed"], acfg["d_model"])
 
     def kernel_weights(self, plan):
-        """Effective (LayerNorm-affine-folded, zero-padded) weights for the kernels, inside autograd."""
+        """Effective (LayerNorm-affine-folded, zero-padded) weights for the kernels, inside autograd.  Under `no_grad` (the chunk loops of
+        test_step / eval_step: 64 calls per 800 x 800 image) they are prepared once and reused for as long as no parameter has been written
+        (every in-place update -- an optimizer step, load_state_dict -- bumps the tensor's version counter)."""
+        if not torch.is_grad_enabled():
+            key = tuple((p.data_ptr(), p._version) for p in self.parameters())
+            cached = getattr(self, "_kw_cache", None)
+            if cached is None or cached[0] != key:
+                self._kw_cache = cached = (key, self._kernel_weights(plan))
+            return cached[1]
+        self._kw_cache = None
+        return self._kernel_weights(plan)
+
+    def _kernel_weights(self, plan):
         def ff(block, spec):
             lin = block.mlp.linears()
             ln = (block.innorm.a_2, block.innorm.b_2) if isinstance(block.innorm, _NormParams) else None
@@ -253,6 +265,7 @@ class PAPR(nn.Module):
             pdist.average_gradients([p for o in self.optimizers.values() if o is not None
                                      for g in o.param_groups for p in g["params"]])
         opts = [opt for opt in self.optimizers.values() if opt is not None]
+        self.proximity_attn._kw_cache = None        # (papr_adam_step writes the parameters through raw pointers: no version bump)
         # one launch for all of them (papr_adam_step) where the reference's loop is `opt.step()` anyway: GradScaler off, plain Adam on
         # device parameters; PAPR_OWN_ADAM=0: torch's optimizers
         if _OWN_ADAM and not self.scaler.is_enabled() and own_adam.supported(opts):

@@ -26,6 +26,8 @@ def mlp_mode(one_product):
     name = os.environ.get("PAPR_GEMM_MODE", "h3")
     if name == "h3" and one_product:
         name = "h1"
+    if name == "h1" and os.environ.get("PAPR_H1_ROWS", "") == "f32":      # (A/B: fp32 rows between a run and its weight gradients)
+        name = "h1_f32rows"
     return hip.MLP_MODES[name]
 
 

@@ -470,7 +470,7 @@ def test_use_amp_selects_the_one_product_arithmetic_call_by_call():
     torch.mean((out16.float() - 0.5) ** 2).backward()
     assert torch.equal(rgb_a, rgb_c) and all(torch.equal(g_a[n], g_c[n]) for n in g_a)
     g_h2 = {n: p.grad.detach().clone() for n, p in m16.named_parameters() if p.grad is not None and "proximity_attn" in n}
-    # (the AMP model's render head runs on MIOpen's fp16 kernels, whose gradients are not bit-reproducible run to run: closeness;
+    # (closeness, not equality: the GradScaler's loss scale multiplies the gradients that reach the attention block by a power of two and back;
     #  rows read in the wrong format would be off by orders of magnitude)
     for n in g_h:
         scale = g_h[n].abs().max().item()
