@@ -121,9 +121,12 @@ int papr_points_knn(const float* points, int64_t P, const int32_t* query_idx, in
 
 /* The grouping papr_segment_reduce consumes, from idx (M = R*k selected point per pair, 0 <= idx < P): order = the stable sort
  * permutation of idx (pair ids ascending inside a group: torch.sort(idx, stable=True).indices), sorted_pts = idx[order],
- * seg[p] = first entry of point p's group, seg[P] = M.  workspace: papr_group_pairs_workspace_bytes(M, P) bytes of device memory. */
+ * seg[p] = first entry of point p's group, seg[P] = M.  A stable counting sort (ABI 20; before: rocPRIM's radix sort).
+ * run >= 1: the caller's promise that every aligned run of `run` consecutive entries of idx holds DISTINCT points -- a ray's k
+ * neighbours (run = k), or run = 1 for no promise at all (one entry per step: slow).  A broken promise still yields a valid grouping,
+ * but the order inside a group is then no longer defined.  workspace: papr_group_pairs_workspace_bytes(M, P) bytes of device memory. */
 size_t papr_group_pairs_workspace_bytes(int64_t M, int64_t P);
-int papr_group_pairs(const int32_t* idx, int64_t M, int64_t P, int64_t* order, int32_t* sorted_pts, int64_t* seg,
+int papr_group_pairs(const int32_t* idx, int64_t M, int64_t P, int32_t run, int64_t* order, int32_t* sorted_pts, int64_t* seg,
                      void* workspace, size_t workspace_bytes, papr_stream_t stream);
 
 size_t papr_segment_reduce_workspace_bytes(int64_t M);
@@ -394,9 +397,11 @@ int papr_profile_enable(int on);
  *   PAPR_SW_KNN_BLOCKS  (1)    0: every point against every ray instead of the binned cloud
  *   PAPR_SW_KNN_T       (0)    rays per wave of the binned form, 0 = chosen from R
  *   PAPR_SW_WGRAD_WGS   (600)  workgroups the 3x3 weight-gradient aims for
- *   PAPR_SW_NT_VARIANT  (0)    tiling of the fp32-MFMA layer GEMM (1, 2: double-buffered; 3: four waves per SIMD) */
+ *   PAPR_SW_NT_VARIANT  (0)    tiling of the fp32-MFMA layer GEMM (1, 2: double-buffered; 3: four waves per SIMD)
+ *   PAPR_SW_C4_DMA      (0)    1: a fused run takes its input rows split ahead of it (split_rows_kernel) and stages them by LDS-DMA instead of splitting
+ *                              them itself while it stages them (an experiment of round 4 that measured slower end to end: DESIGN.md section 3) */
 enum { PAPR_SW_C4_GENERIC = 0, PAPR_SW_C4_FUSED = 1, PAPR_SW_C4_EARLY = 2, PAPR_SW_KNN_BLOCKS = 3, PAPR_SW_KNN_T = 4, PAPR_SW_WGRAD_WGS = 5,
-       PAPR_SW_NT_VARIANT = 6, PAPR_SW_COUNT = 7 };
+       PAPR_SW_NT_VARIANT = 6, PAPR_SW_C4_DMA = 7, PAPR_SW_COUNT = 8 };
 int papr_set_switch(int32_t which, int32_t value);
 int32_t papr_get_switch(int32_t which);
 /* Waits for the recorded events, writes up to `cap` records (oldest first), clears the log and

@@ -32,6 +32,11 @@ struct ChainArgs {
     float* A0; long lda0; int K0;         // input rows (M, lda0), K0 <= 256 real columns (written only with in_norm_writeback)
     float* rowmax0;                       // (M) receives max |.| of every input row, or null
     _Float16* a0_half; long lda0_half;    // (one_product) copy of the staged input rows as scaled f16 rows (see c_half), or null
+    // The input rows ALREADY split (papr_split_rows_launch, gemm.hip): hi / lo planes (M, sr_ld) halfs each -- row m times the power of two
+    // that brings its maximum into [2^13, 2^14), columns from K0 on zero --, 1 / that power (sr_inv) and the maximum itself (sr_max), (M) floats
+    // each.  With them a tile is staged by LDS-DMA (no registers, no vector instructions, the rows' way from memory hidden behind the slot's
+    // matrix instructions) and rowmax0 / in_norm_* are the splitting kernel's business, not the run's.  Null: the run splits A0 itself.
+    const _Float16* sr_hi; const _Float16* sr_lo; const float* sr_inv; const float* sr_max; int sr_ld;
     long M;
     int n_layers;
     int one_product;                      // 1 (PAPR_GEMM_MODE=h1): one f16 product per fp32 product -- hi planes only

@@ -563,6 +563,81 @@ struct H3Scratch {
     void swap() { cur ^= 1; }
 };
 
+
+// The input rows of a fused run, split ahead of it (chain.h: ChainArgs::sr_*): row m -> hi = f16(x s), lo = f16(x s - hi) with s the power of two that
+// brings the row's maximum into [2^13, 2^14), columns [K, Kq) zero; 1 / s; the maximum.  Optionally the LayerNorm core in front of the run
+// (FeedForward.innorm, models/attn.py:39-42) first: rows standardised over their first nw columns, (1 / (std + eps), std) to `stats`, the standardised
+// rows written back over x when `writeback`.  THE SAME ARITHMETIC, instruction for instruction, as the staging of mlp_chain4_kernel (chain4.hip:
+// stage_finish) -- a lane holds four columns of a row, a wave the row: sums of four in the order ((a + b) + (c + d)), then wave_sum -- so a run gives
+// the same bits whichever of the two split its rows (tests/test_hip_chain_variants.py, switch PAPR_SW_C4_DMA).
+struct SplitRowsArgs {
+    float* x; long ld; int K, Kq; long M;
+    _Float16* hi; _Float16* lo; float* inv; float* mx;
+    int nw; float eps; float* stats; int writeback;
+};
+__global__ __launch_bounds__(256) void split_rows_kernel(SplitRowsArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int c = 4 * lane;
+    const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (long)gridDim.x * 4;
+    for (long m0 = wave * 4; m0 < a.M; m0 += n_waves * 4) {
+        float4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long m = m0 + q < a.M ? m0 + q : a.M - 1;
+            v[q] = c < a.K ? *reinterpret_cast<const float4*>(a.x + m * a.ld + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long m = m0 + q;
+            if (a.stats != nullptr) {
+                const int wdt = a.nw;
+                const bool i0 = c < wdt, i1 = c + 1 < wdt, i2 = c + 2 < wdt, i3 = c + 3 < wdt;
+                const float mean = wave_sum(((i0 ? v[q].x : 0.f) + (i1 ? v[q].y : 0.f)) + ((i2 ? v[q].z : 0.f) + (i3 ? v[q].w : 0.f))) / (float)wdt;
+                float4 dl = make_float4(i0 ? v[q].x - mean : 0.f, i1 ? v[q].y - mean : 0.f, i2 ? v[q].z - mean : 0.f, i3 ? v[q].w - mean : 0.f);
+                const float sigma = sqrtf(wave_sum((dl.x * dl.x + dl.y * dl.y) + (dl.z * dl.z + dl.w * dl.w)) / (float)(wdt - 1));
+                const float rinv = 1.0f / (sigma + a.eps);
+                v[q] = make_float4(dl.x * rinv, dl.y * rinv, dl.z * rinv, dl.w * rinv);
+                if (m < a.M) {
+                    if (a.writeback && c < a.K) *reinterpret_cast<float4*>(a.x + m * a.ld + c) = v[q];
+                    if (lane == 0) { a.stats[m * 2] = rinv; a.stats[m * 2 + 1] = sigma; }
+                }
+            }
+            const float smx = wave_max(fmaxf(fmaxf(fabsf(v[q].x), fabsf(v[q].y)), fmaxf(fabsf(v[q].z), fabsf(v[q].w))));
+            float inv;
+            const float sc = h3_scale_from_max(__float_as_uint(smx), inv);
+            if (m < a.M) {
+                if (c < a.Kq) {
+                    half4 hi, lo;
+                    split4(v[q], sc, hi, lo);
+                    *reinterpret_cast<half4*>(a.hi + m * a.Kq + c) = hi;
+                    *reinterpret_cast<half4*>(a.lo + m * a.Kq + c) = lo;
+                }
+                if (lane == 0) { a.inv[m] = inv; a.mx[m] = smx; }
+            }
+        }
+    }
+}
+
+int launch_split_rows(const SplitRowsArgs& a, hipStream_t s) {
+    PAPR_REQUIRE(a.K % 4 == 0 && a.K <= 256 && a.Kq % 16 == 0 && a.Kq >= a.K && a.Kq <= 256 && a.ld % 4 == 0, "split_rows: width %d (planes %d), row stride %ld", a.K, a.Kq, a.ld);
+    if (a.M <= 0) return 0;
+    const long blocks = (a.M + 15) / 16;
+    const int cap = papr_cu_count() * 8;
+    split_rows_kernel<<<dim3((unsigned)(blocks < cap ? blocks : cap)), dim3(256), 0, s>>>(a);
+    PAPR_CHECK_LAUNCH("split_rows");
+    return 0;
+}
+
+// scratch of the pre-split input rows of a fused run, behind everything else of a workspace: planes of up to 256 columns, 1 / scale, maximum
+struct SRScratch {
+    _Float16* hi; _Float16* lo; float* inv; float* mx;
+    SRScratch(void* base, long M) {
+        hi = static_cast<_Float16*>(base); lo = hi + (size_t)M * 256;
+        inv = reinterpret_cast<float*>(lo + (size_t)M * 256); mx = inv + M;
+    }
+    static size_t bytes(long M) { return ((size_t)M * (2 * 256 * sizeof(_Float16) + 2 * sizeof(float)) + 255) / 256 * 256; }
+};
+
 int launch_row_absmax(const float* x, long M, int width, long ld, unsigned* out, hipStream_t s) {
     row_absmax_kernel<<<dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s>>>(x, M, width, ld, out);
     PAPR_CHECK_LAUNCH("row_absmax");
@@ -1295,7 +1370,7 @@ __global__ __launch_bounds__(256) void act_grad_kernel(float* g, long ldg, const
 
 constexpr size_t TN_SLAB_BYTES = (size_t)TN_BATCH * TN_JOB_FLOATS * sizeof(float);      // partial tiles of a batch of weight-gradients
 
-extern "C" size_t papr_mlp_fwd_workspace_bytes(int64_t M) { return H3Scratch::bytes(M); }
+extern "C" size_t papr_mlp_fwd_workspace_bytes(int64_t M) { return H3Scratch::bytes(M) + SRScratch::bytes(M); }
 extern "C" size_t papr_mlp_saved_floats(int32_t n_layers, int64_t M) { return (size_t)n_layers * (M + CHAIN_SIGN_WORDS * chain_sign_rows(M)); }
 
 // Layout of the `row_absmax` buffer of papr_mlp_fwd / papr_mlp_bwd (papr_mlp_saved_floats(n_layers, M) floats):
@@ -1429,6 +1504,16 @@ extern "C" int papr_mlp_fwd(const papr_layer* layers, int n_layers, float* x, in
             c.rowmax0 = saved ? saved + (size_t)i * M : nullptr;
             c.M = M; c.n_layers = e - i;
             c.one_product = GEMM_ONE_PRODUCT ? 1 : 0;
+            if (!GEMM_ONE_PRODUCT && papr_switch(PAPR_SW_C4_DMA)) {
+                // the run's input rows split ahead of it: the run stages its tiles by LDS-DMA (chain.h: sr_*)
+                SRScratch sr(static_cast<char*>(workspace) + H3Scratch::bytes(M), M);
+                SplitRowsArgs q = {};
+                q.x = c.A0; q.ld = c.lda0; q.K = c.K0; q.Kq = (c.K0 + 15) / 16 * 16; q.M = M;
+                q.hi = sr.hi; q.lo = sr.lo; q.inv = sr.inv; q.mx = c.rowmax0 ? c.rowmax0 : sr.mx;
+                q.nw = c.in_norm_width; q.eps = c.in_norm_eps; q.stats = c.in_norm_stats; q.writeback = c.in_norm_writeback;
+                if (int err = launch_split_rows(q, s)) return err;
+                c.sr_hi = q.hi; c.sr_lo = q.lo; c.sr_inv = q.inv; c.sr_max = q.mx; c.sr_ld = q.Kq;
+            }
             const bool half_rows = run_half_rows(layers, n_layers, i, e, ld_out, saved != nullptr);
             if (half_rows) { c.a0_half = reinterpret_cast<_Float16*>(outs[i]) + (size_t)M * ld_out[i]; c.lda0_half = ld_out[i]; }
             size_t used = 0;
@@ -1535,7 +1620,7 @@ extern "C" int papr_mlp_bwd_needs_weight_t(const papr_layer* layers, int n_layer
     return 0;
 }
 
-extern "C" size_t papr_mlp_bwd_workspace_bytes(int64_t M) { return TN_SLAB_BYTES + H3Scratch::bytes(M) + BwdRunScratch::bytes(M); }
+extern "C" size_t papr_mlp_bwd_workspace_bytes(int64_t M) { return TN_SLAB_BYTES + H3Scratch::bytes(M) + BwdRunScratch::bytes(M) + SRScratch::bytes(M); }
 
 extern "C" int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float* x, int ldx, int64_t M,
                             float* const* outs, const int32_t* ld_out, const float* row_absmax, float* d_out,
@@ -1617,6 +1702,7 @@ extern "C" int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float*
             ChainArgs c = {};
             c.A0 = g; c.lda0 = ldg; c.K0 = L.n_out; c.rowmax0 = runs.gmax[CHAIN_MAX_LAYERS];
             c.M = M; c.one_product = GEMM_ONE_PRODUCT ? 1 : 0;
+            const bool split_ahead = !GEMM_ONE_PRODUCT && papr_switch(PAPR_SW_C4_DMA) != 0;       // (the kernel is launched below, once the run's width is known to be its own)
             // h1 mode: f16 rows (see run_half_rows).  x_half: what the forward run stored; g_half: this launch, if it has a layer
             // that is not its last (the copy of the top gradient rows goes behind that layer's rows)
             const bool x_half = run_half_rows(layers, n_layers, b, i + 1, ld_out, row_absmax != nullptr);
@@ -1653,6 +1739,14 @@ extern "C" int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float*
             if (c.n_layers > 0) {
                 split.perm = 1;
                 if (int err = chain_split_launch(split, c.n_layers, s)) return err;
+                if (split_ahead) {                  // the top gradient rows split ahead of the run (chain.h: sr_*); their maxima go where the run would leave them
+                    SRScratch sr(static_cast<char*>(workspace) + TN_SLAB_BYTES + H3Scratch::bytes(M) + BwdRunScratch::bytes(M), M);
+                    SplitRowsArgs q = {};
+                    q.x = c.A0; q.ld = c.lda0; q.K = c.K0; q.Kq = (c.K0 + 15) / 16 * 16; q.M = M;
+                    q.hi = sr.hi; q.lo = sr.lo; q.inv = sr.inv; q.mx = c.rowmax0;
+                    if (int err = launch_split_rows(q, s)) return err;
+                    c.sr_hi = q.hi; c.sr_lo = q.lo; c.sr_inv = q.inv; c.sr_max = q.mx; c.sr_ld = q.Kq;
+                }
                 if (int err = papr_launch_chain(c, true, bytes, flops, s)) return err;
             }
             auto slot = [&](int l) { return l - (b > 0 ? b - 1 : 0); };

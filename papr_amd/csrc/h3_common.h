@@ -20,6 +20,13 @@ __device__ __forceinline__ float pow2_from_biased(int e) {       // 2^(e-127), e
     return __uint_as_float((unsigned)e << 23);
 }
 
+// row maximum -> the power of two that brings it into [2^13, 2^14) (returned) and its reciprocal (inv); a zero row: scale 1 ... (exponent 140)
+__device__ __forceinline__ float h3_scale_from_max(unsigned bits, float& inv) {
+    const int ea = bits ? (int)((bits >> 23) & 0xff) : 127 + 13;
+    inv = pow2_from_biased(127 - 13 + (ea - 127));
+    return pow2_from_biased(127 + 13 - (ea - 127));
+}
+
 // hi = f16(v * s), lo = f16(v * s - hi) for four values; s is a power of two, so v * s is exact and the fused forms
 // below round exactly like the multiply / convert / convert back / subtract / convert sequence they replace:
 // v_fma_mixlo/hi_f16 write one half of a register from an fp32 fma, and take the f16 hi as an operand: 8 instructions

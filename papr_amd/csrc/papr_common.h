@@ -14,7 +14,7 @@ void papr_prof_end(hipStream_t s);
 int papr_switch(int which);
 int papr_cu_count();                       // compute units of the CURRENT device (cached per device id)
 bool papr_first_on_device(int slot);       // true once per (current device, slot): hipFuncSetAttribute calls of a launcher
-enum { PAPR_ONCE_CHAIN4 = 0, PAPR_ONCE_NT_H3, PAPR_ONCE_TN_H3, PAPR_ONCE_CONV, PAPR_ONCE_CONV_WGRAD, PAPR_ONCE_SLOTS };
+enum { PAPR_ONCE_CHAIN4 = 0, PAPR_ONCE_NT_H3, PAPR_ONCE_TN_H3, PAPR_ONCE_CONV, PAPR_ONCE_CONV_WGRAD, PAPR_ONCE_PAIRS, PAPR_ONCE_SLOTS };
 
 #define PAPR_REQUIRE(cond, ...)                \
     do {                                       \

@@ -555,8 +555,9 @@ def points_knn(points, k, query_idx=None, want_dist=True):
     return (nn_idx, nn_dist) if want_dist else nn_idx
 
 
-def group_pairs(flat_idx, P):
-    """(order int64, sorted_pts int32, seg int64[P+1]) of papr_group_pairs: the pairs grouped by selected point."""
+def group_pairs(flat_idx, P, run=1):
+    """(order int64, sorted_pts int32, seg int64[P+1]) of papr_group_pairs: the pairs grouped by selected point.  run: every aligned run of
+    `run` consecutive entries holds distinct points (a ray's k neighbours); 1 = no such promise."""
     M, dev = flat_idx.numel(), flat_idx.device
     lib = hip.lib()
     order = torch.empty(M, device=dev, dtype=torch.int64)
@@ -564,7 +565,7 @@ def group_pairs(flat_idx, P):
     seg = torch.empty(P + 1, device=dev, dtype=torch.int64)
     nb = lib.papr_group_pairs_workspace_bytes(M, P)
     ws = torch.empty(nb, device=dev, dtype=torch.uint8)
-    hip.check(lib.papr_group_pairs(hip.ptr(flat_idx), M, P, hip.ptr(order), hip.ptr(sorted_pts), hip.ptr(seg), hip.ptr(ws), nb, hip.stream_ptr()),
+    hip.check(lib.papr_group_pairs(hip.ptr(flat_idx), M, P, int(run), hip.ptr(order), hip.ptr(sorted_pts), hip.ptr(seg), hip.ptr(ws), nb, hip.stream_ptr()),
               "papr_group_pairs")
     return order, sorted_pts, seg
 
@@ -746,7 +747,7 @@ class _RenderFn(torch.autograd.Function):
         ctx.mark_non_differentiable(sel)
         if keep:
             # pairs grouped by selected point, for the atomic-free scatter of the per-point gradients
-            order, sorted_pts, seg = group_pairs(idx.view(-1), points.shape[0])
+            order, sorted_pts, seg = group_pairs(idx.view(-1), points.shape[0], run=k)
             ctx.saved = dict(rays_o=rays_o, rays_d=rays_d, idx=idx, points=points, influ=influ, key_in=key_in, qry_in=qry_in,
                              val_in=val_in, kst=kst, qst=qst, kst2=kst2, qst2=qst2, k_outs=k_outs, q_outs=q_outs,
                              v_outs=v_outs, g=g, c0=c0, qp=qp, order=order, sorted_pts=sorted_pts, seg=seg, scores=scores, attn=attn, wb=wb, P=points.shape[0],

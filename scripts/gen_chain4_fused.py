@@ -29,6 +29,7 @@ the statement names them -- hence an X and a Y flavour of every variant.  Tempor
 
 import os
 ABLATE = os.environ.get("C4F_ABLATE", "")      # timing experiments (scripts/probes/c4_variant.sh with -DC4_FUSED_INC=...)
+KVAR = os.environ.get("C4F_KVAR", "")          # timing experiments on the k-loop (with C4F_ABLATE=K: the row-phase temporaries are free): noread | dbuf | dbufh
 
 F = {"l0": "v[28:31]", "l1": "v[32:35]", "h0": "v[36:39]", "h1": "v[40:43]"}
 KA = "v44"                                      # k-loop address temporary
@@ -102,6 +103,67 @@ def k_stream(acc_t, ld, kcnt=16):
         if ld:
             post.append(Item("global_load_dwordx4 %s, %%[wv], %s offset:%d" % (wh(ks), SNH, (ks & 3) * 1024), kind="vmem"))
             if ks & 3 == 3 and ks < kcnt - 1:   # the bases move on by four k-steps
+                post += [Item("s_add_u32 s90, s90, 0x1000", kind="salu"), Item("s_addc_u32 s91, s91, 0", kind="salu"),
+                         Item("s_add_u32 s92, s92, 0x1000", kind="salu"), Item("s_addc_u32 s93, s93, 0", kind="salu")]
+        g.append((mf(a1, wh(ks), "h1"), post))
+        steps += g
+    return pro, steps
+
+
+def k_stream_exp(acc_t, ld, kcnt=16):
+    """timing experiments (C4F_KVAR, with C4F_ABLATE=K): noread = no fragment reads at all; dbuf = every fragment in two buffers (the second in
+    v48-v63), read two k-steps ahead; dbufh = only the hi fragments (used twice per k-step, re-read latest) in two buffers"""
+    a0, a1 = vt(acc_t, 16), vt(acc_t + 16, 16)
+    off = {"l0": 4096, "l1": 36864, "h0": 0, "h1": 32768}
+    F2 = {"l0": "v[48:51]", "l1": "v[52:55]", "h0": "v[56:59]", "h1": "v[60:63]"}
+    two = {"dbuf": ("l0", "l1", "h0", "h1"), "dbufh": ("h0", "h1"), "noread": ()}[KVAR]
+    KB = [KA, AD2]
+
+    def reg(kind, ks):
+        return F2[kind] if (kind in two and ks & 1) else F[kind]
+
+    def rd(kind, ks):
+        if KVAR == "noread":
+            return []
+        return [Item("ds_read_b128 %s, %s offset:%d" % (reg(kind, ks), KB[ks & 1] if ks & 7 else "%[pbx]", off[kind] + (256 if ks >= 8 else 0)), lds=("f", kind, ks), kind="lds")]
+
+    def addr(ks):
+        return [Item("v_xor_b32 %s, 0x%x, %%[pbx]" % (KB[ks & 1], 32 * (ks & 7)))] if ks & 7 else []
+
+    pro = rd("l0", 0) + rd("l1", 0) + rd("h0", 0) + rd("h1", 0)
+    if two:
+        pro += addr(1) + [x for kind in two for x in rd(kind, 1)]
+    if ld:
+        pro += [Item("s_mov_b32 s90, %[nhlo]", kind="salu"), Item("s_mov_b32 s91, %[nhhi]", kind="salu"),
+                Item("s_mov_b32 s92, %[nllo]", kind="salu"), Item("s_mov_b32 s93, %[nlhi]", kind="salu")]
+    steps = []
+    for ks in range(kcnt):
+        first = ks == 0
+
+        def nxt(kind):          # the k-step whose fragment `kind` is read behind this k-step's last use of its register
+            n = ks + 2 if kind in two else ks + 1
+            return n if n < kcnt else None
+
+        def mf(acc, w, kind, init=False):
+            need = [] if KVAR == "noread" else [("f", kind, ks)]
+            return Item("v_mfma_f32_32x32x16_f16 %s, %s, %s, %s" % (acc, w, reg(kind, ks), "0" if init else acc), need=need, kind="mfma")
+
+        def rr(kind):
+            n = nxt(kind)
+            return (addr(n) if kind in ("l0", "h0") and (kind == "l0" or "l0" in two or True) else []) + rd(kind, n) if n is not None else []
+        g = []
+        g.append((mf(a0, wh(ks), "l0", first), rr("l0")))
+        g.append((mf(a1, wh(ks), "l1", first), rd("l1", nxt("l1")) if nxt("l1") is not None else []))
+        g.append((mf(a0, wl(ks), "h0"), []))
+        post = []
+        if ld:
+            post.append(Item("global_load_dwordx4 %s, %%[wv], %s offset:%d" % (wl(ks), SNL, (ks & 3) * 1024), kind="vmem"))
+        g.append((mf(a1, wl(ks), "h1"), post))
+        g.append((mf(a0, wh(ks), "h0"), rr("h0")))
+        post = rd("h1", nxt("h1")) if nxt("h1") is not None else []
+        if ld:
+            post.append(Item("global_load_dwordx4 %s, %%[wv], %s offset:%d" % (wh(ks), SNH, (ks & 3) * 1024), kind="vmem"))
+            if ks & 3 == 3 and ks < kcnt - 1:
                 post += [Item("s_add_u32 s90, s90, 0x1000", kind="salu"), Item("s_addc_u32 s91, s91, 0", kind="salu"),
                          Item("s_add_u32 s92, s92, 0x1000", kind="salu"), Item("s_addc_u32 s93, s93, 0", kind="salu")]
         g.append((mf(a1, wh(ks), "h1"), post))
@@ -332,7 +394,7 @@ class Emit:
 
 def build(tile, mode, act, ld, kcnt=16, one=False):
     acc_t, acc_u = (ACC["X"], ACC["Y"]) if tile == "X" else (ACC["Y"], ACC["X"])
-    pro, steps = k_stream_one(acc_t, ld, kcnt) if one else k_stream(acc_t, ld, kcnt)
+    pro, steps = k_stream_one(acc_t, ld, kcnt) if one else (k_stream_exp(acc_t, ld, kcnt) if (KVAR and kcnt == 16) else k_stream(acc_t, ld, kcnt))
     NM = len(steps)                             # matrix instructions of the statement
     p1, p2 = p1_stream(acc_u, mode, act), p2_stream(acc_u, mode, one)
     if ABLATE == "K":                           # (timing experiment, results wrong: the k-loop alone)

@@ -8,6 +8,7 @@ IDENTICAL between
   (default)            hot slots as fused statements
   PAPR_C4_FUSED=0      two-role slots everywhere (one-statement k-loops, C++ row phases with the flags as constants)
   PAPR_C4_GENERIC=1    ... and the generic row phases (flags looked at at run time)
+  PAPR_C4_DMA=1        the run's input rows split ahead of it (round 4: split_rows_kernel) and staged by LDS-DMA, not by the run itself
 and from run to run (the races this file guards against show up as run-to-run differences).  Sizes: a cloud-sized M with ragged last
 tiles and several workgroup iterations, and one below a tile; ReLU and LeakyReLU."""
 import os
@@ -19,12 +20,15 @@ import torch
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-VARIANTS = [("generic rows", {"PAPR_C4_GENERIC": "1"}), ("two-role", {"PAPR_C4_FUSED": "0"}), ("fused", {}), ("fused again", {})]
+VARIANTS = [("generic rows", {"PAPR_C4_GENERIC": "1"}), ("two-role", {"PAPR_C4_FUSED": "0"}), ("fused", {}), ("fused again", {}),
+            # the run takes its input rows split ahead of it (split_rows_kernel) through LDS-DMA instead of splitting them itself while it stages
+            # them (registers + vector instructions): the same arithmetic, instruction for instruction
+            ("rows split ahead", {"PAPR_C4_DMA": "1"}), ("rows split ahead, generic rows", {"PAPR_C4_DMA": "1", "PAPR_C4_GENERIC": "1"})]
 
 
 def _run(tmp_path, name, env, M, n, act):
     out = tmp_path / (name.replace(" ", "_") + ".pt")
-    e = {k: v for k, v in os.environ.items() if k not in ("PAPR_C4_GENERIC", "PAPR_C4_FUSED", "PAPR_GEMM_MODE")}
+    e = {k: v for k, v in os.environ.items() if k not in ("PAPR_C4_GENERIC", "PAPR_C4_FUSED", "PAPR_GEMM_MODE", "PAPR_C4_DMA")}
     e.update(env)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "chain_variants_worker.py"), str(out), str(M), str(n), act], env=e, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (name, r.stderr[-2000:])

@@ -227,9 +227,9 @@ def _segment_inputs(flat, P):
 
 @pytest.mark.parametrize("P,M,hot", [(30000, 512000, 0), (10000, 512000, 40000), (257, 1283, 0), (1, 77, 0), (5, 1, 0), (70000, 6, 0), (9, 0, 0)])
 def test_group_pairs_is_the_stable_sort_with_group_bounds(P, M, hot):
-    """papr_group_pairs (pairs.hip) against torch.sort(stable) + bincount + cumsum on the CPU, bit for bit: the permutation
-    (pair ids ascending inside a group), the sorted keys and the P + 1 bounds; full-size, one hot point, a single point, a
-    single pair, more points than pairs, no pairs."""
+    """papr_group_pairs (pairs.hip) WITHOUT a promise about its input (run = 1: one entry per step) against torch.sort(stable) + bincount +
+    cumsum on the CPU, bit for bit: the permutation (pair ids ascending inside a group), the sorted keys and the P + 1 bounds; full-size, one
+    hot point, a single point, a single pair, more points than pairs, no pairs."""
     from papr_amd import ops
     gen = torch.Generator().manual_seed(3 * P + M)
     flat = torch.randint(0, P, (M,), generator=gen).int()
@@ -239,6 +239,29 @@ def test_group_pairs_is_the_stable_sort_with_group_bounds(P, M, hot):
     want_seg = torch.zeros(P + 1, dtype=torch.int64)
     torch.cumsum(torch.bincount(flat, minlength=P), 0, out=want_seg[1:])
     order, sorted_pts, seg = ops.group_pairs(flat.to("cuda:0"), P)
+    torch.cuda.synchronize()
+    assert torch.equal(order.cpu(), want_order)
+    assert torch.equal(sorted_pts.cpu(), want_pts)
+    assert torch.equal(seg.cpu(), want_seg)
+
+
+@pytest.mark.parametrize("P,R,k", [(10000, 25600, 20), (30000, 25600, 20), (50000, 3000, 63), (64, 500, 64), (300, 41, 300), (25, 1000, 7)])
+def test_group_pairs_with_runs_of_distinct_points_is_the_stable_sort(P, R, k):
+    """The product's call: `run = k`, every ray's k selected points are distinct (a kNN result; or all P points of a small cloud, k = P > 64).
+    One returning LDS add per run places its entries; the result is torch.sort(stable) bit for bit -- incl. more points than one pass of LDS
+    counters holds (P = 50,000), runs longer than a wave (k = 300), and a last workgroup with a short chunk."""
+    from papr_amd import ops
+    gen = torch.Generator().manual_seed(P + R + k)
+    # k distinct points per ray, neighbouring rays share most of theirs (like a render): a window of the cloud that moves with the ray
+    base = (torch.arange(R) * 3) % max(P - 2 * k, 1)
+    flat = torch.stack([base[r] + torch.randperm(min(2 * k, P), generator=gen)[:k] for r in range(R)]).reshape(-1).int() % P if k < P else \
+        torch.stack([torch.randperm(P, generator=gen) for _ in range(R)]).reshape(-1).int()
+    assert all(len(set(row.tolist())) == k for row in flat.view(R, k)[:50])
+    M = R * k
+    want_pts, want_order = torch.sort(flat, stable=True)
+    want_seg = torch.zeros(P + 1, dtype=torch.int64)
+    torch.cumsum(torch.bincount(flat, minlength=P), 0, out=want_seg[1:])
+    order, sorted_pts, seg = ops.group_pairs(flat.to("cuda:0"), P, run=k)
     torch.cuda.synchronize()
     assert torch.equal(order.cpu(), want_order)
     assert torch.equal(sorted_pts.cpu(), want_pts)
