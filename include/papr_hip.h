@@ -389,7 +389,7 @@ typedef struct {
 int papr_profile_enable(int on);
 
 /* Process-wide A/B and test switches (ABI 19; before: environment variables read by the library at first use).  Every value of every
- * switch gives BIT-IDENTICAL results (tests/test_hip_chain_variants.py, scripts/probes/knn_ab.py); they choose between forms of a kernel.
+ * switch but PAPR_SW_TN_JOBPAR gives BIT-IDENTICAL results (tests/test_hip_chain_variants.py, scripts/probes/knn_ab.py); they choose between forms of a kernel.
  * The defaults are what ships; papr_amd/hip.py forwards the historical PAPR_C4_* / PAPR_KNN_* environment names to these calls.
  *   PAPR_SW_C4_GENERIC  (0)    1: the fused-run kernel's specialised row-phase instantiations off
  *   PAPR_SW_C4_FUSED    (1)    0: its hot slots as two-role C++ slots instead of one generated statement
@@ -399,9 +399,11 @@ int papr_profile_enable(int on);
  *   PAPR_SW_WGRAD_WGS   (600)  workgroups the 3x3 weight-gradient aims for
  *   PAPR_SW_NT_VARIANT  (0)    tiling of the fp32-MFMA layer GEMM (1, 2: double-buffered; 3: four waves per SIMD)
  *   PAPR_SW_C4_DMA      (0)    1: a fused run takes its input rows split ahead of it (split_rows_kernel) and stages them by LDS-DMA instead of splitting
- *                              them itself while it stages them (an experiment of round 4 that measured slower end to end: DESIGN.md section 3) */
+ *                              them itself while it stages them (an experiment of round 4 that measured slower end to end: DESIGN.md section 3)
+ *   PAPR_SW_TN_JOBPAR   (1)    0: every workgroup of a batched weight-gradient launch walks all jobs (one partial tile per job and workgroup) instead of the
+ *                              workgroups being dealt to the jobs (one partial tile per workgroup).  NOT bit-identical: the rows meet in another order */
 enum { PAPR_SW_C4_GENERIC = 0, PAPR_SW_C4_FUSED = 1, PAPR_SW_C4_EARLY = 2, PAPR_SW_KNN_BLOCKS = 3, PAPR_SW_KNN_T = 4, PAPR_SW_WGRAD_WGS = 5,
-       PAPR_SW_NT_VARIANT = 6, PAPR_SW_C4_DMA = 7, PAPR_SW_COUNT = 8 };
+       PAPR_SW_NT_VARIANT = 6, PAPR_SW_C4_DMA = 7, PAPR_SW_TN_JOBPAR = 8, PAPR_SW_COUNT = 9 };
 int papr_set_switch(int32_t which, int32_t value);
 int32_t papr_get_switch(int32_t which);
 /* Waits for the recorded events, writes up to `cap` records (oldest first), clears the log and

@@ -929,7 +929,7 @@ __device__ __forceinline__ float inv_scale_from_row_max(float m) {       // 1 / 
 // tile of a job (256 KB per workgroup) drains to memory while the next job's first rows are already on their way,
 // and the launch ramp and tail are paid once per batch instead of once per layer.
 constexpr int TN_BATCH = 8;
-struct TNH3Batch { TNH3Args job[TN_BATCH]; int n; };
+struct TNH3Batch { TNH3Args job[TN_BATCH]; int n; int par; };      // par: job-parallel launch (workgroup b: job b % n, slice b / n), else every workgroup walks all jobs
 
 constexpr int T3_HP = 36;                         // LDS row pitch in halfs
 constexpr int T3_PLANE = SLAB * T3_HP;            // halfs per plane (256 LDS rows x 32 m)
@@ -953,9 +953,14 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_h3_kernel(TNH3Batch batch) {
     __shared__ float red[2][8];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: row tests and tile skips become SALU
     const int wn = wave >> 2, wk = wave & 3;     // wave's corner in LDS-row space: n-tiles 4 wn .. +3, k-tiles 2 wk, 2 wk + 1
-  for (int jb = 0; jb < batch.n; ++jb) {
+  // job-parallel (batch.par): the launch's workgroups are dealt to the jobs -- workgroup b streams slice b / n of job b % n, n times as long as
+  // a slice of the job-serial form, and leaves ONE partial tile instead of n: a seventh / a quarter of the partial-tile traffic and of the
+  // reduction behind it
+  const int jb0 = batch.par ? (int)(blockIdx.x % (unsigned)batch.n) : 0, jb1 = batch.par ? jb0 + 1 : batch.n;
+  const long slice = batch.par ? (long)(blockIdx.x / (unsigned)batch.n) : (long)blockIdx.x;
+  for (int jb = jb0; jb < jb1; ++jb) {
     const TNH3Args& p = batch.job[jb];
-    const long mbeg = (long)blockIdx.x * p.rows_per_slice;
+    const long mbeg = slice * p.rows_per_slice;
     long mend = mbeg + p.rows_per_slice;
     if (mend > p.M) mend = p.M;
     if (mbeg >= mend) continue;                  // (workgroup-uniform: a job with fewer slices than the launch has workgroups)
@@ -1260,7 +1265,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_h3_kernel(TNH3Batch batch) {
     }
 
     // slab in LDS-row order on both axes (un-permuted by the reduction), un-scaled
-    float* out = p.slab + (long)blockIdx.x * SLAB * SLAB;
+    float* out = p.slab + slice * SLAB * SLAB;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1282,7 +1287,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_h3_kernel(TNH3Batch batch) {
         float b = 0.f;
 #pragma unroll
         for (int w = 0; w < 8; ++w) b += cs[w * SLAB + tid];
-        p.bias_slab[(long)blockIdx.x * SLAB + tid] = b;
+        p.bias_slab[slice * SLAB + tid] = b;
     }
     // (the next job's first barrier comes before its first LDS write: the sums above are read by then)
   }
@@ -1329,6 +1334,23 @@ struct TNH3Queue {
     }
     int flush() {
         if (batch.n == 0) return 0;
+        // job-parallel layout: with several jobs of one length the workgroups are dealt to the jobs (see the kernel)
+        batch.par = 0;
+        if (batch.n > 1 && papr_switch(PAPR_SW_TN_JOBPAR)) {
+            bool same = true;
+            for (int j = 1; j < batch.n; ++j) same &= batch.job[j].M == batch.job[0].M;
+            const int n_cu = papr_cu_count() > MAX_SLICES ? MAX_SLICES : papr_cu_count();
+            const int S_each = n_cu / batch.n;
+            if (same && S_each >= 8) {
+                const long M = batch.job[0].M, stages = (M + TN_ROWS - 1) / TN_ROWS;
+                int S = (int)(stages < S_each ? stages : S_each);
+                const long rows_per_slice = ((stages + S - 1) / S) * TN_ROWS;
+                S = (int)((M + rows_per_slice - 1) / rows_per_slice);
+                for (int j = 0; j < batch.n; ++j) { batch.job[j].rows_per_slice = rows_per_slice; red.job[j].S = S; }
+                batch.par = 1;
+                grid = S * batch.n;
+            }
+        }
         if (papr_first_on_device(PAPR_ONCE_TN_H3)) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_h3_kernel<true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T3_LDS_BYTES);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_h3_kernel<false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T3_LDS_BYTES);

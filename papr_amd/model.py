@@ -18,6 +18,7 @@ import torch.nn as nn
 
 from . import adam as own_adam
 from . import dist as pdist
+from .activations import output_activation
 from .config import as_node
 from .ops import RenderPath, prepare_mlp_weights, render_rays
 from .pointcloud import grow_points, grow_points_device
@@ -181,9 +182,7 @@ class PAPR(nn.Module):
         if self.use_pc_feats:
             self.pc_feats = nn.Parameter(torch.randn(points.shape[0], fopt.dim), requires_grad=True)
 
-        if args.models.last_act.lower() != "none":
-            raise NotImplementedError("papr_amd: models.last_act '%s' is not built (every shipped config uses 'none')" % args.models.last_act)
-        self.last_act = nn.Identity()
+        self.last_act = output_activation(args.models.last_act)
         self.proximity_attn = ProximityAttentionParams(self.plan, args.models.attn)
         self.added_points = False
         self.attn_lr = self.pts_lr = 0

@@ -583,8 +583,29 @@ def g15_dynamics():
     save("g15_dynamics.npz", cfg_json=np.array(json.dumps(G15_OVER)), **out)
 
 
+# ----------------------------------------------------------------------------------- G16
+G16_ACTS = ["none", "relu", "leakyrelu", "+1", "relu+1", "tanh", "shifted_tanh", "sigmoid", "gelu", "gaussian", "quadratic", "multi-quadratic",
+            "laplacian", "super-gaussian", "expsin", "clamp", "sine", "softplus_1.5_2.0_-0.25"]
+
+
+def g16_last_act():
+    """models.last_act: the reference's activation_func (models/utils.py:183-229) with its default arguments on one seeded tensor, and the
+    state-dict keys each choice adds to the model (`last_act.a`, ...)."""
+    from models.utils import activation_func
+    x = (torch.randn((2, 5, 7, 3), generator=torch.Generator().manual_seed(16)) * 1.5)
+    out = {"x": npf(x)}
+    for name in G16_ACTS:
+        layer = activation_func(name)
+        out["y/" + name] = npf(layer(x.clone()))
+        out["keys/" + name] = np.array(sorted(layer.state_dict().keys()))
+    save("g16_last_act.npz", **out)
+
+
 if __name__ == "__main__":
     small = {"geoms": {"points": {"init_num": 1000}}}
+    if "--g16" in sys.argv:
+        g16_last_act()
+        sys.exit(0)
     if "--g14" in sys.argv:
         g14_grow()
         sys.exit(0)
@@ -596,6 +617,7 @@ if __name__ == "__main__":
         sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
         g14_grow()
         g15_dynamics()
+        g16_last_act()
         sys.exit(0)
     if "--round3" in sys.argv:
         g13_ref_checkpoint()

@@ -380,3 +380,24 @@ def test_depth_map_is_attention_weighted_plane_distance():
     d = depth_map(sel, attn, o)
     want = (attn[0, ..., :4, 0] * (40.0 - sel[0, ..., 2]).abs()).sum(-1).numpy()     # camera on the z axis: distance to the plane z = 40
     assert d.shape == (5, 6) and np.allclose(d, want, atol=1e-5)
+
+
+def test_output_activation_matches_the_reference_for_every_name():
+    """models.last_act (reference activation_func, models/utils.py:183-229, default arguments): values and the state-dict keys each choice adds."""
+    from papr_amd.activations import output_activation
+    g = golden("g16_last_act.npz")
+    x = torch.from_numpy(g["x"])
+    names = [k[2:] for k in g.files if k.startswith("y/")]
+    assert len(names) == 18
+    for name in names:
+        layer = output_activation(name)
+        np.testing.assert_allclose(layer(x.clone()).detach().numpy(), g["y/" + name], rtol=0, atol=1e-7, err_msg=name)
+        assert sorted(layer.state_dict().keys()) == [str(k) for k in g["keys/" + name]], name
+    with pytest.raises(NotImplementedError):
+        output_activation("no-such-activation")
+    import copy
+    cfg = copy.deepcopy(case_cfg("chair1k"))
+    cfg["models"]["last_act"] = "gaussian"
+    from papr_amd import get_model
+    m = get_model(cfg, device="cpu")
+    assert "last_act.a" in m.state_dict() and float(m.last_act(torch.zeros(1))) == 1.0
