@@ -929,7 +929,7 @@ __device__ __forceinline__ float inv_scale_from_row_max(float m) {       // 1 / 
 // tile of a job (256 KB per workgroup) drains to memory while the next job's first rows are already on their way,
 // and the launch ramp and tail are paid once per batch instead of once per layer.
 constexpr int TN_BATCH = 8;
-struct TNH3Batch { TNH3Args job[TN_BATCH]; int n; int par; };      // par: job-parallel launch (workgroup b: job b % n, slice b / n), else every workgroup walks all jobs
+struct TNH3Batch { TNH3Args job[TN_BATCH]; int n; int par; };      // par: job-parallel launch (workgroup b: slice b / n of job b % n), else every workgroup walks all jobs
 
 constexpr int T3_HP = 36;                         // LDS row pitch in halfs
 constexpr int T3_PLANE = SLAB * T3_HP;            // halfs per plane (256 LDS rows x 32 m)
@@ -953,9 +953,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_h3_kernel(TNH3Batch batch) {
     __shared__ float red[2][8];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: row tests and tile skips become SALU
     const int wn = wave >> 2, wk = wave & 3;     // wave's corner in LDS-row space: n-tiles 4 wn .. +3, k-tiles 2 wk, 2 wk + 1
-  // job-parallel (batch.par): the launch's workgroups are dealt to the jobs -- workgroup b streams slice b / n of job b % n, n times as long as
-  // a slice of the job-serial form, and leaves ONE partial tile instead of n: a seventh / a quarter of the partial-tile traffic and of the
-  // reduction behind it
+  // job-parallel (batch.par): the launch's workgroups are dealt to the jobs -- a workgroup streams ONE
+  // slice of ONE job, n times as long as a slice of the job-serial form, and leaves one partial tile instead of n: an n-th of the
+  // partial-tile traffic and of the reduction behind it
   const int jb0 = batch.par ? (int)(blockIdx.x % (unsigned)batch.n) : 0, jb1 = batch.par ? jb0 + 1 : batch.n;
   const long slice = batch.par ? (long)(blockIdx.x / (unsigned)batch.n) : (long)blockIdx.x;
   for (int jb = jb0; jb < jb1; ++jb) {
@@ -1313,9 +1313,11 @@ struct TNH3Queue {
         if (M <= 0) return 0;
         const bool job_full = N > 131 && K > 131;                       // 128 + 3 < N: all eight tiles live
         PAPR_REQUIRE(g_half == x_half, "gemm_tn_h3: one operand f16, the other fp32");
-        if (batch.n == TN_BATCH || (batch.n > 0 && (job_full != full || g_half != half)))
+        // (jobs with and without dead tiles share a launch -- on the instantiation with the tile tests: one launch and one reduction per run
+        // instead of two, 0.05 ms per step; a batch of full jobs only keeps the test-free one)
+        if (batch.n == TN_BATCH || (batch.n > 0 && g_half != half))
             if (int e = flush()) return e;
-        full = job_full; half = g_half;
+        full = batch.n == 0 ? job_full : (full && job_full); half = g_half;
         const int n_cu = papr_cu_count() > MAX_SLICES ? MAX_SLICES : papr_cu_count();
         long stages = (M + TN_ROWS - 1) / TN_ROWS;
         int S = (int)(stages < n_cu ? stages : n_cu);                   // one workgroup per CU streams one slice
@@ -1334,21 +1336,23 @@ struct TNH3Queue {
     }
     int flush() {
         if (batch.n == 0) return 0;
-        // job-parallel layout: with several jobs of one length the workgroups are dealt to the jobs (see the kernel)
+        // job-parallel layout: with several jobs of one length the workgroups are dealt to the jobs (see the kernel), evenly: a slice's time
+        // follows its ROWS (a 32-row stage costs the same barriers and the same wait whatever the widths: dealt by bytes, the narrow
+        // 256 -> 32 job of the value run got 18 of 256 workgroups and held the launch for 2.26 ms instead of 1.44)
         batch.par = 0;
         if (batch.n > 1 && papr_switch(PAPR_SW_TN_JOBPAR)) {
             bool same = true;
-            for (int j = 1; j < batch.n; ++j) same &= batch.job[j].M == batch.job[0].M;
+            for (int j = 0; j < batch.n; ++j) same &= batch.job[j].M == batch.job[0].M;
             const int n_cu = papr_cu_count() > MAX_SLICES ? MAX_SLICES : papr_cu_count();
-            const int S_each = n_cu / batch.n;
-            if (same && S_each >= 8) {
+            if (same && n_cu / batch.n >= 8) {
                 const long M = batch.job[0].M, stages = (M + TN_ROWS - 1) / TN_ROWS;
-                int S = (int)(stages < S_each ? stages : S_each);
+                int S = n_cu / batch.n;
+                S = (int)(stages < S ? stages : S);
                 const long rows_per_slice = ((stages + S - 1) / S) * TN_ROWS;
                 S = (int)((M + rows_per_slice - 1) / rows_per_slice);
                 for (int j = 0; j < batch.n; ++j) { batch.job[j].rows_per_slice = rows_per_slice; red.job[j].S = S; }
                 batch.par = 1;
-                grid = S * batch.n;
+                grid = S * batch.n;                 // (workgroup b: slice b / n of job b % n -- neighbouring workgroups, which share an XCD's L2 in turn, stream different jobs)
             }
         }
         if (papr_first_on_device(PAPR_ONCE_TN_H3)) {
