@@ -8,12 +8,12 @@ TAG=${1:-r02}; shift
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-KEEP="ray_knn,mlp_chain,gemm_tn_h3,gemm_nt_h3,tail_,features_,segment_reduce,conv3x3,pair_,upconv,maxpool,conv1x1,adam_"
-rocprofv3 --kernel-trace -d $OUT/kt -o kt -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-amp-line --psnr-steps 0 "$@" > $OUT/bench_under_trace.json 2> $OUT/kt.err
+KEEP="ray_knn,mlp_chain,gemm_tn_h3,gemm_nt_h3,tail_,features_,segment_reduce,conv3x3,pairs_,upconv,maxpool,conv1x1,adam_,slab_reduce"
+rocprofv3 --kernel-trace -d $OUT/kt -o kt -- python3 bench.py --steps 10 --warmup 3 --profile-steps 0 --no-cpu-baseline --no-amp-line --no-shipped-line --psnr-steps 0 "$@" > $OUT/bench_under_trace.json 2> $OUT/kt.err
 python3 scripts/rocpd_summary.py $(find $OUT/kt -name "*.db" | head -1) last:10 > $OUT/kernel_trace.txt
 pass() {   # name, counters...
     name=$1; shift
-    rocprofv3 --pmc "$@" -d $OUT/$name -o $name -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-amp-line --psnr-steps 0 > /dev/null 2> $OUT/$name.err
+    rocprofv3 --pmc "$@" -d $OUT/$name -o $name -- python3 bench.py --steps 2 --warmup 1 --profile-steps 0 --no-cpu-baseline --no-amp-line --no-shipped-line --psnr-steps 0 > /dev/null 2> $OUT/$name.err
     python3 scripts/rocpd_pmc.py $(find $OUT/$name -name "*.db") --keep $KEEP --top 30 > $OUT/pmc_$name.txt
 }
 pass fetch FETCH_SIZE
