@@ -144,7 +144,12 @@ def mlp_apply(x, state, prefix, n_layer, act, last_act, skip_layers=()):
     for i in range(n_layer):
         if i in skip_layers:
             x = torch.cat([x, x0], dim=-1)
-        w = state["%s.model.%d.weight" % (prefix, 2 * i + 1)]
+        gkey = "%s.model.%d.weight_g" % (prefix, 2 * i + 1)
+        if gkey in state:                       # weight_norm(nn.Linear) (models/mlp.py:21,35-36): W = g v / |v|, the norm taken row by row
+            v = state["%s.model.%d.weight_v" % (prefix, 2 * i + 1)]
+            w = state[gkey] * v / v.norm(dim=1, keepdim=True)
+        else:
+            w = state["%s.model.%d.weight" % (prefix, 2 * i + 1)]
         b = state["%s.model.%d.bias" % (prefix, 2 * i + 1)]
         x = F.linear(x, w, b)
         x = _act(x, last_act if i == n_layer - 1 else act)

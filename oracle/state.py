@@ -18,8 +18,12 @@ def _mlp_shapes(prefix, d_in, ecfg):
         if i in skips:
             fan_in += d_in
         fan_out = d_out if i == n - 1 else width
-        shapes["%s.mlp.model.%d.weight" % (prefix, 2 * i + 1)] = (fan_out, fan_in)
         shapes["%s.mlp.model.%d.bias" % (prefix, 2 * i + 1)] = (fan_out,)
+        if ecfg.get("use_wn", False):           # weight_norm(nn.Linear): weight_g (out, 1), weight_v (out, in) in place of weight (models/mlp.py:21,35-36)
+            shapes["%s.mlp.model.%d.weight_g" % (prefix, 2 * i + 1)] = (fan_out, 1)
+            shapes["%s.mlp.model.%d.weight_v" % (prefix, 2 * i + 1)] = (fan_out, fan_in)
+        else:
+            shapes["%s.mlp.model.%d.weight" % (prefix, 2 * i + 1)] = (fan_out, fan_in)
     if ecfg["norm"] == "layernorm":
         shapes[prefix + ".innorm.a_2"] = (d_in,)
         shapes[prefix + ".innorm.b_2"] = (d_in,)

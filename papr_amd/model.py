@@ -53,14 +53,30 @@ class _MlpParams(nn.Module):
         mods = [nn.Identity()]
         for i in range(n):
             fan_in = (d_in if i == 0 else width) + (d_in if i in skips else 0)
-            mods += [nn.Linear(fan_in, d_out if i == n - 1 else width), nn.Identity()]
+            lin = nn.Linear(fan_in, d_out if i == n - 1 else width)
+            if ecfg.get("use_wn", False):
+                # `weight_norm(nn.Linear(..), name='weight')` (models/mlp.py:21,35-36): parameters weight_g (out, 1) and weight_v (out, in) in place
+                # of weight, W = g v / |v| row by row.  torch's own (deprecated, still shipped) function: the same parameter names, order and
+                # initial values; the kernels get W from `effective_weight` below
+                import warnings
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    lin = torch.nn.utils.weight_norm(lin, name="weight")
+            mods += [lin, nn.Identity()]
         self.model = nn.ModuleList(mods)
-        for p in self.model.parameters():
+        for p in self.model.parameters():             # (weight_g is two-dimensional too: the reference re-draws it like a weight, mlp.py:43-45)
             if p.dim() > 1:
                 nn.init.xavier_uniform_(p)
 
     def linears(self):
         return [m for m in self.model if isinstance(m, nn.Linear)]
+
+    @staticmethod
+    def effective_weight(lin):
+        """The Linear's weight as the kernels take it: the parameter itself, or g v / |v| under weight norm (differentiable)."""
+        if hasattr(lin, "weight_g"):
+            return torch._weight_norm(lin.weight_v, lin.weight_g, 0)
+        return lin.weight
 
 
 class _FeedForwardParams(nn.Module):
@@ -118,7 +134,7 @@ class ProximityAttentionParams(nn.Module):
         def ff(block, spec):
             lin = block.mlp.linears()
             ln = (block.innorm.a_2, block.innorm.b_2) if isinstance(block.innorm, _NormParams) else None
-            return prepare_mlp_weights(spec, [l.weight for l in lin], [l.bias for l in lin], ln)
+            return prepare_mlp_weights(spec, [_MlpParams.effective_weight(l) for l in lin], [l.bias for l in lin], ln)
 
         def proj(lin, block, spec):
             ln = (block.outnorm.a_2, block.outnorm.b_2) if isinstance(block.outnorm, _NormParams) else None

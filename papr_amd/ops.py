@@ -57,8 +57,7 @@ class MlpSpec:
         for key in ("half_layers", "residual_layers"):
             if ecfg.get(key):
                 raise NotImplementedError("papr_amd: %s.%s is not supported by the HIP path" % (name, key))
-        if ecfg.get("use_wn", False):
-            raise NotImplementedError("papr_amd: weight-norm (%s.use_wn) is not supported by the HIP path" % name)
+        # (use_wn: the weights reach the kernels as g v / |v|, formed in torch ops inside autograd -- papr_amd/model.py: effective_weight)
         if ecfg.get("residual_ff", False) and d_in == self.d_out:
             raise NotImplementedError("papr_amd: %s.residual_ff is not supported by the HIP path" % name)
         if float(ecfg.get("dropout_ff", 0.0)) != 0.0:

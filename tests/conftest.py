@@ -56,6 +56,14 @@ def g13_cfg():
     return deep_merge(load_config("nerfsyn/chair.yml", overrides=G13), PARITY)
 
 
+# weight-normalised embedding MLPs (`use_wn: true`; no shipped scene file sets it): G13's tiny model with 1,000 points
+WN_TINY = {"geoms": {"points": {"init_num": 1000, "select_k": 12}, "point_feats": {"dim": 16}},
+           "models": {"use_renderer": False, "attn": {"d_model": 64, "embed": {
+               "k_L": [4, 4, 4], "q_L": [4], "v_L": [4, 4],
+               "key": {"d_ff": 64, "d_ff_out": 64, "n_ff_layer": 3, "use_wn": True},
+               "query": {"d_ff": 64, "d_ff_out": 64, "n_ff_layer": 3, "use_wn": True},
+               "value": {"d_ff": 64, "d_ff_out": 3, "n_ff_layer": 4, "use_wn": True}}}}}
+
 CASES = {
     "chair1k": ("nerfsyn/chair.yml", SMALL, dict(n_img=1, hw=16, seed=0)),
     "lego1k": ("nerfsyn/lego.yml", SMALL, dict(n_img=1, hw=16, seed=0)),
@@ -63,6 +71,7 @@ CASES = {
     # feature variants no shipped scene file uses: point features in the key as well (use_ink), posenc without the raw
     # coordinate (embed_type 2), un-normalised top-k attention
     "variants1k": ("nerfsyn/chair.yml", VARIANTS, dict(n_img=1, hw=16, seed=0)),
+    "wn_tiny": ("nerfsyn/chair.yml", WN_TINY, dict(n_img=2, hw=8, seed=4)),
 }
 
 

@@ -603,6 +603,15 @@ def g16_last_act():
 
 if __name__ == "__main__":
     small = {"geoms": {"points": {"init_num": 1000}}}
+    if "--g17" in sys.argv:                          # weight-normalised embedding MLPs (`use_wn: true`, models/mlp.py:21,35-36): a tiny model
+        wn = copy.deepcopy(G13_CFG)
+        wn["geoms"]["points"]["init_num"] = 1000
+        for k in ("key", "query", "value"):
+            wn["models"]["attn"]["embed"][k]["use_wn"] = True
+        import warnings
+        warnings.simplefilter("ignore")
+        model_case("wn_tiny", load_cfg("nerfsyn/chair.yml", **wn), n_img=2, hw=8, ray_seed=4)
+        sys.exit(0)
     if "--g16" in sys.argv:
         g16_last_act()
         sys.exit(0)
