@@ -1534,7 +1534,7 @@ extern "C" int papr_mlp_fwd(const papr_layer* layers, int n_layers, float* x, in
                 // the run's input rows split ahead of it: the run stages its tiles by LDS-DMA (chain.h: sr_*)
                 SRScratch sr(static_cast<char*>(workspace) + H3Scratch::bytes(M), M);
                 SplitRowsArgs q = {};
-                q.x = c.A0; q.ld = c.lda0; q.K = c.K0; q.Kq = (c.K0 + 15) / 16 * 16; q.M = M;
+                q.x = c.A0; q.ld = c.lda0; q.K = c.K0; q.Kq = (c.K0 + 31) / 32 * 32; q.M = M;      // (the first k-loop reads whole pairs of k-steps: the planes are zero up to there)
                 q.hi = sr.hi; q.lo = sr.lo; q.inv = sr.inv; q.mx = c.rowmax0 ? c.rowmax0 : sr.mx;
                 q.nw = c.in_norm_width; q.eps = c.in_norm_eps; q.stats = c.in_norm_stats; q.writeback = c.in_norm_writeback;
                 if (int err = launch_split_rows(q, s)) return err;
@@ -1768,7 +1768,7 @@ extern "C" int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float*
                 if (split_ahead) {                  // the top gradient rows split ahead of the run (chain.h: sr_*); their maxima go where the run would leave them
                     SRScratch sr(static_cast<char*>(workspace) + TN_SLAB_BYTES + H3Scratch::bytes(M) + BwdRunScratch::bytes(M), M);
                     SplitRowsArgs q = {};
-                    q.x = c.A0; q.ld = c.lda0; q.K = c.K0; q.Kq = (c.K0 + 15) / 16 * 16; q.M = M;
+                    q.x = c.A0; q.ld = c.lda0; q.K = c.K0; q.Kq = (c.K0 + 31) / 32 * 32; q.M = M;      // (the first k-loop reads whole pairs of k-steps: the planes are zero up to there)
                     q.hi = sr.hi; q.lo = sr.lo; q.inv = sr.inv; q.mx = c.rowmax0;
                     if (int err = launch_split_rows(q, s)) return err;
                     c.sr_hi = q.hi; c.sr_lo = q.lo; c.sr_inv = q.inv; c.sr_max = q.mx; c.sr_ld = q.Kq;

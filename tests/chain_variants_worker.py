@@ -1,5 +1,5 @@
 """One MLP through the fused-run kernels in a fresh process (the library reads PAPR_C4_FUSED / PAPR_C4_GENERIC / PAPR_GEMM_MODE when it
-loads):   python tests/chain_variants_worker.py <out.pt> <M> <n_layers> <act>
+loads):   python tests/chain_variants_worker.py <out.pt> <M> <n_layers> <act> [<d_in> <d_out>]
 
 Training forward (every layer saved), data-gradient run with the saved sign words, the same without them, an inference pass;
 tests/test_hip_chain_variants.py compares the files bit for bit."""
@@ -12,9 +12,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def main(out, M, n, act):
+def main(out, M, n, act, d_in=117, d_out=256):
     from papr_amd import ops
-    d_in, width, d_out = 117, 256, 256
+    width = 256
     gen = torch.Generator().manual_seed(M + n)
     spec = ops.MlpSpec("t", d_in, dict(n_ff_layer=n, d_ff=width, d_ff_out=d_out, norm="none", ff_act=act, ff_last_act="none", skip_layers=[]))
     d = torch.device("cuda:0")
@@ -42,4 +42,4 @@ def main(out, M, n, act):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4])
+    main(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], *[int(a) for a in sys.argv[5:7]])

@@ -26,11 +26,11 @@ VARIANTS = [("generic rows", {"PAPR_C4_GENERIC": "1"}), ("two-role", {"PAPR_C4_F
             ("rows split ahead", {"PAPR_C4_DMA": "1"}), ("rows split ahead, generic rows", {"PAPR_C4_DMA": "1", "PAPR_C4_GENERIC": "1"})]
 
 
-def _run(tmp_path, name, env, M, n, act):
+def _run(tmp_path, name, env, M, n, act, dims=()):
     out = tmp_path / (name.replace(" ", "_") + ".pt")
     e = {k: v for k, v in os.environ.items() if k not in ("PAPR_C4_GENERIC", "PAPR_C4_FUSED", "PAPR_GEMM_MODE", "PAPR_C4_DMA")}
     e.update(env)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "chain_variants_worker.py"), str(out), str(M), str(n), act], env=e, capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "chain_variants_worker.py"), str(out), str(M), str(n), act] + [str(v) for v in dims], env=e, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (name, r.stderr[-2000:])
     return torch.load(out)
 
@@ -47,11 +47,12 @@ def _flat(res):
             yield k, v
 
 
-@pytest.mark.parametrize("M,n,act", [(40000, 5, "relu"), (45, 3, "leakyrelu"), (20000, 4, "leakyrelu")])
-def test_fused_run_kernels_agree_bit_for_bit(tmp_path, M, n, act):
+# (the last case: the value MLP's shape -- 141 input columns, 32 output columns -- and a last tile of 37 rows)
+@pytest.mark.parametrize("M,n,act,dims", [(40000, 5, "relu", ()), (45, 3, "leakyrelu", ()), (20000, 4, "leakyrelu", ()), (30053, 4, "relu", (141, 32))])
+def test_fused_run_kernels_agree_bit_for_bit(tmp_path, M, n, act, dims):
     ref = None
     for name, env in VARIANTS:
-        res = _run(tmp_path, name, env, M, n, act)
+        res = _run(tmp_path, name, env, M, n, act, dims)
         if ref is None:
             ref = res
             continue
