@@ -28,6 +28,7 @@ the statement names them -- hence an X and a Y flavour of every variant.  Tempor
 """
 
 import os
+import sys
 ABLATE = os.environ.get("C4F_ABLATE", "")      # timing experiments (scripts/probes/c4_variant.sh with -DC4_FUSED_INC=...)
 KVAR = os.environ.get("C4F_KVAR", "")          # timing experiments on the k-loop (with C4F_ABLATE=K: the row-phase temporaries are free): noread | dbuf | dbufh
 
@@ -443,7 +444,57 @@ def emit(name, lines):
     print()
 
 
+def classify(line):
+    op = line.split()[0]
+    if op.startswith("v_mfma"): return "mfma"
+    if op.startswith("ds_"): return "lds"
+    if op.startswith(("global_", "buffer_", "flat_")): return "vmem"
+    if op == "s_waitcnt": return "wait"
+    if op == "s_barrier": return "barrier"
+    if op == "s_nop": return "nop"
+    if op.startswith("s_"): return "salu"
+    if op.startswith("v_accvgpr"): return "acc_mov"
+    return "valu"
+
+
+def budget():
+    """per statement: instructions by kind and by stream (k-loop alone; + first half of the row phase; + second half), non-MFMA per MFMA --
+    python scripts/gen_chain4_fused.py --budget > profiles/rNN_chain4_statement_budget.txt"""
+    global ABLATE
+    kinds = ["valu", "acc_mov", "lds", "vmem", "salu", "wait", "nop", "barrier"]
+    def count(lines):
+        c = dict.fromkeys(["mfma"] + kinds, 0)
+        for l in lines:
+            c[classify(l)] += 1
+        return c
+    print("Instruction budget of the hot-slot statements of chain4.hip (scripts/gen_chain4_fused.py --budget; one wave, one slot = one statement).")
+    print("Streams: K = the k-loop of tile T (MFMAs, fragment reads, their waits); P1 / P2 = first / second half of tile U's row phase, counted as")
+    print("(statement built with that stream) - (statement with the k-loop alone): waits the interleaving adds are charged to the stream that needs them.")
+    print("%-26s %5s | %-38s | %-38s | %-38s | %s" % ("statement", "MFMA", "K: valu accmov lds vmem salu wait nop", "P1: valu accmov lds vmem salu wait nop", "P2: valu accmov lds vmem salu wait nop", "non-MFMA per MFMA (all / valu only)"))
+    for one in (False, True):
+        for mode in ("fwd", "inf", "dgrad"):
+            for act in ("relu", "leaky"):
+                for tile, ld in (("X", 0), ("Y", 0), ("Y", 1)):
+                    saved = ABLATE
+                    c = {}
+                    for ab in ("K", "KP1", "KP2", ""):
+                        ABLATE = ab
+                        c[ab] = count(build(tile, mode, act, ld, 16, one))
+                    ABLATE = saved
+                    k = c["K"]
+                    p1 = {x: c["KP1"][x] - k[x] for x in k}
+                    p2 = {x: c["KP2"][x] - k[x] for x in k}
+                    full = c[""]
+                    fmt = lambda d: " ".join("%5d" % d[x] for x in kinds[:7])
+                    non = sum(full[x] for x in kinds)
+                    vonly = full["valu"] + full["acc_mov"]
+                    print("%-26s %5d | %-38s | %-38s | %-38s | %.2f / %.2f" % ("%s%s_%s_%s_%s" % ("h1:" if one else "", mode, act, tile, "LD" if ld else "NL"), full["mfma"], fmt(k), fmt(p1), fmt(p2), non / full["mfma"], vonly / full["mfma"]))
+
+
 if __name__ == "__main__":
+    if "--budget" in sys.argv:
+        budget()
+        sys.exit(0)
     print("// GENERATED by scripts/gen_chain4_fused.py -- do not edit.  The hot slots of chain4.hip, one asm statement each (see the script).")
     total = {}
     for mode in ("fwd", "inf", "dgrad"):
