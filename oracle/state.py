@@ -13,11 +13,16 @@ def _mlp_shapes(prefix, d_in, ecfg):
     shapes = {}
     n, width, d_out = ecfg["n_ff_layer"], ecfg["d_ff"], ecfg["d_ff_out"]
     skips = ecfg.get("skip_layers", [])
+    halves = ecfg.get("half_layers", []) or []
     for i in range(n):
         fan_in = d_in if i == 0 else width
+        fan_out = d_out if i == n - 1 else width
+        if i + 1 in halves:                     # models/mlp.py:27-30
+            fan_out //= 2
+        if i in halves:
+            fan_in //= 2
         if i in skips:
             fan_in += d_in
-        fan_out = d_out if i == n - 1 else width
         shapes["%s.mlp.model.%d.bias" % (prefix, 2 * i + 1)] = (fan_out,)
         if ecfg.get("use_wn", False):           # weight_norm(nn.Linear): weight_g (out, 1), weight_v (out, in) in place of weight (models/mlp.py:21,35-36)
             shapes["%s.mlp.model.%d.weight_g" % (prefix, 2 * i + 1)] = (fan_out, 1)

@@ -50,10 +50,17 @@ class _MlpParams(nn.Module):
         super().__init__()
         n, width, d_out = ecfg["n_ff_layer"], ecfg["d_ff"], ecfg["d_ff_out"]
         skips = ecfg.get("skip_layers", []) or []
+        halves = ecfg.get("half_layers", []) or []
         mods = [nn.Identity()]
         for i in range(n):
-            fan_in = (d_in if i == 0 else width) + (d_in if i in skips else 0)
-            lin = nn.Linear(fan_in, d_out if i == n - 1 else width)
+            fan_in, fan_out = (d_in if i == 0 else width), (d_out if i == n - 1 else width)
+            if i + 1 in halves:                       # (models/mlp.py:27-30: the layer in front of a half layer produces half as much)
+                fan_out //= 2
+            if i in halves:
+                fan_in //= 2
+            if i in skips:
+                fan_in += d_in
+            lin = nn.Linear(fan_in, fan_out)
             if ecfg.get("use_wn", False):
                 # `weight_norm(nn.Linear(..), name='weight')` (models/mlp.py:21,35-36): parameters weight_g (out, 1) and weight_v (out, in) in place
                 # of weight, W = g v / |v| row by row.  torch's own (deprecated, still shipped) function: the same parameter names, order and

@@ -54,9 +54,10 @@ class MlpSpec:
         self.d_out = int(ecfg["d_ff_out"])
         self.norm = ecfg["norm"]
         self.skip_layers = list(ecfg.get("skip_layers", []) or [])
-        for key in ("half_layers", "residual_layers"):
-            if ecfg.get(key):
-                raise NotImplementedError("papr_amd: %s.%s is not supported by the HIP path" % (name, key))
+        # half_layers (models/mlp.py:27-30): layer i in the list takes half the width as input -- layer i - 1 produces only that much
+        self.half_layers = [int(i) for i in (ecfg.get("half_layers", []) or [])]
+        if ecfg.get("residual_layers"):
+            raise NotImplementedError("papr_amd: %s.residual_layers is not supported by the HIP path" % name)
         # (use_wn: the weights reach the kernels as g v / |v|, formed in torch ops inside autograd -- papr_amd/model.py: effective_weight)
         if ecfg.get("residual_ff", False) and d_in == self.d_out:
             raise NotImplementedError("papr_amd: %s.residual_ff is not supported by the HIP path" % name)
@@ -74,11 +75,18 @@ class MlpSpec:
         # per-layer geometry
         self.layers = []
         for i in range(self.n_layer):
-            n_in = self.ld_in if i == 0 else self.width
+            raw_in = self.d_in if i == 0 else self.width
             n_out = self.d_out if i == self.n_layer - 1 else self.width
+            if i + 1 in self.half_layers:
+                n_out //= 2
+            if i in self.half_layers:
+                raw_in //= 2
+            if (i in self.half_layers and (i == 0 or raw_in % 32)) or (i + 1 in self.half_layers and n_out % 32):
+                raise NotImplementedError("papr_amd: %s.half_layers needs halved widths that are multiples of 32 (layer %d: %d -> %d)" % (name, i, raw_in, n_out))
+            n_in = self.ld_in if i == 0 else raw_in
             skip = i in self.skip_layers
             self.layers.append(dict(n_in=n_in, n_out=n_out, n_out_pad=_pad32(n_out) if i == self.n_layer - 1 else n_out,
-                                    raw_in=(self.d_in if i == 0 else self.width), skip=skip,
+                                    raw_in=raw_in, skip=skip,
                                     act=self.last_act if i == self.n_layer - 1 else self.act))
         self.ld_out = [l["n_out_pad"] for l in self.layers]
 

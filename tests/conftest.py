@@ -64,6 +64,14 @@ WN_TINY = {"geoms": {"points": {"init_num": 1000, "select_k": 12}, "point_feats"
                "query": {"d_ff": 64, "d_ff_out": 64, "n_ff_layer": 3, "use_wn": True},
                "value": {"d_ff": 64, "d_ff_out": 3, "n_ff_layer": 4, "use_wn": True}}}}}
 
+# half layers (`half_layers`; no shipped scene file sets them): the key MLP's layer 1 and the value MLP's layer 2 take half the width
+HALF_TINY = {"geoms": {"points": {"init_num": 1000, "select_k": 12}, "point_feats": {"dim": 16}},
+             "models": {"use_renderer": False, "attn": {"d_model": 64, "embed": {
+                 "k_L": [4, 4, 4], "q_L": [4], "v_L": [4, 4],
+                 "key": {"d_ff": 64, "d_ff_out": 64, "n_ff_layer": 3, "half_layers": [1]},
+                 "query": {"d_ff": 64, "d_ff_out": 64, "n_ff_layer": 3},
+                 "value": {"d_ff": 64, "d_ff_out": 3, "n_ff_layer": 4, "half_layers": [2]}}}}}
+
 CASES = {
     "chair1k": ("nerfsyn/chair.yml", SMALL, dict(n_img=1, hw=16, seed=0)),
     "lego1k": ("nerfsyn/lego.yml", SMALL, dict(n_img=1, hw=16, seed=0)),
@@ -72,6 +80,7 @@ CASES = {
     # coordinate (embed_type 2), un-normalised top-k attention
     "variants1k": ("nerfsyn/chair.yml", VARIANTS, dict(n_img=1, hw=16, seed=0)),
     "wn_tiny": ("nerfsyn/chair.yml", WN_TINY, dict(n_img=2, hw=8, seed=4)),
+    "half_tiny": ("nerfsyn/chair.yml", HALF_TINY, dict(n_img=2, hw=8, seed=4)),
 }
 
 

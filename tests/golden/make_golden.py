@@ -612,6 +612,13 @@ if __name__ == "__main__":
         warnings.simplefilter("ignore")
         model_case("wn_tiny", load_cfg("nerfsyn/chair.yml", **wn), n_img=2, hw=8, ray_seed=4)
         sys.exit(0)
+    if "--g18" in sys.argv:                          # half layers (`half_layers`, models/mlp.py:27-30; no shipped scene file sets them): a tiny model
+        hc = copy.deepcopy(G13_CFG)
+        hc["geoms"]["points"]["init_num"] = 1000
+        hc["models"]["attn"]["embed"]["key"]["half_layers"] = [1]
+        hc["models"]["attn"]["embed"]["value"]["half_layers"] = [2]
+        model_case("half_tiny", load_cfg("nerfsyn/chair.yml", **hc), n_img=2, hw=8, ray_seed=4)
+        sys.exit(0)
     if "--g16" in sys.argv:
         g16_last_act()
         sys.exit(0)

@@ -200,7 +200,7 @@ def test_unsupported_options_fail_at_construction():
     from papr_amd import get_model
     from papr_amd.config import deep_merge
     for over in ({"models": {"attn": {"embed": {"key": {"ff_act": "gelu"}}}}},
-                 {"models": {"attn": {"embed": {"value": {"half_layers": [2]}}}}},
+                 {"models": {"attn": {"embed": {"value": {"residual_layers": [2]}}}}},
                  {"exposure_control": {"use": True}},
                  {"models": {"renderer": {"generator": {"type": "big-unet"}}}}):
         cfg = deep_merge(case_cfg("chair1k"), over)
