@@ -180,9 +180,11 @@ __global__ __launch_bounds__(256, 3) void conv3x3_h3_kernel(ConvArgs p) {
 
 // planes hi / lo (N_pad, 9 C) <- weight element (n, ky, kx, c) at w[n sn + c sc + ky sky + kx skx]; flip: taps mirrored
 // (the data-gradient's weight); rows N .. N_pad-1 zero.  One thread per four consecutive c.
-__global__ __launch_bounds__(256) void conv_split_weight_kernel(const float* __restrict__ w, int N, int C, long sn, long sc, long sky, long skx,
-                                                                int flip, long total4, _Float16* __restrict__ hi, _Float16* __restrict__ lo) {
-    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+struct ConvSplitArgs { const float* w; int N, C; long sn, sc, sky, skx; int flip; long total4; _Float16* hi; _Float16* lo; };
+__device__ __forceinline__ void conv_split_weight_block(const ConvSplitArgs& a, long block) {
+    const float* __restrict__ w = a.w; const int N = a.N, C = a.C, flip = a.flip; const long sn = a.sn, sc = a.sc, sky = a.sky, skx = a.skx, total4 = a.total4;
+    _Float16* __restrict__ hi = a.hi; _Float16* __restrict__ lo = a.lo;
+    const long e = block * 256 + threadIdx.x;
     if (e >= total4) return;
     const long K = 9L * C;
     const long n = e * 4 / K;
@@ -407,12 +409,12 @@ __global__ __launch_bounds__(256) void conv_reduce_kernel(const float4* __restri
     out[e] = r;
 }
 
-__global__ __launch_bounds__(256) void tensor_absmax_kernel(const float4* __restrict__ x, long n4, unsigned* __restrict__ out,
-                                                            unsigned* __restrict__ stale) {
+__device__ __forceinline__ void tensor_absmax_block(const float4* __restrict__ x, long n4, unsigned* __restrict__ out, unsigned* __restrict__ stale,
+                                                    long block, long blocks) {
     __shared__ float part[4];
-    if (blockIdx.x == 0 && threadIdx.x == 0) *stale = 0u;       // the slot of 32 calls ago, for its next turn (no memset launch)
+    if (block == 0 && threadIdx.x == 0) *stale = 0u;       // the slot of 32 calls ago, for its next turn (no memset launch)
     float m = 0.f;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    for (long i = block * 256 + threadIdx.x; i < n4; i += blocks * 256) {
         const float4 v = x[i];
         m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
     }
@@ -421,6 +423,23 @@ __global__ __launch_bounds__(256) void tensor_absmax_kernel(const float4* __rest
     __syncthreads();
     if (threadIdx.x == 0)                                   // |x| bit patterns order like unsigned ints
         atomicMax(out, __float_as_uint(fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]))));
+}
+__global__ __launch_bounds__(256) void tensor_absmax_kernel(const float4* __restrict__ x, long n4, unsigned* __restrict__ out,
+                                                            unsigned* __restrict__ stale) {
+    tensor_absmax_block(x, n4, out, stale, blockIdx.x, gridDim.x);
+}
+// What a convolution call does in front of its matrix kernel, in ONE launch: the first nb_abs workgroups take the maximum of the input map,
+// the others split the weight into its f16 planes (two independent 6-us launches before: 20 launches of a training step)
+__global__ __launch_bounds__(256) void conv_prep_kernel(const float4* __restrict__ x, long n4, unsigned* __restrict__ out, unsigned* __restrict__ stale,
+                                                        int nb_abs, ConvSplitArgs sp) {
+    if ((int)blockIdx.x < nb_abs) tensor_absmax_block(x, n4, out, stale, blockIdx.x, nb_abs);
+    else conv_split_weight_block(sp, (long)blockIdx.x - nb_abs);
+}
+// two maxima in one launch (the weight gradient's operands)
+__global__ __launch_bounds__(256) void tensor_absmax2_kernel(const float4* __restrict__ x0, long n0, unsigned* __restrict__ out0, unsigned* __restrict__ stale0, int nb0,
+                                                             const float4* __restrict__ x1, long n1, unsigned* __restrict__ out1, unsigned* __restrict__ stale1) {
+    if ((int)blockIdx.x < nb0) tensor_absmax_block(x0, n0, out0, stale0, blockIdx.x, nb0);
+    else tensor_absmax_block(x1, n1, out1, stale1, (long)blockIdx.x - nb0, (long)gridDim.x - nb0);
 }
 
 }  // namespace
@@ -457,12 +476,11 @@ extern "C" int papr_conv3x3_fwd(const float* x, int32_t B, int32_t H, int32_t W,
     _Float16* planes = reinterpret_cast<_Float16*>(static_cast<char*>(workspace) + 256);
     const long n4 = M * c_in / 4;
     const long want = (n4 + 256 * 16 - 1) / (256 * 16);
-    tensor_absmax_kernel<<<dim3((unsigned)(want < 256 ? want : 256)), dim3(256), 0, s>>>(reinterpret_cast<const float4*>(x), n4, xmax, stale);
-    PAPR_CHECK_LAUNCH("tensor_absmax");
     const long total4 = n_pad * K / 4;
-    conv_split_weight_kernel<<<dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s>>>(w, c_out, c_in, w_stride_n, w_stride_c, w_stride_ky, w_stride_kx,
-                                                                                         flip_taps, total4, planes, planes + n_pad * K);
-    PAPR_CHECK_LAUNCH("conv_split_weight");
+    const int nb_abs = (int)(want < 256 ? want : 256);
+    ConvSplitArgs sp = {w, c_out, c_in, w_stride_n, w_stride_c, w_stride_ky, w_stride_kx, flip_taps, total4, planes, planes + n_pad * K};
+    conv_prep_kernel<<<dim3((unsigned)(nb_abs + (total4 + 255) / 256)), dim3(256), 0, s>>>(reinterpret_cast<const float4*>(x), n4, xmax, stale, nb_abs, sp);
+    PAPR_CHECK_LAUNCH("conv_prep");
     ConvArgs a;
     a.x = x; a.B = B; a.H = H; a.W = W; a.C = c_in;
     a.w_hi = planes; a.w_lo = planes + n_pad * K; a.K = K;
@@ -518,8 +536,16 @@ extern "C" int papr_conv3x3_wgrad(const float* d_out, const float* x, int32_t B,
         tensor_absmax_kernel<<<dim3((unsigned)(want < 256 ? want : 256)), dim3(256), 0, s>>>(reinterpret_cast<const float4*>(t), n4, dst, st);
     };
     // (a maximum the caller already has -- the slot a papr_conv3x3_fwd call on the same tensor left behind -- spares its launch)
-    if (!d_out_max_bits) absmax(d_out, M * c_out / 4, gmax, stale);
-    if (!x_max_bits) absmax(x, M * c_in / 4, xmax, d_out_max_bits ? stale : stale + 1);
+    if (!d_out_max_bits && !x_max_bits) {
+        const long n0 = M * c_out / 4, n1 = M * c_in / 4;
+        const long w0 = (n0 + 256 * 16 - 1) / (256 * 16), w1 = (n1 + 256 * 16 - 1) / (256 * 16);
+        const int nb0 = (int)(w0 < 256 ? w0 : 256), nb1 = (int)(w1 < 256 ? w1 : 256);
+        tensor_absmax2_kernel<<<dim3((unsigned)(nb0 + nb1)), dim3(256), 0, s>>>(reinterpret_cast<const float4*>(d_out), n0, gmax, stale, nb0,
+                                                                                reinterpret_cast<const float4*>(x), n1, xmax, stale + 1);
+    } else {
+        if (!d_out_max_bits) absmax(d_out, M * c_out / 4, gmax, stale);
+        if (!x_max_bits) absmax(x, M * c_in / 4, xmax, d_out_max_bits ? stale : stale + 1);
+    }
     PAPR_CHECK_LAUNCH("tensor_absmax");
     ConvWArgs a;
     a.dy = d_out; a.x = x; a.B = B; a.H = H; a.W = W; a.N = c_out; a.C = c_in;

@@ -91,6 +91,18 @@ class MlpSpec:
         self.ld_out = [l["n_out_pad"] for l in self.layers]
 
 
+_zero_cache = {}
+
+
+def _zeros(dev, shape):
+    """A constant block of fp32 zeros on `dev` (read-only operands such as padding rows and absent biases: made once, not filled every step)."""
+    key = (dev.type, dev.index, tuple(shape))
+    z = _zero_cache.get(key)
+    if z is None:
+        z = _zero_cache[key] = torch.zeros(shape, device=dev, dtype=torch.float32)
+    return z
+
+
 def conv3x3_rows(x, weight, bias, relu, transposed=False, want_max=False):
     """x (B, H, W, C_in) fp32 contiguous, weight = the reference's (C_out, C_in, 3, 3) Conv2d parameter in any memory format
     -> (B, H, W, C_out): 3x3 convolution, stride 1, zero padding 1, on the split-f16 implicit-GEMM kernel.  transposed:
@@ -730,7 +742,7 @@ class _RenderFn(torch.autograd.Function):
         # score_j = (W_q Q + b_q).(W_k K_j + b_k) = K_j.(W_k^T q') + b_k.q'  with q' = W_q Q + b_q: the R*k-row w_k
         # product of the reference (models/attn.py:217) becomes two R-row products (plain library GEMMs)
         qp = mlp_forward(plan.wq, wqw, wqb, Q, R, True)[0]
-        w_aug = torch.cat([wkw[0].t(), wkb[0][None, :], wkb[0].new_zeros((3, wkb[0].shape[0]))], 0).contiguous()
+        w_aug = torch.cat([wkw[0].t(), wkb[0][None, :], _zeros(dev, (3, wkb[0].shape[0]))], 0).contiguous()
         g = linear_rows(qp, w_aug)                           # (R, key.d_out + 4): [W_k^T q' | b_k.q' | 0 0 0]
         c0 = g[:, plan.key.d_out].contiguous()               # (R,)
         # the dot products K_j.g are taken in the key run's last row phase: in inference the (R*k, d_model) key embedding is never written
@@ -785,7 +797,16 @@ class _RenderFn(torch.autograd.Function):
         d_g = torch.empty_like(s["g"])
         d_c0 = torch.empty((R,), device=dev, dtype=torch.float32)
         d_V = torch.empty_like(V)
-        d_influ = torch.zeros((s["P"], 1), device=dev, dtype=torch.float32)
+        # the three per-point gradients share ONE zeroed buffer (points without a pair keep the zeros; one fill launch instead of three):
+        # [features | points | influence], the features first so that their rows stay 16-byte aligned
+        n_pts = s["P"]
+        n_feat = 0
+        if s["feat_shape"] is not None:
+            n_feat = 1
+            for v in s["feat_shape"]:
+                n_feat *= int(v)
+        per_point = torch.zeros((n_feat + 4 * n_pts,), device=dev, dtype=torch.float32)
+        d_influ = per_point[n_feat + 3 * n_pts:].view(n_pts, 1)
         pair_influ = torch.empty((M,), device=dev, dtype=torch.float32)
         d_fused = d_fused.contiguous()
         d_attn = d_attn.contiguous() if d_attn is not None else None
@@ -801,7 +822,7 @@ class _RenderFn(torch.autograd.Function):
         wmax = max(plan.key.width, plan.qry.width, plan.val.width, plan.key.ld_in, plan.val.ld_in, plan.d_model)
         scratch = [torch.empty((M, wmax), device=dev, dtype=torch.float32) for _ in range(2)]
         d_g = d_g[:, :plan.key.d_out].contiguous()           # the tail kernel fills d_model = key.d_out columns
-        d_wkT, _, d_qp = mlp_backward(plan.wk_fold, [wkw[0].t().contiguous()], [wkb[0].new_zeros(plan.key.d_out)], qp, R, [d_g], d_g,
+        d_wkT, _, d_qp = mlp_backward(plan.wk_fold, [wkw[0].t().contiguous()], [_zeros(dev, (plan.key.d_out,))], qp, R, [d_g], d_g,
                                       [t[:R] for t in scratch], True)
         d_qp.addcmul_(d_c0[:, None], wkb[0][None, :])
         d_wk = [d_wkT[0].t()]
@@ -829,11 +850,11 @@ class _RenderFn(torch.autograd.Function):
             hip.check(lib.papr_build_features_bwd_pairs(C.byref(fd), hip.ptr(s["points"]), hip.ptr(s["rays_o"]), hip.ptr(s["rays_d"]), R,
                                                         ctx.rpi, hip.ptr(idx), hip.ptr(d_key), hip.ptr(d_val), hip.ptr(pair_pts),
                                                         hip.stream_ptr()), "papr_build_features_bwd_pairs")
-            d_points = torch.zeros((s["P"], 3), device=dev, dtype=torch.float32)
+            d_points = per_point[n_feat:n_feat + 3 * n_pts].view(n_pts, 3)
         fdim = plan.feat_dim
         rows, ld, col0 = None, 0, 0
         if need_geo and plan.use_feats:
-            d_feats = torch.zeros(s["feat_shape"], device=dev, dtype=torch.float32)
+            d_feats = per_point[:n_feat].view(s["feat_shape"])
             if plan.fdesc.val_has_feats:
                 rows, ld, col0 = d_val, d_val.shape[1], plan.val_w - fdim
             else:
