@@ -10,6 +10,7 @@ from train import render_full
 
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 30000
 chunk = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+os.environ["PAPR_EVAL_CHUNK"] = "config"            # (the chunk named on the command line, not the drivers' choice: train.py, eval_chunk)
 cfg = load_config("nerfsyn/lego.yml", overrides={"use_amp": False, "geoms": {"points": {"init_num": P}},
                                                  "training": {"losses": {"mse": 1.0, "lpips": 0.0}}})
 torch.manual_seed(1); np.random.seed(1)

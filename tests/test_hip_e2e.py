@@ -84,11 +84,24 @@ def test_lego_full_image_render_at_30k_points():
     data = SyntheticRayData(cfg["dataset"], n_views=2, seed=0, device="cuda")
     img, rayd, rayo, c2w = data.full_view(0)
     assert rayd.shape == (1, 800, 800, 3)
-    a = render_full(m, rayo, rayd, c2w, 200, 200)
-    idx = m.select_k_ind.reshape(-1, 20).cpu()              # the last 200 x 200 chunk
-    b = render_full(m, rayo, rayd, c2w, 100, 100)
+    from train import eval_chunk
+    old = os.environ.get("PAPR_EVAL_CHUNK")
+    os.environ["PAPR_EVAL_CHUNK"] = "config"                # the chunks named here, not the drivers' choice
+    try:
+        a = render_full(m, rayo, rayd, c2w, 200, 200)
+        idx = m.select_k_ind.reshape(-1, 20).cpu()          # the last 200 x 200 chunk
+        b = render_full(m, rayo, rayd, c2w, 100, 100)
+    finally:
+        if old is None:
+            del os.environ["PAPR_EVAL_CHUNK"]
+        else:
+            os.environ["PAPR_EVAL_CHUNK"] = old
     assert a.shape == (1, 800, 800, 3) and torch.isfinite(a).all() and float(a.min()) >= 0 and float(a.max()) <= 1
     assert torch.equal(a, b)
+    # the drivers' own chunk (train.py: eval_chunk -- 400 x 400 on a device with room) is a memory decision, not a result: the same bits
+    if old is None:
+        assert eval_chunk(m, 1, 800, 800, 200, 200, rayd.device) == (400, 400)
+        assert torch.equal(render_full(m, rayo, rayd, c2w, 200, 200), a)
     assert _k_nearest_ok(m.points.detach().cpu(), rayo[0].cpu(), rayd[:, 600:, 600:].reshape(-1, 3).cpu(), idx, cfg["eps"])
 
 

@@ -40,11 +40,35 @@ def setup_seed(seed):
     random.seed(seed)
 
 
+EVAL_CHUNK_RAYS = 160000          # rays per evaluate() call the drivers aim for on a 288 GB device (the reference's 200 x 200 suits 24 GB)
+
+
+def eval_chunk(model, N, H, W, max_h, max_w, device):
+    """The chunk of an image that one evaluate() call renders.  The configured `max_height x max_width` is the reference's memory
+    limit, not part of the result -- evaluate() is chunk-invariant bit for bit (tests/test_hip_model.py) and the render head runs once
+    on the whole map --, so on a device with room the drivers take larger chunks: fewer, longer launches (800 x 800 lego view: 84.3 ms
+    in 200 x 200 chunks, 79.7 in 400 x 400).  PAPR_EVAL_CHUNK=config keeps the configured size."""
+    if os.environ.get("PAPR_EVAL_CHUNK", "auto") == "config" or device.type != "cuda":
+        return max_h, max_w
+    k = min(model.points.shape[0], int(model.select_k))
+    per_ray = 4 * k * 1024                      # bytes: the pair rows of a ray (inputs, two 256-wide ping-pong rows, value row) with room to spare
+    free = torch.cuda.mem_get_info(device)[0]
+    h, w = min(max_h, H), min(max_w, W)
+    while True:                                 # double the smaller side while the chunk stays inside the image, the target and a quarter of the free memory
+        nh, nw = (min(2 * h, H), w) if h <= w and h < H else (h, min(2 * w, W))
+        if (nh, nw) == (h, w) and h < H:
+            nh = min(2 * h, H)
+        if (nh, nw) == (h, w) or N * nh * nw > EVAL_CHUNK_RAYS or N * nh * nw * per_ray > free // 4:
+            return h, w
+        h, w = nh, nw
+
+
 def render_full(model, rayo, rayd, c2w, max_h, max_w, extras=False):
     """Chunked evaluate() + render head + compositing (reference eval_step / test_step).  extras: also the foreground image, the
     background mask, the attention weights and the selected points (what test.py:120-141 turns into depth / fgrgb / bkgmask PNGs)."""
     args = model.args
     N, H, W, _ = rayd.shape
+    max_h, max_w = eval_chunk(model, N, H, W, max_h, max_w, rayd.device)
     topk = min(model.points.shape[0], int(model.select_k))
     C = args.models.attn.embed.value.d_ff_out
     fmap = torch.zeros(N, H, W, 1, C, device=rayd.device)
