@@ -30,6 +30,8 @@ the statement names them -- hence an X and a Y flavour of every variant.  Tempor
 import os
 import sys
 ABLATE = os.environ.get("C4F_ABLATE", "")      # timing experiments (scripts/probes/c4_variant.sh with -DC4_FUSED_INC=...)
+PRIO = os.environ.get("C4F_PRIO", "")          # timing experiment: s_setprio flips inside the statement (operand [role]: 1 for the SIMD's older wave): "half" = the
+                                               # younger wave ahead in the first half, the older in the second; "young" = the younger ahead throughout
 KVAR = os.environ.get("C4F_KVAR", "")          # timing experiments on the k-loop (with C4F_ABLATE=K: the row-phase temporaries are free): noread | dbuf | dbufh
 
 F = {"l0": "v[28:31]", "l1": "v[32:35]", "h0": "v[36:39]", "h1": "v[40:43]"}
@@ -412,7 +414,14 @@ def build(tile, mode, act, ld, kcnt=16, one=False):
         e.put(x)
     p1 = p1[head:]
     n1 = max(1, min(NM - 6, round(NM * (len(p1) + 6.0) / (len(p1) + len(p2) + 6))))      # MFMAs that carry P1
+    def prio(tag, older, younger):
+        return ["s_cmp_lg_u32 %[role], 0", "s_cbranch_scc1 .Lp%%=_%sa" % tag, "s_setprio %d" % younger, "s_branch .Lp%%=_%sb" % tag,
+                ".Lp%%=_%sa:" % tag, "s_setprio %d" % older, ".Lp%%=_%sb:" % tag]
     for m, (mf, post) in enumerate(steps):
+        if PRIO and m == 0:
+            e.lines += prio("s", 0, 1)
+        if PRIO == "half" and m == NM // 2:
+            e.lines += prio("m", 1, 0)
         e.put(mf)
         for x in post:
             e.put(x)
@@ -433,6 +442,8 @@ def build(tile, mode, act, ld, kcnt=16, one=False):
                 e.put(x)
             p2 = p2[take:]
     assert not p2
+    if PRIO:
+        e.lines.append("s_setprio 0")
     e.lines += ["s_nop 15", "s_nop 7"]          # the last results leave the matrix pipe 16 passes after issue
     return e.lines
 
