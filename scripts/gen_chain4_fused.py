@@ -448,6 +448,30 @@ def build(tile, mode, act, ld, kcnt=16, one=False):
     return e.lines
 
 
+def build_pair(mode, act):
+    """TWO hot slots in one statement: slot (tile X, step i) and slot (tile Y, step i) -- the two k-loops of a step, the row phases of Y's step i - 1
+    and X's step i beside them.  Between two statements every wave spends ~1.7k cycles in compiled C++ (which slot is next, its descriptors, ~40
+    lane-derived operands recomputed because nothing lane-derived may live across a statement: at two waves per SIMD every dependent instruction costs
+    its full latency) with the matrix pipe idle; between the halves of this statement the same step costs a barrier and seven additions: the second
+    half's lane-derived operands are the first half's plus constants (the other tile's planes: +- 64 KB; its tables: - 256 bytes; the next layer's
+    biases: dbias), its pointers -- another layer's rows, maxima and sign words -- second operands (sgnb, rmpb, crow0b, crow1b).
+    WHY THIS PAIR and not (Y, step i) + (X, step i + 1), which was built first and measured nothing: tile X's slot starts behind a vmcnt(0) for the next
+    step's weight fragments, the last of which are requested at the very end of tile Y's k-loop (they refill their registers in place) -- between two
+    statements the compiled C++ hides that latency, inside one statement it would stand exposed.  Tile Y multiplies with the weights tile X has just
+    used: nothing to wait for.  The halves are the single statements' instruction lists, character for character."""
+    a = build("X", mode, act, 0)
+    b = build("Y", mode, act, 1)
+    ren = lambda l: l.replace("%[sgn]", "%[sgnb]").replace("%[rmp]", "%[rmpb]").replace("%[crow0]", "%[crow0b]").replace("%[crow1]", "%[crow1b]")
+    mid = ["s_waitcnt lgkmcnt(0)", "s_barrier",          # = lds_barrier(): X's step is in its accumulators, Y's rows of the step before are split into its planes
+           "v_add_u32 %[pbx], 0x10000, %[pbx]",         # T: tile X -> tile Y
+           "v_add_u32 %[stw], 0xffff0000, %[stw]", "v_add_u32 %[rdb], 0xffff0000, %[rdb]", "v_add_u32 %[plw], 0xffff0000, %[plw]",      # U: tile Y -> tile X
+           "v_add_u32 %[invad], 0xffffff00, %[invad]",  # U's 1 / scale table (and, through the instructions' offsets, its partial maxima)
+           "v_add_u32 %[biasad], %[dbias], %[biasad]"]  # the biases of the layer X has just multiplied
+    if mode == "fwd":
+        mid.append("v_mov_b32 %[word], 0")
+    return a + mid + [ren(l) for l in b]
+
+
 def emit(name, lines):
     print("#define %s \\" % name)
     for i, l in enumerate(lines):
@@ -517,6 +541,8 @@ if __name__ == "__main__":
                     total[(mode, act, tile, ld)] = len(lines)
             for kcnt in (8, 10):                # the run's first layer on tile Y (on tile X its slot also stages the next tile: no fused form)
                 emit("C4F_%s_%s_Y_LD_K%d" % (mode.upper(), act.upper(), kcnt), build("Y", mode, act, 1, kcnt))
+            if mode != "dgrad":                 # (the data-gradient's second half would need tile Y's sign word, requested by the slot before: not built)
+                emit("C4F2_%s_%s" % (mode.upper(), act.upper()), build_pair(mode, act))
             # one-product mode (h1)
             for tile in ("X", "Y"):
                 for ld in ((0,) if tile == "X" else (0, 1)):

@@ -8,6 +8,7 @@ IDENTICAL between
   (default)            hot slots as fused statements
   PAPR_C4_FUSED=0      two-role slots everywhere (one-statement k-loops, C++ row phases with the flags as constants)
   PAPR_C4_GENERIC=1    ... and the generic row phases (flags looked at at run time)
+  PAPR_C4_PAIRS=0      every hot slot its own statement instead of two slots per statement (forward runs)
   PAPR_C4_DMA=1        the run's input rows split ahead of it (round 4: split_rows_kernel) and staged by LDS-DMA, not by the run itself
 and from run to run (the races this file guards against show up as run-to-run differences).  Sizes: a cloud-sized M with ragged last
 tiles and several workgroup iterations, and one below a tile; ReLU and LeakyReLU."""
@@ -21,6 +22,8 @@ import torch
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 VARIANTS = [("generic rows", {"PAPR_C4_GENERIC": "1"}), ("two-role", {"PAPR_C4_FUSED": "0"}), ("fused", {}), ("fused again", {}),
+            # every hot slot its own statement (the default runs tile Y's step and tile X's next step of a forward run as ONE statement)
+            ("fused, single slots", {"PAPR_C4_PAIRS": "0"}),
             # the run takes its input rows split ahead of it (split_rows_kernel) through LDS-DMA instead of splitting them itself while it stages
             # them (registers + vector instructions): the same arithmetic, instruction for instruction
             ("rows split ahead", {"PAPR_C4_DMA": "1"}), ("rows split ahead, generic rows", {"PAPR_C4_DMA": "1", "PAPR_C4_GENERIC": "1"})]
@@ -28,7 +31,7 @@ VARIANTS = [("generic rows", {"PAPR_C4_GENERIC": "1"}), ("two-role", {"PAPR_C4_F
 
 def _run(tmp_path, name, env, M, n, act, dims=()):
     out = tmp_path / (name.replace(" ", "_") + ".pt")
-    e = {k: v for k, v in os.environ.items() if k not in ("PAPR_C4_GENERIC", "PAPR_C4_FUSED", "PAPR_GEMM_MODE", "PAPR_C4_DMA")}
+    e = {k: v for k, v in os.environ.items() if k not in ("PAPR_C4_GENERIC", "PAPR_C4_FUSED", "PAPR_GEMM_MODE", "PAPR_C4_DMA", "PAPR_C4_PAIRS")}
     e.update(env)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "chain_variants_worker.py"), str(out), str(M), str(n), act] + [str(v) for v in dims], env=e, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (name, r.stderr[-2000:])
