@@ -469,6 +469,9 @@ def build_pair(mode, act):
            "v_add_u32 %[biasad], %[dbias], %[biasad]"]  # the biases of the layer X has just multiplied
     if mode == "fwd":
         mid.append("v_mov_b32 %[word], 0")
+    if mode == "dgrad":                         # the second half's sign word (tile X's, of the layer it has just multiplied) is a second operand
+        ren0 = ren
+        ren = lambda l: ren0(l).replace("%[word]", "%[wordb]")
     return a + mid + [ren(l) for l in b]
 
 
@@ -541,8 +544,7 @@ if __name__ == "__main__":
                     total[(mode, act, tile, ld)] = len(lines)
             for kcnt in (8, 10):                # the run's first layer on tile Y (on tile X its slot also stages the next tile: no fused form)
                 emit("C4F_%s_%s_Y_LD_K%d" % (mode.upper(), act.upper(), kcnt), build("Y", mode, act, 1, kcnt))
-            if mode != "dgrad":                 # (the data-gradient's second half would need tile Y's sign word, requested by the slot before: not built)
-                emit("C4F2_%s_%s" % (mode.upper(), act.upper()), build_pair(mode, act))
+            emit("C4F2_%s_%s" % (mode.upper(), act.upper()), build_pair(mode, act))
             # one-product mode (h1)
             for tile in ("X", "Y"):
                 for ld in ((0,) if tile == "X" else (0, 1)):
