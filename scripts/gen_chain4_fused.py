@@ -448,7 +448,7 @@ def build(tile, mode, act, ld, kcnt=16, one=False):
     return e.lines
 
 
-def build_pair(mode, act):
+def build_pair(mode, act, one=False):
     """TWO hot slots in one statement: slot (tile X, step i) and slot (tile Y, step i) -- the two k-loops of a step, the row phases of Y's step i - 1
     and X's step i beside them.  Between two statements every wave spends ~1.7k cycles in compiled C++ (which slot is next, its descriptors, ~40
     lane-derived operands recomputed because nothing lane-derived may live across a statement: at two waves per SIMD every dependent instruction costs
@@ -459,8 +459,8 @@ def build_pair(mode, act):
     step's weight fragments, the last of which are requested at the very end of tile Y's k-loop (they refill their registers in place) -- between two
     statements the compiled C++ hides that latency, inside one statement it would stand exposed.  Tile Y multiplies with the weights tile X has just
     used: nothing to wait for.  The halves are the single statements' instruction lists, character for character."""
-    a = build("X", mode, act, 0)
-    b = build("Y", mode, act, 1)
+    a = build("X", mode, act, 0, 16, one)
+    b = build("Y", mode, act, 1, 16, one)
     ren = lambda l: l.replace("%[sgn]", "%[sgnb]").replace("%[rmp]", "%[rmpb]").replace("%[crow0]", "%[crow0b]").replace("%[crow1]", "%[crow1b]")
     mid = ["s_waitcnt lgkmcnt(0)", "s_barrier",          # = lds_barrier(): X's step is in its accumulators, Y's rows of the step before are split into its planes
            "v_add_u32 %[pbx], 0x10000, %[pbx]",         # T: tile X -> tile Y
@@ -545,6 +545,7 @@ if __name__ == "__main__":
             for kcnt in (8, 10):                # the run's first layer on tile Y (on tile X its slot also stages the next tile: no fused form)
                 emit("C4F_%s_%s_Y_LD_K%d" % (mode.upper(), act.upper(), kcnt), build("Y", mode, act, 1, kcnt))
             emit("C4F2_%s_%s" % (mode.upper(), act.upper()), build_pair(mode, act))
+            emit("C4F21_%s_%s" % (mode.upper(), act.upper()), build_pair(mode, act, True))      # one-product mode
             # one-product mode (h1)
             for tile in ("X", "Y"):
                 for ld in ((0,) if tile == "X" else (0, 1)):

@@ -38,7 +38,8 @@ def _run(tmp_path, name, env, M, n, act, dims=()):
     return torch.load(out)
 
 
-H1_VARIANTS = [("h1 generic rows", {"PAPR_C4_GENERIC": "1", "PAPR_GEMM_MODE": "h1"}), ("h1", {"PAPR_GEMM_MODE": "h1"}), ("h1 again", {"PAPR_GEMM_MODE": "h1"})]
+H1_VARIANTS = [("h1 generic rows", {"PAPR_C4_GENERIC": "1", "PAPR_GEMM_MODE": "h1"}), ("h1", {"PAPR_GEMM_MODE": "h1"}), ("h1 again", {"PAPR_GEMM_MODE": "h1"}),
+               ("h1 single slots", {"PAPR_GEMM_MODE": "h1", "PAPR_C4_PAIRS": "0"})]
 
 
 def _flat(res):
