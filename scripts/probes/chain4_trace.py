@@ -10,14 +10,19 @@ mode = sys.argv[1] if len(sys.argv) > 1 else "inf"
 d = torch.device("cuda:0")
 n = int(os.environ.get("LAYERS", "4"))
 d_in = int(os.environ.get("D_IN", "256"))
-spec = ops.MlpSpec("b", d_in, dict(n_ff_layer=n, d_ff=256, d_ff_out=256, norm="none", ff_act="relu", ff_last_act="none"))
-ws = [(torch.randn(256, spec.layers[i]["n_in"]) * 0.1).to(d) for i in range(n)]
-bs = [torch.zeros(256, device=d) for _ in range(n)]
-x = torch.randn(M, spec.ld_in, device=d)
-gy = torch.randn(M, 256, device=d)
+d_out = int(os.environ.get("D_OUT", "256"))          # (D_IN=117 LAYERS=5 NORM=1: the key MLP's shape; D_IN=141 D_OUT=32 LAYERS=8: the value MLP's)
+norm = os.environ.get("NORM", "") != ""
+spec = ops.MlpSpec("b", d_in, dict(n_ff_layer=n, d_ff=256, d_ff_out=d_out, norm="layernorm" if norm else "none", ff_act="relu", ff_last_act="none"))
+ws = [(torch.randn(spec.layers[i]["n_out_pad"], spec.layers[i]["n_in"]) * 0.1).to(d) for i in range(n)]
+bs = [torch.zeros(spec.layers[i]["n_out_pad"], device=d) for i in range(n)]
+x0 = torch.randn(M, spec.ld_in, device=d)
+gy = torch.randn(M, spec.ld_out[-1], device=d)
 scratch = [torch.empty((M, 256), device=d) for _ in range(2)]
+dots = torch.randn((M + 19) // 20, 256, device=d) if norm and os.environ.get("DOTS") else None      # (DOTS=1: the attention scores' dot products ride in the run)
 for _ in range(3):
-    outs = ops.mlp_forward(spec, ws, bs, x, M, keep=mode != "inf")
+    x = x0.clone()
+    outs = ops.mlp_forward(spec, ws, bs, x, M, keep=mode != "inf", out_norm=(d_out, 1e-6) if norm else None, in_norm=(d_in, 1e-6) if norm else None,
+                           dot_rows=dots, rows_per_dot=20)
     if mode == "bwd":
         ops.mlp_backward(spec, ws, bs, x, M, outs, gy.clone(), scratch, True)
 torch.cuda.synchronize()
