@@ -82,7 +82,12 @@ int papr_feature_widths(const papr_feature_desc* d, int32_t* key_w, int32_t* qry
 int papr_build_features_fwd(const papr_feature_desc* d, const float* points, const float* pc_feats,
                             const float* rays_o, const float* rays_d, int64_t R, int64_t rays_per_image,
                             const int32_t* idx, float* key, float* qry, float* val,
-                            float* sel_points /* (R,k,3) or NULL */, papr_stream_t stream);
+                            float* sel_points /* (R,k,3) or NULL */,
+                            float* key_stats /* (R*k, 2) or NULL */, float* key_mean /* (R*k) or NULL */, float key_norm_eps,
+                            papr_stream_t stream);
+/* key_stats / key_mean (ABI 24; both or neither; not with key_has_feats): the statistics of the LayerNorm core in front of the key MLP
+ * (FeedForward.innorm, models/attn.py:39-42) for every key row -- key_stats[2m], [2m+1] = 1 / (std_unbiased + key_norm_eps), std; key_mean[m] --
+ * taken while the row is written (the key rows themselves stay raw).  papr_mlp_fwd applies them through papr_row_norm.given_mean. */
 
 /* Backward of K2: d_key / d_val are gradients w.r.t. the raw rows above.  Accumulates (atomic
  * adds) into d_points (P,3) and d_pc_feats (P,feat_dim); the caller zeroes them.  The key's pe(p)
@@ -206,6 +211,10 @@ typedef struct {
     int32_t ld_dot;         /* floats, a multiple of 4 */
     int32_t rows_per_dot;
     float* dots;            /* (M) */
+    /* in_norm only, optional (ABI 24): the rows' means, with stats ALREADY holding 1 / (std + eps), std (papr_build_features_fwd: key_mean /
+     * key_stats): the rows are standardised with them -- x <- (x - mean) / (std + eps) over `width` columns -- and no statistic is computed or
+     * written.  NULL: the call computes the statistics itself. */
+    const float* given_mean;
 } papr_row_norm;
 
 /* `mode` of papr_mlp_fwd / papr_mlp_bwd / papr_mlp_bwd_needs_weight_t: which arithmetic and which kernels carry the call.  An argument of

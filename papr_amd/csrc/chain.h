@@ -40,10 +40,11 @@ struct ChainArgs {
     long M;
     int n_layers;
     int one_product;                      // 1 (PAPR_GEMM_MODE=h1): one f16 product per fp32 product -- hi planes only
-    int in_norm_width;                    // forward: with in_norm_stats, the input rows are standardised over their first
+    int in_norm_width;                    // forward: with in_norm_stats (+ in_norm_mean: given), the input rows are standardised over their first
     float in_norm_eps;                    // in_norm_width columns while they are staged (LayerNorm core in front of the run);
     float* in_norm_stats;                 // (M, 2) = 1/(std+eps), std; in_norm_writeback: the standardised rows replace A0 in
     int in_norm_writeback;                // memory as well (training: the backward pass reads them; runs with a skip layer)
+    const float* in_norm_mean;            // with in_norm_stats (required then): the rows' means; in_norm_stats holds 1/(std+eps), std ALREADY -- the staging applies them
     float norm_eps;                       // forward: with norm_stats, the LAST layer's rows are standardised (LayerNorm core,
     float* norm_stats;                    // papr_row_norm in papr_hip.h) before they are stored; (M, 2) = 1/(std+eps), std
     const float* dot_rows; long ld_dot;   // with norm_stats and dots: dots[m] = (standardised row m) . dot_rows[m / rows_per_dot] -- the

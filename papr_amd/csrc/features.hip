@@ -25,24 +25,30 @@ struct FeatParams {
 
 __device__ __forceinline__ int pe_width(int L, int with_self) { return 3 * (with_self + 2 * L); }
 
-// write pe(x) for one 3-vector at dst (stride 1), returns number of floats written
+// write pe(x) for one 3-vector at dst (stride 1), returns number of floats written; s1 / s2 gather the sum of the values written and of their squares
 __device__ __forceinline__ int write_pe(float* __restrict__ dst, const float x[3], int L, int with_self,
-                                        float factor, float mult) {
+                                        float factor, float mult, float& s1, float& s2) {
     const int per = with_self + 2 * L;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         float* o = dst + c * per;
-        if (with_self) *o++ = x[c];
+        if (with_self) { *o++ = x[c]; s1 += x[c]; s2 += x[c] * x[c]; }
         float f = 1.0f;
         for (int i = 0; i < L; ++i) {
             float s, co;
             sincosf((f * x[c]) * mult, &s, &co);
             o[2 * i] = s;
             o[2 * i + 1] = co;
+            s1 += s + co;
+            s2 += s * s + co * co;
             f *= factor;
         }
     }
     return 3 * per;
+}
+__device__ __forceinline__ int write_pe(float* __restrict__ dst, const float x[3], int L, int with_self, float factor, float mult) {
+    float a = 0.f, b = 0.f;
+    return write_pe(dst, x, L, with_self, factor, mult, a, b);
 }
 
 struct RayGeom {
@@ -121,7 +127,8 @@ __global__ __launch_bounds__(256) void features_fwd_kernel(FeatParams fp, const 
                                                            const float* __restrict__ rays_d, long R,
                                                            long rays_per_image, const int* __restrict__ idx,
                                                            float* __restrict__ key, float* __restrict__ val,
-                                                           float* __restrict__ sel_points, int pitch) {
+                                                           float* __restrict__ sel_points, int pitch,
+                                                           float* __restrict__ key_stats, float* __restrict__ key_mean, float key_eps) {
     extern __shared__ float feat_lds[];
     const papr_feature_desc& d = fp.d;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -142,8 +149,9 @@ __global__ __launch_bounds__(256) void features_fwd_kernel(FeatParams fp, const 
     float s[3] = {g.rx * t, g.ry * t, g.rz * t};
     float u[3] = {vx - s[0], vy - s[1], vz - s[2]};
 
+    float s1 = 0.f, s2 = 0.f;                       // sum and sum of squares of the row being written (this thread's)
     auto emit = [&](const float x[3], int L, float* dst, long ld, int c0) -> int {
-        const int w = write_pe(row, x, L, d.with_self, d.pe_factor, d.pe_mult);
+        const int w = write_pe(row, x, L, d.with_self, d.pe_factor, d.pe_mult, s1, s2);
         wave_lds_sync();
         wave_flush(buf, pitch, w, dst, ld, c0, m0, M);
         wave_lds_sync();
@@ -153,6 +161,18 @@ __global__ __launch_bounds__(256) void features_fwd_kernel(FeatParams fp, const 
     c += emit(p, d.L_key[0], key, d.ld_key, c);
     c += emit(s, d.L_key[1], key, d.ld_key, c);
     c += emit(u, d.L_key[2], key, d.ld_key, c);
+    if (key_stats && mreal < M) {
+        // the statistics of the LayerNorm core in front of the key MLP (FeedForward.innorm, models/attn.py:39-42: unbiased std, eps added to it), while
+        // the row's values are in this thread's hands: the fused run that stages the rows then applies them (papr_row_norm.given_mean) instead of
+        // taking two wave sums, a square root and a division per row in its staging slot -- 8k of that slot's 12-15k cycles.  One pass: the row's
+        // mean is small beside its spread (|mean| < 0.5, sum of squares >= 2 L per vector), the difference below loses no digits that matter
+        const float n = (float)c, mean = s1 / n;
+        const float var = fmaxf(s2 - n * mean * mean, 0.f) / (n - 1.f);
+        const float sigma = sqrtf(var);
+        key_mean[m] = mean;
+        key_stats[2 * m] = 1.0f / (sigma + key_eps);
+        key_stats[2 * m + 1] = sigma;
+    }
     if (d.key_has_feats) { wave_copy_feats(pc_feats, d.feat_dim, pi, key, d.ld_key, c, m0, M); c += d.feat_dim; }
     wave_zero_cols(key, d.ld_key, c, d.ld_key, m0, M);
 
@@ -419,8 +439,10 @@ static int check_desc(const papr_feature_desc* d, const FeatParams& fp, const ch
 extern "C" int papr_build_features_fwd(const papr_feature_desc* d, const float* points, const float* pc_feats,
                                        const float* rays_o, const float* rays_d, int64_t R, int64_t rays_per_image,
                                        const int32_t* idx, float* key, float* qry, float* val, float* sel_points,
-                                       papr_stream_t stream) {
+                                       float* key_stats, float* key_mean, float key_norm_eps, papr_stream_t stream) {
     PAPR_REQUIRE(d && points && rays_o && rays_d && idx && key && qry && val, "papr_build_features_fwd: null pointer");
+    PAPR_REQUIRE((key_stats == nullptr) == (key_mean == nullptr), "papr_build_features_fwd: key_stats and key_mean come together");
+    PAPR_REQUIRE(!key_stats || !d->key_has_feats, "papr_build_features_fwd: key statistics are taken over the encoded columns only (no point features in the key)");
     FeatParams fp;
     fill_params(d, &fp);
     if (int e = check_desc(d, fp, "papr_build_features_fwd")) return e;
@@ -431,7 +453,7 @@ extern "C" int papr_build_features_fwd(const papr_feature_desc* d, const float* 
     const int pitch = stage_pitch(d);
     PAPR_REQUIRE(pitch <= 129, "papr_build_features_fwd: encoding orders too large for the staging buffer");
     features_fwd_kernel<<<dim3((unsigned)((M + 255) / 256)), dim3(256), (size_t)4 * 64 * pitch * sizeof(float), s>>>(
-        fp, points, pc_feats, rays_o, rays_d, R, rays_per_image, idx, key, val, sel_points, pitch);
+        fp, points, pc_feats, rays_o, rays_d, R, rays_per_image, idx, key, val, sel_points, pitch, key_stats, key_mean, key_norm_eps);
     PAPR_CHECK_LAUNCH("features_fwd");
     query_fwd_kernel<<<dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s>>>(fp, rays_d, R, qry);
     PAPR_CHECK_LAUNCH("query_fwd");

@@ -1508,8 +1508,10 @@ extern "C" int papr_mlp_fwd(const papr_layer* layers, int n_layers, float* x, in
                  "papr_mlp_fwd: out_norm->dots needs dot_rows with 16-byte rows of at least `width` floats and rows_per_dot >= 1");
     bool dots_done = false;
     PAPR_REQUIRE(!in_norm || (in_norm->stats && in_norm->width >= 2 && in_norm->width <= ldx), "papr_mlp_fwd: in_norm needs stats and a width <= ldx");
-    if (in_norm && !(chain_run_end(layers, n_layers, 0, true) >= 2))      // not staged by a fused run: one pass over x first
-        if (int e = papr_rownorm_fwd(x, M, in_norm->width, ldx, in_norm->eps, x, in_norm->stats, stream)) return e;
+    if (in_norm && !(chain_run_end(layers, n_layers, 0, true) >= 2)) {     // not staged by a fused run: one pass over x first
+        if (in_norm->given_mean) { if (int e = papr_rownorm_apply(x, M, in_norm->width, ldx, in_norm->stats, in_norm->given_mean, stream)) return e; }
+        else if (int e = papr_rownorm_fwd(x, M, in_norm->width, ldx, in_norm->eps, x, in_norm->stats, stream)) return e;
+    }
     PAPR_REQUIRE(!GEMM_H3_FWD || workspace, "papr_mlp_fwd: workspace required (papr_mlp_fwd_workspace_bytes)");
     H3Scratch h3(workspace, M);
     for (int i = 0; i < n_layers; ++i) {
@@ -1525,12 +1527,20 @@ extern "C" int papr_mlp_fwd(const papr_layer* layers, int n_layers, float* x, in
                 bool run_has_skip = false;
                 for (int l = i; l < e; ++l) run_has_skip |= layers[l].n_skip > 0;
                 c.in_norm_width = in_norm->width; c.in_norm_eps = in_norm->eps; c.in_norm_stats = in_norm->stats;
+                c.in_norm_mean = in_norm->given_mean;
                 c.in_norm_writeback = (row_absmax != nullptr || run_has_skip || e < n_layers) ? 1 : 0;
+                if (c.in_norm_mean == nullptr && !(!GEMM_ONE_PRODUCT && papr_switch(PAPR_SW_C4_DMA))) {
+                    // nobody gave the statistics: one pass over the rows takes them (the run applies them while it stages the rows); the means go
+                    // to the head of the scratch the split-ahead experiment would use
+                    float* means = reinterpret_cast<float*>(static_cast<char*>(workspace) + H3Scratch::bytes(M));
+                    if (int err = papr_rownorm_stats(c.A0, M, in_norm->width, (int)c.lda0, in_norm->eps, in_norm->stats, means, stream)) return err;
+                    c.in_norm_mean = means;
+                }
             }
             c.rowmax0 = saved ? saved + (size_t)i * M : nullptr;
             c.M = M; c.n_layers = e - i;
             c.one_product = GEMM_ONE_PRODUCT ? 1 : 0;
-            if (!GEMM_ONE_PRODUCT && papr_switch(PAPR_SW_C4_DMA)) {
+            if (!GEMM_ONE_PRODUCT && papr_switch(PAPR_SW_C4_DMA) && c.in_norm_mean == nullptr) {
                 // the run's input rows split ahead of it: the run stages its tiles by LDS-DMA (chain.h: sr_*)
                 SRScratch sr(static_cast<char*>(workspace) + H3Scratch::bytes(M), M);
                 SplitRowsArgs q = {};

@@ -12,6 +12,8 @@ void papr_prof_begin2(int kernel, long M, int N, int K, long long bytes, long lo
 void papr_prof_end(hipStream_t s);
 // process-wide A/B switches (papr_set_switch in papr_hip.h; the library reads no environment) and per-device facts
 int papr_switch(int which);
+int papr_rownorm_stats(const float* x, int64_t rows, int width, int ld, float eps, float* stats, float* mean, papr_stream_t stream);      // rowops.hip
+int papr_rownorm_apply(float* x, int64_t rows, int width, int ld, const float* stats, const float* mean, papr_stream_t stream);      // rowops.hip
 int papr_cu_count();                       // compute units of the CURRENT device (cached per device id)
 bool papr_first_on_device(int slot);       // true once per (current device, slot): hipFuncSetAttribute calls of a launcher
 enum { PAPR_ONCE_CHAIN4 = 0, PAPR_ONCE_NT_H3, PAPR_ONCE_TN_H3, PAPR_ONCE_CONV, PAPR_ONCE_CONV_WGRAD, PAPR_ONCE_PAIRS, PAPR_ONCE_SLOTS };

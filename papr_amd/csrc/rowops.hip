@@ -346,6 +346,62 @@ extern "C" int papr_rownorm_fwd(const float* x, int64_t rows, int width, int ld,
     return 0;
 }
 
+// the statistics of rownorm_fwd_kernel alone (x untouched): stats[2m], [2m+1] = 1 / (std + eps), std; mean[m] -- for a fused run that applies them while
+// it stages the rows (ChainArgs::in_norm_mean), when the caller of papr_mlp_fwd has none to give
+template <int VPL>
+__global__ __launch_bounds__(256) void rownorm_stats_kernel(const float* __restrict__ x, long rows, int width, int ld, float eps,
+                                                            float* __restrict__ stats, float* __restrict__ mean_out) {
+    const int lane = threadIdx.x & 63;
+    long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * ld;
+    float v[VPL];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        int c = lane + 64 * i;
+        v[i] = c < width ? xr[c] : 0.f;
+        sum += v[i];
+    }
+    float mean = wave_sum(sum) / (float)width;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        int c = lane + 64 * i;
+        float dlt = c < width ? v[i] - mean : 0.f;
+        ss += dlt * dlt;
+    }
+    float sigma = sqrtf(wave_sum(ss) / (float)(width - 1));
+    if (lane == 0) { stats[row * 2 + 0] = 1.0f / (sigma + eps); stats[row * 2 + 1] = sigma; mean_out[row] = mean; }
+}
+int papr_rownorm_stats(const float* x, int64_t rows, int width, int ld, float eps, float* stats, float* mean, papr_stream_t stream) {
+    PAPR_REQUIRE(width >= 2 && width <= 64 * MAX_VPL && ld >= width, "rownorm_stats: width %d / ld %d unsupported", width, ld);
+    if (rows <= 0) return 0;
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    if (width <= 256) rownorm_stats_kernel<4><<<grid, block, 0, as_stream(stream)>>>(x, rows, width, ld, eps, stats, mean);
+    else rownorm_stats_kernel<MAX_VPL><<<grid, block, 0, as_stream(stream)>>>(x, rows, width, ld, eps, stats, mean);
+    PAPR_CHECK_LAUNCH("rownorm_stats");
+    return 0;
+}
+
+// x <- (x - mean[m]) * stats[2m] over the first `width` columns of every row: the LayerNorm core with GIVEN statistics (papr_row_norm.given_mean), for
+// the MLP whose first layers no fused run stages
+__global__ __launch_bounds__(256) void rownorm_apply_kernel(float* __restrict__ x, long rows, int width, int ld, const float* __restrict__ stats,
+                                                            const float* __restrict__ mean) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    const long m = e / width;
+    if (m >= rows) return;
+    const int c = (int)(e - m * width);
+    x[m * ld + c] = (x[m * ld + c] - mean[m]) * stats[2 * m];
+}
+int papr_rownorm_apply(float* x, int64_t rows, int width, int ld, const float* stats, const float* mean, papr_stream_t stream) {
+    if (rows <= 0) return 0;
+    const long n = rows * width;
+    rownorm_apply_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream)>>>(x, rows, width, ld, stats, mean);
+    PAPR_CHECK_LAUNCH("rownorm_apply");
+    return 0;
+}
+
 // dots[m] = rows[m] . dot_rows[m / rows_per_dot]: one wave per row (the stand-alone form of what a fused run's last row phase does)
 __global__ __launch_bounds__(256) void row_dots_kernel(const float* __restrict__ rows, long M, int width, int ld,
                                                        const float* __restrict__ dot_rows, int ld_dot, int rows_per_dot,

@@ -13,7 +13,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PAPR_HIP_LIB", os.path.join(_PKG, "libpapr_hip.so"))   # override: instrumented builds (scripts/probes)
 
 ACT = {"none": 0, "relu": 1, "leakyrelu": 2}
-EXPECTED_ABI = 23
+EXPECTED_ABI = 24
 # `mode` argument of papr_mlp_fwd / papr_mlp_bwd (include/papr_hip.h: PAPR_MLP_*)
 MLP_MODES = {"h3": 0, "h1": 1, "f32": 2, "fwd": 3, "dgrad": 4, "layers": 5, "h1_f32rows": 6}
 # process-wide A/B switches of the library (papr_set_switch; PAPR_SW_* in include/papr_hip.h).  The library itself reads no environment:
@@ -45,7 +45,8 @@ class Layer(C.Structure):
 
 class RowNorm(C.Structure):
     _fields_ = [("eps", C.c_float), ("width", C.c_int32), ("stats", C.c_void_p),
-                ("dot_rows", C.c_void_p), ("ld_dot", C.c_int32), ("rows_per_dot", C.c_int32), ("dots", C.c_void_p)]
+                ("dot_rows", C.c_void_p), ("ld_dot", C.c_int32), ("rows_per_dot", C.c_int32), ("dots", C.c_void_p),
+                ("given_mean", C.c_void_p)]
 
 
 class ProfileRecord(C.Structure):
@@ -85,7 +86,7 @@ def lib():
     L.papr_ray_knn_workspace_bytes.argtypes = [i64, i64]
     L.papr_ray_knn.argtypes = [vp, i64, vp, vp, i64, i64, i32, f32, vp, vp, vp, vp]
     L.papr_feature_widths.argtypes = [C.POINTER(FeatureDesc), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
-    L.papr_build_features_fwd.argtypes = [C.POINTER(FeatureDesc), vp, vp, vp, vp, i64, i64, vp, vp, vp, vp, vp, vp]
+    L.papr_build_features_fwd.argtypes = [C.POINTER(FeatureDesc), vp, vp, vp, vp, i64, i64, vp, vp, vp, vp, vp, vp, vp, C.c_float, vp]
     L.papr_build_features_bwd.argtypes = [C.POINTER(FeatureDesc), vp, vp, vp, i64, i64, vp, vp, vp, vp, vp, vp]
     L.papr_build_features_bwd_pairs.argtypes = [C.POINTER(FeatureDesc), vp, vp, vp, i64, i64, vp, vp, vp, vp, vp]
     L.papr_segment_reduce.argtypes = [vp, vp, vp, i64, i64, vp, vp, vp, i32, i32, i32, vp, vp, vp, i32, vp, vp]

@@ -448,8 +448,13 @@ def mlp_forward(spec, ws, bs, x, M, keep=True, out_norm=None, in_norm=None, dot_
     tab = _layer_table(spec, ws, bs)
     norm = inorm = None
     if in_norm is not None:
-        outs.in_stats = torch.empty((M, 2), device=dev, dtype=torch.float32)
-        inorm = C.byref(hip.RowNorm(in_norm[1], in_norm[0], outs.in_stats.data_ptr()))
+        # (width, eps) or (width, eps, stats, mean): the statistics GIVEN by the kernel that wrote x (papr_build_features_fwd) -- the call applies them
+        given = in_norm[2:] if len(in_norm) > 2 else None
+        outs.in_stats = given[0] if given else torch.empty((M, 2), device=dev, dtype=torch.float32)
+        rn_in = hip.RowNorm(in_norm[1], in_norm[0], outs.in_stats.data_ptr())
+        if given:
+            rn_in.given_mean = given[1].data_ptr()
+        inorm = C.byref(rn_in)
     if out_norm is not None:
         outs.norm_stats = torch.empty((M, 2), device=dev, dtype=torch.float32)
         rn = hip.RowNorm(out_norm[1], out_norm[0], outs.norm_stats.data_ptr())
@@ -465,6 +470,7 @@ def mlp_forward(spec, ws, bs, x, M, keep=True, out_norm=None, in_norm=None, dot_
 
 _ws_cache = {}
 _SCORES_IN_RUN = os.environ.get("PAPR_SCORES_IN_RUN", "1") != "0"
+_KEY_STATS = os.environ.get("PAPR_KEY_STATS", "1") != "0"      # A/B: the key rows' LayerNorm statistics from papr_build_features_fwd (default) or from the fused run
 
 
 def _workspace(dev, kind, M):
@@ -730,10 +736,17 @@ class _RenderFn(torch.autograd.Function):
         val_in = torch.empty((M, plan.val.ld_in), device=dev, dtype=torch.float32)
         sel = torch.empty((M, 3), device=dev, dtype=torch.float32)
         feats = pc_feats if plan.use_feats else None
+        eps = plan.eps
+        # the statistics of the LayerNorm core in front of the key MLP come from the kernel that writes the key rows (it has every row in one thread's
+        # hands); the fused run applies them while it stages the rows.  PAPR_KEY_STATS=0: the run takes them itself (two wave sums, a square root and a
+        # division per row in its staging slot)
+        key_given = None
+        if plan.kq_norm and not plan.fdesc.key_has_feats and _KEY_STATS:
+            key_given = (torch.empty((M, 2), device=dev, dtype=torch.float32), torch.empty((M,), device=dev, dtype=torch.float32))
         hip.check(lib.papr_build_features_fwd(C.byref(fd), hip.ptr(points), hip.ptr(feats), hip.ptr(rays_o), hip.ptr(rays_d), R,
                                               rays_per_image, hip.ptr(idx), hip.ptr(key_in), hip.ptr(qry_in), hip.ptr(val_in),
-                                              hip.ptr(sel), hip.stream_ptr()), "papr_build_features_fwd")
-        eps = plan.eps
+                                              hip.ptr(sel), hip.ptr(key_given[0]) if key_given else None, hip.ptr(key_given[1]) if key_given else None,
+                                              eps, hip.stream_ptr()), "papr_build_features_fwd")
         # (the LayerNorm cores in front of and behind the key / query MLPs ride in the fused runs: rows are standardised
         # while they are staged, and again in the last row phase)
         q_outs = mlp_forward(plan.qry, qw, qb, qry_in, R, keep, (plan.qry.d_out, eps) if plan.kq_norm else None,
@@ -750,7 +763,7 @@ class _RenderFn(torch.autograd.Function):
         # PAPR_SCORES_IN_RUN=0 for the A/B
         in_run = plan.kq_norm and _SCORES_IN_RUN
         k_outs = mlp_forward(plan.key, kw, kb, key_in, M, keep, (plan.key.d_out, eps) if plan.kq_norm else None,
-                             (plan.key_w, eps) if plan.kq_norm else None, dot_rows=g if in_run else None, rows_per_dot=k)
+                             ((plan.key_w, eps) + (key_given or ())) if plan.kq_norm else None, dot_rows=g if in_run else None, rows_per_dot=k)
         K = k_outs[-1]
         kst, qst, kst2, qst2 = k_outs.in_stats, q_outs.in_stats, k_outs.norm_stats, q_outs.norm_stats
         v_outs = mlp_forward(plan.val, vw, vb, val_in, M, keep)

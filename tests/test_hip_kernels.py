@@ -168,11 +168,20 @@ def test_features_forward_match_oracle(tag):
     # keep every device tensor alive in a local: a temporary would be freed (and reused) before the launch
     pts_d, f_d, ro_d, rd_d = st["points"].to(d), st["pc_feats"].to(d), ro.to(d), rd.reshape(-1, 3).contiguous().to(d)
     idx_d = idx.reshape(R, k).int().to(d)
+    # (with the statistics of the LayerNorm core in front of the key MLP where the key carries no point features: ABI 24)
+    want_stats = not fd.key_has_feats
+    kstats = torch.empty((R * k, 2), device=d) if want_stats else None
+    kmean = torch.empty((R * k,), device=d) if want_stats else None
     hip.check(hip.lib().papr_build_features_fwd(C.byref(fd), hip.ptr(pts_d), hip.ptr(f_d), hip.ptr(ro_d), hip.ptr(rd_d), R,
                                                 rd.shape[1] * rd.shape[2], hip.ptr(idx_d), hip.ptr(key), hip.ptr(qry), hip.ptr(val),
-                                                hip.ptr(sel), hip.stream_ptr()), "features_fwd")
+                                                hip.ptr(sel), hip.ptr(kstats), hip.ptr(kmean), float(cfg["eps"]), hip.stream_ptr()), "features_fwd")
     torch.cuda.synchronize()
     kw, qw, vw = plan.key_w, plan.qry_w, plan.val_w
+    if want_stats:      # mean, unbiased std and 1 / (std + eps) of every key row, against torch on the rows the kernel wrote
+        rows = key.cpu()[:, :kw].double()
+        np.testing.assert_allclose(kmean.cpu().numpy(), rows.mean(1).numpy(), rtol=0, atol=2e-6)
+        np.testing.assert_allclose(kstats.cpu()[:, 1].numpy(), rows.std(1).numpy(), rtol=2e-6, atol=0)
+        np.testing.assert_allclose(kstats.cpu()[:, 0].numpy(), (1.0 / (rows.std(1) + cfg["eps"])).numpy(), rtol=2e-6, atol=0)
     assert torch.equal(sel.cpu(), sel_o.reshape(-1, 3))
     # x, s, u reproduce the reference bit for bit; sin/cos differ by libm (<= 2 ulp of 1.0)
     np.testing.assert_allclose(key.cpu()[:, :kw].numpy(), key_o.reshape(-1, kw).numpy(), rtol=0, atol=5e-7)
