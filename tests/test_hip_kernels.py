@@ -506,6 +506,38 @@ def test_row_dots_from_the_last_row_phase(R, k, d_in, width, d_out, n):
         assert torch.equal(part.dots, inf.dots[:M2])
 
 
+@pytest.mark.parametrize("M,d_in,width,d_out,n", [(24680, 117, 256, 256, 5), (1220, 39, 256, 64, 3), (6000, 27, 64, 32, 2), (45, 117, 256, 256, 5)])
+def test_in_norm_with_given_statistics(M, d_in, width, d_out, n):
+    """papr_row_norm.given_mean (ABI 24): the LayerNorm core in front of an MLP with statistics the CALLER hands over -- mean, std, 1 / (std + eps)
+    of every input row, here taken by torch in float64 -- against the same call letting the library take them, and against torch: the standardised
+    rows it leaves in x (training form) and the MLP's output.  The narrow chain runs without a fused run (the library applies the statistics in a
+    pass of its own)."""
+    from papr_amd import ops
+    gen = torch.Generator().manual_seed(M)
+    ecfg = dict(n_ff_layer=n, d_ff=width, d_ff_out=d_out, norm="none", ff_act="relu", ff_last_act="none", skip_layers=[])
+    spec = ops.MlpSpec("t", d_in, ecfg)
+    d = dev()
+    ws = [((torch.rand(d_out if i == n - 1 else width, d_in if i == 0 else width, generator=gen) * 2 - 1) * 0.15).to(d) for i in range(n)]
+    bs = [((torch.rand(d_out if i == n - 1 else width, generator=gen) * 2 - 1) * 0.1).to(d) for i in range(n)]
+    ew, eb = ops.prepare_mlp_weights(spec, ws, bs)
+    xp = torch.zeros(M, spec.ld_in)
+    xp[:, :d_in] = torch.randn(M, d_in, generator=gen) * 2.0 + 0.3
+    eps = 1e-6
+    x64 = xp[:, :d_in].double()
+    mean, std = x64.mean(1), x64.std(1)
+    stats = torch.stack([1.0 / (std + eps), std], 1).float().to(d)
+    x_own, x_given = xp.to(d), xp.to(d)
+    own = ops.mlp_forward(spec, ew, eb, x_own, M, keep=True, in_norm=(d_in, eps))
+    given = ops.mlp_forward(spec, ew, eb, x_given, M, keep=True, in_norm=(d_in, eps, stats, mean.float().to(d)))
+    want_x = ((x64 - mean[:, None]) / (std[:, None] + eps)).float()
+    np.testing.assert_allclose(x_given.cpu()[:, :d_in].numpy(), want_x.numpy(), rtol=0, atol=3e-6)
+    np.testing.assert_allclose(x_own.cpu()[:, :d_in].numpy(), want_x.numpy(), rtol=0, atol=3e-6)
+    np.testing.assert_allclose(own.in_stats.cpu().numpy(), stats.cpu().numpy(), rtol=3e-6, atol=0)
+    scale = float(given[-1].abs().max())
+    np.testing.assert_allclose(given[-1].cpu().numpy(), own[-1].cpu().numpy(), rtol=0, atol=2e-5 * scale)
+    assert given.in_stats is stats or torch.equal(given.in_stats, stats)
+
+
 # ------------------------------------------------------------------------------------------- K4
 @pytest.mark.parametrize("R,k,d_model,Cc,act,normalize", [(300, 20, 256, 32, "relu", True), (65, 12, 64, 3, "relu", True),
                                                           (17, 1, 256, 32, "none", False), (40, 63, 128, 32, "leakyrelu", True)])
