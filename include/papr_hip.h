@@ -206,7 +206,9 @@ typedef struct {
     /* out_norm only, optional (dots != NULL; ABI 17): dots[m] = y_m . dot_rows[m / rows_per_dot] over `width` columns -- the attention
      * scores' dot products (models/attn.py:219-221, with dot_rows = W_k^T (W_q Q + b_q) of the ray that owns row m) taken where the
      * standardised key rows are produced.  In inference (row_absmax == NULL) outs[n_layers-1] is then UNDEFINED afterwards: a fused run
-     * never writes the (R*k, d_model) key embedding (papr_attn_tail_fwd: precomputed_dots).  Ignored for in_norm. */
+     * never writes the (R*k, d_model) key embedding (papr_attn_tail_fwd: precomputed_dots).  Ignored for in_norm.  A fused run takes them as
+     * (x_m . g - mean_m sum(g)) / (std_m + eps) on the un-standardised row x_m (since round 4: the same value up to rounding, the same bits in
+     * training and inference); papr_row_dots multiplies the standardised rows. */
     const float* dot_rows;  /* (ceil(M / rows_per_dot), ld_dot) */
     int32_t ld_dot;         /* floats, a multiple of 4 */
     int32_t rows_per_dot;
