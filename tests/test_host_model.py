@@ -401,3 +401,27 @@ def test_output_activation_matches_the_reference_for_every_name():
     from papr_amd import get_model
     m = get_model(cfg, device="cpu")
     assert "last_act.a" in m.state_dict() and float(m.last_act(torch.zeros(1))) == 1.0
+
+
+def test_eval_chunk_policy(monkeypatch):
+    """train.eval_chunk: the drivers' chunk of an image per evaluate() call -- the configured size on the CPU and under PAPR_EVAL_CHUNK=config, grown
+    towards 160,000 rays (never beyond the image, never beyond a quarter of the free device memory) otherwise."""
+    import types
+    import train
+    m = types.SimpleNamespace(points=torch.zeros(30000, 3), select_k=20)
+    cuda = types.SimpleNamespace(type="cuda")
+    assert train.eval_chunk(m, 1, 800, 800, 200, 200, torch.device("cpu")) == (200, 200)
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda d: (200 << 30, 288 << 30))
+    monkeypatch.delenv("PAPR_EVAL_CHUNK", raising=False)
+    assert train.eval_chunk(m, 1, 800, 800, 200, 200, cuda) == (400, 400)
+    assert train.eval_chunk(m, 1, 800, 800, 100, 100, cuda) == (400, 400)
+    assert train.eval_chunk(m, 1, 100, 100, 200, 200, cuda) == (100, 100)          # never beyond the image
+    assert train.eval_chunk(m, 1, 1080, 1920, 200, 200, cuda) == (400, 400)
+    h, w = train.eval_chunk(m, 1, 800, 800, 50, 800, cuda)
+    assert h * w <= train.EVAL_CHUNK_RAYS and (h, w) == (200, 800)
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda d: (8 << 30, 288 << 30))   # little memory left: the chunk stops growing
+    h, w = train.eval_chunk(m, 1, 800, 800, 100, 100, cuda)
+    assert h * w * 4 * 20 * 1024 <= (8 << 30) // 4 and (h, w) != (400, 400)
+    monkeypatch.setenv("PAPR_EVAL_CHUNK", "config")
+    assert train.eval_chunk(m, 1, 800, 800, 200, 200, cuda) == (200, 200)
+
