@@ -106,6 +106,36 @@ def cpu_baseline(cfg, state, edge, steps):
                       % (steps, edge, edge, R, state["points"].shape[0], torch.__version__)}
 
 
+_LAUNCHER_KEYS = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE", "ROLE_NAME",
+                  "MASTER_ADDR", "MASTER_PORT", "PAPR_DIST_SINGLE", "PAPR_DIST_BACKEND", "OMP_NUM_THREADS")
+
+
+def child_env():
+    """The environment of a one-process child (child_line, psnr_after_steps): this process's own, WITHOUT what a launcher exported for it -- a child
+    that inherited RANK / MASTER_* would form another group on the store and port its parent has just used."""
+    return {k: v for k, v in os.environ.items() if k not in _LAUNCHER_KEYS and not k.startswith("TORCHELASTIC_")}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks the way the driver's own command line does
+    (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...) as a fresh CHILD process -- this process has not touched the GPU
+    (torch.cuda.device_count() does not initialise it) and never execs -- relay rank 0's JSON line and the child's exit code."""
+    import socket
+    import subprocess
+    n_vis = torch.cuda.device_count()
+    if n_vis < args.gpus:
+        print("bench.py: --gpus %d but only %d GPU(s) visible here: refusing to print a line for fewer ranks than asked for" % (args.gpus, n_vis), file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: no launcher environment, starting %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr)
+    r = subprocess.run(cmd, env=child_env(), cwd=ROOT)
+    return r.returncode
+
+
 def psnr_after_steps(args):
     """Quality leg of BASELINE's metric ("train rays/sec + test PSNR"): train.py (the reference's driver protocol: patch sampling, eval
     every 500 steps below 10,000, full-image chunked render, test.py:107 PSNR) for --psnr-steps steps, fixed seed, same kernels."""
@@ -116,7 +146,7 @@ def psnr_after_steps(args):
                "--set", "use_amp=%s" % ("true" if args.amp else "false"), "training.losses.lpips=0", "seed=1", "index=bench_psnr", "save_dir=%s" % tmp,
                "geoms.points.init_num=%d" % args.points]
         t0 = time.perf_counter()
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=1800, cwd=ROOT)
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=1800, cwd=ROOT, env=child_env())
         wall = time.perf_counter() - t0
     evals = [l for l in r.stdout.splitlines() if l.startswith("Eval step:")]
     if r.returncode != 0 or not evals:
@@ -134,15 +164,26 @@ def main():
     os.environ["PAPR_GEMM_MODE"] = args.gemm_mode       # read by papr_amd/ops.py (mlp_mode) at every call: the `mode` argument of papr_mlp_fwd / _bwd
     from papr_amd import dist as pdist, get_model, get_loss, hip
     from papr_amd.data import SyntheticRayData
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus %d" % args.gpus)
+    if args.gpus > 1 and not pdist.launched():
+        sys.exit(self_launch(args))                     # (before anything here touches the GPU)
+    if pdist.launched() and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        # a line that says dp<WORLD_SIZE> under a command that asked for --gpus N would be read as an N-GPU number
+        if int(os.environ.get("RANK", "0")) == 0:
+            print("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks: the two must agree" % (args.gpus, os.environ["WORLD_SIZE"]), file=sys.stderr)
+        sys.exit(2)
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.device_count() <= local:
+        print("bench.py: rank with LOCAL_RANK %d but %d GPU(s) visible (the render path has no CPU fallback; one GPU per rank)" % (local, torch.cuda.device_count()), file=sys.stderr)
+        sys.exit(2)
     world = pdist.init_from_env("cuda")
     rank = pdist.rank()
-    local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device (the render path has no CPU fallback)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world != args.gpus and rank == 0:
-        print("note: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)" % (args.gpus, world), file=sys.stderr)
+    assert world == args.gpus, (world, args.gpus)
 
     cfg = bench_config(args.scene, args.points, args.amp)
     torch.manual_seed(cfg["seed"])
@@ -198,12 +239,20 @@ def main():
         dt_prof = time.perf_counter() - t1
         hip.profile_enable(False)
         recs = hip.profile_collect()
+    ranks_seen = 1
     if torch.distributed.is_initialized():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
+        one = torch.ones(1, device=dev, dtype=torch.float64)              # every rank that ran the timed steps adds itself
+        torch.distributed.all_reduce(one, op=torch.distributed.ReduceOp.SUM)
+        ranks_seen = int(round(float(one)))
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    if ranks_seen != args.gpus:
+        if rank == 0:
+            print("bench.py: %d ranks took part, --gpus %d" % (ranks_seen, args.gpus), file=sys.stderr)
+        sys.exit(3)
     if rank != 0:
         return
 
@@ -324,7 +373,15 @@ def main():
     out = {
         "metric": "train rays/sec, nerf_synthetic/%s (PAPR), fp32 in/out, GEMM mode '%s'" % (os.path.splitext(os.path.basename(args.scene))[0], args.gemm_mode),
         "value": world * R * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ranks_seen": ranks_seen,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        # north_star's literal figure: "train rays/sec ... as achieved fraction of the kNN HBM roofline" -- LOGICAL bytes (what an every-point search
+        # would read per ray, SURVEY section 8d: 12 P + 12 + 4 k) times the END-TO-END train rays/s of the whole job, over N x the HBM peak.  The
+        # kernel's own physical traffic is in roofline_knn (the cloud is cache-resident, the binned search reads ~8 % of it)
+        "e2e_frac_of_knn_hbm_roofline": {"logical": True, "bytes_per_ray": 12.0 * P + 12 + 4 * k,
+                                         "frac": (world * R * args.steps / dt) * (12.0 * P + 12 + 4 * k) / (world * HBM_PEAK_GBS * 1e9),
+                                         "note": "value x (12 P + 12 + 4 k) B / (n_gpus x 8 TB/s): end-to-end train throughput priced in the kNN stage's logical HBM bytes; "
+                                                 "the step is bound by the embedding MLPs' matrix work (roofline), not by this stream"},
         "dtype": ("f32" if args.gemm_mode == "f32" else "f32 (wide GEMMs: operands split into f16 hi+lo, 3 MFMA, fp32 accumulate)")
                  + ("; use_amp: embedding MLPs one f16 product per fp32 product (PAPR_MLP_H1), GradScaler on, U-Net on the own split-f16 kernels" if args.amp else ""), "data": "synthetic",
         "config": {"workload": "configs/" + args.scene + ": P=%d points, one %dx%d patch (R=%d rays) per rank per step, k=%d, "
@@ -357,7 +414,7 @@ def main():
         cmd = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-amp-line", "--no-shipped-line", "--psnr-steps", "0", "--steps", str(args.steps),
                "--warmup", str(args.warmup), "--scene", args.scene, "--points", str(args.points)] + extra
         try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=child_env())
             return json.loads(r.stdout.strip().splitlines()[-1])
         except Exception as e:
             return {"error": "%s: %s" % (type(e).__name__, str(e)[-300:])}
@@ -373,9 +430,9 @@ def main():
             "value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "final_loss": j["config"]["final_loss"], "dtype": j["dtype"],
             "workload": j["config"]["workload"], "roofline_mlp_chain": chain_of(j),
             "note": "the scene file's own `use_amp: true` (the reference then runs its attention block and U-Net under fp16 autocast, models/attn.py:248, "
-                    "models/unet.py:212): GradScaler on, embedding MLPs one f16 product per fp32 product, U-Net on the own split-f16 kernels.  Tolerance against the "
-                    "fp32 pin only (tests/test_hip_model.py: the reference's own AMP output cannot be produced without CUDA); NOT the headline `value`, which is the "
-                    "fp32 parity mode the 1e-4 bar is stated for"}
+                    "models/unet.py:212): GradScaler on, embedding MLPs one f16 product per fp32 product, U-Net on the own split-f16 kernels.  Pinned to the "
+                    "reference's OWN AMP output (G17: tests/golden/g17_amp_*.npz from make_golden.py --amp, the reference under CPU fp16 autocast; bar = the "
+                    "reference's AMP-vs-fp32 distance, tests/test_hip_amp_golden.py); NOT the headline `value`, which is the fp32 parity mode the 1e-4 bar is stated for"}
     if main_line and not args.no_amp_line:
         j = child_line(["--gemm-mode", "h1"])
         out["throughput_mode_h1"] = j if "error" in j else {

@@ -25,6 +25,9 @@ Reference lines followed (relative to /root/reference):
   attention_tail      models/model.py:519-545 / :473-492
   small_unet          models/unet.py:182-258
   render              models/model.py:494-560
+  amp (render(..., amp=True))   models/attn.py:248, models/unet.py:212: the attention block and the U-Net under fp16 autocast
+                      (`use_amp: true`, configs/default.yml:6-7) -- torch's CPU autocast, which casts the same ops of these regions as the
+                      CUDA list does (linear / matmul / conv2d / conv_transpose2d; tests/golden/make_golden.py, shim 4); pinned by G17
 """
 import math
 
@@ -248,8 +251,13 @@ def small_unet(state, x, prefix="renderer."):
     return F.conv2d(y, g("outc.conv.weight"), g("outc.conv.bias"))
 
 
-def render(state, cfg, rays_o, rays_d, idx=None, want_rgb=True):
-    """Full per-ray path.  Returns a dict of every intermediate the parity tests look at."""
+def _autocast(amp, dtype=torch.float16):
+    return torch.autocast("cpu", dtype=dtype, enabled=bool(amp))
+
+
+def render(state, cfg, rays_o, rays_d, idx=None, want_rgb=True, amp=False):
+    """Full per-ray path.  Returns a dict of every intermediate the parity tests look at.
+    amp: the reference's `use_amp: true` arithmetic (fp16 autocast around the attention block and the U-Net; everything else fp32)."""
     N, H, W, _ = rays_d.shape
     pts = state["points"]
     k = int(cfg["geoms"]["points"]["select_k"])
@@ -264,8 +272,9 @@ def render(state, cfg, rays_o, rays_d, idx=None, want_rgb=True):
     out["idx"] = idx
     key_in, qry_in, val_in, sel, s, u = build_inputs(state, cfg, rays_o, rays_d, idx)
     out.update(key_in=key_in, qry_in=qry_in, val_in=val_in, sel_points=sel, s=s, u=u)
-    K, Q, V = embed_kqv(state, cfg, key_in, qry_in, val_in)
-    scores = attention_scores(state, cfg, K, Q)
+    with _autocast(amp):                            # models/attn.py:248
+        K, Q, V = embed_kqv(state, cfg, key_in, qry_in, val_in)
+        scores = attention_scores(state, cfg, K, Q)
     out.update(K=K, Q=Q, V=V, scores=scores)
     influ = state["points_influ_scores"][idx].reshape(-1, idx.shape[-1])
     fused, attn = attention_tail(scores, influ, V, cfg["geoms"]["background"]["constant"],
@@ -277,7 +286,8 @@ def render(state, cfg, rays_o, rays_d, idx=None, want_rgb=True):
         return out
     fmap = out["fused"]
     if cfg["models"]["use_renderer"]:
-        fg = small_unet(state, fmap.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+        with _autocast(amp):                        # models/unet.py:212
+            fg = small_unet(state, fmap.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
     else:
         fg = fmap
     a_bkg = out["attn"][..., -1:]

@@ -82,3 +82,5 @@ def step(optimizers):
     arr_t = (_Tensor * len(tensors))(*tensors)
     arr_g = (_Group * len(groups))(*groups)
     hip.check(hip.lib().papr_adam_step(arr_t, len(tensors), arr_g, len(groups), hip.stream_ptr()), "papr_adam_step")
+    from . import dist as pdist
+    pdist.bump_param_epoch()                          # (the kernel writes the parameters through raw pointers: no version counter moves)

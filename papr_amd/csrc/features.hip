@@ -26,21 +26,24 @@ struct FeatParams {
 __device__ __forceinline__ int pe_width(int L, int with_self) { return 3 * (with_self + 2 * L); }
 
 // write pe(x) for one 3-vector at dst (stride 1), returns number of floats written; s1 / s2 gather the sum of the values written and of their squares
+// (in double: squares of fp32 values are exact there and ~120 of them add up without a rounding that matters, so the one-pass variance below is
+// good for ANY row -- raw coordinates of +-50 in the Tanks&Temples scenes beside 108 sines and cosines included; fp64 VALU runs at the fp32 rate)
+template <typename Acc>
 __device__ __forceinline__ int write_pe(float* __restrict__ dst, const float x[3], int L, int with_self,
-                                        float factor, float mult, float& s1, float& s2) {
+                                        float factor, float mult, Acc& s1, Acc& s2) {
     const int per = with_self + 2 * L;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         float* o = dst + c * per;
-        if (with_self) { *o++ = x[c]; s1 += x[c]; s2 += x[c] * x[c]; }
+        if (with_self) { *o++ = x[c]; s1 += (Acc)x[c]; s2 += (Acc)x[c] * (Acc)x[c]; }
         float f = 1.0f;
         for (int i = 0; i < L; ++i) {
             float s, co;
             sincosf((f * x[c]) * mult, &s, &co);
             o[2 * i] = s;
             o[2 * i + 1] = co;
-            s1 += s + co;
-            s2 += s * s + co * co;
+            s1 += (Acc)s + (Acc)co;
+            s2 += (Acc)s * (Acc)s + (Acc)co * (Acc)co;
             f *= factor;
         }
     }
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(256) void features_fwd_kernel(FeatParams fp, const 
     float s[3] = {g.rx * t, g.ry * t, g.rz * t};
     float u[3] = {vx - s[0], vy - s[1], vz - s[2]};
 
-    float s1 = 0.f, s2 = 0.f;                       // sum and sum of squares of the row being written (this thread's)
+    double s1 = 0.0, s2 = 0.0;                      // sum and sum of squares of the row being written (this thread's)
     auto emit = [&](const float x[3], int L, float* dst, long ld, int c0) -> int {
         const int w = write_pe(row, x, L, d.with_self, d.pe_factor, d.pe_mult, s1, s2);
         wave_lds_sync();
@@ -164,11 +167,12 @@ __global__ __launch_bounds__(256) void features_fwd_kernel(FeatParams fp, const 
     if (key_stats && mreal < M) {
         // the statistics of the LayerNorm core in front of the key MLP (FeedForward.innorm, models/attn.py:39-42: unbiased std, eps added to it), while
         // the row's values are in this thread's hands: the fused run that stages the rows then applies them (papr_row_norm.given_mean) instead of
-        // taking two wave sums, a square root and a division per row in its staging slot -- 8k of that slot's 12-15k cycles.  One pass: the row's
-        // mean is small beside its spread (|mean| < 0.5, sum of squares >= 2 L per vector), the difference below loses no digits that matter
-        const float n = (float)c, mean = s1 / n;
-        const float var = fmaxf(s2 - n * mean * mean, 0.f) / (n - 1.f);
-        const float sigma = sqrtf(var);
+        // taking two wave sums, a square root and a division per row in its staging slot -- 8k of that slot's 12-15k cycles.  One pass, sums in
+        // double (write_pe): the difference below is exact to ~1e-13 of the sum of squares whatever the row holds
+        const double nd = (double)c, mean_d = s1 / nd;
+        const double var_d = (s2 - nd * mean_d * mean_d) / (nd - 1.0);
+        const float mean = (float)mean_d;
+        const float sigma = sqrtf((float)(var_d > 0.0 ? var_d : 0.0));
         key_mean[m] = mean;
         key_stats[2 * m] = 1.0f / (sigma + key_eps);
         key_stats[2 * m + 1] = sigma;

@@ -636,6 +636,11 @@ struct SRScratch {
         inv = reinterpret_cast<float*>(lo + (size_t)M * 256); mx = inv + M;
     }
     static size_t bytes(long M) { return ((size_t)M * (2 * 256 * sizeof(_Float16) + 2 * sizeof(float)) + 255) / 256 * 256; }
+    // what a workspace reserves for it: the planes only while the split-ahead switch is on (1,032 bytes per row: 3.3 GB of dead scratch at the
+    // 3.2 M rows of a 160,000-ray evaluate chunk otherwise); always the M floats at its head that papr_mlp_fwd uses for the row means of a
+    // LayerNorm core whose statistics nobody gave.  Callers size their workspace per call (papr_mlp_*_workspace_bytes), so a switch flipped
+    // later is seen by the next call.
+    static size_t reserve(long M) { return papr_switch(PAPR_SW_C4_DMA) ? bytes(M) : ((size_t)M * sizeof(float) + 255) / 256 * 256; }
 };
 
 int launch_row_absmax(const float* x, long M, int width, long ld, unsigned* out, hipStream_t s) {
@@ -1396,7 +1401,7 @@ __global__ __launch_bounds__(256) void act_grad_kernel(float* g, long ldg, const
 
 constexpr size_t TN_SLAB_BYTES = (size_t)TN_BATCH * TN_JOB_FLOATS * sizeof(float);      // partial tiles of a batch of weight-gradients
 
-extern "C" size_t papr_mlp_fwd_workspace_bytes(int64_t M) { return H3Scratch::bytes(M) + SRScratch::bytes(M); }
+extern "C" size_t papr_mlp_fwd_workspace_bytes(int64_t M) { return H3Scratch::bytes(M) + SRScratch::reserve(M); }
 extern "C" size_t papr_mlp_saved_floats(int32_t n_layers, int64_t M) { return (size_t)n_layers * (M + CHAIN_SIGN_WORDS * chain_sign_rows(M)); }
 
 // Layout of the `row_absmax` buffer of papr_mlp_fwd / papr_mlp_bwd (papr_mlp_saved_floats(n_layers, M) floats):
@@ -1656,7 +1661,7 @@ extern "C" int papr_mlp_bwd_needs_weight_t(const papr_layer* layers, int n_layer
     return 0;
 }
 
-extern "C" size_t papr_mlp_bwd_workspace_bytes(int64_t M) { return TN_SLAB_BYTES + H3Scratch::bytes(M) + BwdRunScratch::bytes(M) + SRScratch::bytes(M); }
+extern "C" size_t papr_mlp_bwd_workspace_bytes(int64_t M) { return TN_SLAB_BYTES + H3Scratch::bytes(M) + BwdRunScratch::bytes(M) + SRScratch::reserve(M); }
 
 extern "C" int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float* x, int ldx, int64_t M,
                             float* const* outs, const int32_t* ld_out, const float* row_absmax, float* d_out,

@@ -26,7 +26,7 @@ class _ImageScene:
     Which image and which crop, in one process: the REFERENCE's own streams -- the image order of a `DataLoader(dataset, batch_size,
     shuffle)` started afresh every epoch (train.py:205-206: the sampler's permutation comes from the global torch generator) and the two
     `np.random.randint` draws of the GLOBAL numpy stream per patch (dataset/utils.py:110-111) -- so that one seed gives the reference's
-    batch sequence and leaves the numpy stream where the reference's `add_points` finds it (golden G15, tests/test_hip_dynamics.py).
+    batch sequence and leaves the numpy stream where the reference's `add_points` finds it (golden G15, tests/test_dynamics_golden.py).
     own_stream (data parallelism; train.py passes it with seed = args.seed + rank): image and crop from this object's OWN numpy
     RandomState, so that every rank samples different patches while the global numpy stream stays identical on all ranks."""
 

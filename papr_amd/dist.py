@@ -22,9 +22,16 @@ def launched():
 def init_from_env(device=None):
     """Initialise the default process group when started by torch.distributed.run -- with ONE rank as well, so that a
     `--nproc-per-node 1` launch walks the same code as an 8-rank one (a plain `python bench.py` forms no group).  Returns the world size."""
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if td.is_initialized() or not launched():
-        return world
+    if td.is_initialized():
+        return td.get_world_size()
+    if not launched():
+        # no launcher, no group, ONE rank -- whatever a stray WORLD_SIZE export (a scheduler's, say) claims: a caller that multiplied its
+        # throughput by it, or switched to per-rank sampling with no collectives behind it, would be silently wrong
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            import warnings
+            warnings.warn("papr_amd.dist: WORLD_SIZE=%s without RANK / MASTER_ADDR: not a launcher environment, running as one rank" % os.environ["WORLD_SIZE"])
+        return 1
+    world = int(os.environ["WORLD_SIZE"])
     use_gpu = torch.cuda.is_available() and (device is None or torch.device(device).type == "cuda")
     # PAPR_DIST_BACKEND=gloo: several ranks on ONE device (tests on a 1-GPU box: RCCL refuses two ranks per GPU); the
     # collectives then bounce device tensors through the host (_all_reduce_sum / _broadcast below)
@@ -152,8 +159,23 @@ def broadcast_point_cloud(tensors, src=0):
     return out
 
 
+_param_epoch = 0
+
+
+def param_epoch():
+    """Counts the writes to parameters that torch's version counters do not see (`.data` / raw-pointer writers: the broadcast below, papr_adam_step):
+    part of the key of every cache derived from parameter values (model.ProximityAttentionParams.kernel_weights)."""
+    return _param_epoch
+
+
+def bump_param_epoch():
+    global _param_epoch
+    _param_epoch += 1
+
+
 def broadcast_module_state(module, src=0):
     if not active():
         return
     for t in list(module.parameters()) + list(module.buffers()):
         _broadcast(t.data, src)
+    bump_param_epoch()

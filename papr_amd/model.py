@@ -127,9 +127,10 @@ class ProximityAttentionParams(nn.Module):
     def kernel_weights(self, plan):
         """Effective (LayerNorm-affine-folded, zero-padded) weights for the kernels, inside autograd.  Under `no_grad` (the chunk loops of
         test_step / eval_step: 64 calls per 800 x 800 image) they are prepared once and reused for as long as no parameter has been written
-        (every in-place update -- an optimizer step, load_state_dict -- bumps the tensor's version counter)."""
+        (every in-place update -- an optimizer step, load_state_dict -- bumps the tensor's version counter; the writers that go around it --
+        papr_adam_step, dist.broadcast_module_state -- bump dist.param_epoch)."""
         if not torch.is_grad_enabled():
-            key = tuple((p.data_ptr(), p._version) for p in self.parameters())
+            key = (pdist.param_epoch(),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
             cached = getattr(self, "_kw_cache", None)
             if cached is None or cached[0] != key:
                 self._kw_cache = cached = (key, self._kernel_weights(plan))

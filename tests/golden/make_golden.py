@@ -34,6 +34,27 @@ for n in ["LinearLR", "CosineAnnealingLR", "ExponentialLR", "StepLR", "Sequentia
     o = c.__init__
     c.__init__ = (lambda o: lambda self, *a, verbose=None, **k: o(self, *a, **k))(o)
 
+# Shim 4 (round 5, for G17 = the reference under `use_amp: true`): the reference wraps its attention block, U-Net and mapping MLP in
+# `autocast(device_type='cuda', ...)` (models/attn.py:248, models/unet.py:212, models/mlp.py:76) and builds `torch.cuda.amp.GradScaler`
+# (models/model.py:26); without a CUDA device both switch themselves off.  Redirected to torch's CPU autocast / CPU GradScaler, process-locally,
+# BEFORE the reference's modules bind `from torch import autocast`.  With `use_amp: false` (every other fixture) both stay disabled no-ops.
+# What CPU autocast casts differently from the CUDA list: nothing that these three regions execute -- they run linear / addmm / matmul /
+# conv2d / conv_transpose2d (fp16 on both lists), cat / stack (promote on both) and relu, max_pool2d, sin, cos, mean, std, add, mul, div
+# (on neither list: input dtype on both).  The CUDA-only fp32 entries (pow, sum, softmax, norm, layer_norm, exp, log ...) are not called
+# inside the regions (the reference's LayerNorm is hand-written from mean / std; softmax and the compositing run outside autocast).
+# The fp16 kernels themselves differ (oneDNN on the host, rocBLAS / MIOpen on a GPU): both accumulate in fp32 and round the result to
+# fp16 once, so the fixtures pin the reference's AMP arithmetic up to summation order.
+_TorchAutocast = torch.autocast
+
+
+class _CpuAutocast(_TorchAutocast):
+    def __init__(self, device_type, dtype=None, enabled=True, cache_enabled=None):
+        super().__init__("cpu" if device_type == "cuda" else device_type, dtype=dtype, enabled=enabled, cache_enabled=cache_enabled)
+
+
+torch.autocast = _CpuAutocast
+torch.cuda.amp.GradScaler = lambda enabled=True, **kw: torch.amp.GradScaler("cpu", enabled=enabled, **kw)
+
 from utils import DictAsMember, update_dict, setup_seed  # noqa: E402  (reference utils.py)
 from models import get_model, get_loss  # noqa: E402
 from models.utils import posenc as ref_posenc  # noqa: E402
@@ -601,8 +622,109 @@ def g16_last_act():
     save("g16_last_act.npz", **out)
 
 
+# ----------------------------------------------------------------------------------- G17
+def _rel(a, b):
+    """(L-inf, rms) of a - b over the L-inf of b (float64)."""
+    a, b = a.detach().double(), b.detach().double()
+    s = max(b.abs().max().item(), 1e-30)
+    return np.array([(a - b).abs().max().item() / s, (a - b).pow(2).mean().sqrt().item() / s])
+
+
+def g17_amp(tag, scene):
+    """The reference with `use_amp: true` as every shipped YAML has it (configs/default.yml:6-7): attention block and U-Net under fp16 autocast
+    (shim 4 above), GradScaler live.  Same seeded model, rays and neighbour order as g567_<tag>: evaluate / forward outputs, intermediates of the
+    attention block, gradients of mean((rgb - 0.5)^2) taken the way train_step takes them (scaler.scale(loss).backward(), divided by the scale
+    here), and the reference's OWN distance between its AMP and its fp32 results -- the yardstick the build's use_amp path is held to."""
+    small = {"geoms": {"points": {"init_num": 1000}}}
+    cfg32 = load_cfg(scene, **small)
+    cfg16 = copy.deepcopy(cfg32)
+    cfg16["use_amp"] = True
+    assert cfg16["amp_dtype"] == "float16"
+    m32, m16 = build(cfg32), build(cfg16)
+    assert m16.scaler.is_enabled() and m16.scaler.get_scale() == 65536.0
+    ro, rd, c2w = synth_rays(1, 16, 16, seed=0)
+    out, yard = {}, {}
+    with torch.no_grad():
+        f32_, a32_ = m32.evaluate(ro, rd, c2w)
+        idx32 = m32.select_k_ind.clone()
+        f16_, a16_ = m16.evaluate(ro, rd, c2w)
+        idx = m16.select_k_ind.clone()
+    assert torch.equal(idx, idx32)                  # (the selection runs outside autocast)
+    kk = idx.shape[-1]
+
+    def block(m):
+        pts_sel, _ = m._get_points(ro, rd, c2w)
+        key, query, value, kx, qx, vx = m._get_kqv(ro, rd, pts_sel, c2w, idx)
+        with torch.no_grad():
+            return m.proximity_attn(key, query, value, kx, qx, vx)
+    k32, q32, v32, s32 = block(m32)
+    k16, q16, v16, s16 = block(m16)
+    out.update(idx_raw=npf(idx).astype(np.int32), fused=npf(f16_.squeeze(-2).float()), attn=npf(a16_.squeeze(-1).float()),
+               K_head=npf(k16[:8].float()), Q_head=npf(q16[:32, 0].float()), V_head=npf(v16[:64].float()), scores=npf(s16.reshape(-1, kk).float()),
+               dtypes=np.array([str(t.dtype) for t in (k16, q16, v16, s16, f16_, a16_)]))
+    yard.update(fused=_rel(f16_, f32_), attn=_rel(a16_, a32_), K=_rel(k16, k32), Q=_rel(q16, q32), V=_rel(v16, v32), scores=_rel(s16, s32))
+
+    def grads(m):
+        m.clear_grad()
+        rgb = m(ro, rd, c2w)
+        loss = torch.mean((rgb - 0.5) ** 2)
+        m.scaler.scale(loss).backward()
+        sc = m.scaler.get_scale() if m.scaler.is_enabled() else 1.0
+        return rgb.detach(), loss.item(), {n: p.grad.detach() / sc for n, p in m.named_parameters() if p.grad is not None}
+    rgb32, loss32, g32 = grads(m32)
+    rgb16, loss16, g16 = grads(m16)
+    assert rgb16.dtype == torch.float32 and all(torch.isfinite(v).all() for v in g16.values())
+    out.update(rgb=npf(rgb16), loss=np.array(loss16), loss_fp32=np.array(loss32))
+    yard["rgb"] = _rel(rgb16, rgb32)
+    full = ("points", "points_influ_scores", "pc_feats",
+            "proximity_attn.embed.embed_k.mlp.model.1.weight", "proximity_attn.embed.embed_v.mlp.model.1.weight",
+            "proximity_attn.embed.embed_q.mlp.model.1.weight", "proximity_attn.embed.embed_v.mlp.model.11.weight",
+            "proximity_attn.attention_layer.w_q.bias", "proximity_attn.attention_layer.w_k.bias", "renderer.outc.conv.bias",
+            "renderer.inc.double_conv.0.bias")
+    names = sorted(g16)
+    assert names == sorted(g32)
+    for n in names:
+        if n in full or g16[n].dim() == 1:
+            out["grad/" + n] = npf(g16[n])
+    out["grad_names"] = np.array(names)
+    out["grad_stats"] = np.stack([stats(g16[n]) for n in names])
+    out["grad_yard"] = np.stack([_rel(g16[n], g32[n]) for n in names])       # per tensor: (L-inf, rms) of AMP - fp32 over max |fp32 gradient|
+    for k_, v_ in yard.items():
+        out["yard/" + k_] = v_
+    print(tag, "reference AMP vs its own fp32 (L-inf, rms relative to the fp32 tensor's max):", {k_: v_.round(6).tolist() for k_, v_ in yard.items()})
+    print(tag, "gradients: worst rms %.3e, worst L-inf %.3e" % (out["grad_yard"][:, 1].max(), out["grad_yard"][:, 0].max()))
+
+    # three train_step calls of the reference (train.py:155-179) with the flag on: the G7 case
+    model = build(cfg16)
+    g = torch.Generator().manual_seed(21)
+    tgt = torch.rand((1, 16, 16, 3), generator=g)
+
+    class DS:
+        def get_c2w(self, i):
+            return c2w[0]
+
+    loss_fn = get_loss(cfg16["training"]["losses"])
+    args = DictAsMember(copy.deepcopy(cfg16))
+    losses, scales = [], []
+    for step in range(3):
+        loss, _ = ref_train.train_step(step + 1, model, "cpu", DS(), ([0], None, tgt, rd, ro), loss_fn, args)
+        losses.append(loss)
+        scales.append(model.scaler.get_scale())
+    sd = model.state_dict()
+    out.update(traj_losses=np.array(losses, dtype=np.float64), traj_scales=np.array(scales), traj_target=npf(tgt),
+               traj_points_after=npf(sd["points"]), traj_influ_after=npf(sd["points_influ_scores"]))
+    print(tag, "AMP trajectory", losses, "scales", scales)
+    save("g17_amp_%s.npz" % tag, **out)
+
+
 if __name__ == "__main__":
     small = {"geoms": {"points": {"init_num": 1000}}}
+    if "--amp" in sys.argv:                          # G17: the reference under `use_amp: true` (CPU autocast, shim 4)
+        import warnings
+        warnings.simplefilter("ignore")
+        g17_amp("chair1k", "nerfsyn/chair.yml")
+        g17_amp("lego1k", "nerfsyn/lego.yml")
+        sys.exit(0)
     if "--g17" in sys.argv:                          # weight-normalised embedding MLPs (`use_wn: true`, models/mlp.py:21,35-36): a tiny model
         wn = copy.deepcopy(G13_CFG)
         wn["geoms"]["points"]["init_num"] = 1000

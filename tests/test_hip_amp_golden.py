@@ -1,0 +1,130 @@
+"""G17: the HIP `use_amp: true` path against the REFERENCE's own AMP output.
+
+Every shipped YAML selects `use_amp: true` (configs/default.yml:6-7): the reference then runs its attention block and its U-Net under fp16
+autocast (models/attn.py:248, models/unet.py:212) and scales the loss with a GradScaler (models/model.py:26, train.py:172-177).  The build maps the
+flag to the one-product arithmetic of the embedding MLPs (f16 operands, fp32 accumulation), keeps the U-Net on its split-f16 kernels and runs the
+GradScaler.  tests/golden/make_golden.py --amp ran the reference itself with the flag on (CPU autocast; what that casts is stated at shim 4 there)
+and stored, beside its AMP outputs, its OWN AMP-vs-fp32 distance per tensor (`yard/*`, `grad_yard`).
+
+The bar: the build's use_amp results must be no farther from the reference's AMP results than the reference's AMP results are from the reference's
+fp32 results -- the yardstick -- in the rms (L2) sense, and within 1.5 yardsticks in the maximum (one fp16 ulp of a U-Net output IS the maximum of
+the rgb yardstick: a maximum over 768 values cannot be held tighter than the quantisation step it measures).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import case_cfg, case_rays, golden
+from formula import formula_fill
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+def build_amp(tag, points):
+    from papr_amd import get_model
+    from papr_amd.config import deep_merge
+    torch.manual_seed(1)
+    np.random.seed(1)
+    m = get_model(deep_merge(case_cfg(tag), {"use_amp": True}), device="cpu")
+    formula_fill(m.state_dict())
+    with torch.no_grad():
+        m.points.copy_(points)
+    m = m.to("cuda")
+    assert m.use_amp and m.plan.amp_mlp and m.scaler.is_enabled()
+    return m
+
+
+def rel(got, ref):
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    s = max(np.abs(ref).max(), 1e-30)
+    return np.abs(got - ref).max() / s, np.sqrt(((got - ref) ** 2).mean()) / s
+
+
+def by_point(attn, idx, k):
+    return np.concatenate([np.take_along_axis(attn[..., :k], np.argsort(idx, -1), -1), attn[..., k:]], -1)
+
+
+@pytest.mark.parametrize("tag", ["chair1k", "lego1k"])
+def test_use_amp_forward_against_the_reference_amp_golden(tag):
+    g, g32 = golden("g17_amp_%s.npz" % tag), golden("g567_%s.npz" % tag)
+    m = build_amp(tag, T(g32["points"]))
+    ro, rd, c2w = [t.cuda() for t in case_rays(tag)]
+    with torch.no_grad():
+        fused, attn = m.evaluate(ro, rd, c2w)
+        rgb = m(ro, rd, c2w)
+    assert rgb.dtype == torch.float32 and fused.dtype == torch.float32
+    k = g["idx_raw"].shape[-1]
+    idx = m.select_k_ind.cpu().numpy()
+    assert np.array_equal(np.sort(idx, -1), np.sort(g["idx_raw"], -1)), "kNN sets differ"
+    got = {"fused": fused.squeeze(-2).cpu().numpy(), "attn": by_point(attn.squeeze(-1).cpu().numpy(), idx, k), "rgb": rgb.cpu().numpy()}
+    ref16 = {"fused": g["fused"], "attn": by_point(g["attn"], g["idx_raw"], k), "rgb": g["rgb"]}
+    ref32 = {"fused": g32["fused"], "attn": by_point(g32["attn"], g32["idx_raw"], k), "rgb": g32["rgb"]}
+    for n in ("fused", "attn", "rgb"):
+        d16, d32, yard = rel(got[n], ref16[n]), rel(got[n], ref32[n]), g["yard/" + n]
+        print("%s %-5s build-AMP vs reference-AMP: L-inf %.3e rms %.3e | vs reference-fp32: %.3e %.3e | reference AMP vs fp32 (yardstick): %.3e %.3e"
+              % (tag, n, d16[0], d16[1], d32[0], d32[1], yard[0], yard[1]))
+        assert d16[1] <= yard[1] and d16[0] <= 1.5 * yard[0], (n, d16, yard)
+
+
+@pytest.mark.parametrize("tag", ["chair1k", "lego1k"])
+def test_use_amp_gradients_against_the_reference_amp_golden(tag):
+    """Gradients of mean((rgb - 0.5)^2) taken as train_step takes them: scaler.scale(loss).backward(), unscaled by the scale."""
+    g, g32 = golden("g17_amp_%s.npz" % tag), golden("g567_%s.npz" % tag)
+    m = build_amp(tag, T(g32["points"]))
+    ro, rd, c2w = [t.cuda() for t in case_rays(tag)]
+    m.clear_grad()
+    rgb = m(ro, rd, c2w)
+    loss = torch.mean((rgb - 0.5) ** 2)
+    m.scaler.scale(loss).backward()
+    sc = m.scaler.get_scale()
+    assert abs(loss.item() - float(g["loss"])) <= 2.0 * abs(float(g["loss"]) - float(g["loss_fp32"])) + 1e-6
+    named = dict(m.named_parameters())
+    names = [str(n) for n in g["grad_names"]]
+    worst = 0.0
+    for key in g.files:
+        if not key.startswith("grad/"):
+            continue
+        n = key[5:]
+        ref = g[key]
+        assert named[n].grad is not None and torch.isfinite(named[n].grad).all(), n
+        d = rel((named[n].grad / sc).cpu().numpy(), ref)
+        yard = g["grad_yard"][names.index(n)]
+        ratio = d[1] / max(yard[1], 2e-5)
+        worst = max(worst, ratio)
+        print("%s grad %-60s build vs reference-AMP: L-inf %.3e rms %.3e | yardstick %.3e %.3e" % (tag, n, d[0], d[1], yard[0], yard[1]))
+        assert d[1] <= max(yard[1], 2e-5), (n, d, yard)
+    print(tag, "worst rms / yardstick", worst)
+
+
+def test_use_amp_three_train_steps_against_the_reference_amp_trajectory():
+    """The reference's train_step (train.py:155-179) three times with `use_amp: true` (G17 trajectory; same case as G7): losses, the GradScaler's
+    scale, and the point positions after the three Adam steps."""
+    from papr_amd import get_loss
+    g, g7, g32 = golden("g17_amp_chair1k.npz"), golden("g7_trajectory.npz"), golden("g567_chair1k.npz")
+    assert np.array_equal(g["traj_target"], g7["target"])
+    m = build_amp("chair1k", T(g32["points"]))
+    m.clear_optimizer(); m.clear_scheduler(); m.init_optimizers(0)
+    ro, rd, c2w = [t.cuda() for t in case_rays("chair1k")]
+    tgt = T(g["traj_target"]).cuda()
+    loss_fn = get_loss(case_cfg("chair1k")["training"]["losses"])
+    losses, scales = [], []
+    for step in range(3):
+        m.clear_grad()
+        out = m.last_act(m(ro, rd, c2w, step + 1))
+        loss = loss_fn(out, tgt)
+        m.scaler.scale(loss).backward()
+        m.step(step + 1)
+        m.scaler.update()
+        losses.append(loss.item())
+        scales.append(m.scaler.get_scale())
+    yard = np.abs(g["traj_losses"] - g7["losses"])
+    print("build AMP losses", losses, "reference AMP", g["traj_losses"].tolist(), "reference fp32", g7["losses"].tolist(), "yardstick", yard.tolist())
+    assert scales == g["traj_scales"].tolist()
+    assert np.all(np.abs(np.array(losses) - g["traj_losses"]) <= 1.5 * yard + 1e-6), (losses, g["traj_losses"], yard)
+    # points after three Adam steps: the reference's AMP run against its fp32 run is the yardstick (Adam divides by |g|: near-zero gradients
+    # amplify rounding into whole steps of 3 x lr)
+    d16 = np.abs(m.points.detach().cpu().numpy() - g["traj_points_after"])
+    y = np.abs(g["traj_points_after"] - g7["points_after"])
+    print("points after: build vs reference-AMP max %.3e rms %.3e | reference AMP vs fp32 max %.3e rms %.3e" % (d16.max(), np.sqrt((d16 ** 2).mean()), y.max(), np.sqrt((y ** 2).mean())))
+    assert np.sqrt((d16 ** 2).mean()) <= 1.25 * np.sqrt((y ** 2).mean()) + 1e-6 and d16.max() <= 1.5 * y.max() + 1e-6

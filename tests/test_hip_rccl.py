@@ -64,3 +64,30 @@ def test_bench_under_the_launcher_prints_the_same_line_as_the_plain_launch():
     assert dp["value"] == pytest.approx(25600 * 6 / (dp["ms_per_step"] * 6e-3), rel=1e-6)
     # one flat 21.9 MB bucket (a cat and an all-reduce) per step on top of a ~12 ms step
     assert dp["ms_per_step"] <= 1.15 * plain["ms_per_step"] + 0.3, (dp["ms_per_step"], plain["ms_per_step"])
+
+
+def test_bench_gpus_2_on_a_one_gpu_box_refuses_instead_of_printing_a_dp1_line():
+    """`python bench.py --gpus 2` with no launcher around it starts its own ranks (torch.distributed.run as a child process) -- and where fewer
+    GPUs than ranks are visible it exits non-zero with a message and prints NO JSON line: a one-GPU number must never be read as an N-GPU one.
+    A launcher whose WORLD_SIZE disagrees with --gpus is refused the same way."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("more than one GPU visible: the self-launch would run")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "PAPR_DIST_BACKEND"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], env=env, capture_output=True, text=True,
+                       timeout=300, cwd=ROOT)
+    assert r.returncode != 0 and "only 1 GPU(s) visible" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")], (r.returncode, r.stdout, r.stderr[-2000:])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode != 0 and "must agree" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")], (r.returncode, r.stdout, r.stderr[-2000:])
+
+
+def test_bench_line_carries_ranks_seen_and_the_logical_knn_fraction():
+    j = _bench({}, launcher=False)
+    assert j["ranks_seen"] == 1 and j["n_gpus"] == 1
+    e = j["e2e_frac_of_knn_hbm_roofline"]
+    assert e["logical"] is True and e["bytes_per_ray"] == 12 * 10000 + 12 + 4 * 20
+    assert e["frac"] == pytest.approx(j["value"] * e["bytes_per_ray"] / 8e12, rel=1e-9)

@@ -190,3 +190,51 @@ def test_g13_oracle_renders_the_reference_written_checkpoint():
     np.testing.assert_allclose(a_got, a_ref, rtol=0, atol=2e-6)
     np.testing.assert_allclose(out["fused"].numpy(), g["fused"], rtol=0, atol=2e-5)
     np.testing.assert_allclose(out["rgb"].numpy(), g["rgb"], rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("tag", ["chair1k", "lego1k"])
+def test_g17_oracle_amp_mode_matches_the_reference_under_use_amp(tag):
+    """G17 (make_golden.py --amp): the REFERENCE with `use_amp: true` (fp16 autocast around the attention block and the U-Net, models/attn.py:248,
+    models/unet.py:212, redirected to CPU autocast in the generator).  The oracle's amp mode wraps the same two regions; on the same host
+    kernels it reproduces the reference's AMP outputs to fp16 summation-order noise -- far inside the reference's own AMP-vs-fp32 distance
+    (`yard/*`), which is the yardstick the HIP use_amp path is held to (tests/test_hip_amp_golden.py)."""
+    g = golden("g17_amp_%s.npz" % tag)
+    g32 = golden("g567_%s.npz" % tag)
+    cfg, st = oracle_state(tag, g32, grad=True)
+    ro, rd, _ = case_rays(tag)
+    assert np.array_equal(g["idx_raw"], g32["idx_raw"])
+    out = O.render(st, cfg, ro, rd, idx=T(g["idx_raw"]).long(), amp=True)
+    assert [str(out[n].dtype) for n in ("K", "Q", "V", "scores")] == [str(d) for d in g["dtypes"][:4]]
+    assert out["rgb"].dtype == torch.float32 and out["fused"].dtype == torch.float32
+    for name, ref, got in (("fused", g["fused"], out["fused"]), ("attn", g["attn"], out["attn"]), ("rgb", g["rgb"], out["rgb"]),
+                           ("scores", g["scores"], out["scores"])):
+        got = got.detach().float().numpy().reshape(ref.shape)
+        scale = max(np.abs(ref).max(), 1e-30)
+        err, rms = np.abs(got - ref).max() / scale, np.sqrt(((got - ref) ** 2).mean()) / scale
+        yard, yard_rms = float(g["yard/" + name][0]), float(g["yard/" + name][1])
+        if name == "rgb":
+            # the U-Net's output is an fp16 tensor (models/unet.py:212): an input that differs in the last fp32 bit (fused: 3e-7 here) flips single
+            # fp16 roundings of the foreground -- one fp16 ulp is the size of the yardstick's maximum itself, so the maximum cannot tell the two
+            # apart; the rms does (measured 2e-5 against a yardstick of 6e-5 / 1.9e-4)
+            assert err <= yard and rms <= 0.5 * yard_rms, (name, err, rms, yard, yard_rms)
+        else:
+            assert err <= 0.25 * yard and rms <= 0.25 * yard_rms, (name, err, rms, yard, yard_rms)
+    # the amp mode is NOT the fp32 path: it sits about the yardstick away from the fp32 golden
+    d32 = np.abs(out["rgb"].detach().numpy() - g32["rgb"]).max() / np.abs(g32["rgb"]).max()
+    assert 0.3 * g["yard/rgb"][0] <= d32 <= 3.0 * g["yard/rgb"][0]
+    # gradients as train_step takes them (loss scaled by the GradScaler's 65536, unscaled afterwards)
+    loss = torch.mean((out["rgb"] - 0.5) ** 2)
+    (loss * 65536.0).backward()
+    assert abs(loss.item() - float(g["loss"])) < 2e-6
+    names = [str(n) for n in g["grad_names"]]
+    for key in g.files:
+        if key.startswith("grad/"):
+            n = key[5:]
+            ref = g[key]
+            got = (st[n].grad / 65536.0).numpy()
+            scale = max(np.abs(ref).max(), 1e-30)
+            yard = g["grad_yard"][names.index(n)]
+            rms = np.sqrt(((got - ref) ** 2).mean()) / scale
+            # (fp16 rounding flips in the U-Net's backward pass: the same arithmetic fed inputs that differ in the last fp32 bit already sits at
+            # 0.1 - 0.6 of the AMP-vs-fp32 yardstick)
+            assert rms <= max(yard[1], 2e-5), (n, rms, yard)
