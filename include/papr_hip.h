@@ -414,9 +414,12 @@ int papr_profile_enable(int on);
  *   PAPR_SW_TN_JOBPAR   (1)    0: every workgroup of a batched weight-gradient launch walks all jobs (one partial tile per job and workgroup) instead of the
  *                              workgroups being dealt to the jobs (one partial tile per workgroup).  NOT bit-identical: the rows meet in another order
  *   PAPR_SW_C4_PAIRS    (1)    0: every hot slot of a fused forward run its own statement instead of two slots (tile Y's step, tile X's next step) per
- *                              statement (ABI 23) */
+ *                              statement (ABI 23)
+ *   PAPR_SW_C4_PHASE    (6130) the workgroups of a fused run that carry one pair of tiles fewer than the others start late instead of finishing early
+ *                              (out of phase with the rest at no cost).  value = 1000 x (the fewest steps a run must have) + (delay per step of the run in
+ *                              hundreds of cycles); 0: off */
 enum { PAPR_SW_C4_GENERIC = 0, PAPR_SW_C4_FUSED = 1, PAPR_SW_C4_EARLY = 2, PAPR_SW_KNN_BLOCKS = 3, PAPR_SW_KNN_T = 4, PAPR_SW_WGRAD_WGS = 5,
-       PAPR_SW_NT_VARIANT = 6, PAPR_SW_C4_DMA = 7, PAPR_SW_TN_JOBPAR = 8, PAPR_SW_C4_PAIRS = 9, PAPR_SW_COUNT = 10 };
+       PAPR_SW_NT_VARIANT = 6, PAPR_SW_C4_DMA = 7, PAPR_SW_TN_JOBPAR = 8, PAPR_SW_C4_PAIRS = 9, PAPR_SW_C4_PHASE = 10, PAPR_SW_COUNT = 11 };
 int papr_set_switch(int32_t which, int32_t value);
 int32_t papr_get_switch(int32_t which);
 /* Waits for the recorded events, writes up to `cap` records (oldest first), clears the log and
