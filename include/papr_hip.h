@@ -217,6 +217,12 @@ typedef struct {
      * key_stats): the rows are standardised with them -- x <- (x - mean) / (std + eps) over `width` columns -- and no statistic is computed or
      * written.  NULL: the call computes the statistics itself. */
     const float* given_mean;
+    /* out_norm only, optional (ABI 25; with dots and row_absmax, i.e. a training call whose last layer rides in a fused run -- anything else is an
+     * error, not a fallback): outs[n_layers-1] receives the UN-standardised rows x and raw_mean[m] their means; stats and dots as above.  The
+     * consumer standardises on the fly, y = (x - raw_mean) * stats[2m] -- the two instructions the run would have spent per element, bit for bit
+     * (papr_attn_tail_bwd: kp_mean).  Why: the run's last row phase then needs no row statistics at all (they were 10-16k cycles per wave of a
+     * 40k-cycle slot: every lane took them from eight partial tables), only the dot products' finish does. */
+    float* raw_mean;
 } papr_row_norm;
 
 /* `mode` of papr_mlp_fwd / papr_mlp_bwd / papr_mlp_bwd_needs_weight_t: which arithmetic and which kernels carry the call.  An argument of
@@ -294,7 +300,9 @@ int papr_attn_tail_bwd(const papr_tail_desc* d, const float* kp, const float* qp
                        const float* influ, const int32_t* idx, int64_t R, const float* scores,
                        const float* attn, const float* d_fused, const float* d_attn, float* d_kp,
                        float* d_qp, float* d_v, float* d_influ, float* d_score_bias, float* d_pair_influ,
-                       const float* kp_norm_stats, const float* score_bias, papr_stream_t stream);
+                       const float* kp_norm_stats, const float* score_bias, const float* kp_mean, papr_stream_t stream);
+/* kp_mean (ABI 25; R*k floats or NULL; needs kp_norm_stats): the kp rows are RAW (papr_row_norm.raw_mean) -- every element read is standardised
+ * first, (x - kp_mean[row]) * kp_norm_stats[2 row]. */
 
 /* Background compositing, the last line of the attention tail (reference models/model.py:536-545): rgb (R, C) =
  * fg * (1 - a) + bkg * a with normalize (normalize_topk_attn: true), fg + bkg * a without; a = attn[:, col] (the

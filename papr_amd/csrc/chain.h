@@ -50,6 +50,8 @@ struct ChainArgs {
     const float* dot_rows; long ld_dot;   // with norm_stats and dots: dots[m] = (standardised row m) . dot_rows[m / rows_per_dot] -- the
     int rows_per_dot;                     // attention scores' dot products straight from the last row phase (the last layer's C may then
     float* dots;                          // be null: inference never writes the key embedding); (M) floats
+    float* norm_mean;                     // with dots: the last layer's rows are stored RAW and their means go here (M) -- the consumer standardises
+                                          // on the fly (papr_row_norm.raw_mean); the last row phase then takes no statistics at all
     ChainLayer L[CHAIN_MAX_LAYERS];
 };
 

@@ -1581,6 +1581,7 @@ extern "C" int papr_mlp_fwd(const papr_layer* layers, int n_layers, float* x, in
                 if (want_dots) {                    // ... and multiplied with its ray's row there; inference: the rows themselves stay on the chip
                     c.dot_rows = out_norm->dot_rows; c.ld_dot = out_norm->ld_dot; c.rows_per_dot = out_norm->rows_per_dot; c.dots = out_norm->dots;
                     dots_done = true;
+                    if (saved) c.norm_mean = out_norm->raw_mean;      // (training: the rows leave raw, papr_row_norm.raw_mean)
                     if (!saved) { bytes -= 4LL * M * layers[e - 1].n_out; c.L[e - 1 - i].C = nullptr; }
                     bytes += 4LL * M + 4LL * ((M + c.rows_per_dot - 1) / c.rows_per_dot) * layers[e - 1].n_out;
                 }
@@ -1623,6 +1624,8 @@ extern "C" int papr_mlp_fwd(const papr_layer* layers, int n_layers, float* x, in
         have_amax = false;
         if (int e = gemm_nt(a, s)) return e;
     }
+    PAPR_REQUIRE(!(out_norm && out_norm->raw_mean) || (dots_done && row_absmax),
+                 "papr_mlp_fwd: out_norm->raw_mean needs dots, row_absmax and a last layer that rides in a fused run (mode %d)", mode);
     if (out_norm && !norm_done)             // not inside a fused run: one more pass over the rows
         if (int e = papr_rownorm_fwd(outs[n_layers - 1], M, out_norm->width, ld_out[n_layers - 1], out_norm->eps, outs[n_layers - 1],
                                      out_norm->stats, stream)) return e;

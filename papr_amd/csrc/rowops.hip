@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(papr_tail_desc d, const f
                                                        float* __restrict__ d_qp, float* __restrict__ d_v,
                                                        float* __restrict__ d_influ, float* __restrict__ d_score_bias,
                                                        float* __restrict__ d_pair_influ, const float* __restrict__ kp_stats,
-                                                       const float* __restrict__ score_bias) {
+                                                       const float* __restrict__ score_bias, const float* __restrict__ kp_mean) {
     const int lane = threadIdx.x & 63;
     long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= R) return;
@@ -215,6 +215,10 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(papr_tail_desc d, const f
     // from the saved score (and where it is zero, ddot_j is).
     //   dx_jc = ddot_j rinv_j (qp_c - mean(qp)) - y_jc ddot_j (qp . y_j) / ((n - 1) sigma_j)
     float ca = ddot, cb = 0.f, qmean = 0.f;
+    // kp_mean: the kp rows are RAW (papr_row_norm.raw_mean): y = (x - mean) * rinv per element as it is read -- the subtraction and the product the
+    // fused run would have applied before storing the row, so every value below is the one a standardised row would have held
+    float kmean = 0.f, krinv = 1.f;
+    if (kp_mean && lane < k) { kmean = kp_mean[r * k + lane]; krinv = kp_stats[(r * k + lane) * 2]; }
     if (kp_stats) {
         float qs = 0.f;
         for (int c = lane * 4; c < d.d_model; c += 256) {
@@ -237,6 +241,10 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(papr_tail_desc d, const f
         for (int j = 0; j < k; ++j) {               // (requesting the rows of a round ahead of its stores was slower: 335 vs 229 us)
             float gj = bcast(ddot, j);
             float4 kv = *reinterpret_cast<const float4*>(kp + (r * k + j) * d.ld_kp + c);
+            if (kp_mean) {
+                const float mj = bcast(kmean, j), rj = bcast(krinv, j);
+                kv = make_float4((kv.x - mj) * rj, (kv.y - mj) * rj, (kv.z - mj) * rj, (kv.w - mj) * rj);
+            }
             acc.x += gj * kv.x; acc.y += gj * kv.y; acc.z += gj * kv.z; acc.w += gj * kv.w;
             float4 o;
             if (kp_stats) {
@@ -463,14 +471,15 @@ extern "C" int papr_attn_tail_bwd(const papr_tail_desc* d, const float* kp, cons
                                   const float* influ, const int32_t* idx, int64_t R, const float* scores,
                                   const float* attn, const float* d_fused, const float* d_attn, float* d_kp,
                                   float* d_qp, float* d_v, float* d_influ, float* d_score_bias, float* d_pair_influ,
-                                  const float* kp_norm_stats, const float* score_bias, papr_stream_t stream) {
+                                  const float* kp_norm_stats, const float* score_bias, const float* kp_mean, papr_stream_t stream) {
     if (int e = check_tail(d, "papr_attn_tail_bwd")) return e;
+    PAPR_REQUIRE(!kp_mean || kp_norm_stats, "papr_attn_tail_bwd: kp_mean (raw kp rows) needs kp_norm_stats");
     PAPR_REQUIRE(kp && qp && v && influ && idx && scores && attn && d_fused && d_kp && d_qp && d_v && (d_influ || d_pair_influ),
                  "papr_attn_tail_bwd: null pointer");
     if (R <= 0) return 0;
     tail_bwd_kernel<<<dim3((unsigned)((R + 3) / 4)), dim3(256), 0, as_stream(stream)>>>(
         *d, kp, qp, v, influ, idx, R, scores, attn, d_fused, d_attn, d_kp, d_qp, d_v, d_influ, d_score_bias, d_pair_influ,
-        kp_norm_stats, score_bias);
+        kp_norm_stats, score_bias, kp_mean);
     PAPR_CHECK_LAUNCH("tail_bwd");
     return 0;
 }

@@ -13,7 +13,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PAPR_HIP_LIB", os.path.join(_PKG, "libpapr_hip.so"))   # override: instrumented builds (scripts/probes)
 
 ACT = {"none": 0, "relu": 1, "leakyrelu": 2}
-EXPECTED_ABI = 24
+EXPECTED_ABI = 25
 # `mode` argument of papr_mlp_fwd / papr_mlp_bwd (include/papr_hip.h: PAPR_MLP_*)
 MLP_MODES = {"h3": 0, "h1": 1, "f32": 2, "fwd": 3, "dgrad": 4, "layers": 5, "h1_f32rows": 6}
 # process-wide A/B switches of the library (papr_set_switch; PAPR_SW_* in include/papr_hip.h).  The library itself reads no environment:
@@ -46,7 +46,7 @@ class Layer(C.Structure):
 class RowNorm(C.Structure):
     _fields_ = [("eps", C.c_float), ("width", C.c_int32), ("stats", C.c_void_p),
                 ("dot_rows", C.c_void_p), ("ld_dot", C.c_int32), ("rows_per_dot", C.c_int32), ("dots", C.c_void_p),
-                ("given_mean", C.c_void_p)]
+                ("given_mean", C.c_void_p), ("raw_mean", C.c_void_p)]
 
 
 class ProfileRecord(C.Structure):
@@ -136,7 +136,7 @@ def lib():
     L.papr_mlp_bwd.argtypes = [C.POINTER(Layer), i32, vp, i32, i64, C.POINTER(vp), C.POINTER(C.c_int32), vp, vp, vp, vp,
                                i32, C.POINTER(vp), C.POINTER(vp), vp, vp, i32, vp]
     L.papr_attn_tail_fwd.argtypes = [C.POINTER(TailDesc), vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp]
-    L.papr_attn_tail_bwd.argtypes = [C.POINTER(TailDesc), vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.papr_attn_tail_bwd.argtypes = [C.POINTER(TailDesc), vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.papr_profile_enable.argtypes = [i32]
     L.papr_profile_collect.argtypes = [C.POINTER(ProfileRecord), i32]
     L.papr_set_switch.argtypes = [i32, i32]

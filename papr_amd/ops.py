@@ -426,17 +426,19 @@ class LayerOutputs(list):
     """The saved activations of one chain plus the per-row input maxima papr_mlp_fwd leaves for papr_mlp_bwd."""
     row_absmax = None
     norm_stats = None
+    norm_mean = None       # (raw_rows) the last output holds the UN-standardised rows, this their means
     in_stats = None
     dots = None
 
 
-def mlp_forward(spec, ws, bs, x, M, keep=True, out_norm=None, in_norm=None, dot_rows=None, rows_per_dot=1):
+def mlp_forward(spec, ws, bs, x, M, keep=True, out_norm=None, in_norm=None, dot_rows=None, rows_per_dot=1, raw_rows=False):
     """Run the chain; returns the list of layer outputs (all kept, or two ping-pong buffers).
     out_norm = (width, eps): the last output comes back row-standardised (LayerNorm core), outs.norm_stats holds
     the (M, 2) statistics papr_rownorm_bwd needs.  in_norm = (width, eps): x is standardised first (outs.in_stats; x itself
     is overwritten, except in inference inside a fused run, where nobody reads it again).
     dot_rows (with out_norm): outs.dots (M,) = standardised row m . dot_rows[m // rows_per_dot]; without `keep` the last output
-    itself is then undefined (a fused run does not write it)."""
+    itself is then undefined (a fused run does not write it).  raw_rows (with dot_rows and keep; fused runs only -- the library refuses
+    otherwise): the last output stays UN-standardised, outs.norm_mean (M,) holds the rows' means (papr_row_norm.raw_mean)."""
     dev = x.device
     outs = LayerOutputs()
     if keep:
@@ -461,6 +463,9 @@ def mlp_forward(spec, ws, bs, x, M, keep=True, out_norm=None, in_norm=None, dot_
         if dot_rows is not None:
             outs.dots = torch.empty(M, device=dev, dtype=torch.float32)
             rn.dot_rows, rn.ld_dot, rn.rows_per_dot, rn.dots = dot_rows.data_ptr(), dot_rows.stride(0), rows_per_dot, outs.dots.data_ptr()
+            if raw_rows and keep:
+                outs.norm_mean = torch.empty(M, device=dev, dtype=torch.float32)
+                rn.raw_mean = outs.norm_mean.data_ptr()
         norm = C.byref(rn)
     hip.check(hip.lib().papr_mlp_fwd(tab, spec.n_layer, hip.ptr(x), x.shape[1], M, hip.ptr_array(outs),
                                      hip.i32_array(spec.ld_out), hip.ptr(outs.row_absmax), inorm, norm,
@@ -470,6 +475,7 @@ def mlp_forward(spec, ws, bs, x, M, keep=True, out_norm=None, in_norm=None, dot_
 
 _ws_cache = {}
 _SCORES_IN_RUN = os.environ.get("PAPR_SCORES_IN_RUN", "1") != "0"
+_RAW_KEYS = os.environ.get("PAPR_RAW_KEYS", "1") != "0"        # A/B: training keeps the key embedding un-standardised (papr_row_norm.raw_mean), tail_bwd standardises on the fly
 _KEY_STATS = os.environ.get("PAPR_KEY_STATS", "1") != "0"      # A/B: the key rows' LayerNorm statistics from papr_build_features_fwd (default) or from the fused run
 
 
@@ -762,8 +768,14 @@ class _RenderFn(torch.autograd.Function):
         # (1 KB per pair out and back in again otherwise), in training the attention tail does not read it back (the backward pass does);
         # PAPR_SCORES_IN_RUN=0 for the A/B
         in_run = plan.kq_norm and _SCORES_IN_RUN
+        # training: the key embedding stays RAW in memory (its only reader, the tail's backward pass, standardises what it loads): the fused run's
+        # last row phase then takes no row statistics.  Only where the whole key MLP is one fused run (every width a multiple of 32, the fused modes)
+        raw_keys = (in_run and keep and _RAW_KEYS and mlp_mode(plan.key.one_product) in (hip.MLP_MODES["h3"], hip.MLP_MODES["h1"], hip.MLP_MODES["h1_f32rows"])
+                    and 2 <= plan.key.n_layer <= 8 and all(L["n_out"] % 32 == 0 and L["n_out"] <= 256 and not L["skip"] for L in plan.key.layers)
+                    and plan.key.last_act == hip.ACT["none"])
         k_outs = mlp_forward(plan.key, kw, kb, key_in, M, keep, (plan.key.d_out, eps) if plan.kq_norm else None,
-                             ((plan.key_w, eps) + (key_given or ())) if plan.kq_norm else None, dot_rows=g if in_run else None, rows_per_dot=k)
+                             ((plan.key_w, eps) + (key_given or ())) if plan.kq_norm else None, dot_rows=g if in_run else None, rows_per_dot=k,
+                             raw_rows=raw_keys)
         K = k_outs[-1]
         kst, qst, kst2, qst2 = k_outs.in_stats, q_outs.in_stats, k_outs.norm_stats, q_outs.norm_stats
         v_outs = mlp_forward(plan.val, vw, vb, val_in, M, keep)
@@ -828,7 +840,7 @@ class _RenderFn(torch.autograd.Function):
                                          R, hip.ptr(s["scores"]), hip.ptr(s["attn"]), hip.ptr(d_fused), hip.ptr(d_attn), hip.ptr(d_K),
                                          hip.ptr(d_g), hip.ptr(d_V), None, hip.ptr(d_c0), hip.ptr(pair_influ),
                                          hip.ptr(s["kst2"]) if plan.kq_norm else None, hip.ptr(s["c0"]) if plan.kq_norm else None,
-                                         hip.stream_ptr()), "papr_attn_tail_bwd")
+                                         hip.ptr(s["k_outs"].norm_mean), hip.stream_ptr()), "papr_attn_tail_bwd")
         # backward of g = q' W_k, c0 = q'.b_k: R-row products on the library's GEMMs (rocBLAS / hipBLASLt pick 130-270 us
         # kernels for these 25,600 x 256 shapes; the same work is ~100 us here)
         qp = s["qp"]

@@ -32,6 +32,7 @@ import sys
 ABLATE = os.environ.get("C4F_ABLATE", "")      # timing experiments (scripts/probes/c4_variant.sh with -DC4_FUSED_INC=...)
 PRIO = os.environ.get("C4F_PRIO", "")          # timing experiment: s_setprio flips inside the statement (operand [role]: 1 for the SIMD's older wave): "half" = the
                                                # younger wave ahead in the first half, the older in the second; "young" = the younger ahead throughout
+STMOD = os.environ.get("C4F_STORE_MOD", "")    # timing experiment: cache-policy bits on the row stores (" sc1", " nt", " sc0 sc1", ...)
 KVAR = os.environ.get("C4F_KVAR", "")          # timing experiments on the k-loop (with C4F_ABLATE=K: the row-phase temporaries are free): noread | dbuf | dbufh
 
 F = {"l0": "v[28:31]", "l1": "v[32:35]", "h0": "v[36:39]", "h1": "v[40:43]"}
@@ -328,7 +329,7 @@ def p2_stream(acc_u, mode, one=False):
                     it.append(Item("v_xor_b32 %s, 0x%x, %%[rdb]" % (AD, 528 * sx)))
                     src = AD
                 it.append(Item("ds_read_b128 %s, %s" % (R[sx & 1], src), lds=("rb", sx), kind="lds"))
-                it.append(Item("global_store_dwordx4 %%[gso], %s, %%[crow0] offset:%d" % (R[sx & 1], 512 * sx), need=[("rb", sx)], kind="vmem"))
+                it.append(Item("global_store_dwordx4 %%[gso], %s, %%[crow0] offset:%d%s" % (R[sx & 1], 512 * sx, STMOD), need=[("rb", sx)], kind="vmem"))
         return it
     if train:
         # ---- the rows: into the wave's own 128 bytes of every plane row (where its split goes afterwards) ...
@@ -347,7 +348,7 @@ def p2_stream(acc_u, mode, one=False):
                 it.append(Item("v_xor_b32 %s, 0x%x, %%[rdb]" % (AD2, 528 * (sx & 3))))
                 src = AD2
             it.append(Item("ds_read_b128 %s, %s offset:%d" % (R[sx & 1], src, 32768 * (sx >> 2)), lds=("rb", sx), kind="lds"))
-            it.append(Item("global_store_dwordx4 %%[gso], %s, %%[crow%d] offset:%d" % (R[sx & 1], sx >> 2, 1024 * (sx & 3)), need=[("rb", sx)], kind="vmem"))
+            it.append(Item("global_store_dwordx4 %%[gso], %s, %%[crow%d] offset:%d%s" % (R[sx & 1], sx >> 2, 1024 * (sx & 3), STMOD), need=[("rb", sx)], kind="vmem"))
     # ---- split into the planes
     HS = [[["v%d" % (GB + 4 * s + j) for j in range(4)] for s in range(2)]] * 2      # [set][hi / lo][4] (one set: registers are scarce)
     k = 0

@@ -22,7 +22,7 @@ dots = torch.randn((M + 19) // 20, 256, device=d) if norm and os.environ.get("DO
 for _ in range(3):
     x = x0.clone()
     outs = ops.mlp_forward(spec, ws, bs, x, M, keep=mode != "inf", out_norm=(d_out, 1e-6) if norm else None, in_norm=(d_in, 1e-6) if norm else None,
-                           dot_rows=dots, rows_per_dot=20)
+                           dot_rows=dots, rows_per_dot=20, raw_rows=bool(os.environ.get("RAW")) and mode != "inf")
     if mode == "bwd":
         ops.mlp_backward(spec, ws, bs, x, M, outs, gy.clone(), scratch, True)
 torch.cuda.synchronize()

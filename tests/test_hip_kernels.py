@@ -504,6 +504,19 @@ def test_row_dots_from_the_last_row_phase(R, k, d_in, width, d_out, n):
     if M2:
         part = ops.mlp_forward(spec, ew, eb, xp[:M2].to(d), M2, keep=False, out_norm=(d_out, eps), dot_rows=gd, rows_per_dot=k)
         assert torch.equal(part.dots, inf.dots[:M2])
+    # raw rows (papr_row_norm.raw_mean, ABI 25; fused runs only): the last output un-standardised + the rows' means; standardising them with the
+    # two instructions the run would have used gives the bits of the standardised rows; statistics and dots unchanged
+    fused_run = n >= 2 and all(L["n_out"] % 32 == 0 for L in spec.layers)
+    if fused_run:
+        raw = ops.mlp_forward(spec, ew, eb, xp.to(d), M, keep=True, out_norm=(d_out, eps), dot_rows=gd, rows_per_dot=k, raw_rows=True)
+        assert raw.norm_mean is not None and torch.equal(raw.norm_stats, kept.norm_stats) and torch.equal(raw.dots, kept.dots)
+        assert torch.equal((raw[-1][:, :d_out] - raw.norm_mean[:, None]) * raw.norm_stats[:, :1], rows[:, :d_out])
+        nonorm = ops.mlp_forward(spec, ew, eb, xp.to(d), M, keep=False)
+        assert torch.equal(raw[-1][:, :d_out], nonorm[-1][:, :d_out])
+        np.testing.assert_allclose(raw.norm_mean.cpu().numpy(), nonorm[-1][:, :d_out].double().mean(1).cpu().numpy(), rtol=0, atol=1e-5)
+    else:
+        with pytest.raises(RuntimeError):           # no silent fallback: asked of a chain that is no fused run, the call fails
+            ops.mlp_forward(spec, ew, eb, xp.to(d), M, keep=True, out_norm=(d_out, eps), dot_rows=gd, rows_per_dot=k, raw_rows=True)
 
 
 @pytest.mark.parametrize("M,d_in,width,d_out,n", [(24680, 117, 256, 256, 5), (1220, 39, 256, 64, 3), (6000, 27, 64, 32, 2), (45, 117, 256, 256, 5)])
@@ -583,7 +596,7 @@ def test_attention_tail_forward_backward(R, k, d_model, Cc, act, normalize):
     gf_d, ga_d = gf.to(d), ga.to(d)
     hip.check(hip.lib().papr_attn_tail_bwd(C.byref(td), hip.ptr(kpd), hip.ptr(qpd), hip.ptr(vd), hip.ptr(infd), hip.ptr(idxd), R,
                                            hip.ptr(scores), hip.ptr(attn), hip.ptr(gf_d), hip.ptr(ga_d), hip.ptr(d_kp),
-                                           hip.ptr(d_qp), hip.ptr(d_v), hip.ptr(d_inf), hip.ptr(d_sb), None, None, None, hip.stream_ptr()), "tail_bwd")
+                                           hip.ptr(d_qp), hip.ptr(d_v), hip.ptr(d_inf), hip.ptr(d_sb), None, None, None, None, hip.stream_ptr()), "tail_bwd")
     torch.cuda.synchronize()
     tol = lambda ref: 3e-5 * ref.abs().max().item() + 1e-9
     np.testing.assert_allclose(d_kp.cpu().numpy(), kp.grad.reshape(R * k, -1).numpy(), rtol=0, atol=tol(kp.grad))
@@ -632,12 +645,31 @@ def test_attention_tail_backward_through_standardised_keys(R, k, d_model, act):
     gf_d, ga_d = gf.to(d), ga.to(d)                                  # (kept alive: a temporary's block would be handed to the next one)
     hip.check(hip.lib().papr_attn_tail_bwd(C.byref(td), hip.ptr(kpd), hip.ptr(qpd), hip.ptr(vd), hip.ptr(infd), hip.ptr(idxd), R,
                                            hip.ptr(scores), hip.ptr(attn), hip.ptr(gf_d), hip.ptr(ga_d), hip.ptr(d_x),
-                                           hip.ptr(d_qp), hip.ptr(d_v), hip.ptr(d_inf), None, None, hip.ptr(stats), hip.ptr(sbd),
+                                           hip.ptr(d_qp), hip.ptr(d_v), hip.ptr(d_inf), None, None, hip.ptr(stats), hip.ptr(sbd), None,
                                            hip.stream_ptr()), "tail_bwd")
     torch.cuda.synchronize()
     tol = lambda ref: 1e-4 * ref.abs().max().item() + 1e-9
     np.testing.assert_allclose(d_x.cpu().numpy(), x.grad.reshape(R * k, -1).numpy(), rtol=0, atol=tol(x.grad))
     np.testing.assert_allclose(d_qp.cpu().numpy(), qp.grad.reshape(R, -1).numpy(), rtol=0, atol=tol(qp.grad))
+    # kp_mean (ABI 25): the key rows RAW, standardised as they are read -- the same bits as from the standardised rows.  Raw rows whose
+    # (x - mean) * rinv reproduces kpd exactly: x = kpd / rinv + mean need not round-trip, so build them the other way round
+    raw = (torch.randn(R * k, d_model, generator=torch.Generator().manual_seed(R)) * 2.0 + 0.3).to(d)
+    mean = raw.mean(1)
+    st2 = torch.stack([1.0 / (raw.std(1) + 1e-6), raw.std(1)], 1).contiguous()
+    std_rows = ((raw - mean[:, None]) * st2[:, :1]).contiguous()
+    outs = []
+    for rows, mptr in ((std_rows, None), (raw, hip.ptr(mean))):
+        hip.check(hip.lib().papr_attn_tail_fwd(C.byref(td), hip.ptr(std_rows), hip.ptr(qpd), hip.ptr(sbd), hip.ptr(vd), hip.ptr(infd), hip.ptr(idxd), R,
+                                               hip.ptr(scores), hip.ptr(attn), hip.ptr(fused), hip.stream_ptr()), "tail_fwd")
+        a, b, c_ = torch.empty_like(kpd), torch.empty_like(qpd), torch.empty_like(vd)
+        hip.check(hip.lib().papr_attn_tail_bwd(C.byref(td), hip.ptr(rows), hip.ptr(qpd), hip.ptr(vd), hip.ptr(infd), hip.ptr(idxd), R,
+                                               hip.ptr(scores), hip.ptr(attn), hip.ptr(gf_d), hip.ptr(ga_d), hip.ptr(a),
+                                               hip.ptr(b), hip.ptr(c_), hip.ptr(d_inf), None, None, hip.ptr(st2), hip.ptr(sbd), mptr,
+                                               hip.stream_ptr()), "tail_bwd")
+        outs.append((a.clone(), b.clone(), c_.clone()))
+    torch.cuda.synchronize()
+    for u, w_ in zip(outs[0], outs[1]):
+        assert torch.equal(u, w_), "raw key rows standardised on the fly must give the bits of standardised rows"
 
 
 @pytest.mark.parametrize("n_out,n_in,ld_eff", [(256, 117, 120), (256, 256, 256), (32, 39, 40), (5, 3, 8)])
