@@ -103,7 +103,11 @@ int papr_build_features_bwd(const papr_feature_desc* d, const float* points, con
  * index_put_(accumulate=True) backward of the three gathers, models/model.py:330,435,509). */
 int papr_build_features_bwd_pairs(const papr_feature_desc* d, const float* points, const float* rays_o,
                                   const float* rays_d, int64_t R, int64_t rays_per_image, const int32_t* idx,
-                                  const float* d_key, const float* d_val, float* d_pair_points, papr_stream_t stream);
+                                  const float* d_key, const float* d_val, float* d_pair_points,
+                                  const float* key_mean, const float* key_stats, papr_stream_t stream);
+/* key_mean / key_stats (ABI 25; both or neither; what papr_build_features_fwd wrote; not with key_has_feats): d_key is the gradient w.r.t. the
+ * STANDARDISED key rows (the LayerNorm core in front of the key MLP) and its backward pass rides in this kernel -- the standardised values are
+ * recomputed from the encodings, no papr_rownorm_bwd pass over the (R*k, 117) rows. */
 
 /* order (M = R*k) int64: pair ids grouped by selected point (a stable sort of idx); sorted_pts (M) int32:
  * the point of each entry; seg (P+1) int64: group bounds.  d_points[p] += sum of pair_points rows,

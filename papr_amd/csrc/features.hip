@@ -219,13 +219,49 @@ __device__ __forceinline__ void pe_grad(const float* __restrict__ g, const float
     }
 }
 
+// The same through a LayerNorm core in front (FeedForward.innorm of the key MLP, models/attn.py:39-42): g is the gradient w.r.t. the STANDARDISED
+// row y = (pe - mean) * rinv, and what is wanted is the gradient w.r.t. x through  d_pe = rinv (g - mean(g)) - y sum(g y) / ((n - 1) sigma)
+// (rownorm_bwd_kernel's formula).  pe_grad is linear in its gradient row, so  out(d_pe) = rinv (F(g) - mean(g) F(1)) - coef F(y)  with F the
+// functional above: this routine gathers F(g), F(1), F(y) for one 3-vector and the row's two sums over THIS block -- the caller combines them
+// once every block of the row has been seen.  y is recomputed from the sines and cosines the coefficients need anyway (the bits features_fwd
+// wrote and the fused run standardised), so the standardised key rows are not read at all.
+struct LnSums { float sg, sgy; };
+__device__ __forceinline__ void pe_grad_ln(const float* __restrict__ g, const float x[3], int L, int with_self, float factor, float mult,
+                                           float mean, float rinv, LnSums& sums, float Fg[3], float F1[3], float Fy[3]) {
+    const int per = with_self + 2 * L;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float* gc = g + c * per;
+        float ag = 0.f, a1 = 0.f, ay = 0.f;
+        if (with_self) {
+            const float g0 = *gc++, y0 = (x[c] - mean) * rinv;
+            sums.sg += g0; sums.sgy += g0 * y0;
+            ag = g0; a1 = 1.f; ay = y0;
+        }
+        float f = 1.0f;
+        for (int i = 0; i < L; ++i) {
+            float sn, co;
+            sincosf((f * x[c]) * mult, &sn, &co);
+            const float ys = (sn - mean) * rinv, yc = (co - mean) * rinv, gsn = gc[2 * i], gco = gc[2 * i + 1], kf = f * mult;
+            sums.sg += gsn + gco;
+            sums.sgy += gsn * ys + gco * yc;
+            ag += kf * (gsn * co - gco * sn);
+            a1 += kf * (co - sn);
+            ay += kf * (ys * co - yc * sn);
+            f *= factor;
+        }
+        Fg[c] += ag; F1[c] += a1; Fy[c] += ay;
+    }
+}
+
 __global__ __launch_bounds__(256) void features_bwd_kernel(FeatParams fp, const float* __restrict__ points,
                                                            const float* __restrict__ rays_o,
                                                            const float* __restrict__ rays_d, long R,
                                                            long rays_per_image, const int* __restrict__ idx,
                                                            const float* __restrict__ d_key,
                                                            const float* __restrict__ d_val,
-                                                           float* __restrict__ d_points, float4* __restrict__ d_pair, int pitch) {
+                                                           float* __restrict__ d_points, float4* __restrict__ d_pair, int pitch,
+                                                           const float* __restrict__ key_mean, const float* __restrict__ key_stats) {
     extern __shared__ float feat_lds[];
     const papr_feature_desc& d = fp.d;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -253,7 +289,33 @@ __global__ __launch_bounds__(256) void features_bwd_kernel(FeatParams fp, const 
         wave_lds_sync();
         return w;
     };
-    if (d_key) {
+    if (d_key && key_mean) {
+        // d_key is the gradient w.r.t. the STANDARDISED key rows: the LayerNorm core's backward pass rides here (before: papr_rownorm_bwd, a pass that
+        // read the gradient rows and the standardised rows and wrote the gradient rows back: 720 MB per step).  The pe(p) block gets no gradient
+        // (points.detach(), models/model.py:405) but its columns belong to the row's two sums.
+        const float mean = key_mean[m], rinv = key_stats[2 * m], sigma = key_stats[2 * m + 1];
+        const float p3[3] = {points[pi * 3 + 0], points[pi * 3 + 1], points[pi * 3 + 2]};
+        LnSums sums = {0.f, 0.f};
+        float Fg[3][3] = {}, F1[3][3] = {}, Fy[3][3] = {};
+        auto absorb_ln = [&](int c0, const float x[3], int L, int b) -> int {
+            const int w = pe_width(L, d.with_self);
+            wave_fetch(buf, pitch, w, d_key, d.ld_key, c0, m0, M);
+            wave_lds_sync();
+            pe_grad_ln(row, x, L, d.with_self, d.pe_factor, d.pe_mult, mean, rinv, sums, Fg[b], F1[b], Fy[b]);
+            wave_lds_sync();
+            return w;
+        };
+        int c = absorb_ln(0, p3, d.L_key[0], 0);
+        c += absorb_ln(c, s, d.L_key[1], 1);
+        c += absorb_ln(c, u, d.L_key[2], 2);
+        const float n = (float)c, gbar = sums.sg / n;
+        const float coef = sigma > 0.f ? sums.sgy / ((n - 1.f) * sigma) : 0.f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            gs[j] += rinv * (Fg[1][j] - gbar * F1[1][j]) - coef * Fy[1][j];
+            gu[j] += rinv * (Fg[2][j] - gbar * F1[2][j]) - coef * Fy[2][j];
+        }
+    } else if (d_key) {
         int c = pe_width(d.L_key[0], d.with_self);                       // skip pe(p): detached
         c += absorb(d_key, d.ld_key, c, s, d.L_key[1], gs);
         absorb(d_key, d.ld_key, c, u, d.L_key[2], gu);
@@ -478,7 +540,7 @@ extern "C" int papr_build_features_bwd(const papr_feature_desc* d, const float* 
     const int pitch = stage_pitch(d);
     PAPR_REQUIRE(pitch <= 129, "papr_build_features_bwd: encoding orders too large for the staging buffer");
     features_bwd_kernel<<<dim3((unsigned)((M + 255) / 256)), dim3(256), (size_t)4 * 64 * pitch * sizeof(float), s>>>(
-        fp, points, rays_o, rays_d, R, rays_per_image, idx, d_key, d_val, d_points, nullptr, pitch);
+        fp, points, rays_o, rays_d, R, rays_per_image, idx, d_key, d_val, d_points, nullptr, pitch, nullptr, nullptr);
     PAPR_CHECK_LAUNCH("features_bwd");
     if (d_pc_feats) {
         long n = M * (d->feat_dim / 4);
@@ -499,8 +561,10 @@ extern "C" int papr_build_features_bwd(const papr_feature_desc* d, const float* 
 extern "C" int papr_build_features_bwd_pairs(const papr_feature_desc* d, const float* points, const float* rays_o,
                                              const float* rays_d, int64_t R, int64_t rays_per_image, const int32_t* idx,
                                              const float* d_key, const float* d_val, float* d_pair_points,
-                                             papr_stream_t stream) {
+                                             const float* key_mean, const float* key_stats, papr_stream_t stream) {
     PAPR_REQUIRE(d && points && rays_o && rays_d && idx && d_pair_points, "papr_build_features_bwd_pairs: null pointer");
+    PAPR_REQUIRE((key_mean == nullptr) == (key_stats == nullptr) && !(key_mean && (d->key_has_feats || !d_key)),
+                 "papr_build_features_bwd_pairs: key_mean and key_stats come together, with d_key, and not with key_has_feats");
     FeatParams fp;
     fill_params(d, &fp);
     if (int e = check_desc(d, fp, "papr_build_features_bwd_pairs")) return e;
@@ -509,7 +573,7 @@ extern "C" int papr_build_features_bwd_pairs(const papr_feature_desc* d, const f
     const int pitch = stage_pitch(d);
     PAPR_REQUIRE(pitch <= 129, "papr_build_features_bwd_pairs: encoding orders too large for the staging buffer");
     features_bwd_kernel<<<dim3((unsigned)((M + 255) / 256)), dim3(256), (size_t)4 * 64 * pitch * sizeof(float), as_stream(stream)>>>(
-        fp, points, rays_o, rays_d, R, rays_per_image, idx, d_key, d_val, nullptr, reinterpret_cast<float4*>(d_pair_points), pitch);
+        fp, points, rays_o, rays_d, R, rays_per_image, idx, d_key, d_val, nullptr, reinterpret_cast<float4*>(d_pair_points), pitch, key_mean, key_stats);
     PAPR_CHECK_LAUNCH("features_bwd(pairs)");
     return 0;
 }

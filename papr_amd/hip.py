@@ -88,7 +88,7 @@ def lib():
     L.papr_feature_widths.argtypes = [C.POINTER(FeatureDesc), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.papr_build_features_fwd.argtypes = [C.POINTER(FeatureDesc), vp, vp, vp, vp, i64, i64, vp, vp, vp, vp, vp, vp, vp, C.c_float, vp]
     L.papr_build_features_bwd.argtypes = [C.POINTER(FeatureDesc), vp, vp, vp, i64, i64, vp, vp, vp, vp, vp, vp]
-    L.papr_build_features_bwd_pairs.argtypes = [C.POINTER(FeatureDesc), vp, vp, vp, i64, i64, vp, vp, vp, vp, vp]
+    L.papr_build_features_bwd_pairs.argtypes = [C.POINTER(FeatureDesc), vp, vp, vp, i64, i64, vp, vp, vp, vp, vp, vp, vp]
     L.papr_segment_reduce.argtypes = [vp, vp, vp, i64, i64, vp, vp, vp, i32, i32, i32, vp, vp, vp, i32, vp, vp]
     L.papr_segment_reduce_workspace_bytes.restype = C.c_size_t
     L.papr_segment_reduce_workspace_bytes.argtypes = [i64]

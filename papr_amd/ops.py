@@ -475,6 +475,7 @@ def mlp_forward(spec, ws, bs, x, M, keep=True, out_norm=None, in_norm=None, dot_
 
 _ws_cache = {}
 _SCORES_IN_RUN = os.environ.get("PAPR_SCORES_IN_RUN", "1") != "0"
+_LN_IN_FEATURES = os.environ.get("PAPR_LN_IN_FEATURES", "1") != "0"     # A/B: the key in-norm's backward pass inside papr_build_features_bwd_pairs (0: papr_rownorm_bwd)
 _RAW_KEYS = os.environ.get("PAPR_RAW_KEYS", "1") != "0"        # A/B: training keeps the key embedding un-standardised (papr_row_norm.raw_mean), tail_bwd standardises on the fly
 _KEY_STATS = os.environ.get("PAPR_KEY_STATS", "1") != "0"      # A/B: the key rows' LayerNorm statistics from papr_build_features_fwd (default) or from the fused run
 
@@ -794,7 +795,7 @@ class _RenderFn(torch.autograd.Function):
             order, sorted_pts, seg = group_pairs(idx.view(-1), points.shape[0], run=k)
             ctx.saved = dict(rays_o=rays_o, rays_d=rays_d, idx=idx, points=points, influ=influ, key_in=key_in, qry_in=qry_in,
                              val_in=val_in, kst=kst, qst=qst, kst2=kst2, qst2=qst2, k_outs=k_outs, q_outs=q_outs,
-                             v_outs=v_outs, g=g, c0=c0, qp=qp, order=order, sorted_pts=sorted_pts, seg=seg, scores=scores, attn=attn, wb=wb, P=points.shape[0],
+                             v_outs=v_outs, g=g, c0=c0, qp=qp, key_given=key_given, order=order, sorted_pts=sorted_pts, seg=seg, scores=scores, attn=attn, wb=wb, P=points.shape[0],
                              feat_shape=None if pc_feats is None else pc_feats.shape)
         return fused, attn, sel
 
@@ -855,7 +856,10 @@ class _RenderFn(torch.autograd.Function):
         # key branch
         need_pts = ctx.needs_input_grad[6]
         d_kw, d_kb, d_key = mlp_backward(plan.key, kw, kb, s["key_in"], M, s["k_outs"], d_K, scratch, need_pts)
-        if plan.kq_norm and d_key is not None:
+        # the backward pass of the LayerNorm core in front of the key MLP rides in papr_build_features_bwd_pairs where that kernel has the row's
+        # statistics from the forward pass (key_given: the default); otherwise one papr_rownorm_bwd pass over the gradient rows
+        ln_in_features = plan.kq_norm and d_key is not None and s["key_given"] is not None and _LN_IN_FEATURES
+        if plan.kq_norm and d_key is not None and not ln_in_features:
             rownorm_bwd_(d_key, s["key_in"], s["kst"], plan.key_w, eps)
         # query branch (the ray directions need no gradient)
         qscratch = [t[:R] for t in scratch]
@@ -874,6 +878,8 @@ class _RenderFn(torch.autograd.Function):
             fd = plan.feature_desc(k)
             hip.check(lib.papr_build_features_bwd_pairs(C.byref(fd), hip.ptr(s["points"]), hip.ptr(s["rays_o"]), hip.ptr(s["rays_d"]), R,
                                                         ctx.rpi, hip.ptr(idx), hip.ptr(d_key), hip.ptr(d_val), hip.ptr(pair_pts),
+                                                        hip.ptr(s["key_given"][1]) if ln_in_features else None,
+                                                        hip.ptr(s["key_given"][0]) if ln_in_features else None,
                                                         hip.stream_ptr()), "papr_build_features_bwd_pairs")
             d_points = per_point[n_feat:n_feat + 3 * n_pts].view(n_pts, 3)
         fdim = plan.feat_dim

@@ -354,7 +354,7 @@ def test_features_backward_pairs_plus_segment_reduce_is_the_product_path():
     idx_d, gk_d, gv_d = idx.reshape(R, k).int().to(d), gk_p.to(d), gv_p.to(d)
     pair_pts = torch.empty((M, 4), device=d)
     hip.check(hip.lib().papr_build_features_bwd_pairs(C.byref(fd), hip.ptr(pts_d), hip.ptr(ro_d), hip.ptr(rd_d), R, rd.shape[1] * rd.shape[2],
-                                                      hip.ptr(idx_d), hip.ptr(gk_d), hip.ptr(gv_d), hip.ptr(pair_pts), hip.stream_ptr()), "bwd_pairs")
+                                                      hip.ptr(idx_d), hip.ptr(gk_d), hip.ptr(gv_d), hip.ptr(pair_pts), None, None, hip.stream_ptr()), "bwd_pairs")
     order, sorted_pts, seg = _segment_inputs(idx_d.view(-1), P)
     d_pts, d_f = torch.zeros((P, 3), device=d), torch.zeros((P, 64), device=d)
     ws = torch.empty(hip.lib().papr_segment_reduce_workspace_bytes(M) // 4, device=d)
@@ -364,6 +364,65 @@ def test_features_backward_pairs_plus_segment_reduce_is_the_product_path():
     ref, fref = st["points"].grad, st["pc_feats"].grad
     np.testing.assert_allclose(d_pts.cpu().numpy(), ref.numpy(), rtol=0, atol=2e-4 * ref.abs().max().item())
     np.testing.assert_allclose(d_f.cpu().numpy(), fref.numpy(), rtol=0, atol=3e-6 * fref.abs().max().item())
+
+
+def test_features_backward_with_the_key_layernorm_core_inside():
+    """key_mean / key_stats of papr_build_features_bwd_pairs (ABI 25): d_key is the gradient w.r.t. the STANDARDISED key rows and the LayerNorm core's
+    backward pass rides in the kernel -- against autograd through the oracle's feature construction + custom_layernorm (models/attn.py:39-42), and
+    against the two-kernel form it replaces (papr_rownorm_bwd on the gradient rows, then the plain kernel)."""
+    from papr_amd import hip, ops
+    tag = "chair1k"
+    g = golden("g567_%s.npz" % tag)
+    cfg, plan = _plan(tag)
+    from conftest import case_rays
+    ro, rd, _ = case_rays(tag)
+    idx = T(g["idx_raw"]).long()
+    P = g["points"].shape[0]
+    gen = torch.Generator().manual_seed(6)
+    st = {"points": T(g["points"]).clone().requires_grad_(True), "pc_feats": torch.randn(P, 64, generator=gen)}
+    key_o, _, val_o, _, _, _ = O.build_inputs(st, cfg, ro, rd, idx)
+    w = plan.key_w
+    key_n = O.custom_layernorm(key_o, torch.ones(w), torch.zeros(w), plan.eps)
+    gk, gv = torch.randn(key_o.shape, generator=gen), torch.randn(val_o.shape, generator=gen)
+    (key_n * gk).sum().add((val_o * gv).sum()).backward()
+    R, k = idx.reshape(-1, idx.shape[-1]).shape
+    M = R * k
+    d = dev()
+    fd = plan.feature_desc(k)
+    pts_d, ro_d, rd_d = st["points"].detach().to(d), ro.to(d), rd.reshape(-1, 3).contiguous().to(d)
+    idx_d = idx.reshape(R, k).int().to(d)
+    # forward on the device: raw key rows + their statistics, as the render path gets them
+    key_in = torch.empty((M, plan.key.ld_in), device=d); qry_in = torch.empty((R, plan.qry.ld_in), device=d); val_in = torch.empty((M, plan.val.ld_in), device=d)
+    sel = torch.empty((M, 3), device=d); kstats = torch.empty((M, 2), device=d); kmean = torch.empty((M,), device=d)
+    hip.check(hip.lib().papr_build_features_fwd(C.byref(fd), hip.ptr(pts_d), hip.ptr(st["pc_feats"].to(d)), hip.ptr(ro_d), hip.ptr(rd_d), R, rd.shape[1] * rd.shape[2],
+                                                hip.ptr(idx_d), hip.ptr(key_in), hip.ptr(qry_in), hip.ptr(val_in), hip.ptr(sel), hip.ptr(kstats), hip.ptr(kmean),
+                                                plan.eps, hip.stream_ptr()), "features_fwd")
+    gk_p = torch.zeros((M, plan.key.ld_in)); gk_p[:, :w] = gk.reshape(M, -1)
+    gv_p = torch.zeros((M, plan.val.ld_in)); gv_p[:, :plan.val_w] = gv.reshape(M, -1)
+    gk_d, gv_d = gk_p.to(d), gv_p.to(d)
+    pair_a, pair_b = torch.empty((M, 4), device=d), torch.empty((M, 4), device=d)
+    hip.check(hip.lib().papr_build_features_bwd_pairs(C.byref(fd), hip.ptr(pts_d), hip.ptr(ro_d), hip.ptr(rd_d), R, rd.shape[1] * rd.shape[2],
+                                                      hip.ptr(idx_d), hip.ptr(gk_d), hip.ptr(gv_d), hip.ptr(pair_a), hip.ptr(kmean), hip.ptr(kstats), hip.stream_ptr()), "bwd_pairs")
+    # the two-kernel form: standardise the rows as the fused run's staging does, papr_rownorm_bwd, then the plain kernel
+    y = ((key_in[:, :w] - kmean[:, None]) * kstats[:, :1])
+    yp = torch.zeros_like(key_in); yp[:, :w] = y
+    gk2 = gk_d.clone()
+    ops.rownorm_bwd_(gk2, yp, kstats, w, plan.eps)
+    hip.check(hip.lib().papr_build_features_bwd_pairs(C.byref(fd), hip.ptr(pts_d), hip.ptr(ro_d), hip.ptr(rd_d), R, rd.shape[1] * rd.shape[2],
+                                                      hip.ptr(idx_d), hip.ptr(gk2), hip.ptr(gv_d), hip.ptr(pair_b), None, None, hip.stream_ptr()), "bwd_pairs")
+    order, sorted_pts, seg = _segment_inputs(idx_d.view(-1), P)
+    ws = torch.empty(hip.lib().papr_segment_reduce_workspace_bytes(M) // 4, device=d)
+    outs = []
+    for pair in (pair_a, pair_b):
+        d_pts = torch.zeros((P, 3), device=d)
+        hip.check(hip.lib().papr_segment_reduce(hip.ptr(order), hip.ptr(sorted_pts), hip.ptr(seg), M, P, hip.ptr(pair), None, None, 0, 0, 0,
+                                                hip.ptr(d_pts), None, None, 0, hip.ptr(ws), hip.stream_ptr()), "segment_reduce")
+        outs.append(d_pts.cpu())
+    ref = st["points"].grad
+    scale = ref.abs().max().item()
+    np.testing.assert_allclose(outs[0].numpy(), ref.numpy(), rtol=0, atol=3e-4 * scale)
+    np.testing.assert_allclose(outs[0].numpy(), outs[1].numpy(), rtol=0, atol=2e-5 * scale)      # the same arithmetic in another order
+    np.testing.assert_allclose(pair_a.cpu().numpy(), pair_b.cpu().numpy(), rtol=0, atol=2e-5 * pair_b.abs().max().item())
 
 
 # ------------------------------------------------------------------------------------- row norm
