@@ -26,32 +26,33 @@ struct FeatParams {
 __device__ __forceinline__ int pe_width(int L, int with_self) { return 3 * (with_self + 2 * L); }
 
 // write pe(x) for one 3-vector at dst (stride 1), returns number of floats written; s1 / s2 gather the sum of the values written and of their squares
-// (in double: squares of fp32 values are exact there and ~120 of them add up without a rounding that matters, so the one-pass variance below is
-// good for ANY row -- raw coordinates of +-50 in the Tanks&Temples scenes beside 108 sines and cosines included; fp64 VALU runs at the fp32 rate)
-template <typename Acc>
+// The sums behind the one-pass statistics of a row: the sines and cosines (|v| <= 1, ~2 L per component) add up in fp32 without a rounding that
+// matters; the RAW coordinates (with_self; +-50 and more in the Tanks&Temples scenes, squares of 2,500 beside 108 values of size one) go into
+// doubles, where their squares are exact -- nine double operations per vector instead of ~240 for the whole row (which cost features_fwd 26 us)
+struct PeSums { float t1, t2; double r1, r2; };
 __device__ __forceinline__ int write_pe(float* __restrict__ dst, const float x[3], int L, int with_self,
-                                        float factor, float mult, Acc& s1, Acc& s2) {
+                                        float factor, float mult, PeSums& a) {
     const int per = with_self + 2 * L;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         float* o = dst + c * per;
-        if (with_self) { *o++ = x[c]; s1 += (Acc)x[c]; s2 += (Acc)x[c] * (Acc)x[c]; }
+        if (with_self) { *o++ = x[c]; a.r1 += (double)x[c]; a.r2 += (double)x[c] * (double)x[c]; }
         float f = 1.0f;
         for (int i = 0; i < L; ++i) {
             float s, co;
             sincosf((f * x[c]) * mult, &s, &co);
             o[2 * i] = s;
             o[2 * i + 1] = co;
-            s1 += (Acc)s + (Acc)co;
-            s2 += (Acc)s * (Acc)s + (Acc)co * (Acc)co;
+            a.t1 += s + co;
+            a.t2 += s * s + co * co;
             f *= factor;
         }
     }
     return 3 * per;
 }
 __device__ __forceinline__ int write_pe(float* __restrict__ dst, const float x[3], int L, int with_self, float factor, float mult) {
-    float a = 0.f, b = 0.f;
-    return write_pe(dst, x, L, with_self, factor, mult, a, b);
+    PeSums a = {0.f, 0.f, 0.0, 0.0};
+    return write_pe(dst, x, L, with_self, factor, mult, a);
 }
 
 struct RayGeom {
@@ -152,9 +153,9 @@ __global__ __launch_bounds__(256) void features_fwd_kernel(FeatParams fp, const 
     float s[3] = {g.rx * t, g.ry * t, g.rz * t};
     float u[3] = {vx - s[0], vy - s[1], vz - s[2]};
 
-    double s1 = 0.0, s2 = 0.0;                      // sum and sum of squares of the row being written (this thread's)
+    PeSums sums = {0.f, 0.f, 0.0, 0.0};             // sum and sum of squares of the row being written (this thread's)
     auto emit = [&](const float x[3], int L, float* dst, long ld, int c0) -> int {
-        const int w = write_pe(row, x, L, d.with_self, d.pe_factor, d.pe_mult, s1, s2);
+        const int w = write_pe(row, x, L, d.with_self, d.pe_factor, d.pe_mult, sums);
         wave_lds_sync();
         wave_flush(buf, pitch, w, dst, ld, c0, m0, M);
         wave_lds_sync();
@@ -167,9 +168,9 @@ __global__ __launch_bounds__(256) void features_fwd_kernel(FeatParams fp, const 
     if (key_stats && mreal < M) {
         // the statistics of the LayerNorm core in front of the key MLP (FeedForward.innorm, models/attn.py:39-42: unbiased std, eps added to it), while
         // the row's values are in this thread's hands: the fused run that stages the rows then applies them (papr_row_norm.given_mean) instead of
-        // taking two wave sums, a square root and a division per row in its staging slot -- 8k of that slot's 12-15k cycles.  One pass, sums in
-        // double (write_pe): the difference below is exact to ~1e-13 of the sum of squares whatever the row holds
-        const double nd = (double)c, mean_d = s1 / nd;
+        // taking two wave sums, a square root and a division per row in its staging slot -- 8k of that slot's 12-15k cycles.  One pass (PeSums): the
+        // difference below is taken in double, where the large raw coordinates were added
+        const double nd = (double)c, s1 = sums.r1 + (double)sums.t1, s2 = sums.r2 + (double)sums.t2, mean_d = s1 / nd;
         const double var_d = (s2 - nd * mean_d * mean_d) / (nd - 1.0);
         const float mean = (float)mean_d;
         const float sigma = sqrtf((float)(var_d > 0.0 ? var_d : 0.0));

@@ -475,6 +475,7 @@ def mlp_forward(spec, ws, bs, x, M, keep=True, out_norm=None, in_norm=None, dot_
 
 _ws_cache = {}
 _SCORES_IN_RUN = os.environ.get("PAPR_SCORES_IN_RUN", "1") != "0"
+_QK_CHAIN = int(os.environ.get("PAPR_QK_CHAIN", "2"))           # A/B: 0 = w_q and the w_k fold as two single-layer calls each way; 1 = one two-layer run forward; 2 = backward as well
 _LN_IN_FEATURES = os.environ.get("PAPR_LN_IN_FEATURES", "1") != "0"     # A/B: the key in-norm's backward pass inside papr_build_features_bwd_pairs (0: papr_rownorm_bwd)
 _RAW_KEYS = os.environ.get("PAPR_RAW_KEYS", "1") != "0"        # A/B: training keeps the key embedding un-standardised (papr_row_norm.raw_mean), tail_bwd standardises on the fly
 _KEY_STATS = os.environ.get("PAPR_KEY_STATS", "1") != "0"      # A/B: the key rows' LayerNorm statistics from papr_build_features_fwd (default) or from the fused run
@@ -665,6 +666,12 @@ class RenderPath:
         # g = q' W_k seen as a Linear layer (weight W_k^T): its backward runs on the library's own GEMMs
         self.wk_fold = MlpSpec("w_k_fold", self.d_model, dict(n_ff_layer=1, d_ff=self.key.d_out, d_ff_out=self.key.d_out, norm="none",
                                                               ff_act="none", ff_last_act="none"))
+        # q' = W_q Q + b_q and g = W_k^T q' as ONE two-layer run of R rows (before: two single-layer launches of ~45 us each way, each with its own
+        # row-maximum and weight-split launch); half_layers spelled out so that the middle width is d_model whatever key.d_out is
+        self.wqk = None
+        if self.d_model % 32 == 0 and self.key.d_out % 32 == 0 and self.d_model <= 256 and self.key.d_out <= 256:
+            self.wqk = MlpSpec("w_q_k", self.qry.d_out, dict(n_ff_layer=2, d_ff=self.d_model, d_ff_out=self.key.d_out, norm="none",
+                                                            ff_act="none", ff_last_act="none"))
         d = hip.FeatureDesc()
         d.feat_dim = self.feat_dim
         d.L_key = (C.c_int32 * 3)(*e["k_L"])
@@ -695,7 +702,7 @@ class RenderPath:
         # kp operand = the key embedding rows themselves, qp operand = W_k^T (W_q Q + b_q): see render path below
         t.k, t.d_model, t.C = k, self.key.d_out, self.C
         t.scale_dim = self.d_model
-        t.ld_kp, t.ld_qp, t.ld_v = self.key.ld_out[-1], self.key.d_out + 4, self.val.ld_out[-1]
+        t.ld_kp, t.ld_qp, t.ld_v = self.key.ld_out[-1], (self.wqk.ld_out[1] if (self.wqk is not None and _QK_CHAIN) else self.key.d_out + 4), self.val.ld_out[-1]
         t.score_act = hip.ACT[self.score_act]
         t.normalize = int(self.normalize)
         t.bkg_score = self.bkg_score
@@ -761,10 +768,19 @@ class _RenderFn(torch.autograd.Function):
         Q = q_outs[-1]
         # score_j = (W_q Q + b_q).(W_k K_j + b_k) = K_j.(W_k^T q') + b_k.q'  with q' = W_q Q + b_q: the R*k-row w_k
         # product of the reference (models/attn.py:217) becomes two R-row products (plain library GEMMs)
-        qp = mlp_forward(plan.wq, wqw, wqb, Q, R, True)[0]
-        w_aug = torch.cat([wkw[0].t(), wkb[0][None, :], _zeros(dev, (3, wkb[0].shape[0]))], 0).contiguous()
-        g = linear_rows(qp, w_aug)                           # (R, key.d_out + 4): [W_k^T q' | b_k.q' | 0 0 0]
-        c0 = g[:, plan.key.d_out].contiguous()               # (R,)
+        qk_outs = None
+        if plan.wqk is not None and _QK_CHAIN:
+            # one two-layer run: q' (kept: the backward pass and c0 need it), then g = W_k^T q'; c0 = q'.b_k by one papr_row_dots launch
+            qk_outs = mlp_forward(plan.wqk, [wqw[0], wkw[0].t().contiguous()], [wqb[0], _zeros(dev, (plan.wqk.ld_out[1],))], Q, R, True)
+            qp, g = qk_outs[0], qk_outs[1]                   # (R, d_model), (R, key.d_out padded to 32)
+            c0 = torch.empty((R,), device=dev, dtype=torch.float32)
+            bk = wkb[0].contiguous()
+            hip.check(lib.papr_row_dots(hip.ptr(qp), R, plan.d_model, qp.shape[1], hip.ptr(bk), bk.shape[0], max(R, 1), hip.ptr(c0), hip.stream_ptr()), "papr_row_dots")
+        else:
+            qp = mlp_forward(plan.wq, wqw, wqb, Q, R, True)[0]
+            w_aug = torch.cat([wkw[0].t(), wkb[0][None, :], _zeros(dev, (3, wkb[0].shape[0]))], 0).contiguous()
+            g = linear_rows(qp, w_aug)                           # (R, key.d_out + 4): [W_k^T q' | b_k.q' | 0 0 0]
+            c0 = g[:, plan.key.d_out].contiguous()               # (R,)
         # the dot products K_j.g are taken in the key run's last row phase: in inference the (R*k, d_model) key embedding is never written
         # (1 KB per pair out and back in again otherwise), in training the attention tail does not read it back (the backward pass does);
         # PAPR_SCORES_IN_RUN=0 for the A/B
@@ -795,7 +811,7 @@ class _RenderFn(torch.autograd.Function):
             order, sorted_pts, seg = group_pairs(idx.view(-1), points.shape[0], run=k)
             ctx.saved = dict(rays_o=rays_o, rays_d=rays_d, idx=idx, points=points, influ=influ, key_in=key_in, qry_in=qry_in,
                              val_in=val_in, kst=kst, qst=qst, kst2=kst2, qst2=qst2, k_outs=k_outs, q_outs=q_outs,
-                             v_outs=v_outs, g=g, c0=c0, qp=qp, key_given=key_given, order=order, sorted_pts=sorted_pts, seg=seg, scores=scores, attn=attn, wb=wb, P=points.shape[0],
+                             v_outs=v_outs, g=g, c0=c0, qp=qp, qk_outs=qk_outs, key_given=key_given, order=order, sorted_pts=sorted_pts, seg=seg, scores=scores, attn=attn, wb=wb, P=points.shape[0],
                              feat_shape=None if pc_feats is None else pc_feats.shape)
         return fused, attn, sel
 
@@ -847,12 +863,31 @@ class _RenderFn(torch.autograd.Function):
         qp = s["qp"]
         wmax = max(plan.key.width, plan.qry.width, plan.val.width, plan.key.ld_in, plan.val.ld_in, plan.d_model)
         scratch = [torch.empty((M, wmax), device=dev, dtype=torch.float32) for _ in range(2)]
-        d_g = d_g[:, :plan.key.d_out].contiguous()           # the tail kernel fills d_model = key.d_out columns
-        d_wkT, _, d_qp = mlp_backward(plan.wk_fold, [wkw[0].t().contiguous()], [_zeros(dev, (plan.key.d_out,))], qp, R, [d_g], d_g,
-                                      [t[:R] for t in scratch], True)
-        d_qp.addcmul_(d_c0[:, None], wkb[0][None, :])
-        d_wk = [d_wkT[0].t()]
-        d_wkb = [(qp * d_c0[:, None]).sum(0)]               # (two launches, 38 us; torch.mv(qp.t(), d_c0) lands on a 269-us rocBLAS gemv kernel: measured, reverted)
+        fused_qk_bwd = s["qk_outs"] is not None and _QK_CHAIN >= 2
+        if fused_qk_bwd:
+            # the two layers' data- and weight-gradients in one run each; the score bias c0 = q'.b_k = Q.(W_q^T b_k) + b_q.b_k hangs on q' BETWEEN the
+            # two layers of that run, so its share reaches W_q, b_q and Q as rank-one terms (outer products of R-row sums, a handful of small launches)
+            if d_g.shape[1] != plan.wqk.ld_out[1] or not d_g.is_contiguous():
+                d_g = d_g[:, :plan.wqk.ld_out[1]].contiguous()
+            qs = [t[:R] for t in scratch]
+            (d_wq_a, d_wkT), (d_wqb_a, _), d_Q = mlp_backward(plan.wqk, [wqw[0], wkw[0].t().contiguous()], [wqb[0], _zeros(dev, (plan.wqk.ld_out[1],))],
+                                                              Q, R, s["qk_outs"], d_g, qs, True)
+            bk = wkb[0]
+            both = torch.cat([Q[:, :plan.qry.d_out], qp[:, :plan.d_model]], 1)                  # one reduction for Q^T d_c0 and q'^T d_c0
+            red = (both * d_c0[:, None]).sum(0)
+            u, d_wkb_v = red[:plan.qry.d_out], red[plan.qry.d_out:]
+            vq = (wqw[0][:, :plan.qry.d_out] * bk[:plan.d_model, None]).sum(0)                      # W_q^T b_k
+            d_Q[:, :plan.qry.d_out].addcmul_(d_c0[:, None], vq[None, :])
+            d_wq_a[:, :plan.qry.d_out].addcmul_(bk[:plan.d_model, None], u[None, :])
+            d_wq, d_wqb = [d_wq_a], [torch.addcmul(d_wqb_a, bk[:d_wqb_a.shape[0]], d_c0.sum())]
+            d_wk, d_wkb = [d_wkT.t()], [d_wkb_v.contiguous()]
+        else:
+            d_g = d_g[:, :plan.key.d_out].contiguous()           # the tail kernel fills d_model = key.d_out columns
+            d_wkT, _, d_qp = mlp_backward(plan.wk_fold, [wkw[0].t().contiguous()], [_zeros(dev, (plan.key.d_out,))], qp, R, [d_g], d_g,
+                                          [t[:R] for t in scratch], True)
+            d_qp.addcmul_(d_c0[:, None], wkb[0][None, :])
+            d_wk = [d_wkT[0].t()]
+            d_wkb = [(qp * d_c0[:, None]).sum(0)]               # (two launches, 38 us; torch.mv(qp.t(), d_c0) lands on a 269-us rocBLAS gemv kernel: measured, reverted)
         # key branch
         need_pts = ctx.needs_input_grad[6]
         d_kw, d_kb, d_key = mlp_backward(plan.key, kw, kb, s["key_in"], M, s["k_outs"], d_K, scratch, need_pts)
@@ -863,7 +898,8 @@ class _RenderFn(torch.autograd.Function):
             rownorm_bwd_(d_key, s["key_in"], s["kst"], plan.key_w, eps)
         # query branch (the ray directions need no gradient)
         qscratch = [t[:R] for t in scratch]
-        d_wq, d_wqb, d_Q = mlp_backward(plan.wq, wqw, wqb, Q, R, [qp], d_qp.contiguous(), qscratch, True)
+        if not fused_qk_bwd:
+            d_wq, d_wqb, d_Q = mlp_backward(plan.wq, wqw, wqb, Q, R, [qp], d_qp.contiguous(), qscratch, True)
         if plan.kq_norm:
             rownorm_bwd_(d_Q, Q, s["qst2"], plan.qry.d_out, eps)
         d_qw, d_qb, _ = mlp_backward(plan.qry, qw, qb, s["qry_in"], R, s["q_outs"], d_Q, qscratch, False)
