@@ -18,7 +18,8 @@ class _Tensor(C.Structure):
 
 
 class _Group(C.Structure):
-    _fields_ = [("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double), ("weight_decay", C.c_double)]
+    _fields_ = [("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double), ("weight_decay", C.c_double),
+                ("found_slot", C.c_int32), ("pad_", C.c_int32)]
 
 
 MAX_GROUPS = 8
@@ -53,10 +54,34 @@ def _adopt_state(st, p):
             st[name] = torch.empty_like(p, memory_format=torch.preserve_format).copy_(m)
 
 
-def step(optimizers):
+def step_scaled(optimizers, scaler):
+    """`for opt in optimizers: scaler.step(opt)` (reference models/model.py:439-442) under a live torch.amp.GradScaler, as the same launches as
+    step() plus one pass that looks for non-finite gradients: the kernel divides every gradient by the scaler's scale as it reads it and leaves
+    everything untouched when any gradient of the call overflowed.  The scaler is told what it would have found itself -- found_inf per optimizer,
+    stage STEPPED -- so that its update() halves / grows the scale exactly as after its own step() (torch/amp/grad_scaler.py: step, update); the
+    scale never leaves the device and nothing synchronises."""
+    from torch.amp.grad_scaler import OptState
+    scale, _ = scaler._check_scale_growth_tracker("step")
+    for opt in optimizers:
+        st = scaler._per_optimizer_states[id(opt)]
+        if st["stage"] is OptState.STEPPED:
+            raise RuntimeError("step() has already been called since the last update().")
+        if st["stage"] is OptState.UNSCALED:
+            raise RuntimeError("papr_amd: gradients already unscaled by scaler.unscale_(): step through the scaler itself")
+    if len(optimizers) > MAX_GROUPS:
+        raise RuntimeError("papr_amd: %d optimizers (at most %d)" % (len(optimizers), MAX_GROUPS))
+    found_inf = torch.empty(MAX_GROUPS, dtype=torch.float32, device=scale.device)       # one slot per optimizer: each is skipped on its own overflow only
+    step(optimizers, grad_scale=scale, found_inf=found_inf)
+    for i, opt in enumerate(optimizers):
+        st = scaler._per_optimizer_states[id(opt)]
+        st["found_inf_per_device"] = {scale.device: found_inf[i:i + 1]}
+        st["stage"] = OptState.STEPPED
+
+
+def step(optimizers, grad_scale=None, found_inf=None):
     """optimizer.step() of every optimizer in `optimizers` (parameters without a gradient are skipped, like torch does)."""
     tensors, groups = [], []
-    for opt in optimizers:
+    for oi, opt in enumerate(optimizers):
         for g in opt.param_groups:
             gi = len(groups)
             for p in g["params"]:
@@ -76,11 +101,16 @@ def step(optimizers):
                                        p.numel(), gi, 0))
                 tensors[-1]._keep = grad
             b1, b2 = g["betas"]
-            groups.append(_Group(float(g["lr"]), b1, b2, g["eps"], g["weight_decay"]))
+            groups.append(_Group(float(g["lr"]), b1, b2, g["eps"], g["weight_decay"], oi, 0))
     if not tensors:
+        if found_inf is not None:
+            found_inf.zero_()
         return
     arr_t = (_Tensor * len(tensors))(*tensors)
     arr_g = (_Group * len(groups))(*groups)
-    hip.check(hip.lib().papr_adam_step(arr_t, len(tensors), arr_g, len(groups), hip.stream_ptr()), "papr_adam_step")
+    if grad_scale is not None:
+        hip.check(hip.lib().papr_adam_step_scaled(arr_t, len(tensors), arr_g, len(groups), hip.ptr(grad_scale), hip.ptr(found_inf), hip.stream_ptr()), "papr_adam_step_scaled")
+    else:
+        hip.check(hip.lib().papr_adam_step(arr_t, len(tensors), arr_g, len(groups), hip.stream_ptr()), "papr_adam_step")
     from . import dist as pdist
     pdist.bump_param_epoch()                          # (the kernel writes the parameters through raw pointers: no version counter moves)

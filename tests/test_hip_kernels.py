@@ -948,6 +948,64 @@ def test_own_adam_step_matches_torch_adam():
                 np.testing.assert_allclose(oo.state[op]["exp_avg_sq"].cpu().numpy(), ro.state[rp]["exp_avg_sq"].numpy(), rtol=1e-5, atol=1e-12)
 
 
+def test_own_adam_under_a_gradscaler_follows_torchs_scaler_step():
+    """papr_adam_step_scaled through papr_amd.adam.step_scaled (ABI 25; `use_amp: true`: reference models/model.py:439-442 steps every optimizer
+    through `scaler.step`) against torch's own route -- torch.amp.GradScaler.step on fused torch.optim.Adam -- on the same scaled gradients: seven
+    steps of three optimizers, an overflowing step in the middle (inf in one tensor of ONE optimizer: that optimizer stands still, the others step, the scale
+    halves), then the scale grows again (growth_interval 2).  Parameters, moments, step counters and the scale agree step by step."""
+    from papr_amd import adam as own_adam
+    gen = torch.Generator().manual_seed(12)
+    d = dev()
+    shapes = [[(1000, 3)], [(256, 117), (256,), (7,)], [(5, 1)]]
+    hyper = [dict(lr=2e-3, weight_decay=0.0), dict(lr=3e-4, weight_decay=1e-2), dict(lr=1e-3, weight_decay=0.0)]
+    base = [[torch.randn(*sh, generator=gen) for sh in group] for group in shapes]
+    ref_params = [[p.clone().to(d).requires_grad_(True) for p in group] for group in base]
+    own_params = [[p.clone().to(d).requires_grad_(True) for p in group] for group in base]
+    ref_opts = [torch.optim.Adam(ps, fused=True, **h) for ps, h in zip(ref_params, hyper)]
+    own_opts = [torch.optim.Adam(ps, fused=True, **h) for ps, h in zip(own_params, hyper)]
+    ref_sc = torch.amp.GradScaler("cuda", init_scale=1024.0, growth_interval=2)
+    own_sc = torch.amp.GradScaler("cuda", init_scale=1024.0, growth_interval=2)
+    assert own_adam.supported(own_opts)
+    scales = []
+    for it in range(7):
+        # GradScaler.scale() initialises the scale tensor lazily: call it like train_step does
+        ref_sc.scale(torch.zeros((), device=d)); own_sc.scale(torch.zeros((), device=d))
+        sc = ref_sc.get_scale()
+        assert own_sc.get_scale() == sc
+        for gi, (rg, og) in enumerate(zip(ref_params, own_params)):
+            for pi, (rp, op) in enumerate(zip(rg, og)):
+                g = torch.randn(rp.shape, generator=gen) * (10.0 ** -(it % 3)) * sc
+                if it == 3 and gi == 1 and pi == 1:
+                    g[5] = float("inf")
+                rp.grad = g.to(d)
+                op.grad = g.to(d)
+        before = [[p.detach().clone() for p in g_] for g_ in own_params]
+        for o in ref_opts:
+            ref_sc.step(o)
+        own_adam.step_scaled(own_opts, own_sc)
+        ref_sc.update(); own_sc.update()
+        scales.append(own_sc.get_scale())
+        assert own_sc.get_scale() == ref_sc.get_scale()
+        if it == 3:                                   # (the optimizer that overflowed stands still; the other two step, as under scaler.step(opt) one by one)
+            for b, p in zip(before[1], own_params[1]):
+                assert torch.equal(b, p.detach()), "an overflowed optimizer moved a parameter"
+            assert not torch.equal(before[0][0], own_params[0][0].detach())
+        for rg, og, ro, oo in zip(ref_params, own_params, ref_opts, own_opts):
+            for rp, op in zip(rg, og):
+                np.testing.assert_allclose(op.detach().cpu().numpy(), rp.detach().cpu().numpy(), rtol=0, atol=2e-6 * (1 + rp.abs().max().item()))
+                assert float(oo.state[op]["step"]) == float(ro.state[rp]["step"]), (it, float(oo.state[op]["step"]), float(ro.state[rp]["step"]))
+                ma, va = ro.state[rp]["exp_avg"].cpu().numpy(), ro.state[rp]["exp_avg_sq"].cpu().numpy()
+                np.testing.assert_allclose(oo.state[op]["exp_avg"].cpu().numpy(), ma, rtol=1e-5, atol=1e-6 * np.abs(ma).max())      # (moments near zero: cancellation)
+                np.testing.assert_allclose(oo.state[op]["exp_avg_sq"].cpu().numpy(), va, rtol=1e-5, atol=1e-6 * np.abs(va).max())
+    assert scales[3] == 0.5 * scales[2] and max(scales) >= 2048.0, scales      # halved by the overflow, grown every second clean step
+    with pytest.raises(RuntimeError):               # two steps without an update(): the scaler's own error
+        own_sc.scale(torch.zeros((), device=d))
+        for p in own_params[0]:
+            p.grad = torch.zeros_like(p)
+        own_adam.step_scaled(own_opts, own_sc)
+        own_adam.step_scaled(own_opts, own_sc)
+
+
 @pytest.mark.parametrize("mode", ["f32", "fwd", "dgrad", "layers"])
 def test_other_gemm_modes_meet_the_same_mlp_parity(mode):
     """PAPR_GEMM_MODE selects which wide GEMMs use the split-f16 (hi/lo, 3 MFMA) kernels (default `h3`: forward
