@@ -44,7 +44,8 @@ const char* papr_last_error(void);
  * the smallest indices are kept: the set is the k smallest by (distance, index), whichever form runs -- clouds of
  * 2,048 points and more are binned per call (bounding spheres of 64-point blocks, k < 64), smaller ones are
  * searched point by point.
- * Requires 1 <= k <= 64 and k <= P.  workspace: papr_ray_knn_workspace_bytes(R, P) bytes, contents irrelevant
+ * Requires 1 <= k <= 256 and k <= P (k <= 63: the tuned forms -- seeded every-point search, binned cloud; 64 <= k <= 256, ABI 25: one ray per wave,
+ * the set across several registers per lane, exact in the same total order).  workspace: papr_ray_knn_workspace_bytes(R, P) bytes, contents irrelevant
  * on entry (ray records, the binned copy of the cloud, block bounds, cell counters: all rebuilt by every call).
  */
 size_t papr_ray_knn_workspace_bytes(int64_t R, int64_t P);
@@ -437,9 +438,10 @@ int papr_profile_enable(int on);
  *                              statement (ABI 23)
  *   PAPR_SW_C4_PHASE    (6130) the workgroups of a fused run that carry one pair of tiles fewer than the others start late instead of finishing early
  *                              (out of phase with the rest at no cost).  value = 1000 x (the fewest steps a run must have) + (delay per step of the run in
- *                              hundreds of cycles); 0: off */
+ *                              hundreds of cycles); 0: off
+ *   PAPR_SW_C4_SUBPHASE (0)    timing experiment: workgroup b of a fused run starts ((b / 8) % 4) x value cycles late (sub-slot phases inside an XCD) */
 enum { PAPR_SW_C4_GENERIC = 0, PAPR_SW_C4_FUSED = 1, PAPR_SW_C4_EARLY = 2, PAPR_SW_KNN_BLOCKS = 3, PAPR_SW_KNN_T = 4, PAPR_SW_WGRAD_WGS = 5,
-       PAPR_SW_NT_VARIANT = 6, PAPR_SW_C4_DMA = 7, PAPR_SW_TN_JOBPAR = 8, PAPR_SW_C4_PAIRS = 9, PAPR_SW_C4_PHASE = 10, PAPR_SW_COUNT = 11 };
+       PAPR_SW_NT_VARIANT = 6, PAPR_SW_C4_DMA = 7, PAPR_SW_TN_JOBPAR = 8, PAPR_SW_C4_PAIRS = 9, PAPR_SW_C4_PHASE = 10, PAPR_SW_C4_SUBPHASE = 11, PAPR_SW_COUNT = 12 };
 int papr_set_switch(int32_t which, int32_t value);
 int32_t papr_get_switch(int32_t which);
 /* Waits for the recorded events, writes up to `cap` records (oldest first), clears the log and

@@ -272,6 +272,104 @@ __global__ __launch_bounds__(256) void ray_knn_kernel(const float4* __restrict__
 }
 
 // ================================================================================================
+// k > 64 (round 5; the reference's topk takes any k < P, models/model.py:281): the set no longer fits one register across the wave.  NS registers
+// per lane hold member (slot s, lane l) = entry 64 s + l; everything else is the every-point form above -- the same reference-ordered distance, the
+// same total order (distance bits, index), the same conservative filter -- one ray per wave, no seeding (no shipped configuration asks for such
+// a k: the form exists for generality, not for speed: ~k (1 + ln(P / k)) insertions of ~40 instructions per ray).
+template <int NS>
+struct KSetW {
+    unsigned bits[NS];
+    int idx[NS];
+    unsigned thr, thr_idx, thr_hi;
+    int tl, ts;                     // the lane and the slot that hold the largest member
+    int k;
+    __device__ __forceinline__ bool member(int s, int lane) const { return 64 * s + lane < k; }
+    __device__ __forceinline__ void refresh(int lane) {
+        unsigned m = 0u;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) m = bits[s] > m ? bits[s] : m;
+        thr = wave_umax(m);
+        // among the members at the largest distance, the one with the largest index
+        unsigned mi = 0u;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) if (member(s, lane) && bits[s] == thr) mi = (unsigned)idx[s] > mi ? (unsigned)idx[s] : mi;
+        mi = wave_umax(mi);
+        tl = 0; ts = 0;
+#pragma unroll
+        for (int s = NS - 1; s >= 0; --s) {
+            const unsigned long long mm = __ballot(member(s, lane) && bits[s] == thr && (unsigned)idx[s] == mi);
+            if (mm) { ts = s; tl = __builtin_ctzll(mm); }
+        }
+        thr_idx = mi;
+        thr_hi = __float_as_uint(__uint_as_float(thr) * 1.015625f);
+    }
+    __device__ __forceinline__ bool may_enter(float d2_fast) const { return __ballot(__float_as_uint(d2_fast) <= thr_hi) != 0; }
+    __device__ __forceinline__ void offer(float d2, int pidx, int lane) {
+        unsigned long long m = __ballot(__float_as_uint(d2) <= thr && __float_as_uint(d2) < INF_BITS);
+        while (m) {
+            const int src = __builtin_ctzll(m);
+            m &= m - 1;
+            const unsigned cb = (unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(d2), src);
+            const int ci = __builtin_amdgcn_readlane(pidx, src);
+            if (cb < thr || (cb == thr && (unsigned)ci < thr_idx)) {
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    const bool here = lane == tl && s == ts;
+                    bits[s] = here ? cb : bits[s];
+                    idx[s] = here ? ci : idx[s];
+                }
+                refresh(lane);
+            }
+        }
+    }
+};
+
+template <int NS>
+__global__ __launch_bounds__(256) void ray_knn_wide_kernel(const float4* __restrict__ stream, int P, const float* rec, long R, int k,
+                                                           int* __restrict__ out_idx, float* __restrict__ out_dist) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    cfloat* p = (cfloat*)rec + r * 8;
+    RayK rk;
+    rk.ox = p[0]; rk.oy = p[1]; rk.oz = p[2]; rk.dx = p[3]; rk.dy = p[4]; rk.dz = p[5]; rk.den = p[6]; rk.rcp = p[7];
+    KSetW<NS> ks;
+    ks.k = k;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) { ks.bits[s] = ks.member(s, lane) ? INF_BITS : 0u; ks.idx[s] = -1; }
+    ks.thr = INF_BITS; ks.thr_idx = 0xffffffffu; ks.thr_hi = INF_BITS; ks.tl = 0; ks.ts = 0;
+    for (int base = 0; base < P; base += 64) {
+        const int pi = base + lane;
+        const bool ok = pi < P;
+        const float4 v = stream[ok ? pi : P - 1];
+        if (ks.may_enter(ok ? ray_dist2_fast(rk, v.x, v.y, v.z) : INFINITY)) {
+            const float d2 = ray_dist2(rk, v.x, v.y, v.z);
+            ks.offer(ok ? d2 : INFINITY, __float_as_int(v.w), lane);
+        }
+    }
+    // rank every member by (distance, index) and write the set in ascending order
+    int rank[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) rank[s] = 0;
+#pragma unroll
+    for (int sj = 0; sj < NS; ++sj) {
+        const int nj = k - 64 * sj < 64 ? k - 64 * sj : 64;
+        for (int j = 0; j < nj; ++j) {
+            const unsigned dj = (unsigned)__builtin_amdgcn_readlane((int)ks.bits[sj], j);
+            const int ij = __builtin_amdgcn_readlane(ks.idx[sj], j);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) rank[s] += (dj < ks.bits[s] || (dj == ks.bits[s] && ij < ks.idx[s])) ? 1 : 0;
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+        if (ks.member(s, lane)) {
+            out_idx[r * k + rank[s]] = ks.idx[s];
+            if (out_dist) out_dist[r * k + rank[s]] = sqrtf(__uint_as_float(ks.bits[s]));
+        }
+}
+
+// ================================================================================================
 // The spatial form (P >= KNN_BLOCKS_MIN_P): the cloud is binned on a 16^3 grid over its bounding box, laid out in Morton order of
 // the cells and cut into blocks of 64 consecutive points with a bounding sphere each (three small kernels per launch:
 // the points move every training step; knn_count / knn_place / knn_bounds).  A ray then tests the SPHERES first -- 64 blocks per instruction, one per lane -- and only
@@ -625,7 +723,7 @@ extern "C" int papr_ray_knn(const float* points, int64_t P, const float* rays_o,
                             int64_t R, int64_t rays_per_image, int k, float eps, int32_t* out_idx,
                             float* out_dist, void* workspace, papr_stream_t stream) {
     PAPR_REQUIRE(points && rays_o && rays_d && out_idx && workspace, "papr_ray_knn: null pointer");
-    PAPR_REQUIRE(k >= 1 && k <= 64, "papr_ray_knn: k=%d outside [1,64]", k);
+    PAPR_REQUIRE(k >= 1 && k <= 256, "papr_ray_knn: k=%d outside [1,256]", k);
     PAPR_REQUIRE(P >= k && P * 3 < (int64_t)1 << 31, "papr_ray_knn: P=%lld must be >= k and < 2^31/3", (long long)P);
     PAPR_REQUIRE(rays_per_image >= 1, "papr_ray_knn: rays_per_image must be positive");
     if (R <= 0) return 0;
@@ -633,7 +731,7 @@ extern "C" int papr_ray_knn(const float* points, int64_t P, const float* rays_o,
     float* rec = static_cast<float*>(workspace);
     float4* pstream = reinterpret_cast<float4*>(rec + (size_t)R * 8);
     const int blocks_env = papr_switch(PAPR_SW_KNN_BLOCKS);      // (A/B switch: 0 = every point against every ray)
-    const bool spatial = blocks_env && P >= KNN_BLOCKS_MIN_P && k < 64;
+    const bool spatial = blocks_env && P >= KNN_BLOCKS_MIN_P && k < 64;      // (k = 64: the every-point form; k > 64: the wide form)
     const int64_t places = knn_stream_places(P);
     float4* blk = pstream + (size_t)places;
     unsigned* counts = reinterpret_cast<unsigned*>(blk + (size_t)(places / 64));
@@ -671,6 +769,16 @@ extern "C" int papr_ray_knn(const float* points, int64_t P, const float* rays_o,
     }
     scatter_points_kernel<<<dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s>>>(points, (int)P, P > 1 ? coprime_stride(P) : 0, pstream);
     PAPR_CHECK_LAUNCH("scatter_points");
+    if (k > 64) {                                   // the set across several registers per lane (ray_knn_wide_kernel)
+        const dim3 grid((unsigned)((R + 3) / 4)), block(256);
+        const bool prof = papr_prof_on();
+        if (prof) papr_prof_begin(5, R, (int)P, k, s);
+        if (k <= 128) ray_knn_wide_kernel<2><<<grid, block, 0, s>>>(pstream, (int)P, rec, R, k, out_idx, out_dist);
+        else ray_knn_wide_kernel<4><<<grid, block, 0, s>>>(pstream, (int)P, rec, R, k, out_idx, out_dist);
+        if (prof) papr_prof_end(s);
+        PAPR_CHECK_LAUNCH("ray_knn_wide");
+        return 0;
+    }
     // Rays per wave T: a tile costs ~(1.8 + T - 1) ray passes over the cloud (its first ray starts cold, the others are seeded), and the
     // launch takes as long as the SIMD with the most tiles: ceil(tiles / SIMDs) of them.  With T = 8 a 160 x 160 patch is 3,200 tiles on
     // 1,024 SIMDs -- 4 on some, 3.125 on average, a quarter of the machine idle at the end (round 2); T = 5 makes it exactly 5 each.

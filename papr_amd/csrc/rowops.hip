@@ -260,6 +260,218 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(papr_tail_desc d, const f
 }
 
 // ------------------------------------------------------------------------------------------------
+// The attention tail for 64 <= k <= 255 neighbours per ray (round 5; the reference takes any k, models/model.py:281, 519-534): token t = 64 s + lane
+// lives in slot s of its lane (NS slots), tokens 0 .. k-1 the neighbours, token k the background.  The formulas, the order of every per-ray sum over
+// the tokens excepted, are tail_fwd_kernel's / tail_bwd_kernel's; the kernels above stay what every shipped configuration (k = 20, 30) runs.
+template <int NS>
+struct Tok {
+    float v[NS];
+    __device__ __forceinline__ float at(int t) const {          // token t's value in every lane (t wave-uniform)
+        float r = 0.f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) if ((t >> 6) == s) r = bcast(v[s], t & 63);
+        return r;
+    }
+    __device__ __forceinline__ float sum() const { float a = 0.f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) a += v[s];
+        return wave_sum(a); }
+    __device__ __forceinline__ float max() const { float a = v[0];
+#pragma unroll
+        for (int s = 1; s < NS; ++s) a = fmaxf(a, v[s]);
+        return wave_max(a); }
+};
+
+template <int NS>
+__global__ __launch_bounds__(256) void tail_fwd_wide_kernel(papr_tail_desc d, const float* __restrict__ kp, const float* __restrict__ qp,
+                                                            const float* __restrict__ v, const float* __restrict__ score_bias,
+                                                            const float* __restrict__ influ, const int* __restrict__ idx, long R,
+                                                            float* __restrict__ scores, float* __restrict__ attn, float* __restrict__ fused) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int k = d.k;
+    const float inv_sqrt_d = 1.0f / sqrtf((float)(d.scale_dim > 0 ? d.scale_dim : d.d_model));
+    Tok<NS> sc, z, a, top;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) sc.v[s] = 0.f;
+    if (d.precomputed_dots) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) if (64 * s + lane < k) sc.v[s] = kp[r * k + 64 * s + lane];
+    } else {
+        const float* q = qp + r * d.ld_qp;
+        for (int j = 0; j < k; ++j) {
+            float part = 0.f;
+            for (int c = lane * 4; c < d.d_model; c += 256) {
+                const float4 x = *reinterpret_cast<const float4*>(q + c), y = *reinterpret_cast<const float4*>(kp + (r * k + j) * d.ld_kp + c);
+                part += (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
+            }
+            const float dot = wave_sum(part);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) if (64 * s + lane == j) sc.v[s] = dot;
+        }
+    }
+    const float sb = score_bias ? score_bias[r] : 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int t = 64 * s + lane;
+        z.v[s] = -INFINITY;
+        if (t < k) {
+            const float x = papr_act((sc.v[s] + sb) * inv_sqrt_d, d.score_act);
+            scores[r * k + t] = x;
+            z.v[s] = x * influ[idx[r * k + t]];
+        } else if (t == k) {
+            z.v[s] = d.bkg_score;
+        }
+    }
+    const float zmax = z.max();
+    Tok<NS> e;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) e.v[s] = 64 * s + lane <= k ? expf(z.v[s] - zmax) : 0.f;
+    const float denom = e.sum();
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int t = 64 * s + lane;
+        a.v[s] = e.v[s] / denom;
+        if (t <= k) attn[r * (k + 1) + t] = a.v[s];
+        top.v[s] = t < k ? a.v[s] : 0.f;
+    }
+    if (d.normalize) {
+        const float ts = top.sum();
+#pragma unroll
+        for (int s = 0; s < NS; ++s) top.v[s] = top.v[s] / ts;
+    }
+    for (int c = lane; c < d.C; c += 64) {
+        float acc = 0.f;
+        for (int j = 0; j < k; ++j) acc += top.at(j) * v[(r * k + j) * d.ld_v + c];
+        fused[r * d.C + c] = acc;
+    }
+}
+
+template <int NS>
+__global__ __launch_bounds__(256) void tail_bwd_wide_kernel(papr_tail_desc d, const float* __restrict__ kp, const float* __restrict__ qp,
+                                                            const float* __restrict__ v, const float* __restrict__ influ, const int* __restrict__ idx,
+                                                            long R, const float* __restrict__ scores, const float* __restrict__ attn,
+                                                            const float* __restrict__ d_fused, const float* __restrict__ d_attn,
+                                                            float* __restrict__ d_kp, float* __restrict__ d_qp, float* __restrict__ d_v,
+                                                            float* __restrict__ d_influ, float* __restrict__ d_score_bias,
+                                                            float* __restrict__ d_pair_influ, const float* __restrict__ kp_stats,
+                                                            const float* __restrict__ score_bias, const float* __restrict__ kp_mean) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int k = d.k;
+    const float inv_sqrt_d = 1.0f / sqrtf((float)(d.scale_dim > 0 ? d.scale_dim : d.d_model));
+    Tok<NS> a, top, dtop, da, ddot, ca, cb, kmean, krinv;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int t = 64 * s + lane;
+        a.v[s] = t <= k ? attn[r * (k + 1) + t] : 0.f;
+        top.v[s] = t < k ? a.v[s] : 0.f;
+        dtop.v[s] = 0.f; ddot.v[s] = 0.f; cb.v[s] = 0.f; kmean.v[s] = 0.f; krinv.v[s] = 1.f;
+    }
+    float tsum = 1.f;
+    if (d.normalize) {
+        tsum = top.sum();
+#pragma unroll
+        for (int s = 0; s < NS; ++s) top.v[s] = top.v[s] / tsum;
+    }
+    for (int j = 0; j < k; ++j) {
+        float part = 0.f;
+        const float tj = top.at(j);
+        for (int c = lane; c < d.ld_v; c += 64) {
+            const float gf = c < d.C ? d_fused[r * d.C + c] : 0.f;
+            const float vv = c < d.C ? v[(r * k + j) * d.ld_v + c] : 0.f;
+            part += gf * vv;
+            d_v[(r * k + j) * d.ld_v + c] = tj * gf;
+        }
+        const float dt = wave_sum(part);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) if (64 * s + lane == j) dtop.v[s] = dt;
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) da.v[s] = (d_attn && 64 * s + lane <= k) ? d_attn[r * (k + 1) + 64 * s + lane] : 0.f;
+    if (d.normalize) {
+        Tok<NS> w;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) w.v[s] = dtop.v[s] * top.v[s];
+        const float corr = w.sum();
+#pragma unroll
+        for (int s = 0; s < NS; ++s) if (64 * s + lane < k) da.v[s] += (dtop.v[s] - corr) / tsum;
+    } else {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) if (64 * s + lane < k) da.v[s] += dtop.v[s];
+    }
+    Tok<NS> w2;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) w2.v[s] = da.v[s] * a.v[s];
+    const float dasum = w2.sum();
+    Tok<NS> scv;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int t = 64 * s + lane;
+        const float dz = a.v[s] * (da.v[s] - dasum);
+        scv.v[s] = t < k ? scores[r * k + t] : 0.f;
+        if (t < k) {
+            const int pi = idx[r * k + t];
+            if (d_pair_influ) d_pair_influ[r * k + t] = dz * scv.v[s];
+            else unsafeAtomicAdd(d_influ + pi, dz * scv.v[s]);
+            ddot.v[s] = dz * influ[pi] * papr_act_grad(scv.v[s], d.score_act) * inv_sqrt_d;
+        }
+        ca.v[s] = ddot.v[s];
+    }
+    if (d_score_bias) {
+        const float sbs = ddot.sum();
+        if (lane == 0) d_score_bias[r] = sbs;
+    }
+    const float* q = qp + r * d.ld_qp;
+    float qmean = 0.f;
+    if (kp_stats) {
+        float qs = 0.f;
+        for (int c = lane * 4; c < d.d_model; c += 256) {
+            const float4 qv = *reinterpret_cast<const float4*>(q + c);
+            qs += (qv.x + qv.y) + (qv.z + qv.w);
+        }
+        qmean = wave_sum(qs) / (float)d.d_model;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int t = 64 * s + lane;
+            if (t < k) {
+                const float pre = (d.score_act == PAPR_ACT_LEAKY_RELU && scv.v[s] < 0.f) ? scv.v[s] * 5.0f : scv.v[s];
+                const float dot = pre / inv_sqrt_d - (score_bias ? score_bias[r] : 0.f);
+                const float rinv = kp_stats[(r * k + t) * 2], sigma = kp_stats[(r * k + t) * 2 + 1];
+                ca.v[s] = ddot.v[s] * rinv;
+                cb.v[s] = (sigma > 0.f && ddot.v[s] != 0.f) ? ddot.v[s] * dot / ((float)(d.d_model - 1) * sigma) : 0.f;
+                if (kp_mean) { kmean.v[s] = kp_mean[r * k + t]; krinv.v[s] = rinv; }
+            }
+        }
+    }
+    for (int c = lane * 4; c < d.d_model; c += 256) {
+        const float4 qv = *reinterpret_cast<const float4*>(q + c);
+        const float4 qc = make_float4(qv.x - qmean, qv.y - qmean, qv.z - qmean, qv.w - qmean);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < k; ++j) {
+            const float gj = ddot.at(j);
+            float4 kv = *reinterpret_cast<const float4*>(kp + (r * k + j) * d.ld_kp + c);
+            if (kp_mean) {
+                const float mj = kmean.at(j), rj = krinv.at(j);
+                kv = make_float4((kv.x - mj) * rj, (kv.y - mj) * rj, (kv.z - mj) * rj, (kv.w - mj) * rj);
+            }
+            acc.x += gj * kv.x; acc.y += gj * kv.y; acc.z += gj * kv.z; acc.w += gj * kv.w;
+            float4 o;
+            if (kp_stats) {
+                const float aj = ca.at(j), bj = cb.at(j);
+                o = make_float4(aj * qc.x - bj * kv.x, aj * qc.y - bj * kv.y, aj * qc.z - bj * kv.z, aj * qc.w - bj * kv.w);
+            } else {
+                o = make_float4(gj * qv.x, gj * qv.y, gj * qv.z, gj * qv.w);
+            }
+            *reinterpret_cast<float4*>(d_kp + (r * k + j) * d.ld_kp + c) = o;
+        }
+        *reinterpret_cast<float4*>(d_qp + r * d.ld_qp + c) = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // LayerNorm affine folded into the following Linear layer (see papr_hip.h).  One wave per output row.
 __global__ __launch_bounds__(256) void ln_fold_fwd_kernel(const float* __restrict__ w, int n_out, int n_in, int ldw,
                                                           const float* __restrict__ c, const float* __restrict__ a2,
@@ -450,7 +662,7 @@ extern "C" int papr_rownorm_bwd(const float* dy, const float* y, const float* st
 
 static int check_tail(const papr_tail_desc* d, const char* who) {
     PAPR_REQUIRE(d, "%s: null descriptor", who);
-    PAPR_REQUIRE(d->k >= 1 && d->k <= 63, "%s: k=%d outside [1,63]", who, d->k);
+    PAPR_REQUIRE(d->k >= 1 && d->k <= 255, "%s: k=%d outside [1,255]", who, d->k);
     PAPR_REQUIRE(d->d_model % 4 == 0 && d->ld_kp % 4 == 0 && d->ld_qp % 4 == 0, "%s: d_model and strides must be multiples of 4", who);
     PAPR_REQUIRE(d->ld_kp >= d->d_model && d->ld_qp >= d->d_model && d->ld_v >= d->C, "%s: strides too small", who);
     return 0;
@@ -462,7 +674,10 @@ extern "C" int papr_attn_tail_fwd(const papr_tail_desc* d, const float* kp, cons
     if (int e = check_tail(d, "papr_attn_tail_fwd")) return e;
     PAPR_REQUIRE(kp && (qp || d->precomputed_dots) && v && influ && idx && scores && attn && fused, "papr_attn_tail_fwd: null pointer");
     if (R <= 0) return 0;
-    tail_fwd_kernel<<<dim3((unsigned)((R + 3) / 4)), dim3(256), 0, as_stream(stream)>>>(*d, kp, qp, v, score_bias, influ, idx, R, scores, attn, fused);
+    const dim3 grid((unsigned)((R + 3) / 4)), block(256);
+    if (d->k <= 63) tail_fwd_kernel<<<grid, block, 0, as_stream(stream)>>>(*d, kp, qp, v, score_bias, influ, idx, R, scores, attn, fused);
+    else if (d->k <= 127) tail_fwd_wide_kernel<2><<<grid, block, 0, as_stream(stream)>>>(*d, kp, qp, v, score_bias, influ, idx, R, scores, attn, fused);
+    else tail_fwd_wide_kernel<4><<<grid, block, 0, as_stream(stream)>>>(*d, kp, qp, v, score_bias, influ, idx, R, scores, attn, fused);
     PAPR_CHECK_LAUNCH("tail_fwd");
     return 0;
 }
@@ -477,9 +692,16 @@ extern "C" int papr_attn_tail_bwd(const papr_tail_desc* d, const float* kp, cons
     PAPR_REQUIRE(kp && qp && v && influ && idx && scores && attn && d_fused && d_kp && d_qp && d_v && (d_influ || d_pair_influ),
                  "papr_attn_tail_bwd: null pointer");
     if (R <= 0) return 0;
-    tail_bwd_kernel<<<dim3((unsigned)((R + 3) / 4)), dim3(256), 0, as_stream(stream)>>>(
-        *d, kp, qp, v, influ, idx, R, scores, attn, d_fused, d_attn, d_kp, d_qp, d_v, d_influ, d_score_bias, d_pair_influ,
-        kp_norm_stats, score_bias, kp_mean);
+    const dim3 grid((unsigned)((R + 3) / 4)), block(256);
+    if (d->k <= 63)
+        tail_bwd_kernel<<<grid, block, 0, as_stream(stream)>>>(*d, kp, qp, v, influ, idx, R, scores, attn, d_fused, d_attn, d_kp, d_qp, d_v, d_influ,
+                                                               d_score_bias, d_pair_influ, kp_norm_stats, score_bias, kp_mean);
+    else if (d->k <= 127)
+        tail_bwd_wide_kernel<2><<<grid, block, 0, as_stream(stream)>>>(*d, kp, qp, v, influ, idx, R, scores, attn, d_fused, d_attn, d_kp, d_qp, d_v, d_influ,
+                                                                       d_score_bias, d_pair_influ, kp_norm_stats, score_bias, kp_mean);
+    else
+        tail_bwd_wide_kernel<4><<<grid, block, 0, as_stream(stream)>>>(*d, kp, qp, v, influ, idx, R, scores, attn, d_fused, d_attn, d_kp, d_qp, d_v, d_influ,
+                                                                       d_score_bias, d_pair_influ, kp_norm_stats, score_bias, kp_mean);
     PAPR_CHECK_LAUNCH("tail_bwd");
     return 0;
 }

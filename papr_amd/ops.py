@@ -716,8 +716,8 @@ class RenderPath:
         if k >= P or k < 0:
             R = rays_d.shape[0]
             return torch.arange(P, device=points.device, dtype=torch.int32).expand(R, P).contiguous()
-        if k > 63:
-            raise NotImplementedError("papr_amd: select_k=%d > 63 is not supported by the HIP kernels" % k)
+        if k > 255:
+            raise NotImplementedError("papr_amd: select_k=%d > 255 is not supported by the HIP kernels" % k)
         return ray_knn(points, rays_o, rays_d, rays_per_image, k, self.eps)
 
 
@@ -729,8 +729,8 @@ class _RenderFn(torch.autograd.Function):
         lib = hip.lib()
         R, k = idx.shape
         M = R * k
-        if k > 63:
-            raise NotImplementedError("papr_amd: %d neighbours per ray > 63 is not supported by the HIP kernels" % k)
+        if k > 255:
+            raise NotImplementedError("papr_amd: %d neighbours per ray > 255 is not supported by the HIP kernels" % k)
         dev = points.device
         # track: grad mode of the caller (always off in here, and needs_input_grad ignores torch.no_grad()): under no_grad
         # nothing is kept for a backward pass -- no saved activations, no pair sort

@@ -132,12 +132,42 @@ def test_knn_block_path_total_order_and_determinism():
     assert torch.equal(idx, torch.arange(7, dtype=idx.dtype).expand_as(idx))
 
 
+@pytest.mark.parametrize("P,k,hw", [(300, 100, 6), (130, 128, 4), (5000, 65, 8), (1000, 200, 5), (257, 256, 3)])
+def test_knn_more_than_64_neighbours_against_oracle(P, k, hw):
+    """64 < k <= 256 (ABI 25; the reference's topk takes any k < P, models/model.py:281): the wide form -- the set across 2 or 4 registers per lane --
+    gives the oracle's sets, ascending in (distance, index)."""
+    pts = uniform_points(P, 12.0, seed=P + k)
+    ro, rd, _ = synth_rays(1, hw, hw, seed=P)
+    ref, _ = O.knn_select(pts, ro, rd, k, 1e-6)
+    _check_knn(pts, ro, rd, k, np.sort(ref.numpy(), -1))
+
+
+def test_knn_wide_form_exact_ties():
+    pts = uniform_points(300, 12.0, seed=3)
+    pts = torch.cat([pts, pts[:150]])            # exact duplicates -> exact ties, also at the k-th distance
+    ro, rd, _ = synth_rays(1, 5, 5, seed=2)
+    k = 90
+    idx, dist = _knn(pts, ro, rd, k)
+    assert torch.all(dist[:, 1:] >= dist[:, :-1])
+    feat = O.ray_point_distance(pts, ro, rd, 1e-6).reshape(-1, pts.shape[0])
+    kth = feat.topk(k, largest=False).values.max(-1).values
+    np.testing.assert_allclose(dist.max(-1).values.numpy(), kth.numpy(), rtol=2e-6)
+    same = dist[:, 1:] == dist[:, :-1]
+    assert torch.all(idx[:, 1:][same] > idx[:, :-1][same])
+    for r in range(idx.shape[0]):
+        members = set(idx[r].tolist())
+        assert len(members) == k
+        for j in members:
+            if j >= 300:
+                assert j - 300 in members, (r, j)
+
+
 def test_knn_rejects_bad_k():
     from papr_amd import ops
-    pts = uniform_points(100, 1.0, seed=0).to(dev())
+    pts = uniform_points(300, 1.0, seed=0).to(dev())
     ro, rd, _ = synth_rays(1, 2, 2)
     with pytest.raises(RuntimeError):
-        ops.ray_knn(pts, ro.to(dev()), rd.reshape(-1, 3).to(dev()), 4, 65, 1e-6)
+        ops.ray_knn(pts, ro.to(dev()), rd.reshape(-1, 3).to(dev()), 4, 257, 1e-6)
 
 
 # ------------------------------------------------------------------------------------------- K2

@@ -533,6 +533,51 @@ def test_use_amp_selects_the_one_product_arithmetic_call_by_call():
             assert (g_h[n] - g_a[n]).pow(2).mean().sqrt().item() <= 3e-2 * scale, n
 
 
+@pytest.mark.parametrize("k,P", [(100, 300), (64, 1000), (150, 150)])
+def test_more_than_63_neighbours_per_ray_against_the_oracle(k, P):
+    """select_k up to 255 (VERDICT r04 "missing" 3; reference models/model.py:281 takes any k): the wide forms of the neighbour search and of the
+    attention tail (the every-point branch k >= P included: (150, 150) attends over the whole cloud) against the CPU oracle -- the same sets,
+    fused / attention / rgb within the 1e-4 bar, gradients within conftest.grad_check."""
+    from papr_amd import get_model
+    from papr_amd.config import deep_merge
+    cfg = deep_merge(case_cfg("chair1k"), {"geoms": {"points": {"init_num": P, "select_k": k}}})
+    torch.manual_seed(1); np.random.seed(1)
+    m = get_model(cfg, device="cpu")
+    formula_fill(m.state_dict())
+    with torch.no_grad():
+        m.points.copy_(uniform_points(P, 12.0, seed=7))
+        m.points_influ_scores.copy_(torch.rand(P, 1, generator=torch.Generator().manual_seed(3)))
+    state = {n: v.detach().clone() for n, v in m.state_dict().items()}
+    m = m.to("cuda")
+    ro, rd, c2w = synth_rays(1, 8, 8, seed=5)
+    st = O.trainable_state(state, cfg)
+    ref = O.render(st, cfg, ro, rd)
+    torch.mean((ref["rgb"] - 0.5) ** 2).backward()
+    m.clear_grad()
+    rgb = m(*cuda(ro, rd, c2w))
+    torch.mean((rgb - 0.5) ** 2).backward()
+    with torch.no_grad():
+        fused, attn = m.evaluate(*cuda(ro, rd, c2w))
+    kk = min(k, P)
+    got_idx, ref_idx = m.select_k_ind.reshape(-1, kk).cpu().numpy(), ref["idx"].reshape(-1, kk).numpy()
+    assert np.array_equal(np.sort(got_idx, -1), np.sort(ref_idx, -1)), "neighbour sets differ"
+    mine = attn.reshape(-1, kk + 1).cpu().numpy()
+    a_got = np.concatenate([np.take_along_axis(mine[:, :kk], np.argsort(got_idx, -1), -1), mine[:, kk:]], -1)
+    theirs = ref["attn"].reshape(-1, kk + 1).detach().numpy()
+    a_ref = np.concatenate([np.take_along_axis(theirs[:, :kk], np.argsort(ref_idx, -1), -1), theirs[:, kk:]], -1)
+    err = {"rgb": np.abs(rgb.detach().cpu().numpy() - ref["rgb"].detach().numpy()).max(), "attn": np.abs(a_got - a_ref).max(),
+           "fused": np.abs(fused.reshape(ref["fused"].shape).cpu().numpy() - ref["fused"].detach().numpy()).max()}
+    print("k = %d, P = %d: L-inf vs oracle" % (k, P), err)
+    assert max(err.values()) <= RGB_TOL, err
+    named = dict(m.named_parameters())
+    # (64 rays: a single activation-derivative flip -- conftest.grad_check's isolated outliers -- is a visible share of a 3 P-element tensor, so the
+    # bar here is the outlier bar itself: rms 5e-4 and nothing beyond 3e-2 of the tensor's largest entry; the forward bar above is the tight one)
+    for n in ("points", "points_influ_scores", "pc_feats", "proximity_attn.attention_layer.w_k.bias", "proximity_attn.embed.embed_v.mlp.model.1.weight"):
+        got, want = named[n].grad.cpu().numpy().astype(np.float64), st[n].grad.numpy().astype(np.float64)
+        e = np.abs(got - want) / max(np.abs(want).max(), 1e-30)
+        assert np.sqrt((e ** 2).mean()) <= 5e-4 and e.max() <= 3e-2, (n, float(np.sqrt((e ** 2).mean())), float(e.max()))
+
+
 def test_no_grad_weight_cache_sees_writes_that_bypass_the_version_counters():
     """under no_grad the folded / split kernel weights are cached, keyed on the parameters' (data_ptr, version).  papr_adam_step and
     dist.broadcast_module_state write through raw pointers / `.data`: they bump dist.param_epoch, which is part of the key -- an evaluate() behind
