@@ -1716,14 +1716,24 @@ extern "C" int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float*
         const long ld_in = x_half ? ld_x_rows : (i == 0 ? ldx : ld_out[i - 1]);
         PAPR_REQUIRE(d_weight[i], "papr_mlp_bwd: layer %d has null d_weight", i);
         // split-f16 when the forward pass left the row maxima of this layer's input
-        const bool h3w = GEMM_H3_WGRAD && row_absmax && gmax_i && layer_rowmax_saved(layers, n_layers, i) && L.n_out <= SLAB && L.n_in <= SLAB;
-        if (h3w) {
-            if (int e = tnq.push(gi, ldgi, L.n_out, in, ld_in, L.n_in, M, gmax_i, row_absmax + (size_t)i * M, d_weight[i], L.ldw, d_bias[i], g_half, x_half)) return e;
-        } else {
-            PAPR_REQUIRE(!g_half && !x_half, "papr_mlp_bwd: layer %d: f16 rows without the split-f16 weight-gradient", i);
-            if (int e = tnq.flush()) return e;
-            if (int e = gemm_tn(gi, ldgi, L.n_out, in, ld_in, L.n_in, M, d_weight[i], L.ldw, d_bias[i], workspace, s)) return e;
-        }
+        const bool h3w = GEMM_H3_WGRAD && row_absmax && gmax_i && layer_rowmax_saved(layers, n_layers, i);
+        // a layer wider than the 256 x 256 tile of the weight-gradient kernels (d_ff = 512 ...; round 5): block by block -- 256 output rows x 256
+        // input columns of dW each, the operands' column windows through their row strides, the bias gradient with the first column block.  (The
+        // row maxima are the whole rows': a window's slice scale is then at most the row's -- never too small.)
+        for (int n0 = 0; n0 < L.n_out; n0 += SLAB)
+            for (int k0 = 0; k0 < L.n_in; k0 += SLAB) {
+                const int nb = L.n_out - n0 < SLAB ? L.n_out - n0 : SLAB, kb = L.n_in - k0 < SLAB ? L.n_in - k0 : SLAB;
+                float* dw = d_weight[i] + (size_t)n0 * L.ldw + k0;
+                float* db = (k0 == 0 && d_bias[i]) ? d_bias[i] + n0 : nullptr;
+                if (h3w) {
+                    PAPR_REQUIRE((!g_half && !x_half) || (n0 == 0 && k0 == 0 && nb == L.n_out && kb == L.n_in), "papr_mlp_bwd: layer %d: f16 rows of a blocked weight-gradient", i);
+                    if (int e = tnq.push(gi + n0, ldgi, nb, in + k0, ld_in, kb, M, gmax_i, row_absmax + (size_t)i * M, dw, L.ldw, db, g_half, x_half)) return e;
+                } else {
+                    PAPR_REQUIRE(!g_half && !x_half, "papr_mlp_bwd: layer %d: f16 rows without the split-f16 weight-gradient", i);
+                    if (int e = tnq.flush()) return e;
+                    if (int e = gemm_tn(gi + n0, ldgi, nb, in + k0, ld_in, kb, M, dw, L.ldw, db, workspace, s)) return e;
+                }
+            }
         if (L.n_skip > 0) {
             // the skip segment [previous output | x]: dW[:, skip_col ..) = G^T x -- split-f16 like the first segment when the forward
             // run left the maxima of the x rows (row_absmax[0 .. M): a fused run that starts at layer 0), fp32 MFMA otherwise

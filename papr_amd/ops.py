@@ -70,8 +70,10 @@ class MlpSpec:
                 raise NotImplementedError("papr_amd: activation '%s' (%s) has no HIP epilogue (relu/leakyrelu/none)" % (a, name))
         self.act = hip.ACT[ecfg["ff_act"].lower()]
         self.last_act = hip.ACT[ecfg["ff_last_act"].lower()]
-        if self.width % 4 or self.width > 256 or self.d_out > 256:
-            raise NotImplementedError("papr_amd: %s widths must be multiples of 4 and <= 256" % name)
+        # (<= 256 and multiples of 32: the fused runs; wider or odd layers run layer by layer on the split-f16 / fp32 GEMMs, their weight gradients
+        # in 256 x 256 blocks -- 1024: the row kernels' and the LayerNorm fold's limit)
+        if self.width % 4 or self.width > 1024 or self.d_out > 1024:
+            raise NotImplementedError("papr_amd: %s widths must be multiples of 4 and <= 1024" % name)
         # per-layer geometry
         self.layers = []
         for i in range(self.n_layer):
@@ -659,8 +661,8 @@ class RenderPath:
         # single-layer "MLPs" for w_k / w_q so that they share the GEMM drivers
         one = lambda name, d_in: MlpSpec(name, d_in, dict(n_ff_layer=1, d_ff=self.d_model, d_ff_out=self.d_model, norm="none",
                                                           ff_act="none", ff_last_act="none"))
-        if self.d_model % 4 or self.d_model > 256:
-            raise NotImplementedError("papr_amd: d_model must be a multiple of 4 and <= 256")
+        if self.d_model % 4 or self.d_model > 1024:
+            raise NotImplementedError("papr_amd: d_model must be a multiple of 4 and <= 1024")
         self.wk = one("w_k", self.key.d_out)
         self.wq = one("w_q", self.qry.d_out)
         # g = q' W_k seen as a Linear layer (weight W_k^T): its backward runs on the library's own GEMMs
