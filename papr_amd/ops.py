@@ -18,7 +18,7 @@ import torch.nn.functional as F
 from . import hip
 
 
-def mlp_mode(one_product):
+def mlp_mode(one_product, fp32_rows_inside=False):
     """The `mode` argument of papr_mlp_fwd / papr_mlp_bwd (include/papr_hip.h: PAPR_MLP_*) for one call.  The library itself reads no
     environment: PAPR_GEMM_MODE (h3 default | h1 | layers | dgrad | fwd | f32: A/B and benchmark switch) is THIS module's, and a
     `use_amp: true` model asks for the one-product arithmetic call by call (on top of the default mode only, so that the A/B modes
@@ -26,8 +26,8 @@ def mlp_mode(one_product):
     name = os.environ.get("PAPR_GEMM_MODE", "h3")
     if name == "h3" and one_product:
         name = "h1"
-    if name == "h1" and os.environ.get("PAPR_H1_ROWS", "") == "f32":      # (A/B: fp32 rows between a run and its weight gradients)
-        name = "h1_f32rows"
+    if name == "h1" and (os.environ.get("PAPR_H1_ROWS", "") == "f32" or fp32_rows_inside):      # (A/B: fp32 rows between a run and its weight gradients;
+        name = "h1_f32rows"                                                                       # fp32_rows_inside: a run whose INNER rows the host reads)
     return hip.MLP_MODES[name]
 
 
@@ -471,7 +471,7 @@ def mlp_forward(spec, ws, bs, x, M, keep=True, out_norm=None, in_norm=None, dot_
         norm = C.byref(rn)
     hip.check(hip.lib().papr_mlp_fwd(tab, spec.n_layer, hip.ptr(x), x.shape[1], M, hip.ptr_array(outs),
                                      hip.i32_array(spec.ld_out), hip.ptr(outs.row_absmax), inorm, norm,
-                                     hip.ptr(_workspace(dev, "fwd", M)), mlp_mode(spec.one_product), hip.stream_ptr()), "papr_mlp_fwd")
+                                     hip.ptr(_workspace(dev, "fwd", M)), mlp_mode(spec.one_product, getattr(spec, "fp32_rows_inside", False)), hip.stream_ptr()), "papr_mlp_fwd")
     return outs
 
 
@@ -497,7 +497,7 @@ def mlp_backward(spec, ws, bs, x, M, outs, d_out, scratch, need_dx):
     """Returns (d_ws, d_bs, d_x or None).  d_out is consumed."""
     dev = x.device
     tab = _layer_table(spec, ws, bs)
-    if hip.lib().papr_mlp_bwd_needs_weight_t(tab, spec.n_layer, 1 if need_dx else 0, mlp_mode(spec.one_product)):     # (fused runs read W^T in place)
+    if hip.lib().papr_mlp_bwd_needs_weight_t(tab, spec.n_layer, 1 if need_dx else 0, mlp_mode(spec.one_product, getattr(spec, "fp32_rows_inside", False))):     # (fused runs read W^T in place)
         wts = [w.t().contiguous() for w in ws]
         tab = _layer_table(spec, ws, bs, wts)
     d_ws = [torch.empty_like(w) for w in ws]
@@ -507,7 +507,7 @@ def mlp_backward(spec, ws, bs, x, M, outs, d_out, scratch, need_dx):
                                      hip.i32_array(spec.ld_out), hip.ptr(getattr(outs, "row_absmax", None)),
                                      hip.ptr(d_out), hip.ptr(scratch[0]), hip.ptr(scratch[1]),
                                      scratch[0].shape[1], hip.ptr_array(d_ws), hip.ptr_array(d_bs), hip.ptr(d_x),
-                                     hip.ptr(_workspace(dev, "bwd", M)), mlp_mode(spec.one_product), hip.stream_ptr()), "papr_mlp_bwd")
+                                     hip.ptr(_workspace(dev, "bwd", M)), mlp_mode(spec.one_product, getattr(spec, "fp32_rows_inside", False)), hip.stream_ptr()), "papr_mlp_bwd")
     return d_ws, d_bs, d_x
 
 
@@ -674,6 +674,8 @@ class RenderPath:
         if self.d_model % 32 == 0 and self.key.d_out % 32 == 0 and self.d_model <= 256 and self.key.d_out <= 256:
             self.wqk = MlpSpec("w_q_k", self.qry.d_out, dict(n_ff_layer=2, d_ff=self.d_model, d_ff_out=self.key.d_out, norm="none",
                                                             ff_act="none", ff_last_act="none"))
+            self.wqk.fp32_rows_inside = True        # (q', the run's INNER row, is read by the host side: c0 = q'.b_k and its gradients -- in the
+                                                    # process-wide one-product mode a run's inner rows are f16 otherwise)
         d = hip.FeatureDesc()
         d.feat_dim = self.feat_dim
         d.L_key = (C.c_int32 * 3)(*e["k_L"])
