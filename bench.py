@@ -324,6 +324,8 @@ def main():
                     # (since round 5 the R-row products around w_q / w_k ride on this kernel too: two short launches per step that pull the plain
                     # average down -- the figure comparable with earlier rounds is the one over the four R*k-row runs)
                     "avg_launch_ms_pair_row_runs": big_ms / max(len(big), 1), "launches_pair_row_runs": len(big),
+                    # the six runs per step that rounds 1-4 averaged (key / value / query MLP, forward and data-gradient): every launch but the two-layer w_q / w_k run
+                    "avg_launch_ms_mlp_runs": sum(r[4] for r in rs if r[2] != 2) / max(len([r for r in rs if r[2] != 2]), 1),
                     "frac_pair_row_runs": (sum(float(r[6]) for r in big) / (big_ms * 1e-3) / 1e12 / F16_MFMA_PEAK_TF) if big_ms > 0 else None,
                     "note": "achieved / frac = ALGORITHMIC flops (2 M N K of every layer, true input widths 117 / 142 / 39) over the launch time, against the dense f16 MFMA peak; "
                             "frac_issued counts the f16 MFMA products the kernel issues per fp32 product (parity mode: hi.hi + hi.lo + lo.hi = 3) = matrix-pipe utilisation",
