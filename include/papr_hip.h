@@ -439,9 +439,10 @@ int papr_profile_enable(int on);
  *   PAPR_SW_C4_PHASE    (6130) the workgroups of a fused run that carry one pair of tiles fewer than the others start late instead of finishing early
  *                              (out of phase with the rest at no cost).  value = 1000 x (the fewest steps a run must have) + (delay per step of the run in
  *                              hundreds of cycles); 0: off
+ *   PAPR_SW_C4_WCOPIES  (1)    timing experiment: 2-4 = the workgroups of an XCD read a fused run's weight fragments from that many copies of the planes
  *   PAPR_SW_C4_SUBPHASE (0)    timing experiment: workgroup b of a fused run starts ((b / 8) % 4) x value cycles late (sub-slot phases inside an XCD) */
 enum { PAPR_SW_C4_GENERIC = 0, PAPR_SW_C4_FUSED = 1, PAPR_SW_C4_EARLY = 2, PAPR_SW_KNN_BLOCKS = 3, PAPR_SW_KNN_T = 4, PAPR_SW_WGRAD_WGS = 5,
-       PAPR_SW_NT_VARIANT = 6, PAPR_SW_C4_DMA = 7, PAPR_SW_TN_JOBPAR = 8, PAPR_SW_C4_PAIRS = 9, PAPR_SW_C4_PHASE = 10, PAPR_SW_C4_SUBPHASE = 11, PAPR_SW_COUNT = 12 };
+       PAPR_SW_NT_VARIANT = 6, PAPR_SW_C4_DMA = 7, PAPR_SW_TN_JOBPAR = 8, PAPR_SW_C4_PAIRS = 9, PAPR_SW_C4_PHASE = 10, PAPR_SW_C4_SUBPHASE = 11, PAPR_SW_C4_WCOPIES = 12, PAPR_SW_COUNT = 13 };
 int papr_set_switch(int32_t which, int32_t value);
 int32_t papr_get_switch(int32_t which);
 /* Waits for the recorded events, writes up to `cap` records (oldest first), clears the log and

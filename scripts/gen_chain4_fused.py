@@ -407,6 +407,8 @@ def build(tile, mode, act, ld, kcnt=16, one=False):
         p2 = []
     elif ABLATE == "KP2":
         p1 = []
+    if ABLATE == "NOST":                        # (timing experiment, results wrong: the hot slots' row stores never leave -- what do the stores cost, and is it them the phase shift spreads?)
+        p2 = [x for x in p2 if not x.text.startswith("global_store_dwordx4")]
     e = Emit()
     for x in pro:
         e.put(x)
