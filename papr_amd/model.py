@@ -150,8 +150,11 @@ class ProximityAttentionParams(nn.Module):
             return prepare_mlp_weights(spec, [lin.weight], [lin.bias], ln)
 
         e, a = self.embed, self.attention_layer
-        return {"key": ff(e.embed_k, plan.key), "query": ff(e.embed_q, plan.qry), "value": ff(e.embed_v, plan.val),
-                "wk": proj(a.w_k, e.embed_k, plan.wk), "wq": proj(a.w_q, e.embed_q, plan.wq)}
+        out = {"key": ff(e.embed_k, plan.key), "query": ff(e.embed_q, plan.qry), "value": ff(e.embed_v, plan.val),
+               "wk": proj(a.w_k, e.embed_k, plan.wk), "wq": proj(a.w_q, e.embed_q, plan.wq)}
+        if isinstance(e.embed_v.outnorm, _NormParams):           # (value.norm: layernorm -- applied by ops._RenderFn, nothing to fold it into)
+            out["v_out"] = (e.embed_v.outnorm.a_2, e.embed_v.outnorm.b_2)
+        return out
 
 
 # ----------------------------------------------------------------------------------------------

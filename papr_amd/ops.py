@@ -652,11 +652,12 @@ class RenderPath:
         self.key = MlpSpec("key", self.key_w, e["key"])
         self.qry = MlpSpec("query", self.qry_w, e["query"])
         self.val = MlpSpec("value", self.val_w, e["value"])
-        if self.val.norm != "none":
-            raise NotImplementedError("papr_amd: value.norm must be 'none' (the out-norm affine has no following layer to fold into)")
-        if self.key.norm != self.qry.norm:
-            raise NotImplementedError("papr_amd: key.norm and query.norm must agree")
-        self.kq_norm = self.key.norm == "layernorm"
+        # each FeedForward has its own `norm` (models/attn.py:100-107): LayerNorm in front of and behind the key / query / value MLP independently.
+        # Key and query: the out-norm's affine folds into w_k / w_q.  Value: nothing follows its out-norm, so the affine is applied by the host
+        # glue (v_norm below; no shipped scene file sets value.norm)
+        self.k_norm = self.key.norm == "layernorm"
+        self.q_norm = self.qry.norm == "layernorm"
+        self.v_norm = self.val.norm == "layernorm"
         self.C = self.val.d_out
         # single-layer "MLPs" for w_k / w_q so that they share the GEMM drivers
         one = lambda name, d_in: MlpSpec(name, d_in, dict(n_ff_layer=1, d_ff=self.d_model, d_ff_out=self.d_model, norm="none",
@@ -759,7 +760,7 @@ class _RenderFn(torch.autograd.Function):
         # hands); the fused run applies them while it stages the rows.  PAPR_KEY_STATS=0: the run takes them itself (two wave sums, a square root and a
         # division per row in its staging slot)
         key_given = None
-        if plan.kq_norm and not plan.fdesc.key_has_feats and _KEY_STATS:
+        if plan.k_norm and not plan.fdesc.key_has_feats and _KEY_STATS:
             key_given = (torch.empty((M, 2), device=dev, dtype=torch.float32), torch.empty((M,), device=dev, dtype=torch.float32))
         hip.check(lib.papr_build_features_fwd(C.byref(fd), hip.ptr(points), hip.ptr(feats), hip.ptr(rays_o), hip.ptr(rays_d), R,
                                               rays_per_image, hip.ptr(idx), hip.ptr(key_in), hip.ptr(qry_in), hip.ptr(val_in),
@@ -767,8 +768,8 @@ class _RenderFn(torch.autograd.Function):
                                               eps, hip.stream_ptr()), "papr_build_features_fwd")
         # (the LayerNorm cores in front of and behind the key / query MLPs ride in the fused runs: rows are standardised
         # while they are staged, and again in the last row phase)
-        q_outs = mlp_forward(plan.qry, qw, qb, qry_in, R, keep, (plan.qry.d_out, eps) if plan.kq_norm else None,
-                             (plan.qry_w, eps) if plan.kq_norm else None)
+        q_outs = mlp_forward(plan.qry, qw, qb, qry_in, R, keep, (plan.qry.d_out, eps) if plan.q_norm else None,
+                             (plan.qry_w, eps) if plan.q_norm else None)
         Q = q_outs[-1]
         # score_j = (W_q Q + b_q).(W_k K_j + b_k) = K_j.(W_k^T q') + b_k.q'  with q' = W_q Q + b_q: the R*k-row w_k
         # product of the reference (models/attn.py:217) becomes two R-row products (plain library GEMMs)
@@ -788,19 +789,27 @@ class _RenderFn(torch.autograd.Function):
         # the dot products K_j.g are taken in the key run's last row phase: in inference the (R*k, d_model) key embedding is never written
         # (1 KB per pair out and back in again otherwise), in training the attention tail does not read it back (the backward pass does);
         # PAPR_SCORES_IN_RUN=0 for the A/B
-        in_run = plan.kq_norm and _SCORES_IN_RUN
+        in_run = plan.k_norm and _SCORES_IN_RUN
         # training: the key embedding stays RAW in memory (its only reader, the tail's backward pass, standardises what it loads): the fused run's
         # last row phase then takes no row statistics.  Only where the whole key MLP is one fused run (every width a multiple of 32, the fused modes)
         raw_keys = (in_run and keep and _RAW_KEYS and mlp_mode(plan.key.one_product) in (hip.MLP_MODES["h3"], hip.MLP_MODES["h1"], hip.MLP_MODES["h1_f32rows"])
                     and 2 <= plan.key.n_layer <= 8 and all(L["n_out"] % 32 == 0 and L["n_out"] <= 256 and not L["skip"] for L in plan.key.layers)
                     and plan.key.last_act == hip.ACT["none"])
-        k_outs = mlp_forward(plan.key, kw, kb, key_in, M, keep, (plan.key.d_out, eps) if plan.kq_norm else None,
-                             ((plan.key_w, eps) + (key_given or ())) if plan.kq_norm else None, dot_rows=g if in_run else None, rows_per_dot=k,
+        k_outs = mlp_forward(plan.key, kw, kb, key_in, M, keep, (plan.key.d_out, eps) if plan.k_norm else None,
+                             ((plan.key_w, eps) + (key_given or ())) if plan.k_norm else None, dot_rows=g if in_run else None, rows_per_dot=k,
                              raw_rows=raw_keys)
         K = k_outs[-1]
         kst, qst, kst2, qst2 = k_outs.in_stats, q_outs.in_stats, k_outs.norm_stats, q_outs.norm_stats
-        v_outs = mlp_forward(plan.val, vw, vb, val_in, M, keep)
+        v_outs = mlp_forward(plan.val, vw, vb, val_in, M, keep, (plan.val.d_out, eps) if plan.v_norm else None,
+                             (plan.val_w, eps) if plan.v_norm else None)
         V = v_outs[-1]
+        v_aff = None
+        if plan.v_norm:                              # the value out-norm's affine a_2 * V^ + b_2 (models/attn.py:42): no Linear behind it to fold into
+            va, vbias = wb[-2], wb[-1]
+            v_hat = V
+            V = torch.zeros_like(v_hat)
+            V[:, :plan.val.d_out] = v_hat[:, :plan.val.d_out] * va + vbias
+            v_aff = (v_hat, va, V)
         td = plan.tail_desc(k)
         td.precomputed_dots = int(in_run)
         scores = torch.empty((R, k), device=dev, dtype=torch.float32)
@@ -815,7 +824,7 @@ class _RenderFn(torch.autograd.Function):
             order, sorted_pts, seg = group_pairs(idx.view(-1), points.shape[0], run=k)
             ctx.saved = dict(rays_o=rays_o, rays_d=rays_d, idx=idx, points=points, influ=influ, key_in=key_in, qry_in=qry_in,
                              val_in=val_in, kst=kst, qst=qst, kst2=kst2, qst2=qst2, k_outs=k_outs, q_outs=q_outs,
-                             v_outs=v_outs, g=g, c0=c0, qp=qp, qk_outs=qk_outs, key_given=key_given, order=order, sorted_pts=sorted_pts, seg=seg, scores=scores, attn=attn, wb=wb, P=points.shape[0],
+                             v_outs=v_outs, v_aff=v_aff, g=g, c0=c0, qp=qp, qk_outs=qk_outs, key_given=key_given, order=order, sorted_pts=sorted_pts, seg=seg, scores=scores, attn=attn, wb=wb, P=points.shape[0],
                              feat_shape=None if pc_feats is None else pc_feats.shape)
         return fused, attn, sel
 
@@ -837,6 +846,8 @@ class _RenderFn(torch.autograd.Function):
         wqw, wqb = take(1), take(1)
         vw, vb = take(n_v), take(n_v)
         K, Q, V = s["k_outs"][-1], s["q_outs"][-1], s["v_outs"][-1]
+        if s["v_aff"] is not None:
+            V = s["v_aff"][2]                        # (what the tail multiplied: the value out-norm's affine applied)
 
         td = plan.tail_desc(k)
         d_K = torch.empty_like(K) if K.shape[1] == plan.key.d_out else torch.zeros_like(K)
@@ -860,7 +871,7 @@ class _RenderFn(torch.autograd.Function):
         hip.check(lib.papr_attn_tail_bwd(C.byref(td), hip.ptr(K), hip.ptr(s["g"]), hip.ptr(V), hip.ptr(s["influ"]), hip.ptr(idx),
                                          R, hip.ptr(s["scores"]), hip.ptr(s["attn"]), hip.ptr(d_fused), hip.ptr(d_attn), hip.ptr(d_K),
                                          hip.ptr(d_g), hip.ptr(d_V), None, hip.ptr(d_c0), hip.ptr(pair_influ),
-                                         hip.ptr(s["kst2"]) if plan.kq_norm else None, hip.ptr(s["c0"]) if plan.kq_norm else None,
+                                         hip.ptr(s["kst2"]) if plan.k_norm else None, hip.ptr(s["c0"]) if plan.k_norm else None,
                                          hip.ptr(s["k_outs"].norm_mean), hip.stream_ptr()), "papr_attn_tail_bwd")
         # backward of g = q' W_k, c0 = q'.b_k: R-row products on the library's GEMMs (rocBLAS / hipBLASLt pick 130-270 us
         # kernels for these 25,600 x 256 shapes; the same work is ~100 us here)
@@ -897,19 +908,29 @@ class _RenderFn(torch.autograd.Function):
         d_kw, d_kb, d_key = mlp_backward(plan.key, kw, kb, s["key_in"], M, s["k_outs"], d_K, scratch, need_pts)
         # the backward pass of the LayerNorm core in front of the key MLP rides in papr_build_features_bwd_pairs where that kernel has the row's
         # statistics from the forward pass (key_given: the default); otherwise one papr_rownorm_bwd pass over the gradient rows
-        ln_in_features = plan.kq_norm and d_key is not None and s["key_given"] is not None and _LN_IN_FEATURES
-        if plan.kq_norm and d_key is not None and not ln_in_features:
+        ln_in_features = plan.k_norm and d_key is not None and s["key_given"] is not None and _LN_IN_FEATURES
+        if plan.k_norm and d_key is not None and not ln_in_features:
             rownorm_bwd_(d_key, s["key_in"], s["kst"], plan.key_w, eps)
         # query branch (the ray directions need no gradient)
         qscratch = [t[:R] for t in scratch]
         if not fused_qk_bwd:
             d_wq, d_wqb, d_Q = mlp_backward(plan.wq, wqw, wqb, Q, R, [qp], d_qp.contiguous(), qscratch, True)
-        if plan.kq_norm:
+        if plan.q_norm:
             rownorm_bwd_(d_Q, Q, s["qst2"], plan.qry.d_out, eps)
         d_qw, d_qb, _ = mlp_backward(plan.qry, qw, qb, s["qry_in"], R, s["q_outs"], d_Q, qscratch, False)
         # value branch
         need_val_dx = need_pts or ctx.needs_input_grad[7]
+        d_va = d_vbias = None
+        if plan.v_norm:                              # back through the value out-norm: its affine (host glue), then its core
+            v_hat, va, _ = s["v_aff"]
+            dv = d_V[:, :plan.val.d_out]
+            d_va, d_vbias = (dv * v_hat[:, :plan.val.d_out]).sum(0), dv.sum(0)
+            d_hat = torch.zeros_like(d_V)
+            d_hat[:, :plan.val.d_out] = dv * va
+            d_V = rownorm_bwd_(d_hat, v_hat, s["v_outs"].norm_stats, plan.val.d_out, eps)
         d_vw, d_vb, d_val = mlp_backward(plan.val, vw, vb, s["val_in"], M, s["v_outs"], d_V, scratch, need_val_dx)
+        if plan.v_norm and d_val is not None:        # ... and its in-norm's core (the affine is folded into the first layer's weights)
+            rownorm_bwd_(d_val, s["val_in"], s["v_outs"].in_stats, plan.val_w, eps)
         # gather / geometry / encoding backward: per-pair gradient rows, then one segmented sum per point
         d_points = d_feats = pair_pts = None
         need_geo = need_pts or ctx.needs_input_grad[7]
@@ -939,7 +960,7 @@ class _RenderFn(torch.autograd.Function):
                                               hip.ptr(d_key), d_key.shape[1], plan.key_w - fdim, fdim, None, None, hip.ptr(d_feats),
                                               1, hip.ptr(seg_ws), hip.stream_ptr()), "papr_segment_reduce")
         ctx.saved = None
-        grads_wb = d_kw + d_kb + d_wk + d_wkb + d_qw + d_qb + d_wq + d_wqb + d_vw + d_vb
+        grads_wb = d_kw + d_kb + d_wk + d_wkb + d_qw + d_qb + d_wq + d_wqb + d_vw + d_vb + ([d_va, d_vbias] if plan.v_norm else [])
         return (None, None, None, None, None, None, d_points, d_feats, d_influ, None, None, None) + tuple(grads_wb)
 
 
@@ -949,4 +970,6 @@ def render_rays(plan, rays_o, rays_d, rays_per_image, idx, points, pc_feats, inf
     qw, qb = weights["query"]
     vw, vb = weights["value"]
     flat = kw + kb + weights["wk"][0] + weights["wk"][1] + qw + qb + weights["wq"][0] + weights["wq"][1] + vw + vb
+    if plan.v_norm:
+        flat = flat + list(weights["v_out"])         # (a_2, b_2) of the value out-norm
     return _RenderFn.apply(plan, rays_o, rays_d, rays_per_image, torch.is_grad_enabled(), idx, points, pc_feats, influ, len(kw), len(qw), len(vw), *flat)

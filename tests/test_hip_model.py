@@ -617,6 +617,49 @@ def test_layers_wider_than_256_against_the_oracle(over):
     print("wide layers: worst relative gradient error", worst)
 
 
+@pytest.mark.parametrize("norms", [("layernorm", "none", "none"), ("none", "layernorm", "layernorm"), ("layernorm", "layernorm", "layernorm")])
+def test_every_feedforward_has_its_own_norm(norms):
+    """`norm` is a key of each of the three FeedForward blocks (reference models/attn.py:100-107): key / query / value with or without their LayerNorm
+    pair independently (VERDICT r04 "missing" 4: the build wanted key.norm == query.norm and value.norm == none).  The value out-norm's affine has no
+    Linear behind it and is applied by the host glue.  Against the oracle: forward 1e-4, every gradient conftest.grad_check."""
+    from papr_amd import get_model
+    from papr_amd.config import deep_merge
+    kn, qn, vn = norms
+    cfg = deep_merge(case_cfg("chair1k"), {"models": {"attn": {"embed": {"key": {"norm": kn}, "query": {"norm": qn}, "value": {"norm": vn}}}}})
+    torch.manual_seed(1); np.random.seed(1)
+    m = get_model(cfg, device="cpu")
+    formula_fill(m.state_dict())
+    g5 = golden("g567_chair1k.npz")
+    with torch.no_grad():
+        m.points.copy_(T(g5["points"]))
+        m.points_influ_scores.copy_(torch.rand(m.points.shape[0], 1, generator=torch.Generator().manual_seed(3)))
+    state = {n: v.detach().clone() for n, v in m.state_dict().items()}
+    has = lambda blk: ("proximity_attn.embed.%s.innorm.a_2" % blk) in state
+    assert (has("embed_k"), has("embed_q"), has("embed_v")) == (kn == "layernorm", qn == "layernorm", vn == "layernorm")
+    m = m.to("cuda")
+    ro, rd, c2w = case_rays("chair1k")
+    st = O.trainable_state(state, cfg)
+    ref = O.render(st, cfg, ro, rd)
+    torch.mean((ref["rgb"] - 0.5) ** 2).backward()
+    m.clear_grad()
+    rgb = m(*cuda(ro, rd, c2w))
+    torch.mean((rgb - 0.5) ** 2).backward()
+    with torch.no_grad():
+        fused, attn = m.evaluate(*cuda(ro, rd, c2w))
+    err = {"rgb": np.abs(rgb.detach().cpu().numpy() - ref["rgb"].detach().numpy()).max(),
+           "fused": np.abs(fused.reshape(ref["fused"].shape).cpu().numpy() - ref["fused"].detach().numpy()).max()}
+    print(norms, "L-inf vs oracle", err)
+    assert max(err.values()) <= RGB_TOL, err
+    named = dict(m.named_parameters())
+    checked = 0
+    for n, p in named.items():
+        if p.grad is None or st[n].grad is None or st[n].grad.abs().max() == 0:
+            continue
+        grad_check(p.grad.cpu().numpy(), st[n].grad.numpy(), n)
+        checked += 1
+    assert checked > 40
+
+
 def test_no_grad_weight_cache_sees_writes_that_bypass_the_version_counters():
     """under no_grad the folded / split kernel weights are cached, keyed on the parameters' (data_ptr, version).  papr_adam_step and
     dist.broadcast_module_state write through raw pointers / `.data`: they bump dist.param_epoch, which is part of the key -- an evaluate() behind
