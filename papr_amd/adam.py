@@ -54,6 +54,17 @@ def _adopt_state(st, p):
             st[name] = torch.empty_like(p, memory_format=torch.preserve_format).copy_(m)
 
 
+def scaler_supported(scaler):
+    """step_scaled keeps torch.amp.GradScaler's per-optimizer records in step through the fields GradScaler.step / update themselves use
+    (torch/amp/grad_scaler.py).  A scaler of another make, or a torch that renamed them: PAPR.step takes torch's own route instead."""
+    try:
+        from torch.amp.grad_scaler import OptState  # noqa: F401
+    except Exception:
+        return False
+    return (type(scaler).__module__.startswith("torch.") and hasattr(scaler, "_check_scale_growth_tracker") and hasattr(scaler, "_per_optimizer_states")
+            and hasattr(OptState, "STEPPED") and hasattr(OptState, "UNSCALED"))
+
+
 def step_scaled(optimizers, scaler):
     """`for opt in optimizers: scaler.step(opt)` (reference models/model.py:439-442) under a live torch.amp.GradScaler, as the same launches as
     step() plus one pass that looks for non-finite gradients: the kernel divides every gradient by the scaler's scale as it reads it and leaves

@@ -297,7 +297,7 @@ class PAPR(nn.Module):
         # device parameters; PAPR_OWN_ADAM=0: torch's optimizers
         if _OWN_ADAM and not self.scaler.is_enabled() and own_adam.supported(opts):
             own_adam.step(opts)
-        elif _OWN_ADAM and _OWN_ADAM_AMP and self.scaler.is_enabled() and own_adam.supported(opts):
+        elif _OWN_ADAM and _OWN_ADAM_AMP and self.scaler.is_enabled() and own_adam.supported(opts) and own_adam.scaler_supported(self.scaler):
             # `use_amp: true`: the same launches under the GradScaler (torch's route: one inf-check launch and one fused-Adam launch per optimizer,
             # ~0.5 ms per step; here: one check pass, one step pass, the scaler's bookkeeping kept in step)
             own_adam.step_scaled(opts, self.scaler)
