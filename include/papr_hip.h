@@ -159,6 +159,16 @@ int papr_rownorm_bwd(const float* dy, const float* y, const float* stats, int64_
 int papr_row_dots(const float* rows, int64_t M, int width, int ld, const float* dot_rows, int ld_dot, int rows_per_dot,
                   float* dots, papr_stream_t stream);
 
+/* Backward of the score bias c0 = q'.b_k, q' = W_q Q + b_q (the bias row of w_k inside the reference's R k x d_model score product,
+ * models/attn.py:217-225; here one number per ray, papr_row_dots) -- linear in Q: c0 = Q.(W_q^T b_k) + b_q.b_k.  Given d_c0 (R), with
+ * u = Q^T d_c0 and s = sum(d_c0):
+ *   d_Q (R, ldq)[:, :dq] += d_c0 (x) (W_q^T b_k);   d_wq (dm, ldwq)[:, :dq] += b_k (x) u;   d_bq (dm) = d_bq_in + s b_k (may alias d_bq_in);
+ *   d_bk (dm) = W_q u + s b_q.
+ * Q (R, ldq), wq = W_q (dm, ldwq), bk, bq (dm); ldq and ldwq multiples of 4.  Sums in a fixed order; two launches (ABI 26). */
+size_t papr_qk_bias_bwd_workspace_bytes(int dq);
+int papr_qk_bias_bwd(const float* Q, int ldq, int dq, int dm, const float* d_c0, int64_t R, const float* wq, int ldwq, const float* bk, const float* bq,
+                     float* d_Q, float* d_wq, const float* d_bq_in, float* d_bq, float* d_bk, void* workspace, papr_stream_t stream);
+
 /* The affine part of that LayerNorm, y = a_2 * xh + b_2 (models/attn.py:42), folded into the Linear layer behind it:
  *   W (a_2 * xh + b_2) + c  =  (W * a_2) xh + (W b_2 + c).
  * fwd: eff_w (n_out, ld_eff) = W[:, :n_in] * a_2 with columns n_in .. ld_eff-1 zeroed, eff_b = c + W b_2.

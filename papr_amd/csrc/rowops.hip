@@ -647,6 +647,160 @@ extern "C" int papr_row_dots(const float* rows, int64_t M, int width, int ld, co
     return 0;
 }
 
+// The score bias c0 = q'.b_k, q' = W_q Q + b_q (models/attn.py:217-225 computes it inside the R k x d_model score product; here one number per
+// ray) is linear in the query embedding Q itself: c0 = Q.(W_q^T b_k) + b_q.b_k.  With u = Q^T d_c0 (dq) and s = sum(d_c0) its gradient is
+//   d_Q += d_c0 (x) (W_q^T b_k)      d_W_q += b_k (x) u      d_b_q += s b_k      d_b_k = W_q u + s b_q
+// -- two launches (ten torch launches of 5 ... 26 us before, which also read the R x d_model rows q'): qk_bias_rows_kernel walks the R rows of Q
+// once, every workgroup a chunk of rows, and updates d_Q on the way; qk_bias_finish_kernel adds the chunks in a fixed order and applies the rest.
+namespace {
+constexpr int QKB_CHUNKS = 256;                  // row chunks = workgroups of the first launch
+// Thread = (row lane, float4 column group of [Q | 1]): the workgroup's rows r0 + lane, r0 + lane + RL, ... eight at a time (all loads of a batch
+// in flight together: the kernel is a latency chain otherwise).  partial[chunk][dq + 1].
+__global__ __launch_bounds__(256) void qk_bias_rows_kernel(const float* __restrict__ Q, int ldq, int dq, int dm, const float* __restrict__ d_c0, long R,
+                                                           const float* __restrict__ wq, int ldwq, const float* __restrict__ bk, float* __restrict__ d_Q,
+                                                           float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];       // vq = W_q^T b_k (4 gq, zero beyond dq), then the lanes' sums (256 float4)
+    const int gq = (dq + 3) >> 2, ng = gq + 1;
+    float* vq = sm;
+    float4* lsum = reinterpret_cast<float4*>(sm + 4 * gq);
+    {   // vq: thread = (n lane, column group); the n lanes meet in LDS in a fixed order
+        const int nl_count = 256 / gq > 0 ? 256 / gq : 1, span = gq < 256 ? gq : 256;
+        for (int cb = 0; cb < gq; cb += 256) {
+            const int cg = cb + (int)threadIdx.x % span, nl = (int)threadIdx.x / span;
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (cg < gq && nl < nl_count) {
+#pragma unroll 8
+                for (int n = nl; n < dm; n += nl_count) {        // (whole float4 groups: ldwq is a multiple of 4; columns beyond dq are zeroed below)
+                    const float b = bk[n];
+                    const float4 w = *reinterpret_cast<const float4*>(wq + (long)n * ldwq + 4 * cg);
+                    t.x = fmaf(w.x, b, t.x); t.y = fmaf(w.y, b, t.y); t.z = fmaf(w.z, b, t.z); t.w = fmaf(w.w, b, t.w);
+                }
+                if (4 * cg + 1 >= dq) t.y = 0.f;
+                if (4 * cg + 2 >= dq) t.z = 0.f;
+                if (4 * cg + 3 >= dq) t.w = 0.f;
+            }
+            lsum[threadIdx.x] = t;
+            __syncthreads();
+            if (nl == 0 && cg < gq) {
+                float4 r = lsum[threadIdx.x];
+                for (int j = 1; j < nl_count; ++j) { const float4 v = lsum[threadIdx.x + j * gq]; r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w; }
+                *reinterpret_cast<float4*>(vq + 4 * cg) = r;
+            }
+            __syncthreads();
+        }
+    }
+    const long per = (R + gridDim.x - 1) / gridDim.x, r0 = (long)blockIdx.x * per, r1 = r0 + per < R ? r0 + per : R;
+    for (int gb = 0; gb < ng; gb += 256) {
+        const int span = ng - gb < 256 ? ng - gb : 256, RL = 256 / span;
+        const int g = gb + (int)threadIdx.x % span, rl = (int)threadIdx.x / span;
+        const bool ones = g >= gq;                                            // the last group: sum(d_c0)
+        const int gs = ones ? 0 : g;                                          // (it loads group 0 like everybody else and ignores it: no branch around the loads)
+        const float4 v = *reinterpret_cast<const float4*>(vq + 4 * gs);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rl < RL) {
+            for (long rb = r0 + rl; rb < r1; rb += 8L * RL) {
+                float gg[8];
+                float4 x[8], dqv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const long r = rb + (long)u * RL, rc = r < r1 ? r : r1 - 1;     // (clamped: every load of the batch is issued unconditionally)
+                    gg[u] = d_c0[rc];
+                    x[u] = *reinterpret_cast<const float4*>(Q + rc * ldq + 4 * gs);
+                    dqv[u] = *reinterpret_cast<const float4*>(d_Q + rc * ldq + 4 * gs);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const long r = rb + (long)u * RL;
+                    const float gu = r < r1 ? gg[u] : 0.f;
+                    const float4 xv = ones ? make_float4(1.f, 0.f, 0.f, 0.f) : x[u];
+                    acc.x = fmaf(gu, xv.x, acc.x); acc.y = fmaf(gu, xv.y, acc.y); acc.z = fmaf(gu, xv.z, acc.z); acc.w = fmaf(gu, xv.w, acc.w);
+                    if (!ones && r < r1) {
+                        float4 d = dqv[u];
+                        d.x = fmaf(gu, v.x, d.x); d.y = fmaf(gu, v.y, d.y); d.z = fmaf(gu, v.z, d.z); d.w = fmaf(gu, v.w, d.w);
+                        *reinterpret_cast<float4*>(d_Q + r * ldq + 4 * g) = d;
+                    }
+                }
+            }
+        }
+        lsum[threadIdx.x] = acc;
+        __syncthreads();
+        if (rl == 0) {
+            float4 t = lsum[threadIdx.x];
+            for (int j = 1; j < RL; ++j) { const float4 w = lsum[threadIdx.x + j * span]; t.x += w.x; t.y += w.y; t.z += w.z; t.w += w.w; }
+            float* out = partial + (long)blockIdx.x * (dq + 1);
+            if (ones) out[dq] = t.x;
+            else {
+                out[4 * g] = t.x;
+                if (4 * g + 1 < dq) out[4 * g + 1] = t.y;
+                if (4 * g + 2 < dq) out[4 * g + 2] = t.z;
+                if (4 * g + 3 < dq) out[4 * g + 3] = t.w;
+            }
+        }
+        __syncthreads();
+    }
+}
+// Every workgroup adds the chunks for all dq + 1 columns (thread = (chunk lane, column): 1024 / columns lanes stride through the chunks, the lanes
+// meet in LDS in lane order), then handles its share of the d_model rows: d_W_q += b_k (x) u, d_b_q += s b_k, d_b_k = W_q u + s b_q (a wave per row).
+__global__ __launch_bounds__(1024) void qk_bias_finish_kernel(const float* __restrict__ partial, int chunks, int dq, int dm, const float* __restrict__ wq,
+                                                              int ldwq, const float* __restrict__ bk, const float* __restrict__ bq, float* __restrict__ d_wq,
+                                                              const float* __restrict__ d_bq_in, float* __restrict__ d_bq, float* __restrict__ d_bk) {
+    extern __shared__ __attribute__((aligned(16))) float fsm[];      // red [Q^T d_c0 (dq) | sum d_c0], then the lanes' sums (1024)
+    const int cols = dq + 1;
+    float* red = fsm;
+    float* lane_sum = fsm + cols;
+    for (int cb = 0; cb < cols; cb += 1024) {
+        const int span = cols - cb < 1024 ? cols - cb : 1024, ZL = 1024 / span;
+        const int c = cb + (int)threadIdx.x % span, zl = (int)threadIdx.x / span;
+        float t = 0.f;
+        if (zl < ZL)
+#pragma unroll 8
+            for (int z = zl; z < chunks; z += ZL) t += partial[(long)z * cols + c];
+        lane_sum[threadIdx.x] = t;
+        __syncthreads();
+        if (zl == 0) {
+            float r = lane_sum[threadIdx.x];
+            for (int j = 1; j < ZL; ++j) r += lane_sum[threadIdx.x + j * span];
+            red[c] = r;
+        }
+        __syncthreads();
+    }
+    const float ssum = red[dq];
+    const int rows_per = (dm + gridDim.x - 1) / gridDim.x, n0 = blockIdx.x * rows_per, n1 = n0 + rows_per < dm ? n0 + rows_per : dm;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int n = n0 + wave; n < n1; n += 16) {
+        const float b = bk[n];
+        float dot = 0.f;
+        for (int c = lane; c < dq; c += 64) {
+            const long o = (long)n * ldwq + c;
+            dot = fmaf(wq[o], red[c], dot);
+            d_wq[o] = fmaf(b, red[c], d_wq[o]);
+        }
+        dot = wave_sum(dot);
+        if (lane == 0) {
+            d_bk[n] = fmaf(ssum, bq[n], dot);
+            d_bq[n] = fmaf(b, ssum, d_bq_in[n]);
+        }
+    }
+}
+}  // namespace
+
+extern "C" size_t papr_qk_bias_bwd_workspace_bytes(int dq) { return (size_t)QKB_CHUNKS * (dq + 1) * sizeof(float); }
+
+extern "C" int papr_qk_bias_bwd(const float* Q, int ldq, int dq, int dm, const float* d_c0, int64_t R, const float* wq, int ldwq, const float* bk, const float* bq,
+                                float* d_Q, float* d_wq, const float* d_bq_in, float* d_bq, float* d_bk, void* workspace, papr_stream_t stream) {
+    PAPR_REQUIRE(Q && d_c0 && wq && bk && bq && d_Q && d_wq && d_bq_in && d_bq && d_bk && workspace, "papr_qk_bias_bwd: null pointer");
+    PAPR_REQUIRE(dq >= 1 && dm >= 1 && dq <= 1024 && dm <= 1024 && ldq >= dq && ldwq >= dq && R >= 1 && ldq % 4 == 0 && ldwq % 4 == 0,
+                 "papr_qk_bias_bwd: dq %d (ld %d, weight ld %d: multiples of 4), dm %d, R %lld", dq, ldq, ldwq, dm, (long long)R);
+    hipStream_t s = as_stream(stream);
+    float* partial = static_cast<float*>(workspace);
+    const int chunks = R < QKB_CHUNKS ? (int)R : QKB_CHUNKS;
+    qk_bias_rows_kernel<<<dim3((unsigned)chunks), dim3(256), (4 * ((dq + 3) / 4) + 4 * 256) * sizeof(float), s>>>(Q, ldq, dq, dm, d_c0, R, wq, ldwq, bk, d_Q, partial);
+    PAPR_CHECK_LAUNCH("qk_bias_rows");
+    qk_bias_finish_kernel<<<dim3(16), dim3(1024), (dq + 1 + 1024) * sizeof(float), s>>>(partial, chunks, dq, dm, wq, ldwq, bk, bq, d_wq, d_bq_in, d_bq, d_bk);
+    PAPR_CHECK_LAUNCH("qk_bias_finish");
+    return 0;
+}
+
 extern "C" int papr_rownorm_bwd(const float* dy, const float* y, const float* stats, int64_t rows, int width, int ld,
                                 float eps, float* dx, papr_stream_t stream) {
     (void)eps;

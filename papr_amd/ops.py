@@ -431,6 +431,7 @@ class LayerOutputs(list):
     norm_mean = None       # (raw_rows) the last output holds the UN-standardised rows, this their means
     in_stats = None
     dots = None
+    wkT = None             # (the w_q / w_k run: W_k^T as the forward pass laid it out)
 
 
 def mlp_forward(spec, ws, bs, x, M, keep=True, out_norm=None, in_norm=None, dot_rows=None, rows_per_dot=1, raw_rows=False):
@@ -480,6 +481,7 @@ _SCORES_IN_RUN = os.environ.get("PAPR_SCORES_IN_RUN", "1") != "0"
 _QK_CHAIN = int(os.environ.get("PAPR_QK_CHAIN", "2"))           # A/B: 0 = w_q and the w_k fold as two single-layer calls each way; 1 = one two-layer run forward; 2 = backward as well
 _LN_IN_FEATURES = os.environ.get("PAPR_LN_IN_FEATURES", "1") != "0"     # A/B: the key in-norm's backward pass inside papr_build_features_bwd_pairs (0: papr_rownorm_bwd)
 _RAW_KEYS = os.environ.get("PAPR_RAW_KEYS", "1") != "0"        # A/B: training keeps the key embedding un-standardised (papr_row_norm.raw_mean), tail_bwd standardises on the fly
+_QK_BIAS_KERNEL = os.environ.get("PAPR_QK_BIAS_KERNEL", "1") != "0"   # A/B: the score bias' rank-one gradient terms on papr_qk_bias_bwd (0: torch ops)
 _KEY_STATS = os.environ.get("PAPR_KEY_STATS", "1") != "0"      # A/B: the key rows' LayerNorm statistics from papr_build_features_fwd (default) or from the fused run
 
 
@@ -776,7 +778,9 @@ class _RenderFn(torch.autograd.Function):
         qk_outs = None
         if plan.wqk is not None and _QK_CHAIN:
             # one two-layer run: q' (kept: the backward pass and c0 need it), then g = W_k^T q'; c0 = q'.b_k by one papr_row_dots launch
-            qk_outs = mlp_forward(plan.wqk, [wqw[0], wkw[0].t().contiguous()], [wqb[0], _zeros(dev, (plan.wqk.ld_out[1],))], Q, R, True)
+            wkT = wkw[0].t().contiguous()                     # (kept for the backward pass: one transpose launch per step, not two)
+            qk_outs = mlp_forward(plan.wqk, [wqw[0], wkT], [wqb[0], _zeros(dev, (plan.wqk.ld_out[1],))], Q, R, True)
+            qk_outs.wkT = wkT
             qp, g = qk_outs[0], qk_outs[1]                   # (R, d_model), (R, key.d_out padded to 32)
             c0 = torch.empty((R,), device=dev, dtype=torch.float32)
             bk = wkb[0].contiguous()
@@ -885,16 +889,26 @@ class _RenderFn(torch.autograd.Function):
             if d_g.shape[1] != plan.wqk.ld_out[1] or not d_g.is_contiguous():
                 d_g = d_g[:, :plan.wqk.ld_out[1]].contiguous()
             qs = [t[:R] for t in scratch]
-            (d_wq_a, d_wkT), (d_wqb_a, _), d_Q = mlp_backward(plan.wqk, [wqw[0], wkw[0].t().contiguous()], [wqb[0], _zeros(dev, (plan.wqk.ld_out[1],))],
+            (d_wq_a, d_wkT), (d_wqb_a, _), d_Q = mlp_backward(plan.wqk, [wqw[0], s["qk_outs"].wkT], [wqb[0], _zeros(dev, (plan.wqk.ld_out[1],))],
                                                               Q, R, s["qk_outs"], d_g, qs, True)
-            bk = wkb[0]
-            both = torch.cat([Q[:, :plan.qry.d_out], qp[:, :plan.d_model]], 1)                  # one reduction for Q^T d_c0 and q'^T d_c0
-            red = (both * d_c0[:, None]).sum(0)
-            u, d_wkb_v = red[:plan.qry.d_out], red[plan.qry.d_out:]
-            vq = (wqw[0][:, :plan.qry.d_out] * bk[:plan.d_model, None]).sum(0)                      # W_q^T b_k
-            d_Q[:, :plan.qry.d_out].addcmul_(d_c0[:, None], vq[None, :])
-            d_wq_a[:, :plan.qry.d_out].addcmul_(bk[:plan.d_model, None], u[None, :])
-            d_wq, d_wqb = [d_wq_a], [torch.addcmul(d_wqb_a, bk[:d_wqb_a.shape[0]], d_c0.sum())]
+            bk = wkb[0].contiguous()
+            if _QK_BIAS_KERNEL:                      # papr_qk_bias_bwd: the five rank-one terms in two launches
+                d_wkb_v = torch.empty((plan.d_model,), device=dev, dtype=torch.float32)
+                ws = torch.empty((lib.papr_qk_bias_bwd_workspace_bytes(plan.qry.d_out) + 3) // 4, device=dev, dtype=torch.float32)
+                bq_ = wqb[0].contiguous()
+                assert d_wqb_a.shape[0] == plan.d_model and bk.shape[0] >= plan.d_model and d_Q.is_contiguous() and d_wq_a.is_contiguous()
+                hip.check(lib.papr_qk_bias_bwd(hip.ptr(Q), Q.shape[1], plan.qry.d_out, plan.d_model, hip.ptr(d_c0), R, hip.ptr(wqw[0]), wqw[0].shape[1],
+                                               hip.ptr(bk), hip.ptr(bq_), hip.ptr(d_Q), hip.ptr(d_wq_a), hip.ptr(d_wqb_a), hip.ptr(d_wqb_a), hip.ptr(d_wkb_v),
+                                               hip.ptr(ws), hip.stream_ptr()), "papr_qk_bias_bwd")
+                d_wq, d_wqb = [d_wq_a], [d_wqb_a]
+            else:                                    # (A/B: the same in torch ops, ten launches)
+                both = torch.cat([Q[:, :plan.qry.d_out], qp[:, :plan.d_model]], 1)                  # one reduction for Q^T d_c0 and q'^T d_c0
+                red = (both * d_c0[:, None]).sum(0)
+                u, d_wkb_v = red[:plan.qry.d_out], red[plan.qry.d_out:]
+                vq = (wqw[0][:, :plan.qry.d_out] * bk[:plan.d_model, None]).sum(0)                      # W_q^T b_k
+                d_Q[:, :plan.qry.d_out].addcmul_(d_c0[:, None], vq[None, :])
+                d_wq_a[:, :plan.qry.d_out].addcmul_(bk[:plan.d_model, None], u[None, :])
+                d_wq, d_wqb = [d_wq_a], [torch.addcmul(d_wqb_a, bk[:d_wqb_a.shape[0]], d_c0.sum())]
             d_wk, d_wkb = [d_wkT.t()], [d_wkb_v.contiguous()]
         else:
             d_g = d_g[:, :plan.key.d_out].contiguous()           # the tail kernel fills d_model = key.d_out columns

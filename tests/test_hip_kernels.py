@@ -1126,3 +1126,34 @@ def test_grow_points_on_the_device_equals_the_host_procedure(comb, sample):
     assert got[1] == want[1] == add
     for g, w, name in ((got[0], want[0], "coords"), (got[2], want[2], "influ"), (got[3], want[3], "feats")):
         np.testing.assert_allclose(g.cpu().numpy(), np.asarray(w), rtol=0, atol=2e-6, err_msg=name)
+
+
+@pytest.mark.parametrize("R,dq,dm,ldq", [(25600, 64, 256, 64), (777, 48, 96, 64), (3, 5, 7, 8), (300, 1024, 40, 1024)])
+def test_qk_bias_bwd_rank_one_terms_equal_the_torch_formulas(R, dq, dm, ldq):
+    """papr_qk_bias_bwd (the gradient of the score bias c0 = q'.b_k, q' = W_q Q + b_q; models/attn.py:217-225) against autograd of that very
+    expression in float64."""
+    from papr_amd import hip
+    lib = hip.lib()
+    g = torch.Generator().manual_seed(R + dq)
+    rnd = lambda *s: torch.randn(*s, generator=g, dtype=torch.float32)
+    Q, d_c0, wq, bk, bq = rnd(R, ldq), rnd(R) * 0.01, rnd(dm, ldq), rnd(dm), rnd(dm)
+    d_Q0, d_wq0, d_bq0 = rnd(R, ldq), rnd(dm, ldq), rnd(dm)
+    dev = "cuda"
+    c = lambda t: t.to(dev).contiguous()
+    d_Q, d_wq, d_bq, d_bk = c(d_Q0), c(d_wq0), c(d_bq0), torch.empty(dm, device=dev)
+    ws = torch.empty((lib.papr_qk_bias_bwd_workspace_bytes(dq) + 3) // 4, device=dev)
+    Qd, gd, wqd, bkd, bqd = c(Q), c(d_c0), c(wq), c(bk), c(bq)
+    hip.check(lib.papr_qk_bias_bwd(hip.ptr(Qd), ldq, dq, dm, hip.ptr(gd), R, hip.ptr(wqd), ldq, hip.ptr(bkd), hip.ptr(bqd), hip.ptr(d_Q), hip.ptr(d_wq),
+                                   hip.ptr(d_bq), hip.ptr(d_bq), hip.ptr(d_bk), hip.ptr(ws), hip.stream_ptr()), "papr_qk_bias_bwd")
+    A = lambda t: t.double().clone().requires_grad_(True)
+    Qa, wqa, bka, bqa = A(Q[:, :dq]), A(wq[:, :dq]), A(bk), A(bq)
+    c0 = (Qa @ wqa.t() + bqa) @ bka
+    c0.backward(d_c0.double())
+    e_Q, e_wq = d_Q0.double().clone(), d_wq0.double().clone()
+    e_Q[:, :dq] += Qa.grad
+    e_wq[:, :dq] += wqa.grad
+    for name, got, exp in (("d_bk", d_bk, bka.grad), ("d_Q", d_Q, e_Q), ("d_wq", d_wq, e_wq), ("d_bq", d_bq, d_bq0.double() + bqa.grad)):
+        err = (got.cpu().double() - exp).abs().max().item()
+        assert err <= 2e-6 * max(exp.abs().max().item(), 1.0) * max(1.0, (R / 1000.0) ** 0.5), (name, err)
+    # the padding columns are untouched
+    assert torch.equal(d_Q.cpu()[:, dq:], d_Q0[:, dq:]) and torch.equal(d_wq.cpu()[:, dq:], d_wq0[:, dq:])
