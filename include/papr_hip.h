@@ -389,6 +389,44 @@ size_t papr_conv1x1_bwd_workspace_bytes(int64_t M, int32_t c_in, int32_t c_out);
 int papr_conv1x1_bwd(const float* d_out, const float* x, int64_t M, int32_t c_in, const float* w, int32_t c_out, float* d_x, float* d_w,
                      float* d_bias, void* workspace, papr_stream_t stream);
 
+/* K5c  The whole U-Net render head in one call each way: SmallUNet.forward (models/unet.py:206-258) in the shipped variant -- inc (c_in -> 128),
+ * Down 128 -> 256, Down 256 -> 512, Up 512 -> 256, Up 256 -> 128 (transposed-convolution upsampling, single 3x3 convolution + ReLU per stage,
+ * models/unet.py:194-198), 1x1 head -- over an NHWC map x (B, H, W, c_in) -> out (B, H, W, n_classes).  H and W multiples of 4, c_in a multiple
+ * of 32, n_classes <= 4.  Same kernels as the single-layer entry points above, arranged so that no launch is spent on a tensor maximum, a weight
+ * split per layer, a concatenation copy, a ReLU mask or a gradient sum (csrc/small_unet.hip; ABI 26).
+ *   conv_w[i], conv_w_stride[i] = {stride of c_out, c_in, ky, kx} in floats, conv_b[i]: the five Conv2d(3x3) parameters (C_out, C_in, 3, 3) in network
+ *     order inc, down1, down2, up1.conv, up2.conv -- any memory format;
+ *   up_w[j] (j = 0: up1.up 512 -> 256, 1: up2.up 256 -> 128): the ConvTranspose2d parameter (C_in, C_out, 2, 2) as (C_in, 2, 2, C_out) contiguous
+ *     (its channels-last memory), up_b[j];  out_w (n_classes, 128) contiguous, out_b.
+ * state: papr_small_unet_state_bytes(keep) bytes, written by fwd; with keep != 0 it holds what papr_small_unet_bwd reads again (activations,
+ *   pooling positions, the mirrored weight planes, the tensor maxima) and must reach that call unchanged together with x.
+ * bwd: d_out (B, H, W, n_classes) -> d_x (B, H, W, c_in) or NULL, and every parameter gradient, laid out like the parameter arguments above
+ *   (conv_w[i]: (C_out, 3, 3, C_in) contiguous = channels-last memory of (C_out, C_in, 3, 3)); workspace: papr_small_unet_bwd_workspace_bytes(). */
+typedef struct {
+    int32_t B, H, W, c_in, n_classes;
+    const float* conv_w[5];
+    int64_t conv_w_stride[5][4];
+    const float* conv_b[5];
+    const float* up_w[2];
+    const float* up_b[2];
+    const float* out_w;
+    const float* out_b;
+} papr_unet_desc;
+typedef struct {
+    float* conv_w[5];
+    float* conv_b[5];
+    float* up_w[2];
+    float* up_b[2];
+    float* out_w;
+    float* out_b;
+} papr_unet_grads;
+size_t papr_small_unet_state_bytes(int32_t B, int32_t H, int32_t W, int32_t c_in, int32_t keep);
+size_t papr_small_unet_bwd_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t c_in, int32_t n_classes);
+int papr_small_unet_fwd(const papr_unet_desc* net, const float* x, float* out, void* state, int32_t keep, papr_stream_t stream);
+int papr_small_unet_bwd(const papr_unet_desc* net, const float* x, const float* d_out, void* state, float* d_x, const papr_unet_grads* grads, void* workspace,
+                        papr_stream_t stream);
+
+
 /* ------------------------------------------------------------------------------------
  * K8  the optimizer step: every torch.optim.Adam instance of PAPR.step (reference models/model.py:439-460, one
  * `scaler.step(opt)` per parameter group; amsgrad off, maximize off, L2 weight decay) in one launch per 64 tensors.

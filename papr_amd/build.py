@@ -11,7 +11,7 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libpapr_hip.so")
-SOURCES = ["error.hip", "knn.hip", "cloud.hip", "features.hip", "pairs.hip", "rowops.hip", "gemm.hip", "chain4.hip", "conv.hip", "unet.hip", "adam.hip"]
+SOURCES = ["error.hip", "knn.hip", "cloud.hip", "features.hip", "pairs.hip", "rowops.hip", "gemm.hip", "chain4.hip", "conv.hip", "unet.hip", "small_unet.hip", "adam.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics",
          "-Wall", "-Wno-unused-function", "-Wno-inline-asm"]
 # chain4.hip: no packed-fp32 VALU (v_pk_mul_f32 / v_pk_add_f32 come from the SLP vectoriser).  Measured on MI355X (round 2,
@@ -95,7 +95,7 @@ def _stale(target, deps):
 
 def build_library(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    headers = [os.path.join(CSRC, h) for h in ("papr_common.h", "h3_common.h", "chain.h", "chain4_kloop.inc", "chain4_fused.inc", "chain4_krun.inc")] + [os.path.join(os.path.dirname(PKG), "include", "papr_hip.h")]
+    headers = [os.path.join(CSRC, h) for h in ("papr_common.h", "h3_common.h", "unet_parts.h", "chain.h", "chain4_kloop.inc", "chain4_fused.inc", "chain4_krun.inc")] + [os.path.join(os.path.dirname(PKG), "include", "papr_hip.h")]
     objdir = os.path.join(PKG, "build")
     os.makedirs(objdir, exist_ok=True)
     objs, procs = [], []

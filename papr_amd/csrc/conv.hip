@@ -21,6 +21,7 @@
 // its registers are runs of four consecutive output channels (16-byte stores, bias / ReLU in registers).
 #include "papr_common.h"
 #include "h3_common.h"
+#include "unet_parts.h"
 #include <stdlib.h>
 
 namespace {
@@ -35,7 +36,9 @@ struct ConvArgs {
     const float* x; int B, H, W, C;
     const _Float16* w_hi; const _Float16* w_lo; long K;       // planes [N_pad][K], K = 9 C
     const float* bias; float* out; int N; int relu;
-    const unsigned* xmax_bits;
+    const unsigned* xmax_bits; int n_xmax; const unsigned* xmax_bits2;       // max |x|: one word (n_xmax 1) or a slot (PAPR_SLOT_W), and a second slot or null
+    int ldo;                                     // row stride of out (>= N: a channel slice of a wider map)
+    unsigned* out_max;                           // or null (splits == 1): the slot that receives max |out|
     int splits; float* partial;                  // splits > 1: blockIdx.z sums 9 / splits taps into partial[z] (M, N), no bias / act
 };
 
@@ -54,7 +57,8 @@ __global__ __launch_bounds__(256, 3) void conv3x3_h3_kernel(ConvArgs p) {
     const int s_begin = blockIdx.z * (9 / p.splits) * slabs_per_tap, s_end = s_begin + (9 / p.splits) * slabs_per_tap;
 
     // scale of the whole input tensor: max -> [2^13, 2^14)
-    const unsigned mb = *p.xmax_bits;
+    unsigned mb = papr_slot_max(p.xmax_bits, p.n_xmax);
+    if (p.xmax_bits2) { const unsigned o = papr_slot_max(p.xmax_bits2, PAPR_SLOT_W); mb = o > mb ? o : mb; }
     const int ea = mb ? (int)((mb >> 23) & 0xff) : 127 + 13;
     const float x_scale = pow2_from_biased(127 + 13 - (ea - 127)), x_inv = pow2_from_biased(127 - 13 + (ea - 127));
 
@@ -158,11 +162,12 @@ __global__ __launch_bounds__(256, 3) void conv3x3_h3_kernel(ConvArgs p) {
 
     // epilogue: lane = pixel, registers = runs of four channels
     const int hh = lane >> 5;
+    float omax = 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const long m = m0 + wm * 64 + i * 32 + (lane & 31);
         if (m >= M) continue;
-        float* orow = p.splits > 1 ? p.partial + ((long)blockIdx.z * M + m) * p.N : p.out + m * p.N;
+        float* orow = p.splits > 1 ? p.partial + ((long)blockIdx.z * M + m) * p.N : p.out + m * p.ldo;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -173,9 +178,11 @@ __global__ __launch_bounds__(256, 3) void conv3x3_h3_kernel(ConvArgs p) {
                 float4 r = make_float4(__builtin_fmaf(acc[i][j][4 * g], x_inv, b4.x), __builtin_fmaf(acc[i][j][4 * g + 1], x_inv, b4.y),
                                        __builtin_fmaf(acc[i][j][4 * g + 2], x_inv, b4.z), __builtin_fmaf(acc[i][j][4 * g + 3], x_inv, b4.w));
                 if (p.relu && p.splits == 1) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
+                omax = fmaxf(omax, fmaxf(fmaxf(fabsf(r.x), fabsf(r.y)), fmaxf(fabsf(r.z), fabsf(r.w))));
                 *reinterpret_cast<float4*>(orow + col) = r;
             }
     }
+    if (p.out_max && p.splits == 1) papr_wg_max_to_slot(p.out_max, omax);
 }
 
 // planes hi / lo (N_pad, 9 C) <- weight element (n, ky, kx, c) at w[n sn + c sc + ky sky + kx skx]; flip: taps mirrored
@@ -212,7 +219,8 @@ __device__ __forceinline__ void conv_split_weight_block(const ConvSplitArgs& a, 
 // conv_wgrad_reduce_kernel.  Scales: one power of two per tensor for dY and for X.
 struct ConvWArgs {
     const float* dy; const float* x; int B, H, W, N, C;
-    const unsigned* dymax_bits; const unsigned* xmax_bits;
+    const unsigned* dymax_bits; const unsigned* xmax_bits; const unsigned* xmax_bits2; int n_max;      // one word each (n_max 1) or slots (PAPR_SLOT_W); xmax_bits2
+                                                                                                        // or null: x concatenated from two producers
     float* partial;                              // [chunk][N][9][C]
     float* partial_b;                            // [chunk][N] column sums of dY (bias gradient), or null
     long px_per_chunk;                           // multiple of 32
@@ -244,7 +252,9 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wgrad_h3_kernel(ConvWArgs p) {
         return pow2_from_biased(127 + 13 - (ea - 127));
     };
     float g_inv, x_inv;
-    const float g_scale = scale_of(*p.dymax_bits, g_inv), x_scale = scale_of(*p.xmax_bits, x_inv);
+    unsigned xmb = papr_slot_max(p.xmax_bits, p.n_max);
+    if (p.xmax_bits2) { const unsigned o = papr_slot_max(p.xmax_bits2, p.n_max); xmb = o > xmb ? o : xmb; }
+    const float g_scale = scale_of(papr_slot_max(p.dymax_bits, p.n_max), g_inv), x_scale = scale_of(xmb, x_inv);
 
     // block of the thread: channels 4 q .. 4 q + 3 (q = tid % 32), pixels 4 r .. 4 r + 3 of the 32-pixel slab (r = tid / 32)
     const int q = tid & 31, r = tid >> 5;
@@ -380,7 +390,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float4* __
     // The two maximum slots this call's successors (16 calls on) will atomicMax into are cleared HERE, whatever maxima the
     // caller supplied: clearing only as a side effect of the absmax launches left a slot uncleared whenever a supplied
     // maximum spared its launch, and the scale of a later call would become a running maximum over history.
-    if (blockIdx.x == 0 && threadIdx.x == 0) { stale2[0] = 0u; stale2[1] = 0u; }
+    if (stale2 && blockIdx.x == 0 && threadIdx.x == 0) { stale2[0] = 0u; stale2[1] = 0u; }
     if (out_b && e < nb4) {                          // bias gradient: the chunks' column sums
         float4 r = partial_b[e];
         for (int z = 1; z < chunks; ++z) { const float4 v = partial_b[(long)z * nb4 + e]; r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w; }
@@ -397,16 +407,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float4* __
 
 // out = act(bias + partial[0] + partial[1] + ...): the tap groups of a split launch meet in a fixed order
 __global__ __launch_bounds__(256) void conv_reduce_kernel(const float4* __restrict__ partial, int splits, long mn4, int n4,
-                                                          const float4* __restrict__ bias, int relu, float4* __restrict__ out) {
-    const long e = (long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= mn4) return;
-    float4 r = bias ? bias[e % n4] : make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int z = 0; z < splits; ++z) {
-        const float4 v = partial[(long)z * mn4 + e];
-        r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w;
+                                                          const float4* __restrict__ bias, int relu, float4* __restrict__ out, int ldo4,
+                                                          unsigned* __restrict__ out_max) {
+    float mx = 0.f;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < mn4; e += (long)gridDim.x * 256) {
+        const long m = e / n4;
+        const int c = (int)(e - m * n4);
+        float4 r = bias ? bias[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int z = 0; z < splits; ++z) {
+            const float4 v = partial[(long)z * mn4 + e];
+            r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w;
+        }
+        if (relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
+        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(r.x), fabsf(r.y)), fmaxf(fabsf(r.z), fabsf(r.w))));
+        out[m * ldo4 + c] = r;
     }
-    if (relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
-    out[e] = r;
+    if (out_max) papr_wg_max_to_slot(out_max, mx);          // (uniform per launch)
 }
 
 __device__ __forceinline__ void tensor_absmax_block(const float4* __restrict__ x, long n4, unsigned* __restrict__ out, unsigned* __restrict__ stale,
@@ -435,6 +451,34 @@ __global__ __launch_bounds__(256) void conv_prep_kernel(const float4* __restrict
     if ((int)blockIdx.x < nb_abs) tensor_absmax_block(x, n4, out, stale, blockIdx.x, nb_abs);
     else conv_split_weight_block(sp, (long)blockIdx.x - nb_abs);
 }
+// What a whole SmallUNet call does in front of its first layer, in ONE launch: partial maxima of the input map (no atomics: the first layer's
+// kernel takes the largest of the 64), the call's maximum slots zeroed, and every 3x3 weight of the network -- the data-gradient's mirrored
+// forms too when a backward pass will follow -- split into its f16 planes.
+struct UnetPrepJobs { ConvSplitArgs job[PAPR_UNET_MAX_JOBS]; int first_block[PAPR_UNET_MAX_JOBS + 1]; int n_jobs; };
+__global__ __launch_bounds__(256) void unet_prep_kernel(const float4* __restrict__ x, long n4, unsigned* __restrict__ in_partial, unsigned* __restrict__ slots,
+                                                        int n_slots, UnetPrepJobs jobs) {
+    const int b = blockIdx.x;
+    if (b < PAPR_UNET_IN_PARTS) {
+        __shared__ float part[4];
+        if (b == 0)                                   // (the input's own slot is written below, words 0 .. 63 by these 64 workgroups, the rest stays zero)
+            for (int i = threadIdx.x; i < n_slots * PAPR_SLOT_W; i += 256)
+                if (slots + i < in_partial || slots + i >= in_partial + PAPR_UNET_IN_PARTS) slots[i] = 0u;
+        float m = 0.f;
+        for (long i = (long)b * 256 + threadIdx.x; i < n4; i += (long)PAPR_UNET_IN_PARTS * 256) {
+            const float4 v = x[i];
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        }
+        m = wave_max(m);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) in_partial[b] = __float_as_uint(fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3])));
+        return;
+    }
+    const int sb = b - PAPR_UNET_IN_PARTS;
+    int j = 0;
+    while (j + 1 < jobs.n_jobs && sb >= jobs.first_block[j + 1]) ++j;
+    conv_split_weight_block(jobs.job[j], (long)sb - jobs.first_block[j]);
+}
 // two maxima in one launch (the weight gradient's operands)
 __global__ __launch_bounds__(256) void tensor_absmax2_kernel(const float4* __restrict__ x0, long n0, unsigned* __restrict__ out0, unsigned* __restrict__ stale0, int nb0,
                                                              const float4* __restrict__ x1, long n1, unsigned* __restrict__ out1, unsigned* __restrict__ stale1) {
@@ -455,11 +499,59 @@ static int conv_splits(long M, int c_in, int c_out) {
     if (c_in < 128 || tiles >= 400) return 1;
     return tiles * 3 >= 400 ? 3 : 9;
 }
+int papr_i_conv_splits(long M, int c_in, int c_out) { return conv_splits(M, c_in, c_out); }
 
 extern "C" size_t papr_conv3x3_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t c_in, int32_t c_out) {
     const long M = (long)B * H * W;
     const int sp = conv_splits(M, c_in, c_out);
     return 256 + papr_conv3x3_weight_halfs(c_out, c_in) * sizeof(_Float16) + (sp > 1 ? (size_t)sp * M * c_out * sizeof(float) : 0);
+}
+
+int papr_i_conv3x3(const PaprConvLaunch& c, hipStream_t s) {
+    const long M = (long)c.B * c.H * c.W, K = 9L * c.c_in, n_pad = (c.c_out + CV_BN - 1) / CV_BN * CV_BN;
+    ConvArgs a;
+    a.x = c.x; a.B = c.B; a.H = c.H; a.W = c.W; a.C = c.c_in;
+    a.w_hi = c.w_hi; a.w_lo = c.w_lo; a.K = K;
+    a.bias = c.bias; a.out = c.out; a.N = c.c_out; a.relu = c.relu;
+    a.xmax_bits = c.xmax; a.n_xmax = c.n_xmax; a.xmax_bits2 = c.xmax2;
+    a.ldo = c.ldo; a.out_max = c.out_max;
+    a.splits = conv_splits(M, c.c_in, c.c_out);
+    a.partial = c.partial;
+    PAPR_REQUIRE(a.splits == 1 || c.partial, "conv3x3: a split launch needs its partial buffer");
+    if (papr_first_on_device(PAPR_ONCE_CONV))
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_h3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CV_LDS_BYTES);
+    const bool prof = papr_prof_on();
+    if (prof) papr_prof_begin2(11, M, c.c_out, (int)K, 4LL * M * (c.c_in + c.c_out), 2LL * M * c.c_out * K, s);
+    conv3x3_h3_kernel<<<dim3((unsigned)((M + CV_BM - 1) / CV_BM), (unsigned)(n_pad / CV_BN), (unsigned)a.splits), dim3(256), CV_LDS_BYTES, s>>>(a);
+    PAPR_CHECK_LAUNCH("conv3x3_h3");
+    if (a.splits > 1) {
+        const long mn4 = M * c.c_out / 4;
+        const long rb = (mn4 + 255) / 256;             // (with a maximum to leave: a bounded grid, one atomic per workgroup)
+        conv_reduce_kernel<<<dim3((unsigned)(c.out_max && rb > 1024 ? 1024 : rb)), dim3(256), 0, s>>>(reinterpret_cast<const float4*>(a.partial), a.splits, mn4, c.c_out / 4,
+                                                                                     reinterpret_cast<const float4*>(c.bias), c.relu, reinterpret_cast<float4*>(c.out),
+                                                                                     c.ldo / 4, c.out_max);
+        PAPR_CHECK_LAUNCH("conv_reduce");
+    }
+    if (prof) papr_prof_end(s);
+    return 0;
+}
+
+int papr_i_unet_prep(const float* x, long n4, unsigned* in_partial, unsigned* slots, int n_slots, const PaprSplitJob* jobs, int n_jobs, hipStream_t s) {
+    PAPR_REQUIRE(n_jobs >= 1 && n_jobs <= PAPR_UNET_MAX_JOBS, "unet_prep: %d split jobs", n_jobs);
+    UnetPrepJobs t;
+    t.n_jobs = n_jobs;
+    int blocks = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        const PaprSplitJob& q = jobs[j];
+        const long n_pad = (q.N + CV_BN - 1) / CV_BN * CV_BN, total4 = n_pad * 9L * q.C / 4;
+        t.job[j] = ConvSplitArgs{q.w, q.N, q.C, q.sn, q.sc, q.sky, q.skx, q.flip, total4, q.hi, q.lo};
+        t.first_block[j] = blocks;
+        blocks += (int)((total4 + 255) / 256);
+    }
+    t.first_block[n_jobs] = blocks;
+    unet_prep_kernel<<<dim3((unsigned)(PAPR_UNET_IN_PARTS + blocks)), dim3(256), 0, s>>>(reinterpret_cast<const float4*>(x), n4, in_partial, slots, n_slots, t);
+    PAPR_CHECK_LAUNCH("unet_prep");
+    return 0;
 }
 
 extern "C" int papr_conv3x3_fwd(const float* x, int32_t B, int32_t H, int32_t W, int32_t c_in, const float* w, int64_t w_stride_n,
@@ -481,26 +573,13 @@ extern "C" int papr_conv3x3_fwd(const float* x, int32_t B, int32_t H, int32_t W,
     ConvSplitArgs sp = {w, c_out, c_in, w_stride_n, w_stride_c, w_stride_ky, w_stride_kx, flip_taps, total4, planes, planes + n_pad * K};
     conv_prep_kernel<<<dim3((unsigned)(nb_abs + (total4 + 255) / 256)), dim3(256), 0, s>>>(reinterpret_cast<const float4*>(x), n4, xmax, stale, nb_abs, sp);
     PAPR_CHECK_LAUNCH("conv_prep");
-    ConvArgs a;
-    a.x = x; a.B = B; a.H = H; a.W = W; a.C = c_in;
-    a.w_hi = planes; a.w_lo = planes + n_pad * K; a.K = K;
-    a.bias = bias; a.out = out; a.N = c_out; a.relu = relu; a.xmax_bits = xmax;
-    a.splits = conv_splits(M, c_in, c_out);
-    a.partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + 256 + papr_conv3x3_weight_halfs(c_out, c_in) * sizeof(_Float16));
-    if (papr_first_on_device(PAPR_ONCE_CONV))
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_h3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CV_LDS_BYTES);
-    const bool prof = papr_prof_on();
-    if (prof) papr_prof_begin2(11, M, c_out, (int)K, 4LL * M * (c_in + c_out), 2LL * M * c_out * K, s);
-    conv3x3_h3_kernel<<<dim3((unsigned)((M + CV_BM - 1) / CV_BM), (unsigned)(n_pad / CV_BN), (unsigned)a.splits), dim3(256), CV_LDS_BYTES, s>>>(a);
-    PAPR_CHECK_LAUNCH("conv3x3_h3");
-    if (a.splits > 1) {
-        const long mn4 = M * c_out / 4;
-        conv_reduce_kernel<<<dim3((unsigned)((mn4 + 255) / 256)), dim3(256), 0, s>>>(reinterpret_cast<const float4*>(a.partial), a.splits, mn4, c_out / 4,
-                                                                                     reinterpret_cast<const float4*>(bias), relu, reinterpret_cast<float4*>(out));
-        PAPR_CHECK_LAUNCH("conv_reduce");
-    }
-    if (prof) papr_prof_end(s);
-    return 0;
+    PaprConvLaunch c{};
+    c.x = x; c.B = B; c.H = H; c.W = W; c.c_in = c_in;
+    c.w_hi = planes; c.w_lo = planes + n_pad * K;
+    c.bias = bias; c.c_out = c_out; c.relu = relu; c.out = out; c.ldo = c_out;
+    c.xmax = xmax; c.n_xmax = 1;
+    c.partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + 256 + papr_conv3x3_weight_halfs(c_out, c_in) * sizeof(_Float16));
+    return papr_i_conv3x3(c, s);
 }
 
 // pixels per workgroup of the weight-gradient launch: enough chunks for ~600 workgroups, at least 8 slabs each
@@ -518,6 +597,45 @@ extern "C" size_t papr_conv3x3_wgrad_workspace_bytes(int32_t B, int32_t H, int32
     return 256 + (size_t)chunks * c_out * (9 * c_in + 1) * sizeof(float);
 }
 
+size_t papr_i_conv3x3_wgrad_partial_bytes(long M, int c_in, int c_out) {
+    const long px = wgrad_px_per_chunk(M, c_in, c_out), chunks = (M + px - 1) / px;
+    return (size_t)chunks * c_out * (9 * c_in + 1) * sizeof(float);
+}
+
+// stale: the two maximum slots conv_wgrad_reduce_kernel clears for the stand-alone entry point's slot rotation (or null)
+static int conv3x3_wgrad_launch(const float* d_y, const float* x, int B, int H, int W, int c_in, int c_out, float* d_w, float* d_b, const unsigned* dymax,
+                                const unsigned* xmax, const unsigned* xmax2, int n_max, float* partial, unsigned* stale, hipStream_t s) {
+    const long M = (long)B * H * W, px = wgrad_px_per_chunk(M, c_in, c_out), chunks = (M + px - 1) / px;
+    ConvWArgs a;
+    a.dy = d_y; a.x = x; a.B = B; a.H = H; a.W = W; a.N = c_out; a.C = c_in;
+    a.dymax_bits = dymax; a.xmax_bits = xmax; a.xmax_bits2 = xmax2; a.n_max = n_max;
+    a.partial = partial;
+    a.partial_b = d_b ? a.partial + (size_t)chunks * c_out * 9 * c_in : nullptr;
+    a.px_per_chunk = px;
+    if (papr_first_on_device(PAPR_ONCE_CONV_WGRAD)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_h3_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CV_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_h3_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CV_LDS_BYTES);
+    }
+    const int ct = c_in <= 32 ? 32 : 128;
+    const int tiles = ((c_out + 127) / 128) * ((c_in + ct - 1) / ct);
+    const bool prof = papr_prof_on();
+    if (prof) papr_prof_begin2(12, M, c_out, 9 * c_in, 4LL * M * (c_in + c_out), 2LL * M * c_out * 9 * c_in, s);
+    if (ct == 32) conv3x3_wgrad_h3_kernel<32><<<dim3((unsigned)chunks, (unsigned)tiles, 9), dim3(256), CV_LDS_BYTES, s>>>(a);
+    else conv3x3_wgrad_h3_kernel<128><<<dim3((unsigned)chunks, (unsigned)tiles, 9), dim3(256), CV_LDS_BYTES, s>>>(a);
+    PAPR_CHECK_LAUNCH("conv3x3_wgrad_h3");
+    const long n4 = (long)c_out * 9 * c_in / 4;
+    conv_wgrad_reduce_kernel<<<dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s>>>(reinterpret_cast<const float4*>(a.partial), (int)chunks, n4, reinterpret_cast<float4*>(d_w),
+                                                                                      reinterpret_cast<const float4*>(a.partial_b), c_out / 4, reinterpret_cast<float4*>(d_b), stale);
+    PAPR_CHECK_LAUNCH("conv_wgrad_reduce");
+    if (prof) papr_prof_end(s);
+    return 0;
+}
+
+int papr_i_conv3x3_wgrad(const float* d_y, const float* x, int B, int H, int W, int c_in, int c_out, float* d_w, float* d_b, const unsigned* dymax,
+                         const unsigned* xmax, const unsigned* xmax2, float* partial, hipStream_t s) {
+    return conv3x3_wgrad_launch(d_y, x, B, H, W, c_in, c_out, d_w, d_b, dymax, xmax, xmax2, PAPR_SLOT_W, partial, nullptr, s);
+}
+
 extern "C" int papr_conv3x3_wgrad(const float* d_out, const float* x, int32_t B, int32_t H, int32_t W, int32_t c_in, int32_t c_out,
                                   float* d_w, float* d_bias, const uint32_t* d_out_max_bits, const uint32_t* x_max_bits, void* workspace,
                                   int32_t slot, papr_stream_t stream) {
@@ -526,7 +644,7 @@ extern "C" int papr_conv3x3_wgrad(const float* d_out, const float* x, int32_t B,
                  "papr_conv3x3_wgrad: B %d, H %d, W %d, c_in %d, c_out %d (channels must be multiples of 4)", B, H, W, c_in, c_out);
     PAPR_REQUIRE(slot >= 0 && slot < 32, "papr_conv3x3_wgrad: slot %d outside 0 .. 31", slot);
     hipStream_t s = as_stream(stream);
-    const long M = (long)B * H * W, px = wgrad_px_per_chunk(M, c_in, c_out), chunks = (M + px - 1) / px;
+    const long M = (long)B * H * W;
     unsigned* head = static_cast<unsigned*>(workspace);       // 64 slots: two per call (d_out, x), cleared 16 calls later
     unsigned* gmax = head + 2 * slot;
     unsigned* xmax = gmax + 1;
@@ -547,27 +665,6 @@ extern "C" int papr_conv3x3_wgrad(const float* d_out, const float* x, int32_t B,
         if (!x_max_bits) absmax(x, M * c_in / 4, xmax, d_out_max_bits ? stale : stale + 1);
     }
     PAPR_CHECK_LAUNCH("tensor_absmax");
-    ConvWArgs a;
-    a.dy = d_out; a.x = x; a.B = B; a.H = H; a.W = W; a.N = c_out; a.C = c_in;
-    a.dymax_bits = d_out_max_bits ? d_out_max_bits : gmax; a.xmax_bits = x_max_bits ? x_max_bits : xmax;
-    a.partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + 256);
-    a.partial_b = d_bias ? a.partial + (size_t)chunks * c_out * 9 * c_in : nullptr;
-    a.px_per_chunk = px;
-    if (papr_first_on_device(PAPR_ONCE_CONV_WGRAD)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_h3_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CV_LDS_BYTES);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_h3_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CV_LDS_BYTES);
-    }
-    const int ct = c_in <= 32 ? 32 : 128;
-    const int tiles = ((c_out + 127) / 128) * ((c_in + ct - 1) / ct);
-    const bool prof = papr_prof_on();
-    if (prof) papr_prof_begin2(12, M, c_out, 9 * c_in, 4LL * M * (c_in + c_out), 2LL * M * c_out * 9 * c_in, s);
-    if (ct == 32) conv3x3_wgrad_h3_kernel<32><<<dim3((unsigned)chunks, (unsigned)tiles, 9), dim3(256), CV_LDS_BYTES, s>>>(a);
-    else conv3x3_wgrad_h3_kernel<128><<<dim3((unsigned)chunks, (unsigned)tiles, 9), dim3(256), CV_LDS_BYTES, s>>>(a);
-    PAPR_CHECK_LAUNCH("conv3x3_wgrad_h3");
-    const long n4 = (long)c_out * 9 * c_in / 4;
-    conv_wgrad_reduce_kernel<<<dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s>>>(reinterpret_cast<const float4*>(a.partial), (int)chunks, n4, reinterpret_cast<float4*>(d_w),
-                                                                                      reinterpret_cast<const float4*>(a.partial_b), c_out / 4, reinterpret_cast<float4*>(d_bias), stale);
-    PAPR_CHECK_LAUNCH("conv_wgrad_reduce");
-    if (prof) papr_prof_end(s);
-    return 0;
+    return conv3x3_wgrad_launch(d_out, x, B, H, W, c_in, c_out, d_w, d_bias, d_out_max_bits ? d_out_max_bits : gmax, x_max_bits ? x_max_bits : xmax, nullptr, 1,
+                                reinterpret_cast<float*>(static_cast<char*>(workspace) + 256), stale, s);
 }

@@ -72,3 +72,29 @@ __device__ __forceinline__ float wave_max(float v) {
     const float c = __int_as_float(__builtin_amdgcn_readlane(r, 32)), d = __int_as_float(__builtin_amdgcn_readlane(r, 48));
     return fmaxf(fmaxf(a, b), fmaxf(c, d));
 }
+
+// Tensor maxima left by the kernel that PRODUCES a tensor for the kernels that scale by it (small_unet.hip).  A "slot" is PAPR_SLOT_W = 256 words
+// (zeroed beforehand): a workgroup adds ONE atomicMax of its max |.| (bit pattern) to word (its linear block index mod 256), a consumer wave takes
+// the largest of the 256 (one 16-byte load per lane).  Not one word: same-address atomics are served one at a time at the memory side, ~10 ns each
+// -- 12,800 of them (a wave each of a 3,200-workgroup elementwise launch) made a 7-us kernel a 150-us one, and even one per workgroup of a
+// 1,024-workgroup launch cost 10 us; spread over 256 words the queue per word is four deep.  Every thread of the workgroup must call the writer.
+constexpr int PAPR_SLOT_W = 256;
+__device__ __forceinline__ void papr_wg_max_to_slot(unsigned* slot, float v) {
+    __shared__ float papr_wmax[16];
+    v = wave_max(v);
+    if ((threadIdx.x & 63) == 0) papr_wmax[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = papr_wmax[0];
+        for (unsigned i = 1; i < (blockDim.x + 63) >> 6; ++i) m = fmaxf(m, papr_wmax[i]);
+        const unsigned bid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        if (m > 0.f) atomicMax(slot + (bid & (PAPR_SLOT_W - 1)), __float_as_uint(m));
+    }
+}
+// the maximum a slot holds (n == PAPR_SLOT_W), or the single word a caller of the single-layer entry points supplies (n == 1); in every lane
+__device__ __forceinline__ unsigned papr_slot_max(const unsigned* slot, int n) {
+    if (n == 1) return *slot;
+    const uint4 v = reinterpret_cast<const uint4*>(slot)[threadIdx.x & 63];
+    const unsigned a = v.x > v.y ? v.x : v.y, b = v.z > v.w ? v.z : v.w;
+    return __float_as_uint(wave_max(__uint_as_float(a > b ? a : b)));       // (bit patterns of non-negative floats order like the floats)
+}

@@ -21,15 +21,18 @@
 // that the lanes of a write hit different banks); the accumulators leave through LDS, so stores are rows of 256 bytes.
 #include "papr_common.h"
 #include "h3_common.h"
+#include "unet_parts.h"
 
 namespace {
+
+__device__ __forceinline__ float absmax4f(const float4& v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); }
 
 // ---------------------------------------------------------------- MaxPool2d(2)
 // out[b][y][x][c] = max over the 2 x 2 window; which = position (0..3, row-major) of the FIRST maximum in scan order (a
 // later element replaces the current one only if it is greater, or NaN: torch's max_pool2d rule, so ties -- frequent
 // after a ReLU -- send the gradient where torch sends it).  H and W odd: the last row / column is dropped (floor).
-__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float4* __restrict__ x, int H, int W, int C4, long total, float4* __restrict__ out,
-                                                           unsigned* __restrict__ which) {
+__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float4* __restrict__ x, int LD4, int H, int W, int C4, long total, float4* __restrict__ out,
+                                                           unsigned* __restrict__ which) {       // (LD4: float4 per input pixel row, >= C4: a channel slice of a wider map)
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     if (e >= total) return;
     const int Ho = H >> 1, Wo = W >> 1;
@@ -38,8 +41,8 @@ __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float4* __restr
     const int xo = (int)(r % Wo); r /= Wo;
     const int yo = (int)(r % Ho);
     const long b = r / Ho;
-    const float4* src = x + ((b * H + 2 * yo) * W + 2 * xo) * C4 + c;
-    const float4 v[4] = {src[0], src[C4], src[(long)W * C4], src[(long)W * C4 + C4]};
+    const float4* src = x + ((b * H + 2 * yo) * W + 2 * xo) * LD4 + c;
+    const float4 v[4] = {src[0], src[LD4], src[(long)W * LD4], src[(long)W * LD4 + LD4]};
     float4 m = v[0];
     unsigned w = 0;
 #pragma unroll
@@ -78,6 +81,40 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float4* __restr
     d_in[e] = g;
 }
 
+// The same at a seam of the whole-network backward pass (small_unet.hip): the pooled map's source was a ReLU output y that also feeds the skip
+// concatenation, so  d_in = (pool-backward(d_out) + skip gradient) * (y > 0)  -- pooling, the sum of the two uses and the ReLU mask in one pass
+// (three launches and a slice copy otherwise) -- and max |d_in| for the convolutions that consume it.
+__global__ __launch_bounds__(256) void maxpool2_bwd_fused_kernel(const float4* __restrict__ d_out, const unsigned* __restrict__ which, int H, int W, int C4,
+                                                                 long total_in, const float4* __restrict__ skip, int LDS4, const float4* __restrict__ y, int LDY4,
+                                                                 float4* __restrict__ d_in, unsigned* __restrict__ out_max) {
+    float mx = 0.f;
+    const int Ho = H >> 1, Wo = W >> 1;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total_in; e += (long)gridDim.x * 256) {
+        const int c = (int)(e % C4);
+        const long pix = e / C4;
+        long r = pix;
+        const int xi = (int)(r % W); r /= W;
+        const int yi = (int)(r % H);
+        const long b = r / H;
+        float4 g = skip[pix * LDS4 + c];
+        const float4 yv = y[pix * LDY4 + c];
+        const int yo = yi >> 1, xo = xi >> 1;
+        if (yo < Ho && xo < Wo) {
+            const long o = ((b * Ho + yo) * Wo + xo) * C4 + c;
+            const unsigned w = which[o], me = (unsigned)((yi & 1) * 2 + (xi & 1));
+            const float4 d = d_out[o];
+            if ((w & 0xff) == me) g.x += d.x;
+            if (((w >> 8) & 0xff) == me) g.y += d.y;
+            if (((w >> 16) & 0xff) == me) g.z += d.z;
+            if ((w >> 24) == me) g.w += d.w;
+        }
+        g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f; g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+        d_in[e] = g;
+        mx = fmaxf(mx, absmax4f(g));
+    }
+    papr_wg_max_to_slot(out_max, mx);
+}
+
 // ---------------------------------------------------------------- ConvTranspose2d(kernel 2, stride 2)
 constexpr int UP_T = 64;                       // tile edge (i and j)
 constexpr int UP_BK = 64;                      // k-slab
@@ -97,6 +134,12 @@ struct UpArgs {
     int B, H, W, C_in, C_out;
     int px_per_chunk;      // weight-gradient: pixels per workgroup along blockIdx.z (multiple of UP_BK); the chunks' tiles go to
                            // out + z * C_in * 4 C_out and meet in upconv_wgrad_reduce_kernel
+    int ldo;               // forward: row stride of out (>= C_out: a channel slice of the skip concatenation)
+    int ldg;               // data- / weight-gradient: row stride of g (>= C_out: a slice of the concatenation's gradient)
+    const float* mask;     // data-gradient, or null: the layer's input was a ReLU output y (M, C_in): d_x *= (y > 0)
+    unsigned* out_max;     // forward / data-gradient, or null: atomicMax of max |out|
+    const unsigned* pmax_bits; const unsigned* qmax_bits;      // weight-gradient, instead of `maxes`: the slots (papr_common.h) of max |x|, max |g|
+    float* partial_b;      // weight-gradient, or null: [chunk][4 C_out] column sums of g (the bias gradient), from the workgroups of the first c_in tile
 };
 
 __device__ __forceinline__ float comp4u(const float4& v, int j) { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); }
@@ -154,7 +197,7 @@ __global__ __launch_bounds__(256) void upconv2x2_h3_kernel(UpArgs p) {
             const int tap = k0 / p.C_out, n = k0 - tap * p.C_out;
             const int tapoff = (tap >> 1) * W2 + (tap & 1);
 #pragma unroll
-            for (int q = 0; q < UP_QN; ++q) rp[q] = *reinterpret_cast<const float4*>(p.g + (prow[q] + tapoff) * p.C_out + n + kc);
+            for (int q = 0; q < UP_QN; ++q) rp[q] = *reinterpret_cast<const float4*>(p.g + (prow[q] + tapoff) * p.ldg + n + kc);
         } else {
 #pragma unroll
             for (int u = 0; u < UP_TN; ++u) {
@@ -162,7 +205,7 @@ __global__ __launch_bounds__(256) void upconv2x2_h3_kernel(UpArgs p) {
                 okt[u] = m < pend;
                 m = okt[u] ? m : pend - 1;
                 rp[u] = firsthalf ? *reinterpret_cast<const float4*>(p.x + (long)m * p.C_in + i0 + 4 * ig)
-                                  : *reinterpret_cast<const float4*>(p.g + ((long)opix(m) + tapoffJ) * p.C_out + nJ + 4 * ig);
+                                  : *reinterpret_cast<const float4*>(p.g + ((long)opix(m) + tapoffJ) * p.ldg + nJ + 4 * ig);
             }
         }
     };
@@ -183,7 +226,8 @@ __global__ __launch_bounds__(256) void upconv2x2_h3_kernel(UpArgs p) {
     //  block sixteen times over for their own)
     float mx = 0.f;
     if (MODE == 2) {
-        if (tid < 128) mx = p.maxes[tid];
+        if (p.pmax_bits) mx = __uint_as_float(papr_slot_max(wave == 0 ? p.pmax_bits : p.qmax_bits, PAPR_SLOT_W));
+        else if (tid < 128) mx = p.maxes[tid];
     } else {
         for (int k0 = 0; k0 < K; k0 += UP_BK) {
             load_p(k0);
@@ -233,6 +277,8 @@ __global__ __launch_bounds__(256) void upconv2x2_h3_kernel(UpArgs p) {
             }
         }
     };
+    const bool do_bias = MODE == 2 && p.partial_b != nullptr && blockIdx.x == 0;
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
     auto store_slab = [&]() {
         if (MODE == 0) {
             put_rows(rp, prow_ok, p_scale, Ph, Pl);
@@ -242,7 +288,14 @@ __global__ __launch_bounds__(256) void upconv2x2_h3_kernel(UpArgs p) {
             put_rows(rq, nullptr, 1.0f, Qh, Ql);
         } else {
             if (firsthalf) put_cols(rp, okt, p_scale, Ph, Pl);
-            else put_cols(rp, okt, q_scale, Qh, Ql);
+            else {
+                if (do_bias) {
+#pragma unroll
+                    for (int u = 0; u < UP_TN; ++u)
+                        if (okt[u]) { bsum.x += rp[u].x; bsum.y += rp[u].y; bsum.z += rp[u].z; bsum.w += rp[u].w; }
+                }
+                put_cols(rp, okt, q_scale, Qh, Ql);
+            }
         }
     };
 
@@ -285,6 +338,7 @@ __global__ __launch_bounds__(256) void upconv2x2_h3_kernel(UpArgs p) {
     __syncthreads();
     const float inv = p_inv * q_inv;
     const int c4 = (tid & 15) * 4;
+    float omax = 0.f;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int row = (tid >> 4) + 16 * q;
@@ -294,13 +348,32 @@ __global__ __launch_bounds__(256) void upconv2x2_h3_kernel(UpArgs p) {
             const int m = i0 + row;
             if (m >= M) continue;
             if (p.bias) { const float4 b4 = *reinterpret_cast<const float4*>(p.bias + nJ + c4); v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w; }
-            *reinterpret_cast<float4*>(p.out + ((long)opix(m) + tapoffJ) * p.C_out + nJ + c4) = v;
+            omax = fmaxf(omax, absmax4f(v));
+            *reinterpret_cast<float4*>(p.out + ((long)opix(m) + tapoffJ) * p.ldo + nJ + c4) = v;
         } else if (MODE == 1) {
             const int m = i0 + row;
             if (m >= M) continue;
+            if (p.mask) {
+                const float4 yv = *reinterpret_cast<const float4*>(p.mask + (long)m * p.C_in + j0 + c4);
+                v.x = yv.x > 0.f ? v.x : 0.f; v.y = yv.y > 0.f ? v.y : 0.f; v.z = yv.z > 0.f ? v.z : 0.f; v.w = yv.w > 0.f ? v.w : 0.f;
+            }
+            omax = fmaxf(omax, absmax4f(v));
             *reinterpret_cast<float4*>(p.out + (long)m * p.C_in + j0 + c4) = v;
         } else {
             *reinterpret_cast<float4*>(p.out + ((long)blockIdx.z * p.C_in + i0 + row) * J4 + j0 + c4) = v;
+        }
+    }
+    if (MODE != 2 && p.out_max) papr_wg_max_to_slot(p.out_max, omax);
+    if (MODE == 2 && do_bias) {                      // the bias gradient's share of this chunk: the eight pixel lanes of a column group meet in order
+        __syncthreads();
+        float4* bs = reinterpret_cast<float4*>(planes);
+        if (!firsthalf) bs[kg * 16 + ig] = bsum;
+        __syncthreads();
+        if (tid < 16) {
+            float4 t = bs[tid];
+#pragma unroll
+            for (int g = 1; g < UP_TN; ++g) { const float4 v = bs[g * 16 + tid]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+            *reinterpret_cast<float4*>(p.partial_b + (long)blockIdx.z * J4 + j0 + 4 * tid) = t;
         }
     }
 }
@@ -357,6 +430,24 @@ __global__ __launch_bounds__(256) void upconv_wgrad_reduce_kernel(const float4* 
     out[e] = r;
 }
 
+// the same with the bias gradient from the weight-gradient launch's own column sums: d_bias[n] = sum over chunks and the four taps of partial_b[chunk][tap][n]
+__global__ __launch_bounds__(256) void upconv_wgrad_reduce2_kernel(const float4* __restrict__ partial, int chunks, long n4, float4* __restrict__ out,
+                                                                   const float4* __restrict__ partial_b, int nb4, float4* __restrict__ out_b) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (out_b && e < nb4) {
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int z = 0; z < chunks; ++z)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { const float4 v = partial_b[((long)z * 4 + t) * nb4 + e]; r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w; }
+        out_b[e] = r;
+    }
+    if (e >= n4) return;
+    float4 r = partial[e];
+#pragma unroll 4
+    for (int z = 1; z < chunks; ++z) { const float4 v = partial[(long)z * n4 + e]; r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w; }
+    out[e] = r;
+}
+
 // pixels per workgroup of the weight-gradient launch: ~512 workgroups, at least two slabs each
 static int up_px_per_chunk(long M, int c_in, int c_out) {
     const long tiles = (long)(c_in / UP_T) * (4 * c_out / UP_T);
@@ -395,19 +486,28 @@ __global__ __launch_bounds__(256) void conv1x1_fwd_kernel(const float* __restric
 }
 
 // d_x[m][c] = sum_n d_y[m][n] w[n][c]   (one thread per float4 of d_x)
-__global__ __launch_bounds__(256) void conv1x1_dgrad_kernel(const float* __restrict__ dy, long M, int C, const float* __restrict__ w, int N, float* __restrict__ dx) {
-    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+// (mask, or null: x was a ReLU output y (M, C): d_x *= (y > 0); out_max, or null: atomicMax of max |d_x|)
+__global__ __launch_bounds__(256) void conv1x1_dgrad_kernel(const float* __restrict__ dy, long M, int C, const float* __restrict__ w, int N, float* __restrict__ dx,
+                                                            const float* __restrict__ mask, unsigned* __restrict__ out_max) {
     const int C4 = C >> 2;
-    if (e >= M * C4) return;
-    const long m = e / C4;
-    const int c = (int)(e - m * C4) * 4;
-    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int n = 0; n < N; ++n) {
-        const float g = dy[m * N + n];
-        const float4 ww = *reinterpret_cast<const float4*>(w + (long)n * C + c);
-        r.x = __builtin_fmaf(g, ww.x, r.x); r.y = __builtin_fmaf(g, ww.y, r.y); r.z = __builtin_fmaf(g, ww.z, r.z); r.w = __builtin_fmaf(g, ww.w, r.w);
+    float mx = 0.f;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < M * C4; e += (long)gridDim.x * 256) {
+        const long m = e / C4;
+        const int c = (int)(e - m * C4) * 4;
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int n = 0; n < N; ++n) {
+            const float g = dy[m * N + n];
+            const float4 ww = *reinterpret_cast<const float4*>(w + (long)n * C + c);
+            r.x = __builtin_fmaf(g, ww.x, r.x); r.y = __builtin_fmaf(g, ww.y, r.y); r.z = __builtin_fmaf(g, ww.z, r.z); r.w = __builtin_fmaf(g, ww.w, r.w);
+        }
+        if (mask) {
+            const float4 yv = *reinterpret_cast<const float4*>(mask + m * C + c);
+            r.x = yv.x > 0.f ? r.x : 0.f; r.y = yv.y > 0.f ? r.y : 0.f; r.z = yv.z > 0.f ? r.z : 0.f; r.w = yv.w > 0.f ? r.w : 0.f;
+        }
+        mx = fmaxf(mx, absmax4f(r));
+        *reinterpret_cast<float4*>(dx + m * C + c) = r;
     }
-    *reinterpret_cast<float4*>(dx + m * C + c) = r;
+    if (out_max) papr_wg_max_to_slot(out_max, mx);
 }
 
 // partial[chunk][n][c] = sum over the chunk's pixels of d_y[m][n] x[m][c]; partial_b[chunk][n] = sum d_y[m][n].
@@ -488,13 +588,28 @@ static long c1_px_per_chunk(long M) {
 
 }  // namespace
 
+int papr_i_maxpool2_fwd(const float* x, int ld_in, int B, int H, int W, int C, float* out, unsigned* which, hipStream_t s) {
+    const long total = (long)B * (H / 2) * (W / 2) * (C / 4);
+    maxpool2_fwd_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(reinterpret_cast<const float4*>(x), ld_in / 4, H, W, C / 4, total,
+                                                                                  reinterpret_cast<float4*>(out), which);
+    PAPR_CHECK_LAUNCH("maxpool2_fwd");
+    return 0;
+}
+
 extern "C" int papr_maxpool2_fwd(const float* x, int32_t B, int32_t H, int32_t W, int32_t C, float* out, uint32_t* which, papr_stream_t stream) {
     PAPR_REQUIRE(x && out, "papr_maxpool2_fwd: null pointer");
     PAPR_REQUIRE(B >= 1 && H >= 2 && W >= 2 && C >= 4 && C % 4 == 0, "papr_maxpool2_fwd: B %d, H %d, W %d, C %d (multiple of 4)", B, H, W, C);
-    const long total = (long)B * (H / 2) * (W / 2) * (C / 4);
-    maxpool2_fwd_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream)>>>(reinterpret_cast<const float4*>(x), H, W, C / 4, total,
-                                                                                                  reinterpret_cast<float4*>(out), which);
-    PAPR_CHECK_LAUNCH("maxpool2_fwd");
+    return papr_i_maxpool2_fwd(x, C, B, H, W, C, out, which, as_stream(stream));
+}
+
+int papr_i_maxpool2_bwd_fused(const float* d_out, const unsigned* which, int B, int H, int W, int C, const float* skip, int ld_skip, const float* y, int ld_y,
+                              float* d_in, unsigned* out_max, hipStream_t s) {
+    const long total = (long)B * H * W * (C / 4);
+    const long nb = (total + 255) / 256;
+    maxpool2_bwd_fused_kernel<<<dim3((unsigned)(nb > 1024 ? 1024 : nb)), dim3(256), 0, s>>>(reinterpret_cast<const float4*>(d_out), which, H, W, C / 4, total,
+                                                                                        reinterpret_cast<const float4*>(skip), ld_skip / 4,
+                                                                                        reinterpret_cast<const float4*>(y), ld_y / 4, reinterpret_cast<float4*>(d_in), out_max);
+    PAPR_CHECK_LAUNCH("maxpool2_bwd_fused");
     return 0;
 }
 
@@ -515,15 +630,30 @@ static int up_check(const char* who, int32_t B, int32_t H, int32_t W, int32_t c_
     return 0;
 }
 
+int papr_i_upconv_fwd(const float* x, int B, int H, int W, int c_in, const float* wm, const float* bias, int c_out, float* out, int ldo, unsigned* out_max,
+                      hipStream_t s) {
+    UpArgs a{};
+    a.x = x; a.wm = wm; a.bias = bias; a.out = out; a.B = B; a.H = H; a.W = W; a.C_in = c_in; a.C_out = c_out; a.ldo = ldo; a.ldg = c_out; a.out_max = out_max;
+    const long M = (long)B * H * W;
+    upconv2x2_h3_kernel<0><<<dim3((unsigned)((M + UP_T - 1) / UP_T), (unsigned)(4 * c_out / UP_T)), dim3(256), 0, s>>>(a);
+    PAPR_CHECK_LAUNCH("upconv2x2_h3<fwd>");
+    return 0;
+}
+
 extern "C" int papr_upconv2x2_fwd(const float* x, int32_t B, int32_t H, int32_t W, int32_t c_in, const float* wm, const float* bias, int32_t c_out,
                                   float* out, papr_stream_t stream) {
     PAPR_REQUIRE(x && wm && out, "papr_upconv2x2_fwd: null pointer");
     if (int rc = up_check("papr_upconv2x2_fwd", B, H, W, c_in, c_out)) return rc;
+    return papr_i_upconv_fwd(x, B, H, W, c_in, wm, bias, c_out, out, c_out, nullptr, as_stream(stream));
+}
+
+int papr_i_upconv_dgrad(const float* g, int ldg, int B, int H, int W, int c_in, const float* wm, int c_out, const float* mask_y, float* d_x, unsigned* out_max,
+                        hipStream_t s) {
     UpArgs a{};
-    a.x = x; a.wm = wm; a.bias = bias; a.out = out; a.B = B; a.H = H; a.W = W; a.C_in = c_in; a.C_out = c_out;
+    a.g = g; a.wm = wm; a.out = d_x; a.B = B; a.H = H; a.W = W; a.C_in = c_in; a.C_out = c_out; a.ldo = c_out; a.ldg = ldg; a.mask = mask_y; a.out_max = out_max;
     const long M = (long)B * H * W;
-    upconv2x2_h3_kernel<0><<<dim3((unsigned)((M + UP_T - 1) / UP_T), (unsigned)(4 * c_out / UP_T)), dim3(256), 0, as_stream(stream)>>>(a);
-    PAPR_CHECK_LAUNCH("upconv2x2_h3<fwd>");
+    upconv2x2_h3_kernel<1><<<dim3((unsigned)((M + UP_T - 1) / UP_T), (unsigned)(c_in / UP_T)), dim3(256), 0, s>>>(a);
+    PAPR_CHECK_LAUNCH("upconv2x2_h3<dgrad>");
     return 0;
 }
 
@@ -531,12 +661,7 @@ extern "C" int papr_upconv2x2_dgrad(const float* d_out, int32_t B, int32_t H, in
                                     papr_stream_t stream) {
     PAPR_REQUIRE(d_out && wm && d_x, "papr_upconv2x2_dgrad: null pointer");
     if (int rc = up_check("papr_upconv2x2_dgrad", B, H, W, c_in, c_out)) return rc;
-    UpArgs a{};
-    a.g = d_out; a.wm = wm; a.out = d_x; a.B = B; a.H = H; a.W = W; a.C_in = c_in; a.C_out = c_out;
-    const long M = (long)B * H * W;
-    upconv2x2_h3_kernel<1><<<dim3((unsigned)((M + UP_T - 1) / UP_T), (unsigned)(c_in / UP_T)), dim3(256), 0, as_stream(stream)>>>(a);
-    PAPR_CHECK_LAUNCH("upconv2x2_h3<dgrad>");
-    return 0;
+    return papr_i_upconv_dgrad(d_out, c_out, B, H, W, c_in, wm, c_out, nullptr, d_x, nullptr, as_stream(stream));
 }
 
 extern "C" size_t papr_upconv2x2_wgrad_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t c_in, int32_t c_out) {
@@ -551,7 +676,7 @@ extern "C" int papr_upconv2x2_wgrad(const float* d_out, const float* x, int32_t 
     const long M = (long)B * H * W, px = up_px_per_chunk(M, c_in, c_out), chunks = (M + px - 1) / px;
     hipStream_t s = as_stream(stream);
     UpArgs a{};
-    a.x = x; a.g = d_out; a.B = B; a.H = H; a.W = W; a.C_in = c_in; a.C_out = c_out; a.px_per_chunk = (int)px;
+    a.x = x; a.g = d_out; a.B = B; a.H = H; a.W = W; a.C_in = c_in; a.C_out = c_out; a.px_per_chunk = (int)px; a.ldg = c_out; a.ldo = c_out;
     float* maxes = static_cast<float*>(workspace);
     float* colsum = maxes + 128;
     PAPR_REQUIRE(c_out <= 1024, "papr_upconv2x2_wgrad: c_out %d > 1024", c_out);
@@ -570,6 +695,31 @@ extern "C" int papr_upconv2x2_wgrad(const float* d_out, const float* x, int32_t 
     return 0;
 }
 
+size_t papr_i_upconv_wgrad_bytes(long M, int c_in, int c_out) {
+    const long px = up_px_per_chunk(M, c_in, c_out), chunks = (M + px - 1) / px;
+    return (size_t)chunks * 4 * c_out * sizeof(float) + (size_t)chunks * c_out * 4 * c_in * sizeof(float);
+}
+
+// (maxima from the producers, the bias gradient from the launch's own column sums: no statistics launch)
+int papr_i_upconv_wgrad(const float* g, int ldg, const float* x, int B, int H, int W, int c_in, int c_out, const unsigned* xmax, const unsigned* gmax, float* d_wm,
+                        float* d_bias, void* ws, hipStream_t s) {
+    const long M = (long)B * H * W, px = up_px_per_chunk(M, c_in, c_out), chunks = (M + px - 1) / px;
+    UpArgs a{};
+    a.x = x; a.g = g; a.B = B; a.H = H; a.W = W; a.C_in = c_in; a.C_out = c_out; a.px_per_chunk = (int)px; a.ldg = ldg; a.ldo = c_out;
+    a.pmax_bits = xmax; a.qmax_bits = gmax;
+    float* partial_b = static_cast<float*>(ws);
+    a.partial_b = d_bias ? partial_b : nullptr;
+    a.out = partial_b + (size_t)chunks * 4 * c_out;
+    upconv2x2_h3_kernel<2><<<dim3((unsigned)(c_in / UP_T), (unsigned)(4 * c_out / UP_T), (unsigned)chunks), dim3(256), 0, s>>>(a);
+    PAPR_CHECK_LAUNCH("upconv2x2_h3<wgrad>");
+    const long n4 = (long)c_in * c_out;
+    upconv_wgrad_reduce2_kernel<<<dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s>>>(reinterpret_cast<const float4*>(a.out), (int)chunks, n4,
+                                                                                          reinterpret_cast<float4*>(d_wm), reinterpret_cast<const float4*>(a.partial_b),
+                                                                                          c_out / 4, reinterpret_cast<float4*>(d_bias));
+    PAPR_CHECK_LAUNCH("upconv_wgrad_reduce");
+    return 0;
+}
+
 extern "C" int papr_conv1x1_fwd(const float* x, int64_t M, int32_t c_in, const float* w, const float* bias, int32_t c_out, float* out, papr_stream_t stream) {
     PAPR_REQUIRE(x && w && out, "papr_conv1x1_fwd: null pointer");
     PAPR_REQUIRE(M >= 1 && c_in >= 4 && c_in % 4 == 0 && c_out >= 1 && c_out <= C1_MAXN, "papr_conv1x1_fwd: M %lld, c_in %d (multiple of 4), c_out %d (1 .. 4)",
@@ -584,27 +734,32 @@ extern "C" size_t papr_conv1x1_bwd_workspace_bytes(int64_t M, int32_t c_in, int3
     return (size_t)chunks * c_out * (c_in + 1) * sizeof(float);
 }
 
+int papr_i_conv1x1_bwd(const float* d_out, const float* x, long M, int c_in, const float* w, int c_out, const float* mask_y, float* d_x, unsigned* out_max,
+                       float* d_w, float* d_b, void* ws, hipStream_t s) {
+    if (d_x) {
+        const long n4 = M * (c_in / 4);
+        const long nb = (n4 + 255) / 256;
+        conv1x1_dgrad_kernel<<<dim3((unsigned)(out_max && nb > 1024 ? 1024 : nb)), dim3(256), 0, s>>>(d_out, M, c_in, w, c_out, d_x, mask_y, out_max);
+        PAPR_CHECK_LAUNCH("conv1x1_dgrad");
+    }
+    if (d_w) {
+        const long px = c1_px_per_chunk(M), chunks = (M + px - 1) / px;
+        float* partial = static_cast<float*>(ws);
+        float* partial_b = d_b ? partial + (size_t)chunks * c_out * c_in : nullptr;
+        conv1x1_wgrad_kernel<<<dim3((unsigned)chunks), dim3(256), 0, s>>>(d_out, x, M, c_in, c_out, px, partial, partial_b);
+        PAPR_CHECK_LAUNCH("conv1x1_wgrad");
+        const int NC = c_out * c_in;
+        conv1x1_wgrad_reduce_kernel<<<dim3((unsigned)((NC + c_out + 3) / 4)), dim3(256), 0, s>>>(partial, partial_b, (int)chunks, NC, c_out, d_w, d_b);
+        PAPR_CHECK_LAUNCH("conv1x1_wgrad_reduce");
+    }
+    return 0;
+}
+
 extern "C" int papr_conv1x1_bwd(const float* d_out, const float* x, int64_t M, int32_t c_in, const float* w, int32_t c_out, float* d_x, float* d_w,
                                 float* d_bias, void* workspace, papr_stream_t stream) {
     PAPR_REQUIRE(d_out && x && w, "papr_conv1x1_bwd: null pointer");
     PAPR_REQUIRE(M >= 1 && c_in >= 32 && c_in <= 256 && (c_in & (c_in - 1)) == 0 && c_out >= 1 && c_out <= C1_MAXN,
                  "papr_conv1x1_bwd: M %lld, c_in %d (32, 64, 128 or 256), c_out %d (1 .. 4)", (long long)M, c_in, c_out);
     PAPR_REQUIRE(!d_w || workspace, "papr_conv1x1_bwd: the weight gradient needs the workspace");
-    hipStream_t s = as_stream(stream);
-    if (d_x) {
-        const long n4 = M * (c_in / 4);
-        conv1x1_dgrad_kernel<<<dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s>>>(d_out, M, c_in, w, c_out, d_x);
-        PAPR_CHECK_LAUNCH("conv1x1_dgrad");
-    }
-    if (d_w) {
-        const long px = c1_px_per_chunk(M), chunks = (M + px - 1) / px;
-        float* partial = static_cast<float*>(workspace);
-        float* partial_b = d_bias ? partial + (size_t)chunks * c_out * c_in : nullptr;
-        conv1x1_wgrad_kernel<<<dim3((unsigned)chunks), dim3(256), 0, s>>>(d_out, x, M, c_in, c_out, px, partial, partial_b);
-        PAPR_CHECK_LAUNCH("conv1x1_wgrad");
-        const int NC = c_out * c_in;
-        conv1x1_wgrad_reduce_kernel<<<dim3((unsigned)((NC + c_out + 3) / 4)), dim3(256), 0, s>>>(partial, partial_b, (int)chunks, NC, c_out, d_w, d_bias);
-        PAPR_CHECK_LAUNCH("conv1x1_wgrad_reduce");
-    }
-    return 0;
+    return papr_i_conv1x1_bwd(d_out, x, M, c_in, w, c_out, nullptr, d_x, nullptr, d_w, d_bias, workspace, as_stream(stream));
 }

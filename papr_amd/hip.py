@@ -26,7 +26,7 @@ EXPORTS = [
     "papr_segment_reduce_workspace_bytes", "papr_segment_reduce", "papr_group_pairs_workspace_bytes", "papr_group_pairs", "papr_points_knn",
     "papr_rownorm_fwd", "papr_rownorm_bwd", "papr_row_dots", "papr_qk_bias_bwd_workspace_bytes", "papr_qk_bias_bwd", "papr_ln_fold_fwd", "papr_ln_fold_bwd", "papr_mlp_fwd_workspace_bytes", "papr_mlp_bwd_workspace_bytes", "papr_mlp_saved_floats", "papr_mlp_bwd_needs_weight_t", "papr_mlp_fwd",
     "papr_mlp_bwd",
-    "papr_attn_tail_fwd", "papr_attn_tail_bwd", "papr_conv3x3_weight_halfs", "papr_conv3x3_workspace_bytes", "papr_conv3x3_fwd", "papr_conv3x3_wgrad_workspace_bytes", "papr_conv3x3_wgrad", "papr_maxpool2_fwd", "papr_maxpool2_bwd", "papr_upconv2x2_fwd", "papr_upconv2x2_dgrad", "papr_upconv2x2_wgrad_workspace_bytes", "papr_upconv2x2_wgrad", "papr_conv1x1_fwd", "papr_conv1x1_bwd_workspace_bytes", "papr_conv1x1_bwd", "papr_adam_step", "papr_adam_step_scaled", "papr_composite_fwd", "papr_composite_bwd_workspace_bytes", "papr_composite_bwd", "papr_profile_enable", "papr_profile_collect", "papr_set_switch", "papr_get_switch",
+    "papr_attn_tail_fwd", "papr_attn_tail_bwd", "papr_conv3x3_weight_halfs", "papr_conv3x3_workspace_bytes", "papr_conv3x3_fwd", "papr_conv3x3_wgrad_workspace_bytes", "papr_conv3x3_wgrad", "papr_maxpool2_fwd", "papr_maxpool2_bwd", "papr_upconv2x2_fwd", "papr_upconv2x2_dgrad", "papr_upconv2x2_wgrad_workspace_bytes", "papr_upconv2x2_wgrad", "papr_conv1x1_fwd", "papr_conv1x1_bwd_workspace_bytes", "papr_conv1x1_bwd", "papr_small_unet_state_bytes", "papr_small_unet_bwd_workspace_bytes", "papr_small_unet_fwd", "papr_small_unet_bwd", "papr_adam_step", "papr_adam_step_scaled", "papr_composite_fwd", "papr_composite_bwd_workspace_bytes", "papr_composite_bwd", "papr_profile_enable", "papr_profile_collect", "papr_set_switch", "papr_get_switch",
 ]
 
 
@@ -58,6 +58,17 @@ class TailDesc(C.Structure):
     _fields_ = [("k", C.c_int32), ("d_model", C.c_int32), ("C", C.c_int32), ("ld_kp", C.c_int32),
                 ("ld_qp", C.c_int32), ("ld_v", C.c_int32), ("score_act", C.c_int32), ("normalize", C.c_int32),
                 ("bkg_score", C.c_float), ("scale_dim", C.c_int32), ("precomputed_dots", C.c_int32)]
+
+
+class UnetDesc(C.Structure):             # papr_unet_desc
+    _fields_ = [("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("c_in", C.c_int32), ("n_classes", C.c_int32),
+                ("conv_w", C.c_void_p * 5), ("conv_w_stride", (C.c_int64 * 4) * 5), ("conv_b", C.c_void_p * 5),
+                ("up_w", C.c_void_p * 2), ("up_b", C.c_void_p * 2), ("out_w", C.c_void_p), ("out_b", C.c_void_p)]
+
+
+class UnetGrads(C.Structure):            # papr_unet_grads
+    _fields_ = [("conv_w", C.c_void_p * 5), ("conv_b", C.c_void_p * 5), ("up_w", C.c_void_p * 2), ("up_b", C.c_void_p * 2),
+                ("out_w", C.c_void_p), ("out_b", C.c_void_p)]
 
 
 _lib = None
@@ -121,6 +132,12 @@ def lib():
     L.papr_conv1x1_bwd_workspace_bytes.restype = C.c_size_t
     L.papr_conv1x1_bwd_workspace_bytes.argtypes = [i64, i32, i32]
     L.papr_conv1x1_bwd.argtypes = [vp, vp, i64, i32, vp, i32, vp, vp, vp, vp, vp]
+    L.papr_small_unet_state_bytes.restype = C.c_size_t
+    L.papr_small_unet_state_bytes.argtypes = [i32, i32, i32, i32, i32]
+    L.papr_small_unet_bwd_workspace_bytes.restype = C.c_size_t
+    L.papr_small_unet_bwd_workspace_bytes.argtypes = [i32, i32, i32, i32, i32]
+    L.papr_small_unet_fwd.argtypes = [C.POINTER(UnetDesc), vp, vp, vp, i32, vp]
+    L.papr_small_unet_bwd.argtypes = [C.POINTER(UnetDesc), vp, vp, vp, vp, C.POINTER(UnetGrads), vp, vp]
     L.papr_adam_step.argtypes = [vp, i32, vp, i32, vp]
     L.papr_adam_step_scaled.argtypes = [vp, i32, vp, i32, vp, vp, vp]
     L.papr_composite_fwd.argtypes = [vp, vp, i32, i32, vp, i64, i32, i32, vp, vp]

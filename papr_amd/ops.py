@@ -307,6 +307,92 @@ class _Conv1x1Fn(torch.autograd.Function):
         return d_x, (d_w.reshape(ctx.wshape) if want_w else None), d_b
 
 
+class _SmallUNetFn(torch.autograd.Function):
+    """out (B, H, W, n_classes) = SmallUNet(x (B, H, W, c_in)) as ONE library call each way (papr_small_unet_fwd / _bwd; the reference's
+    SmallUNet.forward, models/unet.py:206-258): all weight splits and the input maximum in one launch, every other tensor maximum from the kernel
+    that produces the tensor, skip concatenations written in place, ReLU masks and the skip tensors' gradient sums inside the kernels at the seams.
+    params: conv weight x5, conv bias x5 (inc, down1, down2, up1.conv, up2.conv), up weight x2, up bias x2, out weight, out bias -- the reference's
+    parameter tensors as they are."""
+
+    @staticmethod
+    def _desc(x, params):
+        B, H, W, c_in = x.shape
+        cw, cb, uw, ub, ow, ob = params[0:5], params[5:10], params[10:12], params[12:14], params[14], params[15]
+        d = hip.UnetDesc()
+        d.B, d.H, d.W, d.c_in, d.n_classes = B, H, W, c_in, ow.shape[0]
+        keep = []
+        for i in range(5):
+            w = cw[i].detach()
+            d.conv_w[i] = w.data_ptr()
+            for j, st in enumerate(w.stride()):
+                d.conv_w_stride[i][j] = st
+            bb = cb[i].detach().contiguous()
+            d.conv_b[i] = bb.data_ptr()
+            keep += [w, bb]
+        wms = []
+        for j in range(2):
+            wm = uw[j].detach().permute(0, 2, 3, 1).contiguous()        # (no copy for a channels-last parameter)
+            bb = ub[j].detach().contiguous()
+            d.up_w[j], d.up_b[j] = wm.data_ptr(), bb.data_ptr()
+            wms.append(wm)
+            keep += [wm, bb]
+        w2 = ow.detach().reshape(ow.shape[0], ow.shape[1]).contiguous()
+        b2 = ob.detach().contiguous()
+        d.out_w, d.out_b = w2.data_ptr(), b2.data_ptr()
+        keep += [w2, b2]
+        return d, keep, wms
+
+    @staticmethod
+    def forward(ctx, x, track, *params):
+        _need_hip_rows(x, "the U-Net head")
+        lib = hip.lib()
+        B, H, W, c_in = x.shape
+        keep_state = bool(track and (ctx.needs_input_grad[0] or any(ctx.needs_input_grad[2:])))
+        d, alive, _ = _SmallUNetFn._desc(x, params)
+        state = torch.empty(lib.papr_small_unet_state_bytes(B, H, W, c_in, 1 if keep_state else 0), device=x.device, dtype=torch.uint8)
+        out = torch.empty((B, H, W, d.n_classes), device=x.device, dtype=torch.float32)
+        hip.check(lib.papr_small_unet_fwd(C.byref(d), hip.ptr(x), hip.ptr(out), hip.ptr(state), 1 if keep_state else 0, hip.stream_ptr()), "papr_small_unet_fwd")
+        if keep_state:
+            ctx.save_for_backward(x, state, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        x, state = ctx.saved_tensors[:2]
+        params = ctx.saved_tensors[2:]
+        lib = hip.lib()
+        B, H, W, c_in = x.shape
+        dev = x.device
+        d, alive, wms = _SmallUNetFn._desc(x, params)
+        g = hip.UnetGrads()
+        E = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)
+        d_cw = [E(params[i].shape[0], 3, 3, params[i].shape[1]) for i in range(5)]
+        d_cb = [E(params[i].shape[0]) for i in range(5)]
+        d_uw = [torch.empty_like(wm) for wm in wms]
+        d_ub = [E(wm.shape[3]) for wm in wms]
+        d_ow, d_ob = E(d.n_classes, params[14].shape[1]), E(d.n_classes)
+        for i in range(5):
+            g.conv_w[i], g.conv_b[i] = d_cw[i].data_ptr(), d_cb[i].data_ptr()
+        for j in range(2):
+            g.up_w[j], g.up_b[j] = d_uw[j].data_ptr(), d_ub[j].data_ptr()
+        g.out_w, g.out_b = d_ow.data_ptr(), d_ob.data_ptr()
+        d_x = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        ws = torch.empty(lib.papr_small_unet_bwd_workspace_bytes(B, H, W, c_in, d.n_classes), device=dev, dtype=torch.uint8)
+        hip.check(lib.papr_small_unet_bwd(C.byref(d), hip.ptr(x), hip.ptr(d_out.contiguous()), hip.ptr(state), hip.ptr(d_x), C.byref(g), hip.ptr(ws), hip.stream_ptr()),
+                  "papr_small_unet_bwd")
+        grads = [t.permute(0, 3, 1, 2) for t in d_cw] + d_cb + [t.permute(0, 3, 1, 2) for t in d_uw] + d_ub + [d_ow.reshape(params[14].shape), d_ob]
+        return (d_x, None) + tuple(grads)
+
+
+def small_unet_rows(x, net):
+    """x (B, H, W, c_in) contiguous -> (B, H, W, n_classes): `net` = a papr_amd.unet.SmallUNet (the reference's module attribute names)."""
+    c = lambda m: m.double_conv[0]
+    convs = [c(net.inc), c(net.down1.maxpool_conv[1]), c(net.down2.maxpool_conv[1]), c(net.up1.conv), c(net.up2.conv)]
+    ups = [net.up1.up, net.up2.up]
+    params = [m.weight for m in convs] + [m.bias for m in convs] + [m.weight for m in ups] + [m.bias for m in ups] + [net.outc.conv.weight, net.outc.conv.bias]
+    return _SmallUNetFn.apply(x, torch.is_grad_enabled(), *params)
+
+
 class _CompositeFn(torch.autograd.Function):
     """rgb = fg * (1 - a) + bkg * a (normalize) or fg + bkg * a, a = the background token's attention: the last line of the
     reference's forward (models/model.py:536-545) and its autograd as one launch forward, two backward (papr_composite_fwd / _bwd)

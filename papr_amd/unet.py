@@ -20,6 +20,7 @@ import torch.nn.functional as F
 _OWN_CONV = os.environ.get("PAPR_UNET_CONV", "1") == "1"
 _AMP_OWN = os.environ.get("PAPR_UNET_AMP", "own") == "own"        # under use_amp: the head on the own kernels (default) or torch's fp16 autocast + MIOpen (A/B)
 _OWN_REST = os.environ.get("PAPR_UNET_REST", "1") == "1"       # (0: pooling, transposed and 1x1 convolutions on torch / MIOpen, A/B)
+_WHOLE_NET = os.environ.get("PAPR_UNET_NET", "1") == "1"       # (0: layer by layer -- one autograd function per layer, torch glue between them; A/B)
 
 
 class ConvStage(nn.Module):
@@ -108,6 +109,12 @@ class SmallUNet(nn.Module):
             self.to(memory_format=torch.channels_last)
 
     def forward(self, x, gamma=None, beta=None):
+        # the whole network as one library call each way (papr_small_unet_fwd / _bwd) where its shapes allow: two exact poolings (H, W multiples
+        # of 4), input channels a multiple of 32, biases present; otherwise layer by layer below
+        if (_WHOLE_NET and _own_path(x) and not (self.use_amp and not _AMP_OWN) and x.shape[2] % 4 == 0 and x.shape[3] % 4 == 0 and x.shape[2] >= 4
+                and x.shape[3] >= 4 and x.shape[1] % 32 == 0 and self.outc.conv.out_channels <= 4 and x.shape[0] * x.shape[2] * x.shape[3] * 2048 < 2 ** 31):
+            from .ops import small_unet_rows
+            return small_unet_rows(x.permute(0, 2, 3, 1).contiguous(), self).permute(0, 3, 1, 2)
         with torch.autocast(device_type="cuda", dtype=self.amp_dtype, enabled=self.use_amp and x.is_cuda and not _AMP_OWN):
             x1 = self.inc(x)
             x2 = self.down1(x1)

@@ -880,20 +880,25 @@ def test_conv1x1_forward_and_gradients_match_torch(B, H, W, c_in, c_out):
     np.testing.assert_allclose(bd.grad.cpu().numpy(), b.grad.numpy(), rtol=0, atol=3e-6 * b.grad.abs().max().item())
 
 
-@pytest.mark.parametrize("hw", [(40, 40), (24, 36)])
+@pytest.mark.parametrize("hw,batch,whole", [((40, 40), 1, True), ((24, 36), 1, True), ((40, 40), 1, False), ((24, 36), 1, False), ((26, 37), 1, True), ((32, 20), 2, True),
+                                            ((160, 160), 1, True), ((160, 160), 1, False)])
 @pytest.mark.parametrize("use_amp", [False, True])
-def test_small_unet_on_own_kernels_matches_torch_module(hw, use_amp):
+def test_small_unet_on_own_kernels_matches_torch_module(hw, batch, whole, use_amp, monkeypatch):
     """The whole SmallUNet (reference models/unet.py:182-258) on this library's kernels against the same module run by torch
     in float64 on the CPU: output and every parameter / input gradient; and no layer of the device run may go through
     aten / MIOpen convolution or pooling (profiler check of the launched kernels).  use_amp (what every shipped scene file sets;
     the reference autocasts the module to fp16 there, models/unet.py:212): the same kernels, the same bars -- the head is not handed
     to torch autocast + MIOpen."""
     import copy
+    import papr_amd.unet as unet_mod
     from papr_amd.unet import SmallUNet
+    # whole: the network as one library call each way (papr_small_unet_fwd / _bwd: H, W multiples of 4); otherwise layer by layer (one autograd
+    # function per layer; what (26, 37) takes whatever the switch says)
+    monkeypatch.setattr(unet_mod, "_WHOLE_NET", whole)
     torch.manual_seed(3)
     net = SmallUNet(32, 3, use_amp=use_amp)
-    x = torch.randn(1, 32, *hw)
-    gy = torch.randn(1, 3, *hw) * 1e-2
+    x = torch.randn(batch, 32, *hw)
+    gy = torch.randn(batch, 3, *hw) * 1e-2
     ref = copy.deepcopy(net).double()
     xr = x.double().requires_grad_(True)
     yr = ref(xr)
@@ -908,10 +913,29 @@ def test_small_unet_on_own_kernels_matches_torch_module(hw, use_amp):
     names = [e.key for e in prof.key_averages()]
     foreign = [n for n in names if any(t in n.lower() for t in ("igemm", "miopen", "max_pool", "naive_conv", "cijk_"))]
     assert not foreign, foreign
+    if whole and hw[0] % 4 == 0 and hw[1] % 4 == 0:      # one call each way: no concatenation copy, no ReLU-mask launch, one weight-split launch
+        assert any("unet_prep" in n for n in names) and not any("conv_prep" in n or "CatArray" in n or "threshold" in n for n in names), names
     np.testing.assert_allclose(yd.detach().cpu().numpy(), yr.detach().float().numpy(), rtol=0, atol=1e-5 * yr.abs().max().item())
-    np.testing.assert_allclose(xd.grad.cpu().numpy(), xr.grad.float().numpy(), rtol=0, atol=2e-5 * xr.grad.abs().max().item())
+    gx, gx_ref = xd.grad.cpu().numpy(), xr.grad.float().numpy()
+    if hw[0] * hw[1] < 160 * 160:
+        np.testing.assert_allclose(gx, gx_ref, rtol=0, atol=2e-5 * xr.grad.abs().max().item())
+        flip = 1.0
+    else:
+        # 4.6 M ReLU / pooling decisions: one of them falls the other way in fp32 than in float64 (a pre-activation within rounding of zero), and its
+        # receptive field in d_x (16 x 16 pixels x 32 channels = 1 % of the map) differs by its whole contribution -- in both forms of the device
+        # run alike (whole network and layer by layer give the same 8,318 elements).  Held: 98 % of the elements at the bar, the rest within 2 %
+        # of the largest gradient; parameter gradients (sums over all pixels): 99.5 % of a tensor's elements at ten times their bar, the rest within 2 %
+        err = np.abs(gx - gx_ref)
+        bar = 2e-5 * xr.grad.abs().max().item()
+        assert (err > bar).mean() <= 0.02 and err.max() <= 2e-2 * xr.grad.abs().max().item(), ((err > bar).mean(), err.max())
+        flip = 10.0
     for (name, pd), pr in zip(net_d.named_parameters(), ref.parameters()):
-        np.testing.assert_allclose(pd.grad.cpu().numpy(), pr.grad.float().numpy(), rtol=0, atol=5e-5 * pr.grad.abs().max().item(), err_msg=name)
+        got, want, top = pd.grad.cpu().numpy(), pr.grad.float().numpy(), pr.grad.abs().max().item()
+        if flip == 1.0:
+            np.testing.assert_allclose(got, want, rtol=0, atol=5e-5 * top, err_msg=name)
+        else:                                            # (the flipped unit's own weight row carries its whole contribution: 0.12 % of down2's weight gradient)
+            err = np.abs(got - want)
+            assert (err > flip * 5e-5 * top).sum() <= max(2, 0.005 * err.size) and err.max() <= 2e-2 * top, (name, (err > flip * 5e-5 * top).sum(), err.max(), top)
 
 
 @pytest.mark.parametrize("R,k,Cn,normalize", [(25600, 20, 3, True), (1000, 5, 3, False), (77, 1, 8, True)])
