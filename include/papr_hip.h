@@ -169,6 +169,12 @@ size_t papr_qk_bias_bwd_workspace_bytes(int dq);
 int papr_qk_bias_bwd(const float* Q, int ldq, int dq, int dm, const float* d_c0, int64_t R, const float* wq, int ldwq, const float* bk, const float* bq,
                      float* d_Q, float* d_wq, const float* d_bq_in, float* d_bq, float* d_bk, void* workspace, papr_stream_t stream);
 
+/* The `mse` loss term (torch.nn.MSELoss() in the reference's BasicLoss, models/__init__.py:8-52): *loss = mean((pred - target)^2) over n numbers and,
+ * with grad != NULL, grad[i] = 2 (pred[i] - target[i]) / n -- one launch (ABI 26).  workspace: papr_mse_workspace_bytes() bytes, ZEROED before its first
+ * use and then left to the calls (a ticket counter the kernel resets; calls sharing one workspace must run on one stream). */
+size_t papr_mse_workspace_bytes(void);
+int papr_mse_fwd(const float* pred, const float* target, int64_t n, float* loss, float* grad, void* workspace, papr_stream_t stream);
+
 /* The affine part of that LayerNorm, y = a_2 * xh + b_2 (models/attn.py:42), folded into the Linear layer behind it:
  *   W (a_2 * xh + b_2) + c  =  (W * a_2) xh + (W b_2 + c).
  * fwd: eff_w (n_out, ld_eff) = W[:, :n_in] * a_2 with columns n_in .. ld_eff-1 zeroed, eff_b = c + W b_2.

@@ -393,11 +393,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float4* __
     if (stale2 && blockIdx.x == 0 && threadIdx.x == 0) { stale2[0] = 0u; stale2[1] = 0u; }
     if (out_b && e < nb4) {                          // bias gradient: the chunks' column sums
         float4 r = partial_b[e];
+#pragma unroll 8
         for (int z = 1; z < chunks; ++z) { const float4 v = partial_b[(long)z * nb4 + e]; r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w; }
         out_b[e] = r;
     }
     if (e >= n4) return;
     float4 r = partial[e];
+#pragma unroll 8                                   // (the loads of eight chunks in flight together: 34 -> 67 chunks in a row were a latency chain of as many round trips)
     for (int z = 1; z < chunks; ++z) {
         const float4 v = partial[(long)z * n4 + e];
         r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w;
@@ -414,6 +416,7 @@ __global__ __launch_bounds__(256) void conv_reduce_kernel(const float4* __restri
         const long m = e / n4;
         const int c = (int)(e - m * n4);
         float4 r = bias ? bias[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 3
         for (int z = 0; z < splits; ++z) {
             const float4 v = partial[(long)z * mn4 + e];
             r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w;

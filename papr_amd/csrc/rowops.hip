@@ -801,6 +801,62 @@ extern "C" int papr_qk_bias_bwd(const float* Q, int ldq, int dq, int dm, const f
     return 0;
 }
 
+// The MSE training loss (torch.nn.MSELoss(), the reference's models/__init__.py:8-52 `mse` term) forward and its gradient direction in ONE launch:
+// loss = mean((pred - target)^2), grad[i] = 2 (pred[i] - target[i]) / n (the backward pass multiplies it by the incoming scalar).  A patch of rays
+// is 76,800 numbers: torch spends an elementwise launch, a two-stage 16-us reduction and three more launches backwards on it.  Up to 64 workgroups
+// leave fp64 partial sums; the one that arrives last (a ticket counter in the workspace, which it resets) adds them in index order.
+namespace {
+constexpr int MSE_MAX_WGS = 64;
+__global__ __launch_bounds__(256) void mse_fwd_kernel(const float* __restrict__ pred, const float* __restrict__ target, long n, float* __restrict__ loss,
+                                                      float* __restrict__ grad, unsigned* __restrict__ ticket, double* __restrict__ partial) {
+    __shared__ double part[4];
+    __shared__ bool last;
+    const float two_inv = 2.0f / (float)n;
+    double acc = 0.0;
+    const long n4 = (n % 4 == 0 && (reinterpret_cast<uintptr_t>(pred) | reinterpret_cast<uintptr_t>(target) | reinterpret_cast<uintptr_t>(grad)) % 16 == 0) ? n / 4 : 0;
+    const long stride = (long)gridDim.x * 256, t0 = (long)blockIdx.x * 256 + threadIdx.x;
+    for (long i = t0; i < n4; i += stride) {
+        const float4 a = reinterpret_cast<const float4*>(pred)[i], b = reinterpret_cast<const float4*>(target)[i];
+        const float4 d = make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
+        acc += (double)(d.x * d.x) + (double)(d.y * d.y) + (double)(d.z * d.z) + (double)(d.w * d.w);
+        if (grad) reinterpret_cast<float4*>(grad)[i] = make_float4(d.x * two_inv, d.y * two_inv, d.z * two_inv, d.w * two_inv);
+    }
+    for (long i = 4 * n4 + t0; i < n; i += stride) {
+        const float d = pred[i] - target[i];
+        acc += (double)(d * d);
+        if (grad) grad[i] = d * two_inv;
+    }
+    for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(partial + blockIdx.x, (part[0] + part[1]) + (part[2] + part[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (last && threadIdx.x == 0) {
+        __threadfence();
+        double t = 0.0;
+        for (unsigned w = 0; w < gridDim.x; ++w) t += __hip_atomic_load(partial + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *loss = (float)(t / (double)n);
+        *ticket = 0u;                                // (for the next call on this workspace)
+    }
+}
+}  // namespace
+
+extern "C" size_t papr_mse_workspace_bytes(void) { return 16 + MSE_MAX_WGS * sizeof(double); }
+
+extern "C" int papr_mse_fwd(const float* pred, const float* target, int64_t n, float* loss, float* grad, void* workspace, papr_stream_t stream) {
+    PAPR_REQUIRE(pred && target && loss && workspace && n >= 1, "papr_mse_fwd: null pointer or empty input");
+    long wgs = (n / 4 + 255) / 256;
+    wgs = wgs < 1 ? 1 : (wgs > MSE_MAX_WGS ? MSE_MAX_WGS : wgs);
+    mse_fwd_kernel<<<dim3((unsigned)wgs), dim3(256), 0, as_stream(stream)>>>(pred, target, n, loss, grad, static_cast<unsigned*>(workspace),
+                                                                            reinterpret_cast<double*>(static_cast<char*>(workspace) + 16));
+    PAPR_CHECK_LAUNCH("mse_fwd");
+    return 0;
+}
+
 extern "C" int papr_rownorm_bwd(const float* dy, const float* y, const float* stats, int64_t rows, int width, int ld,
                                 float eps, float* dx, papr_stream_t stream) {
     (void)eps;

@@ -425,7 +425,7 @@ __global__ __launch_bounds__(256) void upconv_wgrad_reduce_kernel(const float4* 
     }
     if (e >= n4) return;
     float4 r = partial[e];
-#pragma unroll 4
+#pragma unroll 8
     for (int z = 1; z < chunks; ++z) { const float4 v = partial[(long)z * n4 + e]; r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w; }
     out[e] = r;
 }
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(256) void upconv_wgrad_reduce2_kernel(const float4*
     }
     if (e >= n4) return;
     float4 r = partial[e];
-#pragma unroll 4
+#pragma unroll 8
     for (int z = 1; z < chunks; ++z) { const float4 v = partial[(long)z * n4 + e]; r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w; }
     out[e] = r;
 }

@@ -24,7 +24,7 @@ EXPORTS = [
     "papr_abi_version", "papr_last_error", "papr_ray_knn_workspace_bytes", "papr_ray_knn",
     "papr_feature_widths", "papr_build_features_fwd", "papr_build_features_bwd", "papr_build_features_bwd_pairs",
     "papr_segment_reduce_workspace_bytes", "papr_segment_reduce", "papr_group_pairs_workspace_bytes", "papr_group_pairs", "papr_points_knn",
-    "papr_rownorm_fwd", "papr_rownorm_bwd", "papr_row_dots", "papr_qk_bias_bwd_workspace_bytes", "papr_qk_bias_bwd", "papr_ln_fold_fwd", "papr_ln_fold_bwd", "papr_mlp_fwd_workspace_bytes", "papr_mlp_bwd_workspace_bytes", "papr_mlp_saved_floats", "papr_mlp_bwd_needs_weight_t", "papr_mlp_fwd",
+    "papr_rownorm_fwd", "papr_rownorm_bwd", "papr_row_dots", "papr_qk_bias_bwd_workspace_bytes", "papr_qk_bias_bwd", "papr_mse_workspace_bytes", "papr_mse_fwd", "papr_ln_fold_fwd", "papr_ln_fold_bwd", "papr_mlp_fwd_workspace_bytes", "papr_mlp_bwd_workspace_bytes", "papr_mlp_saved_floats", "papr_mlp_bwd_needs_weight_t", "papr_mlp_fwd",
     "papr_mlp_bwd",
     "papr_attn_tail_fwd", "papr_attn_tail_bwd", "papr_conv3x3_weight_halfs", "papr_conv3x3_workspace_bytes", "papr_conv3x3_fwd", "papr_conv3x3_wgrad_workspace_bytes", "papr_conv3x3_wgrad", "papr_maxpool2_fwd", "papr_maxpool2_bwd", "papr_upconv2x2_fwd", "papr_upconv2x2_dgrad", "papr_upconv2x2_wgrad_workspace_bytes", "papr_upconv2x2_wgrad", "papr_conv1x1_fwd", "papr_conv1x1_bwd_workspace_bytes", "papr_conv1x1_bwd", "papr_small_unet_state_bytes", "papr_small_unet_bwd_workspace_bytes", "papr_small_unet_fwd", "papr_small_unet_bwd", "papr_adam_step", "papr_adam_step_scaled", "papr_composite_fwd", "papr_composite_bwd_workspace_bytes", "papr_composite_bwd", "papr_profile_enable", "papr_profile_collect", "papr_set_switch", "papr_get_switch",
 ]
@@ -110,6 +110,9 @@ def lib():
     L.papr_rownorm_fwd.argtypes = [vp, i64, i32, i32, f32, vp, vp, vp]
     L.papr_rownorm_bwd.argtypes = [vp, vp, vp, i64, i32, i32, f32, vp, vp]
     L.papr_row_dots.argtypes = [vp, i64, i32, i32, vp, i32, i32, vp, vp]
+    L.papr_mse_workspace_bytes.restype = C.c_size_t
+    L.papr_mse_workspace_bytes.argtypes = []
+    L.papr_mse_fwd.argtypes = [vp, vp, i64, vp, vp, vp, vp]
     L.papr_qk_bias_bwd_workspace_bytes.restype = C.c_size_t
     L.papr_qk_bias_bwd_workspace_bytes.argtypes = [i32]
     L.papr_qk_bias_bwd.argtypes = [vp, i32, i32, i32, vp, i64, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]

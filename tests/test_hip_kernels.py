@@ -1181,3 +1181,20 @@ def test_qk_bias_bwd_rank_one_terms_equal_the_torch_formulas(R, dq, dm, ldq):
         assert err <= 2e-6 * max(exp.abs().max().item(), 1.0) * max(1.0, (R / 1000.0) ** 0.5), (name, err)
     # the padding columns are untouched
     assert torch.equal(d_Q.cpu()[:, dq:], d_Q0[:, dq:]) and torch.equal(d_wq.cpu()[:, dq:], d_wq0[:, dq:])
+
+
+@pytest.mark.parametrize("shape", [(1, 160, 160, 3), (7,), (3, 5, 11), (1, 1)])
+def test_own_mse_loss_equals_torch_mse_loss_and_its_gradient(shape):
+    """papr_amd.loss.MSELoss on the device (papr_mse_fwd: loss and gradient direction in one launch) against torch.nn.MSELoss in float64."""
+    from papr_amd.loss import MSELoss, _MseFn
+    g = torch.Generator().manual_seed(len(shape))
+    pred, tgt = torch.rand(*shape, generator=g), torch.rand(*shape, generator=g)
+    pr = pred.double().requires_grad_(True)
+    ref = torch.nn.functional.mse_loss(pr, tgt.double())
+    (ref * 3.0).backward()
+    pd = pred.to(dev()).requires_grad_(True)
+    got = MSELoss()(pd, tgt.to(dev()))
+    assert isinstance(got.grad_fn, _MseFn._backward_cls)
+    (got * 3.0).backward()
+    assert abs(got.item() - ref.item()) <= 2e-7 * ref.item()
+    np.testing.assert_allclose(pd.grad.cpu().numpy(), pr.grad.float().numpy(), rtol=2e-6, atol=0)
