@@ -185,6 +185,19 @@ int papr_ln_fold_fwd(const float* w, int32_t n_out, int32_t n_in, int32_t ldw, c
 int papr_ln_fold_bwd(const float* w, int32_t n_out, int32_t n_in, int32_t ldw, const float* a2, const float* b2,
                      const float* d_eff_w, int32_t ld_eff, const float* d_eff_b, float* d_w, float* d_a2, float* d_b2,
                      papr_stream_t stream);
+/* The same for several layers in one launch each way (ABI 26): a PAPR step folds four affines (in front of the key and the query MLP, behind them
+ * into w_k and w_q).  Forward reads w, c (or NULL), a2, b2 and writes eff_w, eff_b; backward reads w, a2, b2, d_eff_w, d_eff_b and writes d_w, d_a2,
+ * d_b2 (the gradient of c is d_eff_b itself); the fields of the other direction are ignored. */
+#define PAPR_LN_FOLD_MAX_JOBS 8
+typedef struct {
+    const float* w; int32_t n_out, n_in, ldw;
+    const float* c; const float* a2; const float* b2;
+    float* eff_w; int32_t ld_eff; float* eff_b;
+    const float* d_eff_w; const float* d_eff_b; float* d_w; float* d_a2; float* d_b2;
+} papr_ln_fold_job;
+int papr_ln_fold_fwd_batch(const papr_ln_fold_job* jobs, int32_t n, papr_stream_t stream);
+int papr_ln_fold_bwd_batch(const papr_ln_fold_job* jobs, int32_t n, papr_stream_t stream);
+
 
 /* ------------------------------------------------------------------------------------
  * K3  embedding MLP chain on MFMA      replaces MLP.forward (models/mlp.py:47-59) and its autograd.

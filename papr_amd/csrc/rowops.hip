@@ -473,10 +473,10 @@ __global__ __launch_bounds__(256) void tail_bwd_wide_kernel(papr_tail_desc d, co
 
 // ------------------------------------------------------------------------------------------------
 // LayerNorm affine folded into the following Linear layer (see papr_hip.h).  One wave per output row.
-__global__ __launch_bounds__(256) void ln_fold_fwd_kernel(const float* __restrict__ w, int n_out, int n_in, int ldw,
-                                                          const float* __restrict__ c, const float* __restrict__ a2,
-                                                          const float* __restrict__ b2, float* __restrict__ eff_w, int ld_eff,
-                                                          float* __restrict__ eff_b) {
+__device__ __forceinline__ void ln_fold_fwd_block(const float* __restrict__ w, int n_out, int n_in, int ldw,
+                                                  const float* __restrict__ c, const float* __restrict__ a2,
+                                                  const float* __restrict__ b2, float* __restrict__ eff_w, int ld_eff,
+                                                  float* __restrict__ eff_b) {
     const int lane = threadIdx.x & 63;
     const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (o >= n_out) return;
@@ -489,14 +489,28 @@ __global__ __launch_bounds__(256) void ln_fold_fwd_kernel(const float* __restric
     acc = wave_sum(acc);
     if (lane == 0) eff_b[o] = (c ? c[o] : 0.f) + acc;
 }
+__global__ __launch_bounds__(256) void ln_fold_fwd_kernel(const float* __restrict__ w, int n_out, int n_in, int ldw,
+                                                          const float* __restrict__ c, const float* __restrict__ a2,
+                                                          const float* __restrict__ b2, float* __restrict__ eff_w, int ld_eff,
+                                                          float* __restrict__ eff_b) {
+    ln_fold_fwd_block(w, n_out, n_in, ldw, c, a2, b2, eff_w, ld_eff, eff_b);
+}
+// all folds of a model in one launch (blockIdx.y = job): a PAPR step folds four LayerNorm affines -- in front of the key and the query MLP, behind
+// them into w_k and w_q -- 5 us of launch each for a microsecond of work
+struct LnFoldJobs { papr_ln_fold_job job[PAPR_LN_FOLD_MAX_JOBS]; };
+__global__ __launch_bounds__(256) void ln_fold_fwd_batch_kernel(LnFoldJobs t) {
+    const papr_ln_fold_job& j = t.job[blockIdx.y];
+    if ((int)blockIdx.x * 4 >= j.n_out) return;
+    ln_fold_fwd_block(j.w, j.n_out, j.n_in, j.ldw, j.c, j.a2, j.b2, j.eff_w, j.ld_eff, j.eff_b);
+}
 
 // a workgroup of sixteen waves owns 64 columns over all rows: wave q takes the rows q, q + 16, ...; the sixteen partial column
 // sums meet in LDS in a fixed order (the matrices are tiny -- 256 x 128 -- and the launch is latency: four waves took 22 us)
-__global__ __launch_bounds__(1024) void ln_fold_bwd_kernel(const float* __restrict__ w, int n_out, int n_in, int ldw,
-                                                          const float* __restrict__ a2, const float* __restrict__ b2,
-                                                          const float* __restrict__ d_eff_w, int ld_eff,
-                                                          const float* __restrict__ d_eff_b, float* __restrict__ d_w,
-                                                          float* __restrict__ d_a2, float* __restrict__ d_b2) {
+__device__ __forceinline__ void ln_fold_bwd_block(const float* __restrict__ w, int n_out, int n_in, int ldw,
+                                                  const float* __restrict__ a2, const float* __restrict__ b2,
+                                                  const float* __restrict__ d_eff_w, int ld_eff,
+                                                  const float* __restrict__ d_eff_b, float* __restrict__ d_w,
+                                                  float* __restrict__ d_a2, float* __restrict__ d_b2) {
     __shared__ float part[2][16][64];
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + lane;
@@ -532,8 +546,52 @@ __global__ __launch_bounds__(1024) void ln_fold_bwd_kernel(const float* __restri
         d_b2[i] = tb;
     }
 }
+__global__ __launch_bounds__(1024) void ln_fold_bwd_kernel(const float* __restrict__ w, int n_out, int n_in, int ldw,
+                                                          const float* __restrict__ a2, const float* __restrict__ b2,
+                                                          const float* __restrict__ d_eff_w, int ld_eff,
+                                                          const float* __restrict__ d_eff_b, float* __restrict__ d_w,
+                                                          float* __restrict__ d_a2, float* __restrict__ d_b2) {
+    ln_fold_bwd_block(w, n_out, n_in, ldw, a2, b2, d_eff_w, ld_eff, d_eff_b, d_w, d_a2, d_b2);
+}
+__global__ __launch_bounds__(1024) void ln_fold_bwd_batch_kernel(LnFoldJobs t) {
+    const papr_ln_fold_job& j = t.job[blockIdx.y];
+    if ((int)blockIdx.x * 64 >= j.n_in) return;       // (uniform per workgroup: before the block's barrier)
+    ln_fold_bwd_block(j.w, j.n_out, j.n_in, j.ldw, j.a2, j.b2, j.d_eff_w, j.ld_eff, j.d_eff_b, j.d_w, j.d_a2, j.d_b2);
+}
 
 }  // namespace
+
+static int ln_fold_check(const char* who, const papr_ln_fold_job* jobs, int n, bool bwd) {
+    PAPR_REQUIRE(jobs && n >= 1 && n <= PAPR_LN_FOLD_MAX_JOBS, "%s: %d jobs (1 .. %d)", who, n, PAPR_LN_FOLD_MAX_JOBS);
+    for (int i = 0; i < n; ++i) {
+        const papr_ln_fold_job& j = jobs[i];
+        PAPR_REQUIRE(j.w && j.a2 && j.b2, "%s: job %d: null pointer", who, i);
+        PAPR_REQUIRE(bwd ? (j.d_eff_w && j.d_eff_b && j.d_w && j.d_a2 && j.d_b2) : (j.eff_w && j.eff_b), "%s: job %d: null %s pointer", who, i, bwd ? "gradient" : "output");
+        PAPR_REQUIRE(j.n_out >= 1 && j.n_in >= 1 && j.ldw >= j.n_in && j.ld_eff >= j.n_in && j.ld_eff <= 1024, "%s: job %d: n_out %d, n_in %d, ldw %d, ld_eff %d", who, i,
+                     j.n_out, j.n_in, j.ldw, j.ld_eff);
+    }
+    return 0;
+}
+
+extern "C" int papr_ln_fold_fwd_batch(const papr_ln_fold_job* jobs, int32_t n, papr_stream_t stream) {
+    if (int rc = ln_fold_check("papr_ln_fold_fwd_batch", jobs, n, false)) return rc;
+    LnFoldJobs t;
+    int most = 0;
+    for (int i = 0; i < n; ++i) { t.job[i] = jobs[i]; most = jobs[i].n_out > most ? jobs[i].n_out : most; }
+    ln_fold_fwd_batch_kernel<<<dim3((unsigned)((most + 3) / 4), (unsigned)n), dim3(256), 0, as_stream(stream)>>>(t);
+    PAPR_CHECK_LAUNCH("ln_fold_fwd_batch");
+    return 0;
+}
+
+extern "C" int papr_ln_fold_bwd_batch(const papr_ln_fold_job* jobs, int32_t n, papr_stream_t stream) {
+    if (int rc = ln_fold_check("papr_ln_fold_bwd_batch", jobs, n, true)) return rc;
+    LnFoldJobs t;
+    int most = 0;
+    for (int i = 0; i < n; ++i) { t.job[i] = jobs[i]; most = jobs[i].n_in > most ? jobs[i].n_in : most; }
+    ln_fold_bwd_batch_kernel<<<dim3((unsigned)((most + 63) / 64), (unsigned)n), dim3(1024), 0, as_stream(stream)>>>(t);
+    PAPR_CHECK_LAUNCH("ln_fold_bwd_batch");
+    return 0;
+}
 
 extern "C" int papr_ln_fold_fwd(const float* w, int32_t n_out, int32_t n_in, int32_t ldw, const float* c, const float* a2,
                                 const float* b2, float* eff_w, int32_t ld_eff, float* eff_b, papr_stream_t stream) {

@@ -24,7 +24,7 @@ EXPORTS = [
     "papr_abi_version", "papr_last_error", "papr_ray_knn_workspace_bytes", "papr_ray_knn",
     "papr_feature_widths", "papr_build_features_fwd", "papr_build_features_bwd", "papr_build_features_bwd_pairs",
     "papr_segment_reduce_workspace_bytes", "papr_segment_reduce", "papr_group_pairs_workspace_bytes", "papr_group_pairs", "papr_points_knn",
-    "papr_rownorm_fwd", "papr_rownorm_bwd", "papr_row_dots", "papr_qk_bias_bwd_workspace_bytes", "papr_qk_bias_bwd", "papr_mse_workspace_bytes", "papr_mse_fwd", "papr_ln_fold_fwd", "papr_ln_fold_bwd", "papr_mlp_fwd_workspace_bytes", "papr_mlp_bwd_workspace_bytes", "papr_mlp_saved_floats", "papr_mlp_bwd_needs_weight_t", "papr_mlp_fwd",
+    "papr_rownorm_fwd", "papr_rownorm_bwd", "papr_row_dots", "papr_qk_bias_bwd_workspace_bytes", "papr_qk_bias_bwd", "papr_mse_workspace_bytes", "papr_mse_fwd", "papr_ln_fold_fwd", "papr_ln_fold_bwd", "papr_ln_fold_fwd_batch", "papr_ln_fold_bwd_batch", "papr_mlp_fwd_workspace_bytes", "papr_mlp_bwd_workspace_bytes", "papr_mlp_saved_floats", "papr_mlp_bwd_needs_weight_t", "papr_mlp_fwd",
     "papr_mlp_bwd",
     "papr_attn_tail_fwd", "papr_attn_tail_bwd", "papr_conv3x3_weight_halfs", "papr_conv3x3_workspace_bytes", "papr_conv3x3_fwd", "papr_conv3x3_wgrad_workspace_bytes", "papr_conv3x3_wgrad", "papr_maxpool2_fwd", "papr_maxpool2_bwd", "papr_upconv2x2_fwd", "papr_upconv2x2_dgrad", "papr_upconv2x2_wgrad_workspace_bytes", "papr_upconv2x2_wgrad", "papr_conv1x1_fwd", "papr_conv1x1_bwd_workspace_bytes", "papr_conv1x1_bwd", "papr_small_unet_state_bytes", "papr_small_unet_bwd_workspace_bytes", "papr_small_unet_fwd", "papr_small_unet_bwd", "papr_adam_step", "papr_adam_step_scaled", "papr_composite_fwd", "papr_composite_bwd_workspace_bytes", "papr_composite_bwd", "papr_profile_enable", "papr_profile_collect", "papr_set_switch", "papr_get_switch",
 ]
@@ -58,6 +58,15 @@ class TailDesc(C.Structure):
     _fields_ = [("k", C.c_int32), ("d_model", C.c_int32), ("C", C.c_int32), ("ld_kp", C.c_int32),
                 ("ld_qp", C.c_int32), ("ld_v", C.c_int32), ("score_act", C.c_int32), ("normalize", C.c_int32),
                 ("bkg_score", C.c_float), ("scale_dim", C.c_int32), ("precomputed_dots", C.c_int32)]
+
+
+class LnFoldJob(C.Structure):            # papr_ln_fold_job
+    _fields_ = [("w", C.c_void_p), ("n_out", C.c_int32), ("n_in", C.c_int32), ("ldw", C.c_int32), ("c", C.c_void_p), ("a2", C.c_void_p), ("b2", C.c_void_p),
+                ("eff_w", C.c_void_p), ("ld_eff", C.c_int32), ("eff_b", C.c_void_p), ("d_eff_w", C.c_void_p), ("d_eff_b", C.c_void_p), ("d_w", C.c_void_p),
+                ("d_a2", C.c_void_p), ("d_b2", C.c_void_p)]
+
+
+LN_FOLD_MAX_JOBS = 8
 
 
 class UnetDesc(C.Structure):             # papr_unet_desc
@@ -149,6 +158,8 @@ def lib():
     L.papr_composite_bwd.argtypes = [vp, vp, vp, i32, i32, vp, i64, i32, i32, vp, vp, vp, vp, vp]
     L.papr_ln_fold_fwd.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp]
     L.papr_ln_fold_bwd.argtypes = [vp, i32, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp]
+    L.papr_ln_fold_fwd_batch.argtypes = [C.POINTER(LnFoldJob), i32, vp]
+    L.papr_ln_fold_bwd_batch.argtypes = [C.POINTER(LnFoldJob), i32, vp]
     L.papr_mlp_fwd_workspace_bytes.restype = C.c_size_t
     L.papr_mlp_fwd_workspace_bytes.argtypes = [i64]
     L.papr_mlp_bwd_workspace_bytes.restype = C.c_size_t

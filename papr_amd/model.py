@@ -20,12 +20,14 @@ from . import adam as own_adam
 from . import dist as pdist
 from .activations import output_activation
 from .config import as_node
-from .ops import RenderPath, prepare_mlp_weights, render_rays
+from . import hip
+from .ops import RenderPath, ln_fold_batch, ln_fold_job, prepare_mlp_weights, render_rays
 from .pointcloud import grow_points, grow_points_device
 from .schedule import create_learning_rate_fn, fast_forward
 from .unet import get_generator
 
 _OWN_ADAM = os.environ.get("PAPR_OWN_ADAM", "1") == "1"
+_LN_FOLD_BATCH = os.environ.get("PAPR_LN_FOLD_BATCH", "1") == "1"      # (0: one papr_ln_fold launch per LayerNorm affine each way, A/B)
 _OWN_ADAM_AMP = os.environ.get("PAPR_OWN_ADAM_AMP", "1") == "1"        # (0: torch's fused Adam through GradScaler.step under use_amp, A/B)
 _OWN_COMPOSITE = os.environ.get("PAPR_OWN_COMPOSITE", "1") == "1"      # (0: the compositing line in torch ops, A/B)
 
@@ -143,15 +145,21 @@ class ProximityAttentionParams(nn.Module):
         def ff(block, spec):
             lin = block.mlp.linears()
             ln = (block.innorm.a_2, block.innorm.b_2) if isinstance(block.innorm, _NormParams) else None
-            return prepare_mlp_weights(spec, [_MlpParams.effective_weight(l) for l in lin], [l.bias for l in lin], ln)
+            return spec, [_MlpParams.effective_weight(l) for l in lin], [l.bias for l in lin], ln
 
         def proj(lin, block, spec):
             ln = (block.outnorm.a_2, block.outnorm.b_2) if isinstance(block.outnorm, _NormParams) else None
-            return prepare_mlp_weights(spec, [lin.weight], [lin.bias], ln)
+            return spec, [lin.weight], [lin.bias], ln
 
         e, a = self.embed, self.attention_layer
-        out = {"key": ff(e.embed_k, plan.key), "query": ff(e.embed_q, plan.qry), "value": ff(e.embed_v, plan.val),
-               "wk": proj(a.w_k, e.embed_k, plan.wk), "wq": proj(a.w_q, e.embed_q, plan.wq)}
+        todo = {"key": ff(e.embed_k, plan.key), "query": ff(e.embed_q, plan.qry), "value": ff(e.embed_v, plan.val),
+                "wk": proj(a.w_k, e.embed_k, plan.wk), "wq": proj(a.w_q, e.embed_q, plan.wq)}
+        # the LayerNorm affines folded into the Linear layers behind them (in front of key / query / value MLP, behind key / query into w_k / w_q): all
+        # of them in ONE launch each way (four launches of 5 us each way before; PAPR_LN_FOLD_BATCH=0 for the A/B)
+        folds = {n: ln_fold_job(*t) for n, t in todo.items()} if _LN_FOLD_BATCH else {}
+        names = [n for n, f in folds.items() if f is not None]
+        done = dict(zip(names, ln_fold_batch([folds[n] for n in names]))) if len(names) > 1 and len(names) <= hip.LN_FOLD_MAX_JOBS else {}
+        out = {n: prepare_mlp_weights(*t, prefolded=done.get(n)) for n, t in todo.items()}
         if isinstance(e.embed_v.outnorm, _NormParams):           # (value.norm: layernorm -- applied by ops._RenderFn, nothing to fold it into)
             out["v_out"] = (e.embed_v.outnorm.a_2, e.embed_v.outnorm.b_2)
         return out

@@ -457,11 +457,76 @@ class _LnFoldFn(torch.autograd.Function):
         return d_w, d_eff_b, d_a2, d_b2, None
 
 
-def prepare_mlp_weights(spec, weights, biases, ln_in=None):
+class _LnFoldBatchFn(torch.autograd.Function):
+    """_LnFoldFn for several layers at once: one launch each way (papr_ln_fold_fwd_batch / _bwd_batch).  Arguments: the tuple of the layers' ld_eff, then
+    (w, c, a2, b2) per layer; returns (eff_w, eff_b) per layer, flat."""
+
+    @staticmethod
+    def _jobs(n):
+        return (hip.LnFoldJob * n)()
+
+    @staticmethod
+    def forward(ctx, ld_effs, *t):
+        n = len(ld_effs)
+        t = [x.contiguous() for x in t]
+        jobs, outs = _LnFoldBatchFn._jobs(n), []
+        for i in range(n):
+            w, c, a2, b2 = t[4 * i:4 * i + 4]
+            n_out, n_in = w.shape
+            eff_w = torch.empty((n_out, ld_effs[i]), device=w.device, dtype=torch.float32)
+            eff_b = torch.empty((n_out,), device=w.device, dtype=torch.float32)
+            j = jobs[i]
+            j.w, j.n_out, j.n_in, j.ldw, j.c, j.a2, j.b2 = w.data_ptr(), n_out, n_in, n_in, c.data_ptr(), a2.data_ptr(), b2.data_ptr()
+            j.eff_w, j.ld_eff, j.eff_b = eff_w.data_ptr(), ld_effs[i], eff_b.data_ptr()
+            outs += [eff_w, eff_b]
+        hip.check(hip.lib().papr_ln_fold_fwd_batch(jobs, n, hip.stream_ptr()), "papr_ln_fold_fwd_batch")
+        ctx.save_for_backward(*[x for i in range(n) for x in (t[4 * i], t[4 * i + 2], t[4 * i + 3])])
+        ctx.ld_effs = ld_effs
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *d):
+        n = len(ctx.ld_effs)
+        sv = ctx.saved_tensors
+        jobs, grads, alive = _LnFoldBatchFn._jobs(n), [], []
+        for i in range(n):
+            w, a2, b2 = sv[3 * i:3 * i + 3]
+            n_out, n_in = w.shape
+            d_eff_w = d[2 * i].contiguous() if d[2 * i] is not None else torch.zeros((n_out, ctx.ld_effs[i]), device=w.device, dtype=torch.float32)
+            d_eff_b = d[2 * i + 1].contiguous() if d[2 * i + 1] is not None else torch.zeros((n_out,), device=w.device, dtype=torch.float32)
+            d_w, d_a2, d_b2 = torch.empty_like(w), torch.empty_like(a2), torch.empty_like(b2)
+            j = jobs[i]
+            j.w, j.n_out, j.n_in, j.ldw, j.a2, j.b2 = w.data_ptr(), n_out, n_in, n_in, a2.data_ptr(), b2.data_ptr()
+            j.d_eff_w, j.ld_eff, j.d_eff_b, j.d_w, j.d_a2, j.d_b2 = d_eff_w.data_ptr(), ctx.ld_effs[i], d_eff_b.data_ptr(), d_w.data_ptr(), d_a2.data_ptr(), d_b2.data_ptr()
+            grads += [d_w, d_eff_b, d_a2, d_b2]
+            alive += [d_eff_w, d_eff_b]
+        hip.check(hip.lib().papr_ln_fold_bwd_batch(jobs, n, hip.stream_ptr()), "papr_ln_fold_bwd_batch")
+        return (None,) + tuple(grads)
+
+
+def ln_fold_job(spec, weights, biases, ln_in):
+    """(w, c, a2, b2, ld_eff) if the first layer of `spec` folds the LayerNorm affine `ln_in` on the device kernel (what prepare_mlp_weights would
+    hand to _LnFoldFn), else None."""
+    if ln_in is None:
+        return None
+    L, w = spec.layers[0], weights[0]
+    if L["skip"] or not w.is_cuda or L["n_in"] > 1024:
+        return None
+    return (w, biases[0], ln_in[0], ln_in[1], L["n_in"])
+
+
+def ln_fold_batch(folds):
+    """[(w, c, a2, b2, ld_eff), ...] -> [(eff_w, eff_b), ...] in one launch each way."""
+    out = _LnFoldBatchFn.apply(tuple(f[4] for f in folds), *[x for f in folds for x in f[:4]])
+    return [(out[2 * i], out[2 * i + 1]) for i in range(len(folds))]
+
+
+def prepare_mlp_weights(spec, weights, biases, ln_in=None, prefolded=None):
     """Reference-shaped Linear parameters -> effective, padded weights for the kernels (differentiable).
 
     ln_in = (a_2, b_2) of the input LayerNorm: the kernels only standardise rows, the affine part is
-    folded here:  W (a * xh + b) + c = (W * a) xh + (W b + c).
+    folded here:  W (a * xh + b) + c = (W * a) xh + (W b + c).  prefolded = (eff_w, eff_b) of the first layer when the caller has folded it already
+    (ln_fold_batch: all folds of a model in one launch).
     """
     eff_w, eff_b = [], []
     for i, (w, b) in enumerate(zip(weights, biases)):
@@ -469,7 +534,9 @@ def prepare_mlp_weights(spec, weights, biases, ln_in=None):
         # (no slice when the layer has no skip block: its backward would zero-fill and copy a full-size gradient)
         main = w[:, :L["raw_in"]] if L["skip"] else w
         extra = w[:, L["raw_in"]:] if L["skip"] else None
-        if ln_in is not None and i == 0 and extra is None and w.is_cuda and L["n_in"] <= 1024:
+        if prefolded is not None and i == 0:
+            main, b = prefolded
+        elif ln_in is not None and i == 0 and extra is None and w.is_cuda and L["n_in"] <= 1024:
             main, b = _LnFoldFn.apply(main, b, ln_in[0], ln_in[1], L["n_in"])      # (already padded to the kernel's row length)
         elif ln_in is not None:
             a, sh = ln_in
