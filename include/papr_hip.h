@@ -423,6 +423,8 @@ int papr_conv1x1_bwd(const float* d_out, const float* x, int64_t M, int32_t c_in
  *   (conv_w[i]: (C_out, 3, 3, C_in) contiguous = channels-last memory of (C_out, C_in, 3, 3)); workspace: papr_small_unet_bwd_workspace_bytes(). */
 typedef struct {
     int32_t B, H, W, c_in, n_classes;
+    int32_t one_product;      /* 0: three f16 products per fp32 product (fp32-parity); 1: one -- the arithmetic of the reference's fp16 autocast (`use_amp: true`,
+                                 models/unet.py:212), fp32 accumulation and fp32 maps either way.  The 1x1 head is plain fp32 in both */
     const float* conv_w[5];
     int64_t conv_w_stride[5][4];
     const float* conv_b[5];

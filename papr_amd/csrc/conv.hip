@@ -42,6 +42,9 @@ struct ConvArgs {
     int splits; float* partial;                  // splits > 1: blockIdx.z sums 9 / splits taps into partial[z] (M, N), no bias / act
 };
 
+// ONE: a single f16 product per fp32 product (hi planes only) -- the arithmetic of the reference's fp16 autocast (`use_amp: true`, models/unet.py:212),
+// with fp32 accumulation and fp32 maps in and out
+template <bool ONE>
 __global__ __launch_bounds__(256, 3) void conv3x3_h3_kernel(ConvArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     _Float16* Ah = reinterpret_cast<_Float16*>(smem);
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_h3_kernel(ConvArgs p) {
             const int c = tid + 256 * q;
             const long o = (long)(n0 + (c >> 2)) * p.K + (long)s * CV_BK + (c & 3) * 8;
             r.wh[q] = *reinterpret_cast<const half8*>(p.w_hi + o);
-            r.wl[q] = *reinterpret_cast<const half8*>(p.w_lo + o);
+            if (!ONE) r.wl[q] = *reinterpret_cast<const half8*>(p.w_lo + o);
         }
     };
     auto store_slab = [&](const SlabRegs& r) {
@@ -103,14 +106,14 @@ __global__ __launch_bounds__(256, 3) void conv3x3_h3_kernel(ConvArgs p) {
             split4(r.a[q], r.ok[q] ? x_scale : 0.f, hi, lo);
             const int off = ((tid >> 3) + 32 * q) * CV_HP + a_kq;
             *reinterpret_cast<half4*>(Ah + off) = hi;
-            *reinterpret_cast<half4*>(Al + off) = lo;
+            if (!ONE) *reinterpret_cast<half4*>(Al + off) = lo;
         }
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int c = tid + 256 * q;
             const int off = (c >> 2) * CV_HP + (c & 3) * 8;
             *reinterpret_cast<half8*>(Wh + off) = r.wh[q];
-            *reinterpret_cast<half8*>(Wl + off) = r.wl[q];
+            if (!ONE) *reinterpret_cast<half8*>(Wl + off) = r.wl[q];
         }
     };
 
@@ -131,16 +134,20 @@ __global__ __launch_bounds__(256, 3) void conv3x3_h3_kernel(ConvArgs p) {
             for (int i = 0; i < 2; ++i) {
                 const int o = (wm * 64 + i * 32) * CV_HP + frag + ks;
                 ah[i] = *reinterpret_cast<const half8*>(Ah + o);
-                al[i] = *reinterpret_cast<const half8*>(Al + o);
+                if (!ONE) al[i] = *reinterpret_cast<const half8*>(Al + o);
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int o = (wn * 64 + j * 32) * CV_HP + frag + ks;
-                const half8 wh = *reinterpret_cast<const half8*>(Wh + o), wl = *reinterpret_cast<const half8*>(Wl + o);
+                const half8 wh = *reinterpret_cast<const half8*>(Wh + o);
+                half8 wl;
+                if (!ONE) wl = *reinterpret_cast<const half8*>(Wl + o);
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, ah[i], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, al[i], acc[i][j], 0, 0, 0);
+                    if (!ONE) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, ah[i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, al[i], acc[i][j], 0, 0, 0);
+                    }
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, ah[i], acc[i][j], 0, 0, 0);
                 }
             }
@@ -228,7 +235,7 @@ struct ConvWArgs {
 
 // CT = channels of x per tile: 128, or 32 for the network's first layer (32 input channels: a 128-wide tile would multiply
 // three quarters of zeros) -- then the four waves stack along n, 32 x 32 each.
-template <int CT>
+template <int CT, bool ONE>
 __global__ __launch_bounds__(256, 3) void conv3x3_wgrad_h3_kernel(ConvWArgs p) {
     constexpr int NI = CT == 128 ? 2 : 1, NJ = NI, CQ = CT / 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -295,7 +302,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wgrad_h3_kernel(ConvWArgs p) {
             split4(col, 1.0f, hi, lo);
             const int off = (q + rq * j) * CV_HP + 4 * r;
             *reinterpret_cast<half4*>(hi_plane + off) = hi;
-            *reinterpret_cast<half4*>(lo_plane + off) = lo;
+            if (!ONE) *reinterpret_cast<half4*>(lo_plane + off) = lo;
         }
     };
     // bias gradient = column sums of dY: the workgroups of the centre tap and the first c tile add up their pixels
@@ -332,16 +339,20 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wgrad_h3_kernel(ConvWArgs p) {
                 for (int j = 0; j < NJ; ++j) {
                     const int o = (wn * 64 + j * 32) * CV_HP + frag + ks;
                     xh[j] = *reinterpret_cast<const half8*>(Xh + o);
-                    xl[j] = *reinterpret_cast<const half8*>(Xl + o);
+                    if (!ONE) xl[j] = *reinterpret_cast<const half8*>(Xl + o);
                 }
 #pragma unroll
                 for (int i = 0; i < NI; ++i) {
                     const int o = (wm * 32 * NI + i * 32) * CV_HP + frag + ks;
-                    const half8 gh = *reinterpret_cast<const half8*>(Gh + o), gl = *reinterpret_cast<const half8*>(Gl + o);
+                    const half8 gh = *reinterpret_cast<const half8*>(Gh + o);
+                    half8 gl;
+                    if (!ONE) gl = *reinterpret_cast<const half8*>(Gl + o);
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gl, xh[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, xl[j], acc[i][j], 0, 0, 0);
+                        if (!ONE) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gl, xh[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, xl[j], acc[i][j], 0, 0, 0);
+                        }
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, xh[j], acc[i][j], 0, 0, 0);
                     }
                 }
@@ -521,11 +532,15 @@ int papr_i_conv3x3(const PaprConvLaunch& c, hipStream_t s) {
     a.splits = conv_splits(M, c.c_in, c.c_out);
     a.partial = c.partial;
     PAPR_REQUIRE(a.splits == 1 || c.partial, "conv3x3: a split launch needs its partial buffer");
-    if (papr_first_on_device(PAPR_ONCE_CONV))
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_h3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CV_LDS_BYTES);
+    if (papr_first_on_device(PAPR_ONCE_CONV)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_h3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CV_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_h3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CV_LDS_BYTES);
+    }
     const bool prof = papr_prof_on();
     if (prof) papr_prof_begin2(11, M, c.c_out, (int)K, 4LL * M * (c.c_in + c.c_out), 2LL * M * c.c_out * K, s);
-    conv3x3_h3_kernel<<<dim3((unsigned)((M + CV_BM - 1) / CV_BM), (unsigned)(n_pad / CV_BN), (unsigned)a.splits), dim3(256), CV_LDS_BYTES, s>>>(a);
+    const dim3 grid((unsigned)((M + CV_BM - 1) / CV_BM), (unsigned)(n_pad / CV_BN), (unsigned)a.splits);
+    if (c.one_product) conv3x3_h3_kernel<true><<<grid, dim3(256), CV_LDS_BYTES, s>>>(a);
+    else conv3x3_h3_kernel<false><<<grid, dim3(256), CV_LDS_BYTES, s>>>(a);
     PAPR_CHECK_LAUNCH("conv3x3_h3");
     if (a.splits > 1) {
         const long mn4 = M * c.c_out / 4;
@@ -607,7 +622,7 @@ size_t papr_i_conv3x3_wgrad_partial_bytes(long M, int c_in, int c_out) {
 
 // stale: the two maximum slots conv_wgrad_reduce_kernel clears for the stand-alone entry point's slot rotation (or null)
 static int conv3x3_wgrad_launch(const float* d_y, const float* x, int B, int H, int W, int c_in, int c_out, float* d_w, float* d_b, const unsigned* dymax,
-                                const unsigned* xmax, const unsigned* xmax2, int n_max, float* partial, unsigned* stale, hipStream_t s) {
+                                const unsigned* xmax, const unsigned* xmax2, int n_max, float* partial, unsigned* stale, bool one_product, hipStream_t s) {
     const long M = (long)B * H * W, px = wgrad_px_per_chunk(M, c_in, c_out), chunks = (M + px - 1) / px;
     ConvWArgs a;
     a.dy = d_y; a.x = x; a.B = B; a.H = H; a.W = W; a.N = c_out; a.C = c_in;
@@ -616,15 +631,20 @@ static int conv3x3_wgrad_launch(const float* d_y, const float* x, int B, int H, 
     a.partial_b = d_b ? a.partial + (size_t)chunks * c_out * 9 * c_in : nullptr;
     a.px_per_chunk = px;
     if (papr_first_on_device(PAPR_ONCE_CONV_WGRAD)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_h3_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CV_LDS_BYTES);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_h3_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CV_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_h3_kernel<128, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CV_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_h3_kernel<32, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CV_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_h3_kernel<128, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CV_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_h3_kernel<32, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CV_LDS_BYTES);
     }
     const int ct = c_in <= 32 ? 32 : 128;
     const int tiles = ((c_out + 127) / 128) * ((c_in + ct - 1) / ct);
     const bool prof = papr_prof_on();
     if (prof) papr_prof_begin2(12, M, c_out, 9 * c_in, 4LL * M * (c_in + c_out), 2LL * M * c_out * 9 * c_in, s);
-    if (ct == 32) conv3x3_wgrad_h3_kernel<32><<<dim3((unsigned)chunks, (unsigned)tiles, 9), dim3(256), CV_LDS_BYTES, s>>>(a);
-    else conv3x3_wgrad_h3_kernel<128><<<dim3((unsigned)chunks, (unsigned)tiles, 9), dim3(256), CV_LDS_BYTES, s>>>(a);
+    const dim3 grid((unsigned)chunks, (unsigned)tiles, 9);
+    if (ct == 32 && one_product) conv3x3_wgrad_h3_kernel<32, true><<<grid, dim3(256), CV_LDS_BYTES, s>>>(a);
+    else if (ct == 32) conv3x3_wgrad_h3_kernel<32, false><<<grid, dim3(256), CV_LDS_BYTES, s>>>(a);
+    else if (one_product) conv3x3_wgrad_h3_kernel<128, true><<<grid, dim3(256), CV_LDS_BYTES, s>>>(a);
+    else conv3x3_wgrad_h3_kernel<128, false><<<grid, dim3(256), CV_LDS_BYTES, s>>>(a);
     PAPR_CHECK_LAUNCH("conv3x3_wgrad_h3");
     const long n4 = (long)c_out * 9 * c_in / 4;
     conv_wgrad_reduce_kernel<<<dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s>>>(reinterpret_cast<const float4*>(a.partial), (int)chunks, n4, reinterpret_cast<float4*>(d_w),
@@ -635,8 +655,8 @@ static int conv3x3_wgrad_launch(const float* d_y, const float* x, int B, int H, 
 }
 
 int papr_i_conv3x3_wgrad(const float* d_y, const float* x, int B, int H, int W, int c_in, int c_out, float* d_w, float* d_b, const unsigned* dymax,
-                         const unsigned* xmax, const unsigned* xmax2, float* partial, hipStream_t s) {
-    return conv3x3_wgrad_launch(d_y, x, B, H, W, c_in, c_out, d_w, d_b, dymax, xmax, xmax2, PAPR_SLOT_W, partial, nullptr, s);
+                         const unsigned* xmax, const unsigned* xmax2, float* partial, bool one_product, hipStream_t s) {
+    return conv3x3_wgrad_launch(d_y, x, B, H, W, c_in, c_out, d_w, d_b, dymax, xmax, xmax2, PAPR_SLOT_W, partial, nullptr, one_product, s);
 }
 
 extern "C" int papr_conv3x3_wgrad(const float* d_out, const float* x, int32_t B, int32_t H, int32_t W, int32_t c_in, int32_t c_out,
@@ -669,5 +689,5 @@ extern "C" int papr_conv3x3_wgrad(const float* d_out, const float* x, int32_t B,
     }
     PAPR_CHECK_LAUNCH("tensor_absmax");
     return conv3x3_wgrad_launch(d_out, x, B, H, W, c_in, c_out, d_w, d_bias, d_out_max_bits ? d_out_max_bits : gmax, x_max_bits ? x_max_bits : xmax, nullptr, 1,
-                                reinterpret_cast<float*>(static_cast<char*>(workspace) + 256), stale, s);
+                                reinterpret_cast<float*>(static_cast<char*>(workspace) + 256), stale, false, s);
 }

@@ -147,6 +147,7 @@ extern "C" int papr_small_unet_fwd(const papr_unet_desc* u, const float* x, floa
     unsigned* which1 = keep ? reinterpret_cast<unsigned*>(base + y.which1) : nullptr;
     unsigned* which2 = keep ? reinterpret_cast<unsigned*>(base + y.which2) : nullptr;
     float* partial = F(y.scratch);
+    const bool one = u->one_product != 0;
 
     // ---- one launch: the input's maximum, the slots, every weight's planes
     PaprSplitJob jobs[PAPR_UNET_MAX_JOBS];
@@ -176,7 +177,7 @@ extern "C" int papr_small_unet_fwd(const papr_unet_desc* u, const float* x, floa
         c.bias = u->conv_b[i]; c.c_out = d.L[i].c_out; c.relu = 1;
         c.out = o; c.ldo = ldo;
         c.xmax = S(xslot); c.n_xmax = PAPR_SLOT_W; c.xmax2 = xslot2 >= 0 ? S(xslot2) : nullptr; c.out_max = oslot >= 0 ? S(oslot) : nullptr;
-        c.partial = partial;
+        c.partial = partial; c.one_product = one;
         return papr_i_conv3x3(c, s);
     };
     const int H = d.H, W = d.W;
@@ -189,10 +190,10 @@ extern "C" int papr_small_unet_fwd(const papr_unet_desc* u, const float* x, floa
     if (int rc = papr_i_maxpool2_fwd(cat1, 2 * C2, d.B, H / 2, W / 2, C2, pool2, which2, s)) return rc;
     if (int rc = conv(2, pool2, H / 4, W / 4, S_X2, -1, x3, C3, S_X3)) return rc;
     // up1: transposed convolution into cat1[:, 256:], 3x3 over the concatenation -> y1
-    if (int rc = papr_i_upconv_fwd(x3, d.B, H / 4, W / 4, C3, u->up_w[0], u->up_b[0], C2, cat1 + C2, 2 * C2, S(S_UP1), s)) return rc;
+    if (int rc = papr_i_upconv_fwd(x3, d.B, H / 4, W / 4, C3, u->up_w[0], u->up_b[0], C2, cat1 + C2, 2 * C2, S(S_UP1), one, s)) return rc;
     if (int rc = conv(3, cat1, H / 2, W / 2, S_X2, S_UP1, y1, C2, S_Y1)) return rc;
     // up2 -> y2
-    if (int rc = papr_i_upconv_fwd(y1, d.B, H / 2, W / 2, C2, u->up_w[1], u->up_b[1], C1, cat2 + C1, 2 * C1, S(S_UP2), s)) return rc;
+    if (int rc = papr_i_upconv_fwd(y1, d.B, H / 2, W / 2, C2, u->up_w[1], u->up_b[1], C1, cat2 + C1, 2 * C1, S(S_UP2), one, s)) return rc;
     if (int rc = conv(4, cat2, H, W, S_X1, S_UP2, y2, C1, -1)) return rc;       // (y2 only feeds the fp32 1x1 head: no scale needed)
     // the 1x1 head
     return papr_conv1x1_fwd(y2, d.M1, C1, u->out_w, u->out_b, d.ncls, out, stream);
@@ -220,6 +221,7 @@ extern "C" int papr_small_unet_bwd(const papr_unet_desc* u, const float* x, cons
     float *d_y2 = G(b.d_y2), *d_cat2 = G(b.d_cat2), *d_y1 = G(b.d_y1), *d_cat1 = G(b.d_cat1), *d_x3 = G(b.d_x3), *d_pool2 = G(b.d_pool2), *d_x2 = G(b.d_x2),
           *d_pool1 = G(b.d_pool1), *d_x1 = G(b.d_x1);
     float* partial = G(b.partial);
+    const bool one = u->one_product != 0;
     const int H = d.H, W = d.W;
 
     // the data-gradient of 3x3 layer i: the same kernel over the mirrored planes, no bias, no activation
@@ -233,12 +235,12 @@ extern "C" int papr_small_unet_bwd(const papr_unet_desc* u, const float* x, cons
         c.bias = nullptr; c.c_out = d.L[i].c_in; c.relu = 0;
         c.out = o; c.ldo = d.L[i].c_in;
         c.xmax = S(dyslot); c.n_xmax = PAPR_SLOT_W; c.out_max = oslot >= 0 ? S(oslot) : nullptr;
-        c.partial = partial;
+        c.partial = partial; c.one_product = one;
         return papr_i_conv3x3(c, s);
     };
     auto wgrad = [&](int i, const float* dy, const float* in, int Hh, int Ww, int dyslot, int xslot, int xslot2) {
         return papr_i_conv3x3_wgrad(dy, in, d.B, Hh, Ww, d.L[i].c_in, d.L[i].c_out, g->conv_w[i], g->conv_b[i], S(dyslot), S(xslot), xslot2 >= 0 ? S(xslot2) : nullptr,
-                                    partial, s);
+                                    partial, one, s);
     };
 
     // 1x1 head: d_y2 = (d_out w) * (y2 > 0)
@@ -247,14 +249,14 @@ extern "C" int papr_small_unet_bwd(const papr_unet_desc* u, const float* x, cons
     if (int rc = dgrad(4, d_y2, H, W, S_DY2, d_cat2, S_DCAT2)) return rc;
     if (int rc = wgrad(4, d_y2, cat2, H, W, S_DY2, S_X1, S_UP2)) return rc;
     // up2.up: its output is the right half of cat2; its input y1 is up1.conv's ReLU output
-    if (int rc = papr_i_upconv_dgrad(d_cat2 + C1, 2 * C1, d.B, H / 2, W / 2, C2, u->up_w[1], C1, y1, d_y1, S(S_DY1), s)) return rc;
-    if (int rc = papr_i_upconv_wgrad(d_cat2 + C1, 2 * C1, y1, d.B, H / 2, W / 2, C2, C1, S(S_Y1), S(S_DCAT2), g->up_w[1], g->up_b[1], partial, s)) return rc;
+    if (int rc = papr_i_upconv_dgrad(d_cat2 + C1, 2 * C1, d.B, H / 2, W / 2, C2, u->up_w[1], C1, y1, d_y1, S(S_DY1), one, s)) return rc;
+    if (int rc = papr_i_upconv_wgrad(d_cat2 + C1, 2 * C1, y1, d.B, H / 2, W / 2, C2, C1, S(S_Y1), S(S_DCAT2), g->up_w[1], g->up_b[1], partial, one, s)) return rc;
     // up1.conv (over cat1 = [x2 | up1.up(x3)])
     if (int rc = dgrad(3, d_y1, H / 2, W / 2, S_DY1, d_cat1, S_DCAT1)) return rc;
     if (int rc = wgrad(3, d_y1, cat1, H / 2, W / 2, S_DY1, S_X2, S_UP1)) return rc;
     // up1.up: input x3 = down2's ReLU output
-    if (int rc = papr_i_upconv_dgrad(d_cat1 + C2, 2 * C2, d.B, H / 4, W / 4, C3, u->up_w[0], C2, x3, d_x3, S(S_DX3), s)) return rc;
-    if (int rc = papr_i_upconv_wgrad(d_cat1 + C2, 2 * C2, x3, d.B, H / 4, W / 4, C3, C2, S(S_X3), S(S_DCAT1), g->up_w[0], g->up_b[0], partial, s)) return rc;
+    if (int rc = papr_i_upconv_dgrad(d_cat1 + C2, 2 * C2, d.B, H / 4, W / 4, C3, u->up_w[0], C2, x3, d_x3, S(S_DX3), one, s)) return rc;
+    if (int rc = papr_i_upconv_wgrad(d_cat1 + C2, 2 * C2, x3, d.B, H / 4, W / 4, C3, C2, S(S_X3), S(S_DCAT1), g->up_w[0], g->up_b[0], partial, one, s)) return rc;
     // down2
     if (int rc = dgrad(2, d_x3, H / 4, W / 4, S_DX3, d_pool2, -1)) return rc;
     if (int rc = wgrad(2, d_x3, pool2, H / 4, W / 4, S_DX3, S_X2, -1)) return rc;

@@ -147,7 +147,8 @@ __device__ __forceinline__ float absmax4(float m, const float4& v) { return fmax
 __device__ __forceinline__ int up_logical(int R) { return 4 * (R & 15) + (R >> 4); }      // LDS row of a transposed operand -> index in the tile
 
 // MODE 0 forward, 1 data-gradient, 2 weight-gradient
-template <int MODE>
+// ONE: a single f16 product per fp32 product (hi planes only): the reference's fp16-autocast arithmetic (`use_amp: true`)
+template <int MODE, bool ONE>
 __global__ __launch_bounds__(256) void upconv2x2_h3_kernel(UpArgs p) {
     __shared__ __attribute__((aligned(16))) _Float16 planes[4 * UP_PLANE];
     __shared__ float red[20];
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(256) void upconv2x2_h3_kernel(UpArgs p) {
             split4(r[q], (ok == nullptr || ok[q]) ? sc : 0.f, hi, lo);
             const int off = (kr + 16 * q) * UP_HP + kc;
             *reinterpret_cast<half4*>(hi_plane + off) = hi;
-            *reinterpret_cast<half4*>(lo_plane + off) = lo;
+            if (!ONE) *reinterpret_cast<half4*>(lo_plane + off) = lo;
         }
     };
     auto put_cols = [&](const float4* r, const bool* ok, float sc, _Float16* hi_plane, _Float16* lo_plane) {       // transposed
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(256) void upconv2x2_h3_kernel(UpArgs p) {
                 split4(col, 1.0f, hi, lo);
                 const int off = (ig + 16 * j) * UP_HP + UP_TN * kg + 4 * h;
                 *reinterpret_cast<half4*>(hi_plane + off) = hi;
-                *reinterpret_cast<half4*>(lo_plane + off) = lo;
+                if (!ONE) *reinterpret_cast<half4*>(lo_plane + off) = lo;
             }
         }
     };
@@ -312,10 +313,12 @@ __global__ __launch_bounds__(256) void upconv2x2_h3_kernel(UpArgs p) {
 #pragma unroll
         for (int ks = 0; ks < UP_BK; ks += 16) {
             const int op = (wm_ * 32) * UP_HP + frag + ks, oq = (wn_ * 32) * UP_HP + frag + ks;
-            const half8 ph = *reinterpret_cast<const half8*>(Ph + op), pl = *reinterpret_cast<const half8*>(Pl + op);
-            const half8 qh = *reinterpret_cast<const half8*>(Qh + oq), ql = *reinterpret_cast<const half8*>(Ql + oq);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, qh, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, ql, acc, 0, 0, 0);
+            const half8 ph = *reinterpret_cast<const half8*>(Ph + op), qh = *reinterpret_cast<const half8*>(Qh + oq);
+            if (!ONE) {
+                const half8 pl = *reinterpret_cast<const half8*>(Pl + op), ql = *reinterpret_cast<const half8*>(Ql + oq);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, qh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, ql, acc, 0, 0, 0);
+            }
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, qh, acc, 0, 0, 0);
         }
         lds_barrier();                               // everybody has read the slab
@@ -631,11 +634,13 @@ static int up_check(const char* who, int32_t B, int32_t H, int32_t W, int32_t c_
 }
 
 int papr_i_upconv_fwd(const float* x, int B, int H, int W, int c_in, const float* wm, const float* bias, int c_out, float* out, int ldo, unsigned* out_max,
-                      hipStream_t s) {
+                      bool one_product, hipStream_t s) {
     UpArgs a{};
     a.x = x; a.wm = wm; a.bias = bias; a.out = out; a.B = B; a.H = H; a.W = W; a.C_in = c_in; a.C_out = c_out; a.ldo = ldo; a.ldg = c_out; a.out_max = out_max;
     const long M = (long)B * H * W;
-    upconv2x2_h3_kernel<0><<<dim3((unsigned)((M + UP_T - 1) / UP_T), (unsigned)(4 * c_out / UP_T)), dim3(256), 0, s>>>(a);
+    const dim3 grid((unsigned)((M + UP_T - 1) / UP_T), (unsigned)(4 * c_out / UP_T));
+    if (one_product) upconv2x2_h3_kernel<0, true><<<grid, dim3(256), 0, s>>>(a);
+    else upconv2x2_h3_kernel<0, false><<<grid, dim3(256), 0, s>>>(a);
     PAPR_CHECK_LAUNCH("upconv2x2_h3<fwd>");
     return 0;
 }
@@ -644,15 +649,17 @@ extern "C" int papr_upconv2x2_fwd(const float* x, int32_t B, int32_t H, int32_t 
                                   float* out, papr_stream_t stream) {
     PAPR_REQUIRE(x && wm && out, "papr_upconv2x2_fwd: null pointer");
     if (int rc = up_check("papr_upconv2x2_fwd", B, H, W, c_in, c_out)) return rc;
-    return papr_i_upconv_fwd(x, B, H, W, c_in, wm, bias, c_out, out, c_out, nullptr, as_stream(stream));
+    return papr_i_upconv_fwd(x, B, H, W, c_in, wm, bias, c_out, out, c_out, nullptr, false, as_stream(stream));
 }
 
 int papr_i_upconv_dgrad(const float* g, int ldg, int B, int H, int W, int c_in, const float* wm, int c_out, const float* mask_y, float* d_x, unsigned* out_max,
-                        hipStream_t s) {
+                        bool one_product, hipStream_t s) {
     UpArgs a{};
     a.g = g; a.wm = wm; a.out = d_x; a.B = B; a.H = H; a.W = W; a.C_in = c_in; a.C_out = c_out; a.ldo = c_out; a.ldg = ldg; a.mask = mask_y; a.out_max = out_max;
     const long M = (long)B * H * W;
-    upconv2x2_h3_kernel<1><<<dim3((unsigned)((M + UP_T - 1) / UP_T), (unsigned)(c_in / UP_T)), dim3(256), 0, s>>>(a);
+    const dim3 grid((unsigned)((M + UP_T - 1) / UP_T), (unsigned)(c_in / UP_T));
+    if (one_product) upconv2x2_h3_kernel<1, true><<<grid, dim3(256), 0, s>>>(a);
+    else upconv2x2_h3_kernel<1, false><<<grid, dim3(256), 0, s>>>(a);
     PAPR_CHECK_LAUNCH("upconv2x2_h3<dgrad>");
     return 0;
 }
@@ -661,7 +668,7 @@ extern "C" int papr_upconv2x2_dgrad(const float* d_out, int32_t B, int32_t H, in
                                     papr_stream_t stream) {
     PAPR_REQUIRE(d_out && wm && d_x, "papr_upconv2x2_dgrad: null pointer");
     if (int rc = up_check("papr_upconv2x2_dgrad", B, H, W, c_in, c_out)) return rc;
-    return papr_i_upconv_dgrad(d_out, c_out, B, H, W, c_in, wm, c_out, nullptr, d_x, nullptr, as_stream(stream));
+    return papr_i_upconv_dgrad(d_out, c_out, B, H, W, c_in, wm, c_out, nullptr, d_x, nullptr, false, as_stream(stream));
 }
 
 extern "C" size_t papr_upconv2x2_wgrad_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t c_in, int32_t c_out) {
@@ -685,7 +692,7 @@ extern "C" int papr_upconv2x2_wgrad(const float* d_out, const float* x, int32_t 
     PAPR_CHECK_LAUNCH("up_stats");
     a.maxes = maxes;
     a.out = colsum + (size_t)64 * c_out;
-    upconv2x2_h3_kernel<2><<<dim3((unsigned)(c_in / UP_T), (unsigned)(4 * c_out / UP_T), (unsigned)chunks), dim3(256), 0, s>>>(a);
+    upconv2x2_h3_kernel<2, false><<<dim3((unsigned)(c_in / UP_T), (unsigned)(4 * c_out / UP_T), (unsigned)chunks), dim3(256), 0, s>>>(a);
     PAPR_CHECK_LAUNCH("upconv2x2_h3<wgrad>");
     const long n4 = (long)c_in * c_out;
     upconv_wgrad_reduce_kernel<<<dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s>>>(reinterpret_cast<const float4*>(a.out), (int)chunks, n4,
@@ -702,7 +709,7 @@ size_t papr_i_upconv_wgrad_bytes(long M, int c_in, int c_out) {
 
 // (maxima from the producers, the bias gradient from the launch's own column sums: no statistics launch)
 int papr_i_upconv_wgrad(const float* g, int ldg, const float* x, int B, int H, int W, int c_in, int c_out, const unsigned* xmax, const unsigned* gmax, float* d_wm,
-                        float* d_bias, void* ws, hipStream_t s) {
+                        float* d_bias, void* ws, bool one_product, hipStream_t s) {
     const long M = (long)B * H * W, px = up_px_per_chunk(M, c_in, c_out), chunks = (M + px - 1) / px;
     UpArgs a{};
     a.x = x; a.g = g; a.B = B; a.H = H; a.W = W; a.C_in = c_in; a.C_out = c_out; a.px_per_chunk = (int)px; a.ldg = ldg; a.ldo = c_out;
@@ -710,7 +717,9 @@ int papr_i_upconv_wgrad(const float* g, int ldg, const float* x, int B, int H, i
     float* partial_b = static_cast<float*>(ws);
     a.partial_b = d_bias ? partial_b : nullptr;
     a.out = partial_b + (size_t)chunks * 4 * c_out;
-    upconv2x2_h3_kernel<2><<<dim3((unsigned)(c_in / UP_T), (unsigned)(4 * c_out / UP_T), (unsigned)chunks), dim3(256), 0, s>>>(a);
+    const dim3 grid((unsigned)(c_in / UP_T), (unsigned)(4 * c_out / UP_T), (unsigned)chunks);
+    if (one_product) upconv2x2_h3_kernel<2, true><<<grid, dim3(256), 0, s>>>(a);
+    else upconv2x2_h3_kernel<2, false><<<grid, dim3(256), 0, s>>>(a);
     PAPR_CHECK_LAUNCH("upconv2x2_h3<wgrad>");
     const long n4 = (long)c_in * c_out;
     upconv_wgrad_reduce2_kernel<<<dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s>>>(reinterpret_cast<const float4*>(a.out), (int)chunks, n4,

@@ -14,6 +14,7 @@ struct PaprConvLaunch {                      // one 3x3 layer (or its data-gradi
     const unsigned* xmax2;                   // ... and a second slot (or null): a map concatenated from two producers
     unsigned* out_max;                       // or null: the slot that receives max |out| (zeroed by the caller)
     float* partial;                          // papr_i_conv_splits() > 1: splits x (B H W) x c_out floats
+    bool one_product;                        // one f16 product per fp32 product (the arithmetic of the reference's fp16 autocast) instead of three
 };
 int papr_i_conv_splits(long M, int c_in, int c_out);
 int papr_i_conv3x3(const PaprConvLaunch& c, hipStream_t s);
@@ -27,7 +28,7 @@ int papr_i_unet_prep(const float* x, long n4, unsigned* in_partial, unsigned* sl
 size_t papr_i_conv3x3_wgrad_partial_bytes(long M, int c_in, int c_out);
 // d_w (c_out, 3, 3, c_in), d_b (c_out) or null; maxima: the producers' slots (xmax2: see above, or null)
 int papr_i_conv3x3_wgrad(const float* d_y, const float* x, int B, int H, int W, int c_in, int c_out, float* d_w, float* d_b, const unsigned* dymax,
-                         const unsigned* xmax, const unsigned* xmax2, float* partial, hipStream_t s);
+                         const unsigned* xmax, const unsigned* xmax2, float* partial, bool one_product, hipStream_t s);
 
 // ---- unet.hip
 int papr_i_maxpool2_fwd(const float* x, int ld_in, int B, int H, int W, int C, float* out, unsigned* which, hipStream_t s);
@@ -35,13 +36,13 @@ int papr_i_maxpool2_fwd(const float* x, int ld_in, int B, int H, int W, int C, f
 int papr_i_maxpool2_bwd_fused(const float* d_out, const unsigned* which, int B, int H, int W, int C, const float* skip, int ld_skip, const float* y, int ld_y,
                               float* d_in, unsigned* out_max, hipStream_t s);
 int papr_i_upconv_fwd(const float* x, int B, int H, int W, int c_in, const float* wm, const float* bias, int c_out, float* out, int ldo, unsigned* out_max,
-                      hipStream_t s);
+                      bool one_product, hipStream_t s);
 // d_x (B H W, c_in) = dgrad(g rows at g + pixel * ldg) * (mask_y > 0)   (mask_y (B H W, c_in) or null)
 int papr_i_upconv_dgrad(const float* g, int ldg, int B, int H, int W, int c_in, const float* wm, int c_out, const float* mask_y, float* d_x, unsigned* out_max,
-                        hipStream_t s);
+                        bool one_product, hipStream_t s);
 size_t papr_i_upconv_wgrad_bytes(long M, int c_in, int c_out);
 int papr_i_upconv_wgrad(const float* g, int ldg, const float* x, int B, int H, int W, int c_in, int c_out, const unsigned* xmax, const unsigned* gmax, float* d_wm,
-                        float* d_bias, void* ws, hipStream_t s);
+                        float* d_bias, void* ws, bool one_product, hipStream_t s);
 // the 1x1 head backwards: d_x = (d_out w) * (mask_y > 0) with its maximum; d_w, d_b as papr_conv1x1_bwd
 int papr_i_conv1x1_bwd(const float* d_out, const float* x, long M, int c_in, const float* w, int c_out, const float* mask_y, float* d_x, unsigned* out_max,
                        float* d_w, float* d_b, void* ws, hipStream_t s);

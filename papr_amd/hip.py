@@ -70,7 +70,7 @@ LN_FOLD_MAX_JOBS = 8
 
 
 class UnetDesc(C.Structure):             # papr_unet_desc
-    _fields_ = [("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("c_in", C.c_int32), ("n_classes", C.c_int32),
+    _fields_ = [("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("c_in", C.c_int32), ("n_classes", C.c_int32), ("one_product", C.c_int32),
                 ("conv_w", C.c_void_p * 5), ("conv_w_stride", (C.c_int64 * 4) * 5), ("conv_b", C.c_void_p * 5),
                 ("up_w", C.c_void_p * 2), ("up_b", C.c_void_p * 2), ("out_w", C.c_void_p), ("out_b", C.c_void_p)]
 

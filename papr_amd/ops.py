@@ -315,11 +315,11 @@ class _SmallUNetFn(torch.autograd.Function):
     parameter tensors as they are."""
 
     @staticmethod
-    def _desc(x, params):
+    def _desc(x, params, one_product):
         B, H, W, c_in = x.shape
         cw, cb, uw, ub, ow, ob = params[0:5], params[5:10], params[10:12], params[12:14], params[14], params[15]
         d = hip.UnetDesc()
-        d.B, d.H, d.W, d.c_in, d.n_classes = B, H, W, c_in, ow.shape[0]
+        d.B, d.H, d.W, d.c_in, d.n_classes, d.one_product = B, H, W, c_in, ow.shape[0], 1 if one_product else 0
         keep = []
         for i in range(5):
             w = cw[i].detach()
@@ -343,12 +343,13 @@ class _SmallUNetFn(torch.autograd.Function):
         return d, keep, wms
 
     @staticmethod
-    def forward(ctx, x, track, *params):
+    def forward(ctx, x, track, one_product, *params):
         _need_hip_rows(x, "the U-Net head")
         lib = hip.lib()
         B, H, W, c_in = x.shape
-        keep_state = bool(track and (ctx.needs_input_grad[0] or any(ctx.needs_input_grad[2:])))
-        d, alive, _ = _SmallUNetFn._desc(x, params)
+        keep_state = bool(track and (ctx.needs_input_grad[0] or any(ctx.needs_input_grad[3:])))
+        ctx.one_product = one_product
+        d, alive, _ = _SmallUNetFn._desc(x, params, one_product)
         state = torch.empty(lib.papr_small_unet_state_bytes(B, H, W, c_in, 1 if keep_state else 0), device=x.device, dtype=torch.uint8)
         out = torch.empty((B, H, W, d.n_classes), device=x.device, dtype=torch.float32)
         hip.check(lib.papr_small_unet_fwd(C.byref(d), hip.ptr(x), hip.ptr(out), hip.ptr(state), 1 if keep_state else 0, hip.stream_ptr()), "papr_small_unet_fwd")
@@ -363,7 +364,7 @@ class _SmallUNetFn(torch.autograd.Function):
         lib = hip.lib()
         B, H, W, c_in = x.shape
         dev = x.device
-        d, alive, wms = _SmallUNetFn._desc(x, params)
+        d, alive, wms = _SmallUNetFn._desc(x, params, ctx.one_product)
         g = hip.UnetGrads()
         E = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)
         d_cw = [E(params[i].shape[0], 3, 3, params[i].shape[1]) for i in range(5)]
@@ -381,16 +382,17 @@ class _SmallUNetFn(torch.autograd.Function):
         hip.check(lib.papr_small_unet_bwd(C.byref(d), hip.ptr(x), hip.ptr(d_out.contiguous()), hip.ptr(state), hip.ptr(d_x), C.byref(g), hip.ptr(ws), hip.stream_ptr()),
                   "papr_small_unet_bwd")
         grads = [t.permute(0, 3, 1, 2) for t in d_cw] + d_cb + [t.permute(0, 3, 1, 2) for t in d_uw] + d_ub + [d_ow.reshape(params[14].shape), d_ob]
-        return (d_x, None) + tuple(grads)
+        return (d_x, None, None) + tuple(grads)
 
 
-def small_unet_rows(x, net):
-    """x (B, H, W, c_in) contiguous -> (B, H, W, n_classes): `net` = a papr_amd.unet.SmallUNet (the reference's module attribute names)."""
+def small_unet_rows(x, net, one_product=False):
+    """x (B, H, W, c_in) contiguous -> (B, H, W, n_classes): `net` = a papr_amd.unet.SmallUNet (the reference's module attribute names).  one_product:
+    one f16 product per fp32 product in the 3x3 and transposed convolutions (the arithmetic of the reference's fp16 autocast, `use_amp: true`)."""
     c = lambda m: m.double_conv[0]
     convs = [c(net.inc), c(net.down1.maxpool_conv[1]), c(net.down2.maxpool_conv[1]), c(net.up1.conv), c(net.up2.conv)]
     ups = [net.up1.up, net.up2.up]
     params = [m.weight for m in convs] + [m.bias for m in convs] + [m.weight for m in ups] + [m.bias for m in ups] + [net.outc.conv.weight, net.outc.conv.bias]
-    return _SmallUNetFn.apply(x, torch.is_grad_enabled(), *params)
+    return _SmallUNetFn.apply(x, torch.is_grad_enabled(), bool(one_product), *params)
 
 
 class _CompositeFn(torch.autograd.Function):

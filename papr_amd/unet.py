@@ -21,6 +21,7 @@ _OWN_CONV = os.environ.get("PAPR_UNET_CONV", "1") == "1"
 _AMP_OWN = os.environ.get("PAPR_UNET_AMP", "own") == "own"        # under use_amp: the head on the own kernels (default) or torch's fp16 autocast + MIOpen (A/B)
 _OWN_REST = os.environ.get("PAPR_UNET_REST", "1") == "1"       # (0: pooling, transposed and 1x1 convolutions on torch / MIOpen, A/B)
 _WHOLE_NET = os.environ.get("PAPR_UNET_NET", "1") == "1"       # (0: layer by layer -- one autograd function per layer, torch glue between them; A/B)
+_AMP_ONE = os.environ.get("PAPR_UNET_AMP_ONE", "1") == "1"     # under use_amp, whole-network path: one f16 product per fp32 product (0: three, as without use_amp; A/B)
 
 
 class ConvStage(nn.Module):
@@ -114,7 +115,9 @@ class SmallUNet(nn.Module):
         if (_WHOLE_NET and _own_path(x) and not (self.use_amp and not _AMP_OWN) and x.shape[2] % 4 == 0 and x.shape[3] % 4 == 0 and x.shape[2] >= 4
                 and x.shape[3] >= 4 and x.shape[1] % 32 == 0 and self.outc.conv.out_channels <= 4 and x.shape[0] * x.shape[2] * x.shape[3] * 2048 < 2 ** 31):
             from .ops import small_unet_rows
-            return small_unet_rows(x.permute(0, 2, 3, 1).contiguous(), self).permute(0, 3, 1, 2)
+            # use_amp: the reference autocasts this module to fp16 (models/unet.py:212: f16 operands, f16 maps); here f16 OPERANDS (one product per
+            # fp32 product, fp32 accumulation) and fp32 maps -- pinned to the reference's own AMP output by G17 (tests/test_hip_amp_golden.py)
+            return small_unet_rows(x.permute(0, 2, 3, 1).contiguous(), self, one_product=self.use_amp and _AMP_ONE).permute(0, 3, 1, 2)
         with torch.autocast(device_type="cuda", dtype=self.amp_dtype, enabled=self.use_amp and x.is_cuda and not _AMP_OWN):
             x1 = self.inc(x)
             x2 = self.down1(x1)

@@ -888,7 +888,7 @@ def test_small_unet_on_own_kernels_matches_torch_module(hw, batch, whole, use_am
     in float64 on the CPU: output and every parameter / input gradient; and no layer of the device run may go through
     aten / MIOpen convolution or pooling (profiler check of the launched kernels).  use_amp (what every shipped scene file sets;
     the reference autocasts the module to fp16 there, models/unet.py:212): the same kernels, the same bars -- the head is not handed
-    to torch autocast + MIOpen."""
+    to torch autocast + MIOpen (one f16 product per fp32 product on the whole-network path: see the bars below)."""
     import copy
     import papr_amd.unet as unet_mod
     from papr_amd.unet import SmallUNet
@@ -915,8 +915,24 @@ def test_small_unet_on_own_kernels_matches_torch_module(hw, batch, whole, use_am
     assert not foreign, foreign
     if whole and hw[0] % 4 == 0 and hw[1] % 4 == 0:      # one call each way: no concatenation copy, no ReLU-mask launch, one weight-split launch
         assert any("unet_prep" in n for n in names) and not any("conv_prep" in n or "CatArray" in n or "threshold" in n for n in names), names
-    np.testing.assert_allclose(yd.detach().cpu().numpy(), yr.detach().float().numpy(), rtol=0, atol=1e-5 * yr.abs().max().item())
+    # use_amp on the whole-network path: ONE f16 product per fp32 product (operands rounded to 11 bits, fp32 accumulation: the arithmetic of the
+    # reference's fp16 autocast, which also rounds the maps) -- bars 100 x the fp32-parity ones, the measured errors sit at ~1/3 of them
+    one = use_amp and whole and hw[0] % 4 == 0 and hw[1] % 4 == 0
+    amp = 100.0 if one else 1.0
+    np.testing.assert_allclose(yd.detach().cpu().numpy(), yr.detach().float().numpy(), rtol=0, atol=amp * 1e-5 * yr.abs().max().item())
     gx, gx_ref = xd.grad.cpu().numpy(), xr.grad.float().numpy()
+    if one:
+        # gradients: a ReLU pre-activation within the f16 operand noise of zero (~1e-3 of the units) falls the other way and moves its whole
+        # contribution (the reference's own autocast run does the same: G17 holds the build to ITS distance from fp32); rms bars, the maximum loose
+        err = np.abs(gx - gx_ref)
+        top = xr.grad.abs().max().item()
+        worst = max((np.sqrt(((pd.grad.cpu().numpy() - pr.grad.float().numpy()) ** 2).mean()) / pr.grad.abs().max().item(), name)
+                    for (name, pd), pr in zip(net_d.named_parameters(), ref.parameters()))
+        print("one-product U-Net: out err %.2e of max, d_x err max %.2e rms %.2e of max, worst parameter-gradient rms %.2e of its max (%s)"
+              % (np.abs(yd.detach().cpu().numpy() - yr.detach().float().numpy()).max() / yr.abs().max().item(), err.max() / top, np.sqrt((err ** 2).mean()) / top, worst[0], worst[1]))
+        assert err.max() <= 0.25 * top and np.sqrt((err ** 2).mean()) <= 1e-2 * top
+        assert worst[0] <= 3e-2, worst          # (measured 0.8 - 1.2e-2: bias gradients, plain sums of gradient maps that went through five one-product layers)
+        return
     if hw[0] * hw[1] < 160 * 160:
         np.testing.assert_allclose(gx, gx_ref, rtol=0, atol=2e-5 * xr.grad.abs().max().item())
         flip = 1.0
