@@ -460,9 +460,9 @@ typedef struct { float* p; const float* g; float* m; float* v; float* step; int6
 typedef struct { double lr, beta1, beta2, eps, weight_decay; int32_t found_slot; int32_t pad_; } papr_adam_group;      /* found_slot (ABI 25): papr_adam_step_scaled */
 int papr_adam_step(const papr_adam_tensor* tensors, int32_t n_tensors, const papr_adam_group* groups, int32_t n_groups, papr_stream_t stream);
 /* The same under a GradScaler (ABI 25; `use_amp: true`: reference train.py:172-177 scales the loss, models/model.py:442 steps through the scaler):
- * grad_scale (one float on the device, a power of two) -- every gradient is divided by it as it is read; found_inf (PAPR_ADAM_MAX_GROUPS floats on
- * the device, written: element s = 0, or 1 once any gradient element of a tensor whose group names found_slot s is NaN / +-inf) -- the tensors of
- * that slot then do not move at all: no parameter, no moment, no step counter.  One slot per OPTIMIZER gives torch.amp.GradScaler.step's contract
+ * grad_scale (one float on the device, a power of two) -- every gradient is divided by it as it is read; found_inf (PAPR_ADAM_MAX_GROUPS + 1 floats
+ * on the device, written: element s = 0, or 1 once any gradient element of a tensor whose group names found_slot s is NaN / +-inf; the last element
+ * (ABI 26) = 1 once any slot is) -- the tensors of an overflowed slot then do not move at all: no parameter, no moment, no step counter.  One slot per OPTIMIZER gives torch.amp.GradScaler.step's contract
  * (the reference steps its optimizers one by one: an overflow in one of them skips that one only); the caller hands the slots to the scaler's
  * update().  The gradients themselves are left scaled. */
 int papr_adam_step_scaled(const papr_adam_tensor* tensors, int32_t n_tensors, const papr_adam_group* groups, int32_t n_groups,

@@ -81,12 +81,15 @@ def step_scaled(optimizers, scaler):
             raise RuntimeError("papr_amd: gradients already unscaled by scaler.unscale_(): step through the scaler itself")
     if len(optimizers) > MAX_GROUPS:
         raise RuntimeError("papr_amd: %d optimizers (at most %d)" % (len(optimizers), MAX_GROUPS))
-    found_inf = torch.empty(MAX_GROUPS, dtype=torch.float32, device=scale.device)       # one slot per optimizer: each is skipped on its own overflow only
+    found_inf = torch.empty(MAX_GROUPS + 1, dtype=torch.float32, device=scale.device)   # one slot per optimizer (each is skipped on its own overflow only) + "any"
     step(optimizers, grad_scale=scale, found_inf=found_inf)
+    # update() adds up every found_inf it is shown (one small launch per optimizer beyond the first) and only asks whether the sum is positive: it is
+    # shown the kernel's own "any slot" flag once, under the first optimizer
     for i, opt in enumerate(optimizers):
         st = scaler._per_optimizer_states[id(opt)]
-        st["found_inf_per_device"] = {scale.device: found_inf[i:i + 1]}
+        st["found_inf_per_device"] = {scale.device: found_inf[MAX_GROUPS:MAX_GROUPS + 1]} if i == 0 else {}
         st["stage"] = OptState.STEPPED
+    return found_inf
 
 
 def step(optimizers, grad_scale=None, found_inf=None):

@@ -37,7 +37,10 @@ __global__ __launch_bounds__(256) void adam_check_kernel(AdamBatch b, float* __r
         const long e = base + (long)u * 256 + threadIdx.x;
         if (e < t.n) { const float g = t.g[e]; bad |= !(fabsf(g) <= 3.402823466e38f); }      // (NaN and +-inf fail the comparison)
     }
-    if (__any(bad) && (threadIdx.x & 63) == 0) found_inf[b.g[t.group].found_slot] = 1.0f;      // (racing stores of the same value)
+    if (__any(bad) && (threadIdx.x & 63) == 0) {                 // (racing stores of the same value)
+        found_inf[b.g[t.group].found_slot] = 1.0f;
+        found_inf[PAPR_ADAM_MAX_GROUPS] = 1.0f;                  // "any slot": what GradScaler.update() makes of the slots (their sum > 0)
+    }
 }
 
 __global__ __launch_bounds__(64) void adam_bump_steps_kernel(AdamBatch b, int n, const float* __restrict__ found_inf) {
@@ -116,7 +119,7 @@ static int adam_step_impl(const papr_adam_tensor* tensors, int32_t n_tensors, co
     if (found_inf) {                                 // every gradient of the call is looked at before any tensor moves
         for (int i = 0; i < n_groups; ++i)
             PAPR_REQUIRE(groups[i].found_slot >= 0 && groups[i].found_slot < PAPR_ADAM_MAX_GROUPS, "papr_adam_step_scaled: group %d: found_slot %d", i, groups[i].found_slot);
-        PAPR_REQUIRE(hipMemsetAsync(found_inf, 0, PAPR_ADAM_MAX_GROUPS * sizeof(float), s) == hipSuccess, "papr_adam_step_scaled: memset failed");
+        PAPR_REQUIRE(hipMemsetAsync(found_inf, 0, (PAPR_ADAM_MAX_GROUPS + 1) * sizeof(float), s) == hipSuccess, "papr_adam_step_scaled: memset failed");
         for (int first = 0; first < n_tensors; first += PAPR_ADAM_MAX_TENSORS) {
             AdamBatch b;
             const int n = n_tensors - first < PAPR_ADAM_MAX_TENSORS ? n_tensors - first : PAPR_ADAM_MAX_TENSORS;
