@@ -105,6 +105,14 @@ def _zeros(dev, shape):
     return z
 
 
+def _const(dev, n, value):
+    key = (dev.type, dev.index, int(n), float(value))
+    z = _zero_cache.get(key)
+    if z is None:
+        z = _zero_cache[key] = torch.full((n,), value, device=dev, dtype=torch.float32)
+    return z
+
+
 def conv3x3_rows(x, weight, bias, relu, transposed=False, want_max=False):
     """x (B, H, W, C_in) fp32 contiguous, weight = the reference's (C_out, C_in, 3, 3) Conv2d parameter in any memory format
     -> (B, H, W, C_out): 3x3 convolution, stride 1, zero padding 1, on the split-f16 implicit-GEMM kernel.  transposed:
@@ -509,11 +517,15 @@ class _LnFoldBatchFn(torch.autograd.Function):
 def ln_fold_job(spec, weights, biases, ln_in):
     """(w, c, a2, b2, ld_eff) if the first layer of `spec` folds the LayerNorm affine `ln_in` on the device kernel (what prepare_mlp_weights would
     hand to _LnFoldFn), else None."""
-    if ln_in is None:
-        return None
     L, w = spec.layers[0], weights[0]
     if L["skip"] or not w.is_cuda or L["n_in"] > 1024:
         return None
+    if ln_in is None:
+        # no LayerNorm in front, but the first layer's rows want zero padding to the kernel's row length (F.pad: a fill and a copy forward, a slice
+        # copy backward): the same kernel with a_2 = 1, b_2 = 0 does it inside the launch the other folds already pay for
+        if L["n_in"] == w.shape[1] or L["n_out_pad"] != L["n_out"]:
+            return None
+        return (w, biases[0], _const(w.device, w.shape[1], 1.0), _zeros(w.device, (w.shape[1],)), L["n_in"])
     return (w, biases[0], ln_in[0], ln_in[1], L["n_in"])
 
 
