@@ -271,6 +271,43 @@ def test_c_abi_library_exports_every_declared_symbol():
     assert lib.papr_mlp_fwd_workspace_bytes(1000) >= 2 * 1000 * 4 + 2 * 512 * 704 * 2
 
 
+def test_c_abi_round5_entry_points_validate_their_arguments_before_touching_a_device():
+    """The ABI-26 entry points (whole-network U-Net, score-bias gradient, batched folds, MSE) refuse bad shapes and null pointers with a message and
+    a non-zero status; the U-Net's size queries are consistent.  No device call is reached: this runs on the CPU box."""
+    from papr_amd import hip
+    lib = ctypes.CDLL(hip.LIB_PATH)
+    lib.papr_last_error.restype = ctypes.c_char_p
+    sz = lib.papr_small_unet_state_bytes
+    sz.restype, sz.argtypes = ctypes.c_size_t, [ctypes.c_int32] * 5
+    keep, lean = sz(1, 160, 160, 32, 1), sz(1, 160, 160, 32, 0)
+    acts = 4 * (25600 * 256 + 6400 * 512 + 6400 * 128 + 1600 * 256 + 1600 * 512 + 6400 * 256 + 25600 * 128)      # cat2, cat1, pool1, pool2, x3, y1, y2
+    assert lean >= acts and keep > lean and sz(1, 320, 320, 32, 1) > 2 * keep
+    bw = lib.papr_small_unet_bwd_workspace_bytes
+    bw.restype, bw.argtypes = ctypes.c_size_t, [ctypes.c_int32] * 5
+    assert bw(1, 160, 160, 32, 3) >= 4 * (25600 * (128 + 256 + 128) + 6400 * (256 + 512 + 256 + 128) + 1600 * (512 + 256))
+    d = hip.UnetDesc()
+    d.B, d.H, d.W, d.c_in, d.n_classes = 1, 30, 40, 32, 3
+    fwd = lib.papr_small_unet_fwd
+    fwd.argtypes = [ctypes.POINTER(hip.UnetDesc)] + [ctypes.c_void_p] * 3 + [ctypes.c_int32, ctypes.c_void_p]
+    assert fwd(ctypes.byref(d), None, None, None, 1, None) != 0 and b"multiples of 4" in lib.papr_last_error()
+    d.H = 40
+    d.c_in = 48
+    assert fwd(ctypes.byref(d), None, None, None, 1, None) != 0 and b"multiple of 32" in lib.papr_last_error()
+    d.c_in = 32
+    assert fwd(ctypes.byref(d), None, None, None, 1, None) != 0 and b"null weight" in lib.papr_last_error()
+    qk = lib.papr_qk_bias_bwd
+    qk.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 9
+    assert qk(*([None, 64, 64, 256, None, 10, None, 64] + [None] * 9)) != 0 and b"null pointer" in lib.papr_last_error()
+    fb = lib.papr_ln_fold_fwd_batch
+    fb.argtypes = [ctypes.POINTER(hip.LnFoldJob), ctypes.c_int32, ctypes.c_void_p]
+    jobs = (hip.LnFoldJob * 1)()
+    assert fb(jobs, 0, None) != 0 and fb(jobs, hip.LN_FOLD_MAX_JOBS + 1, None) != 0 and b"jobs" in lib.papr_last_error()
+    assert fb(jobs, 1, None) != 0 and b"null pointer" in lib.papr_last_error()
+    mse = lib.papr_mse_fwd
+    mse.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    assert mse(None, None, 10, None, None, None, None) != 0 and b"papr_mse_fwd" in lib.papr_last_error()
+
+
 def test_generated_kernel_sources_are_current():
     """chain4_kloop.inc / chain4_fused.inc are what their generators print (a stale include would still build -- and run another kernel
     than the scripts describe)."""
