@@ -1214,3 +1214,34 @@ def test_own_mse_loss_equals_torch_mse_loss_and_its_gradient(shape):
     (got * 3.0).backward()
     assert abs(got.item() - ref.item()) <= 2e-7 * ref.item()
     np.testing.assert_allclose(pd.grad.cpu().numpy(), pr.grad.float().numpy(), rtol=2e-6, atol=0)
+
+
+@pytest.mark.parametrize("c_in,n_classes,hw,batch", [(64, 4, (16, 24), 1), (32, 1, (8, 8), 3), (96, 2, (4, 12), 1)])
+def test_small_unet_whole_network_call_other_channel_counts(c_in, n_classes, hw, batch):
+    """papr_small_unet_fwd / _bwd beyond the shipped 32 -> 3 head: other input widths (multiples of 32), 1 .. 4 classes, the smallest maps (4 pixels
+    on a side: 1 x 1 at the bottom of the U), batches -- output and every gradient against the same module in float64 on the CPU."""
+    import copy
+    from papr_amd.unet import SmallUNet
+    torch.manual_seed(c_in + n_classes)
+    net = SmallUNet(c_in, n_classes)
+    x = torch.randn(batch, c_in, *hw)
+    gy = torch.randn(batch, n_classes, *hw) * 1e-2
+    ref = copy.deepcopy(net).double()
+    xr = x.double().requires_grad_(True)
+    yr = ref(xr)
+    (yr * gy.double()).sum().backward()
+    d = dev()
+    net_d = net.to(d)
+    xd = x.to(d).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA]) as prof:
+        yd = net_d(xd)
+        (yd * gy.to(d)).sum().backward()
+        torch.cuda.synchronize()
+    assert any("unet_prep" in e.key for e in prof.key_averages())              # (the whole-network path ran)
+    np.testing.assert_allclose(yd.detach().cpu().numpy(), yr.detach().float().numpy(), rtol=0, atol=1e-5 * yr.abs().max().item())
+    np.testing.assert_allclose(xd.grad.cpu().numpy(), xr.grad.float().numpy(), rtol=0, atol=2e-5 * xr.grad.abs().max().item())
+    for (name, pd), pr in zip(net_d.named_parameters(), ref.parameters()):
+        np.testing.assert_allclose(pd.grad.cpu().numpy(), pr.grad.float().numpy(), rtol=0, atol=5e-5 * pr.grad.abs().max().item(), err_msg=name)
+    # no_grad (nothing kept for a backward pass) gives the same bits
+    with torch.no_grad():
+        assert torch.equal(net_d(xd), yd)
