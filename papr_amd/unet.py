@@ -5,11 +5,13 @@ configuration (single conv per stage, transposed-conv upsampling, no normalisati
 modulation); it keeps the reference's module attribute names so that state-dict keys are
 interchangeable.  On the device every layer runs on this library's kernels over NHWC maps: the 3x3
 convolutions on conv.hip, max-pooling, the transposed convolutions and the 1x1 output layer on
-unet.hip -- with `use_amp: true` as well: the reference wraps this
-module in fp16 autocast there (models/unet.py:212); here the same split-f16 kernels run (fp32 in and
-out, 22-bit operands, fp32 accumulation: MORE precise than the reference's fp16 layers, and as fast as
-torch autocast + MIOpen on this head: 10.24 ms per chair step either way, round 3).  PAPR_UNET_AMP=autocast
-brings torch's autocast back (A/B); on the CPU or with PAPR_UNET_CONV=0 the layers are torch's.
+unet.hip.  Where the map's height and width are multiples of 4 (training patches, whole 800 x 800 views) the
+whole network is ONE library call each way (papr_small_unet_fwd / _bwd, csrc/small_unet.hip: one launch splits every 3x3 weight, tensor maxima
+come from the producing kernels, skip concatenations are written in place, ReLU masks and skip-gradient sums ride in the seam kernels;
+PAPR_UNET_NET=0: layer by layer, which other sizes take anyway).  With `use_amp: true` as well: the reference wraps this module in fp16
+autocast there (models/unet.py:212); here the same kernels run with fp32 maps and fp32 accumulation -- on the whole-network path with ONE f16
+product per fp32 product (the reference's operand precision under autocast; PAPR_UNET_AMP_ONE=0: three, as without use_amp), layer by layer
+with three.  PAPR_UNET_AMP=autocast brings torch's autocast back (A/B); on the CPU or with PAPR_UNET_CONV=0 the layers are torch's.
 """
 import os
 
