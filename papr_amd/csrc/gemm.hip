@@ -1035,13 +1035,19 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_h3_kernel(TNH3Batch batch) {
     // (f16 rows: the wave's four row maxima of a stage are one 16-byte scalar load, asked for a stage ahead -- at the top of a stage
     //  it would wait for a round trip to L2 before the first fragment read.  The index is clamped to the slice; up to three floats
     //  behind the array may be read for rows past M, whose factors are 0 anyway: both arrays have memory behind them.)
+    // (The address is the same in every lane, and the compiler knows: it loaded the sixteen bytes with a vector load, moved them to scalar registers
+    //  with eight v_readfirstlane -- each behind an s_waitcnt vmcnt that, loads returning in order, also waited for every row load of the stages
+    //  ahead -- and did the factors' bit arithmetic on the scalar unit, ~100 scalar instructions per stage: 130 us of a 630-us launch.  `lane0`, a
+    //  zero the compiler cannot see through, keeps value and arithmetic in vector registers, where the wait sits at the first use a stage later.)
+    int lane0;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(lane0));
     auto row_maxima = [&](long st, float4& mg, float4& mx) {
         if (!HALF) return;
         long base = mbeg + st * TN_ROWS + 4 * wave;
         const long top = (mend - 1) & ~3L;
         base = base < top ? base : top;
-        mg = *reinterpret_cast<const float4*>(p.gmax + base);
-        mx = *reinterpret_cast<const float4*>(p.xmax + base);
+        mg = *reinterpret_cast<const float4*>(p.gmax + base + lane0);
+        mx = *reinterpret_cast<const float4*>(p.xmax + base + lane0);
     };
     auto row_factors = [&](long st, const float4& mg, const float4& mx, float (&sg)[4], float (&sx)[4], float (&fg)[4]) {
 #pragma unroll
