@@ -96,10 +96,29 @@ __device__ __forceinline__ void wave_flush(const float* buf, int pitch, int w, f
     }
 }
 // src[(m0 + r) * ld + c0 + c]  ->  buf[r][c]   (rows beyond M read row M-1)
+// (four floats per load instruction, like wave_flush, and several instructions' loads in flight before their LDS writes: a float per lane and
+//  iteration was 39 dependent load -> write steps per block.  The last group of a block may read up to three floats of the next block or of the
+//  row's padding: inside the row while c0 + 4 ceil(w / 4) <= ld, which the caller's rows satisfy; otherwise float by float.)
 __device__ __forceinline__ void wave_fetch(float* buf, int pitch, int w, const float* __restrict__ src, long ld, int c0, long m0, long M) {
-    const int lane = threadIdx.x & 63, total = 64 * w;
+    const int lane = threadIdx.x & 63;
+    const int wq = (w + 3) >> 2, total = 64 * wq;
+    if (c0 + 4 * wq <= ld) {
+        const float inv_wq = 1.0f / (float)wq;
+#pragma unroll 4
+        for (int e = lane; e < total; e += 64) {
+            const int r = (int)(((float)e + 0.5f) * inv_wq), c = 4 * (e - r * wq);
+            const long m = m0 + r < M ? m0 + r : M - 1;
+            const f32x4_a4 v = *reinterpret_cast<const f32x4_a4*>(src + m * ld + c0 + c);
+            float* b = buf + r * pitch + c;
+            b[0] = v.x;
+            if (c + 1 < w) b[1] = v.y;
+            if (c + 2 < w) b[2] = v.z;
+            if (c + 3 < w) b[3] = v.w;
+        }
+        return;
+    }
     const float inv_w = 1.0f / (float)w;
-    for (int e = lane; e < total; e += 64) {
+    for (int e = lane; e < 64 * w; e += 64) {
         const int r = (int)(((float)e + 0.5f) * inv_w), c = e - r * w;
         const long m = m0 + r < M ? m0 + r : M - 1;
         buf[r * pitch + c] = src[m * ld + c0 + c];
@@ -109,6 +128,27 @@ __device__ __forceinline__ void wave_fetch(float* buf, int pitch, int w, const f
 __device__ __forceinline__ void wave_copy_feats(const float* __restrict__ pc_feats, int feat_dim, int pi, float* __restrict__ dst, long ld, int c0,
                                                 long m0, long M) {
     const int lane = threadIdx.x & 63;
+    const int q4 = feat_dim >> 2;                    // 16-byte pieces per row
+    if ((feat_dim & 3) == 0 && q4 >= 1 && q4 <= 64 && (64 % q4) == 0) {
+        // 64 / q4 rows per instruction, four instructions' loads in flight before their stores (a row per instruction, load then store, was a
+        // chain of 64 round trips per wave: ~half of what features_fwd spent outside its encoding blocks)
+        const int rp = 64 / q4, c4 = lane % q4, rl = lane / q4;
+        for (int r0 = 0; r0 < 64; r0 += 4 * rp) {
+            float4 v[4];
+            int row[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                row[u] = r0 + u * rp + rl;
+                const int pr = __shfl(pi, row[u] & 63, 64);
+                v[u] = *reinterpret_cast<const float4*>(pc_feats + (long)pr * feat_dim + 4 * c4);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (row[u] < 64 && m0 + row[u] < M)
+                    *reinterpret_cast<f32x4_a4*>(dst + (m0 + row[u]) * ld + c0 + 4 * c4) = f32x4_a4{v[u].x, v[u].y, v[u].z, v[u].w};
+        }
+        return;
+    }
     for (int r = 0; r < 64; ++r) {
         const int pr = __builtin_amdgcn_readlane(pi, r);
         if (m0 + r >= M) break;
