@@ -471,11 +471,13 @@ __global__ __launch_bounds__(256) void segment_reduce_kernel(const long* __restr
         m = j < 64 ? __builtin_amdgcn_readlane(ma, j) : __builtin_amdgcn_readlane(mb, j - 64);
         pt = j < 64 ? __builtin_amdgcn_readlane(pa, j) : __builtin_amdgcn_readlane(pb, j - 64);
     };
-    for (int j0 = 0; j0 < n; j0 += 4) {
-        int m[4], pt[4];
-        float vs[4], v0[4], v1[4];
+    constexpr int SEG_U = 8;                         // entries whose rows are in flight together (the rows are a gather over ~130 MB: a round trip each;
+                                                     // four at a time: 62 us per step, eight: see DESIGN section 6)
+    for (int j0 = 0; j0 < n; j0 += SEG_U) {
+        int m[SEG_U], pt[SEG_U];
+        float vs[SEG_U], v0[SEG_U], v1[SEG_U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {                // issue the loads of four entries before using any
+        for (int u = 0; u < SEG_U; ++u) {            // issue the loads of the batch's entries before using any
             entry(j0 + u < n ? j0 + u : n - 1, m[u], pt[u]);
             vs[u] = v0[u] = v1[u] = 0.f;
             if (has_small) vs[u] = lane < 3 ? pair_points[(long)m[u] * 4 + lane] : pair_influ[m[u]];
@@ -483,7 +485,7 @@ __global__ __launch_bounds__(256) void segment_reduce_kernel(const long* __restr
             if (c1_ok) v1[u] = rows[(long)m[u] * ld + col0 + lane + 64];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < SEG_U; ++u) {
             if (j0 + u >= n) break;
             if (pt[u] != cur) { flush(cur); cur = pt[u]; }
             small += vs[u]; acc0 += v0[u]; acc1 += v1[u];
