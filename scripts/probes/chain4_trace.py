@@ -13,6 +13,7 @@ d_in = int(os.environ.get("D_IN", "256"))
 d_out = int(os.environ.get("D_OUT", "256"))          # (D_IN=117 LAYERS=5 NORM=1: the key MLP's shape; D_IN=141 D_OUT=32 LAYERS=8: the value MLP's)
 norm = os.environ.get("NORM", "") != ""
 spec = ops.MlpSpec("b", d_in, dict(n_ff_layer=n, d_ff=256, d_ff_out=d_out, norm="layernorm" if norm else "none", ff_act="relu", ff_last_act="none"))
+spec.one_product = os.environ.get("ONE", "") != ""          # (ONE=1: the one-product arithmetic, f16 rows)
 ws = [(torch.randn(spec.layers[i]["n_out_pad"], spec.layers[i]["n_in"]) * 0.1).to(d) for i in range(n)]
 bs = [torch.zeros(spec.layers[i]["n_out_pad"], device=d) for i in range(n)]
 x0 = torch.randn(M, spec.ld_in, device=d)
