@@ -146,6 +146,27 @@ __global__ __launch_bounds__(256) void tail_fwd_kernel(papr_tail_desc d, const f
     if (lane <= k) attn[r * (k + 1) + lane] = a;
     float top = lane < k ? a : 0.f;
     if (d.normalize) top = top / wave_sum(top);
+    const int g4 = d.C >> 2;                         // 16-byte pieces per value row
+    if ((d.C & 3) == 0 && (d.ld_v & 3) == 0 && g4 >= 1 && g4 <= 32 && (64 % g4) == 0) {
+        // 64 / g4 value rows per instruction (a 32-channel row is 128 bytes: one row at a time left half the wave idle and was a chain of k round
+        // trips), every lane's rows summed in ascending order, then the row groups met by a butterfly: a fixed order
+        const int rp = 64 / g4, c4 = lane % g4, jl = lane / g4;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+        for (int j0 = 0; j0 < k; j0 += rp) {
+            const int j = j0 + jl, jc = j < k ? j : k - 1;
+            const float ts = __shfl(top, jc, 64);   // (every lane takes part: the lanes a cross-lane read takes from must be active)
+            const float tj = j < k ? ts : 0.f;
+            const float4 vv = *reinterpret_cast<const float4*>(v + (r * k + jc) * d.ld_v + 4 * c4);
+            acc.x += tj * vv.x; acc.y += tj * vv.y; acc.z += tj * vv.z; acc.w += tj * vv.w;
+        }
+        for (int off = g4; off < 64; off <<= 1) {
+            acc.x += __shfl_xor(acc.x, off, 64); acc.y += __shfl_xor(acc.y, off, 64);
+            acc.z += __shfl_xor(acc.z, off, 64); acc.w += __shfl_xor(acc.w, off, 64);
+        }
+        if (jl == 0) *reinterpret_cast<float4*>(fused + r * d.C + 4 * c4) = acc;
+        return;
+    }
     for (int c = lane; c < d.C; c += 64) {
         float acc = 0.f;
         for (int j = 0; j < k; ++j) acc += bcast(top, j) * v[(r * k + j) * d.ld_v + c];
@@ -174,6 +195,23 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(papr_tail_desc d, const f
     if (d.normalize) { tsum = wave_sum(top); top = top / tsum; }
     // d_top_j = d_fused . v_j ;  d_v_j = top_j d_fused     (channels across lanes)
     float my_dtop = 0.f;
+    const int g4 = d.C >> 2;
+    if ((d.C & 3) == 0 && d.ld_v == d.C && g4 >= 1 && g4 <= 32 && (64 % g4) == 0) {
+        // (as in tail_fwd_kernel: 64 / g4 rows per instruction; a row's dot product meets over its g4 neighbouring lanes)
+        const int rp = 64 / g4, c4 = lane % g4, jl = lane / g4;
+        const float4 gf = *reinterpret_cast<const float4*>(d_fused + r * d.C + 4 * c4);
+#pragma unroll 4
+        for (int j0 = 0; j0 < k; j0 += rp) {
+            const int j = j0 + jl, jc = j < k ? j : k - 1;
+            const float tj = __shfl(top, jc, 64);
+            const float4 vv = *reinterpret_cast<const float4*>(v + (r * k + jc) * d.ld_v + 4 * c4);
+            float part = (gf.x * vv.x + gf.y * vv.y) + (gf.z * vv.z + gf.w * vv.w);
+            if (j < k) *reinterpret_cast<float4*>(d_v + (r * k + j) * d.ld_v + 4 * c4) = make_float4(tj * gf.x, tj * gf.y, tj * gf.z, tj * gf.w);
+            for (int off = 1; off < g4; off <<= 1) part += __shfl_xor(part, off, 64);
+            const float got = __shfl(part, (lane % rp) * g4, 64);        // lane L = j0 + jl' wants the row of group jl' = L % rp
+            if (lane >= j0 && lane < j0 + rp && lane < k) my_dtop = got;
+        }
+    } else
     for (int j = 0; j < k; ++j) {
         float part = 0.f;
         float tj = bcast(top, j);
