@@ -1006,21 +1006,34 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_h3_kernel(TNH3Batch batch) {
     const int cg = 4 * lane < p.N ? 4 * lane : 0, cx = 4 * lane < p.K ? 4 * lane : 0;
     float4 rg[4], rx[4];
     // (f16 rows: the four halfs of a lane ride in .x and .y of the float4)
-    auto load_g = [&](long m) {
-        if (gh) { const float2 t = *reinterpret_cast<const float2*>(reinterpret_cast<const _Float16*>(p.G) + m * p.ldg + cg); return make_float4(t.x, t.y, 0.f, 0.f); }
-        return *reinterpret_cast<const float4*>(p.G + m * p.ldg + cg);
+    // Row addresses: the slice's first row and the lane's column once per job (64-bit), a row inside the slice as a 32-bit index clamped with one
+    // s_min and multiplied by a 32-bit byte stride -- the scalar unit spent ~12 instructions per row load on 64-bit products and compares before
+    // (sixteen row loads per stage and wave)
+    const int nrows = (int)(mend - mbeg);
+    const int gstride = (int)p.ldg * (gh ? 2 : 4), xstride = (int)p.ldx * (xh ? 2 : 4);        // bytes per row
+    const char* const gbase = reinterpret_cast<const char*>(p.G) + (mbeg * p.ldg + cg) * (gh ? 2 : 4);
+    const char* const xbase = reinterpret_cast<const char*>(p.X) + (mbeg * p.ldx + cx) * (xh ? 2 : 4);
+    auto row_in_slice = [&](long st, int r) {
+        if (!HALF) { const long m = mbeg + st * TN_ROWS + 4 * wave + r; return (int)((m < mend ? m : mend - 1) - mbeg); }
+        const int i = (int)st * TN_ROWS + 4 * wave + r;
+        return i < nrows ? i : nrows - 1;
     };
-    auto load_x = [&](long m) {
-        if (xh) { const float2 t = *reinterpret_cast<const float2*>(reinterpret_cast<const _Float16*>(p.X) + m * p.ldx + cx); return make_float4(t.x, t.y, 0.f, 0.f); }
-        return *reinterpret_cast<const float4*>(p.X + m * p.ldx + cx);
+    // (the f16-row form only: it was bound by its scalar instructions, 601 -> 572 us on a five-layer run; the fp32-row form, bound elsewhere,
+    //  measured 1,015-1,019 us this way against 998-1,014 and keeps its 64-bit row arithmetic)
+    auto load_g = [&](int rel) {
+        if (gh) { const float2 t = *reinterpret_cast<const float2*>(gbase + (long)rel * gstride); return make_float4(t.x, t.y, 0.f, 0.f); }
+        return *reinterpret_cast<const float4*>(p.G + (mbeg + rel) * p.ldg + cg);
+    };
+    auto load_x = [&](int rel) {
+        if (xh) { const float2 t = *reinterpret_cast<const float2*>(xbase + (long)rel * xstride); return make_float4(t.x, t.y, 0.f, 0.f); }
+        return *reinterpret_cast<const float4*>(p.X + (mbeg + rel) * p.ldx + cx);
     };
     auto load_stage = [&](long st, float4 (&qg)[4], float4 (&qx)[4]) {      // unconditional, from clamped rows
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            long m = mbeg + st * TN_ROWS + 4 * wave + r;
-            m = m < mend ? m : mend - 1;
-            qg[r] = load_g(m);
-            qx[r] = load_x(m);
+            const int rel = row_in_slice(st, r);
+            qg[r] = load_g(rel);
+            qx[r] = load_x(rel);
         }
     };
     // element j of a lane's four columns of one row, as fp32 (an f16 row: still times the row's scale)
@@ -1101,14 +1114,13 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_h3_kernel(TNH3Batch batch) {
         constexpr bool odd_slot = decltype(oddc)::value;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            long m = mbeg + st * TN_ROWS + 4 * wave + r;
-            m = m < mend ? m : mend - 1;
+            const int rel = row_in_slice(st, r);
             if (do_g) {
-                const float2 t = *reinterpret_cast<const float2*>(reinterpret_cast<const _Float16*>(p.G) + m * p.ldg + cg);
+                const float2 t = *reinterpret_cast<const float2*>(gbase + (long)rel * gstride);
                 if (odd_slot) { rg[r].z = t.x; rg[r].w = t.y; } else { rg[r].x = t.x; rg[r].y = t.y; }
             }
             if (do_x) {
-                const float2 t = *reinterpret_cast<const float2*>(reinterpret_cast<const _Float16*>(p.X) + m * p.ldx + cx);
+                const float2 t = *reinterpret_cast<const float2*>(xbase + (long)rel * xstride);
                 if (odd_slot) { rx[r].z = t.x; rx[r].w = t.y; } else { rx[r].x = t.x; rx[r].y = t.y; }
             }
         }
@@ -1236,9 +1248,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_h3_kernel(TNH3Batch batch) {
                     else {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            long m = mbeg + (st + 2) * TN_ROWS + 4 * wave + r;
-                            m = m < mend ? m : mend - 1;
-                            rg[r] = load_g(m);
+                            rg[r] = load_g(row_in_slice(st + 2, r));
                         }
                     }
                 }
@@ -1253,9 +1263,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_h3_kernel(TNH3Batch batch) {
                     else {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            long m = mbeg + (st + 2) * TN_ROWS + 4 * wave + r;
-                            m = m < mend ? m : mend - 1;
-                            rx[r] = load_x(m);
+                            rx[r] = load_x(row_in_slice(st + 2, r));
                         }
                     }
 #endif
