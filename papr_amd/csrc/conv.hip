@@ -81,13 +81,17 @@ __global__ __launch_bounds__(256, 3) void conv3x3_h3_kernel(ConvArgs p) {
     }
     // W slab copy: chunk c = t + 256 q (q < 2): row c / 4, halfs 8 (c % 4) .. + 7
     struct SlabRegs { float4 a[4]; bool ok[4]; half8 wh[2], wl[2]; };
+    // (slabs are asked for in order: the tap and the channel slab of the next one are counters -- a division by the run-time slabs_per_tap per
+    //  slab was a third of the loop's 138 scalar instructions, and with one product per fp32 product the loop is bound by them)
+    int nx_tap = s_begin / slabs_per_tap, nx_cs = s_begin - nx_tap * slabs_per_tap;
     auto load_slab = [&](int s, SlabRegs& r) {
-        const int tap = s / slabs_per_tap, c0 = (s - tap * slabs_per_tap) * CV_BK;
+        const int tap = nx_tap, c0 = nx_cs * CV_BK;
+        if (++nx_cs == slabs_per_tap) { nx_cs = 0; ++nx_tap; }
         const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int yy = py[q] + dy, xx = px[q] + dx;
-            r.ok[q] = prow_ok[q] && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+            r.ok[q] = prow_ok[q] & ((unsigned)yy < (unsigned)p.H) & ((unsigned)xx < (unsigned)p.W);      // (no short circuits: each was a branch around the next compare)
             const long off = r.ok[q] ? pbase[q] + ((long)dy * p.W + dx) * p.C : pbase[q];
             r.a[q] = *reinterpret_cast<const float4*>(p.x + off + c0 + a_kq);
         }
@@ -282,11 +286,11 @@ __global__ __launch_bounds__(256, 3) void conv3x3_wgrad_h3_kernel(ConvWArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const long pix = ps + 4 * r + j;
-            okg[j] = n_ok && pix < pend;
+            okg[j] = n_ok & (pix < pend);
             const long pc = pix < M ? pix : M - 1;
             rg[j] = *reinterpret_cast<const float4*>(p.dy + pc * p.N + ncol);
             const int yy = py[j] + dy_, xx = px[j] + dx_;
-            okx[j] = c_ok && pix < pend && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+            okx[j] = c_ok & (pix < pend) & ((unsigned)yy < (unsigned)p.H) & ((unsigned)xx < (unsigned)p.W);
             const long src = okx[j] ? pc + (long)dy_ * p.W + dx_ : pc;
             if (CT == 128 || q < CQ) rx[j] = *reinterpret_cast<const float4*>(p.x + src * p.C + ccol);
             px[j] += 32;                                  // the same thread's pixel of the next slab
