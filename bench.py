@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--points", type=int, default=10000, help="point-cloud size (chair.yml: 10000 at init, <=30000 late)")
     ap.add_argument("--scene", default="nerfsyn/chair.yml")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gemm-mode", default="h3", choices=["f32", "fwd", "dgrad", "layers", "h3", "h1"],
+    ap.add_argument("--gemm-mode", default="h3", choices=["f32", "fwd", "dgrad", "layers", "h3", "h1", "h3_f16rows"],
                     help="h3 (default): split-f16 MFMA everywhere, consecutive layers fused into one launch; layers: the same "
                          "arithmetic, one launch per layer; dgrad: forward + data-gradient only; fwd: forward only; f32: fp32 MFMA everywhere; "
                          "h1: h3 with one f16 product per fp32 product in the fused runs (reduced precision, reported as throughput_mode_h1)")

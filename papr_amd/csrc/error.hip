@@ -13,7 +13,7 @@ void papr_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* papr_last_error(void) { return g_err; }
-extern "C" int papr_abi_version(void) { return 26; }
+extern "C" int papr_abi_version(void) { return 27; }
 
 // ---- process-wide switches and per-device caches ------------------------------------------------
 #include <atomic>

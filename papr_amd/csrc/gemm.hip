@@ -528,10 +528,12 @@ int launch_nt(const NTArgs& a, hipStream_t s) {
 //   the reference's fp16 autocast of the attention block (models/attn.py:248, `use_amp: true`); own tolerance in the tests.
 static thread_local int t_mode = 4;            // 0 f32, 1 fwd, 2 dgrad, 3 layers, 4 h3, 5 h1
 static thread_local bool t_h1_f32_rows = false;
+static thread_local bool t_h3_f16_rows = false;   // PAPR_MLP_H3_F16ROWS: h3 whose fused runs keep f16 rows for their weight gradients (round 6's gated experiment)
 static inline bool mode_from_arg(int32_t m) {  // false: not a mode of papr_hip.h
     t_h1_f32_rows = m == PAPR_MLP_H1_F32ROWS;
+    t_h3_f16_rows = m == PAPR_MLP_H3_F16ROWS;
     switch (m) { case PAPR_MLP_F32: t_mode = 0; return true; case PAPR_MLP_FWD: t_mode = 1; return true; case PAPR_MLP_DGRAD: t_mode = 2; return true;
-                 case PAPR_MLP_LAYERS: t_mode = 3; return true; case PAPR_MLP_H3: t_mode = 4; return true;
+                 case PAPR_MLP_LAYERS: t_mode = 3; return true; case PAPR_MLP_H3: case PAPR_MLP_H3_F16ROWS: t_mode = 4; return true;
                  case PAPR_MLP_H1: case PAPR_MLP_H1_F32ROWS: t_mode = 5; return true; default: return false; }
 }
 #define GEMM_MODE t_mode
@@ -949,7 +951,8 @@ __device__ __forceinline__ half8 lds_read8(const _Float16* q) {
 __device__ __forceinline__ float comp4(const float4& v, int j) { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); }
 
 // FMT 0: fp32 operands, three f16 products per fp32 product.  PAPR_GEMM_MODE=h1: FMT 1 = fp32 operands, one product (hi planes
-// only); FMT 2 = both operands are f16 rows (g_half / x_half), one product, two stages of rows in flight.
+// only); FMT 2 = both operands are f16 rows (g_half / x_half), one product, two stages of rows in flight; FMT 3 (round 6, mode PAPR_MLP_H3_F16ROWS:
+// the first layer of a run of the parity arithmetic) = G f16 rows, X fp32 rows, one product.
 template <bool FULL, int FMT>
 __global__ __launch_bounds__(512, 2) void gemm_tn_h3_kernel(TNH3Batch batch) {
     constexpr bool ONE = FMT != 0, HALF = FMT == 2;
@@ -969,7 +972,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_h3_kernel(TNH3Batch batch) {
     long mend = mbeg + p.rows_per_slice;
     if (mend > p.M) mend = p.M;
     if (mbeg >= mend) continue;                  // (workgroup-uniform: a job with fewer slices than the launch has workgroups)
-    constexpr bool gh = HALF, xh = HALF;
+    constexpr bool gh = FMT >= 2, xh = FMT == 2;
 
     // slice scales
     float gm = 0.f, xm = 0.f;
@@ -1055,7 +1058,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_h3_kernel(TNH3Batch batch) {
     int lane0;
     asm volatile("v_mov_b32 %0, 0" : "=v"(lane0));
     auto row_maxima = [&](long st, float4& mg, float4& mx) {
-        if (!HALF) return;
+        if (!gh) return;
         long base = mbeg + st * TN_ROWS + 4 * wave;
         const long top = (mend - 1) & ~3L;
         base = base < top ? base : top;
@@ -1331,12 +1334,13 @@ struct TNH3Queue {
         PAPR_REQUIRE(N % 4 == 0 && K % 4 == 0 && ldg % 4 == 0 && ldx % 4 == 0, "gemm_tn_h3: sizes must be multiples of 4");
         if (M <= 0) return 0;
         const bool job_full = N > 131 && K > 131;                       // 128 + 3 < N: all eight tiles live
-        PAPR_REQUIRE(g_half == x_half, "gemm_tn_h3: one operand f16, the other fp32");
+        PAPR_REQUIRE(g_half || !x_half, "gemm_tn_h3: X f16 rows with G fp32 rows");
+        const int fmt = g_half ? (x_half ? 2 : 3) : 0;
         // (jobs with and without dead tiles share a launch -- on the instantiation with the tile tests: one launch and one reduction per run
         // instead of two, 0.05 ms per step; a batch of full jobs only keeps the test-free one)
-        if (batch.n == TN_BATCH || (batch.n > 0 && g_half != half))
+        if (batch.n == TN_BATCH || (batch.n > 0 && fmt != half))
             if (int e = flush()) return e;
-        full = batch.n == 0 ? job_full : (full && job_full); half = g_half;
+        full = batch.n == 0 ? job_full : (full && job_full); half = fmt;
         const int n_cu = papr_cu_count() > MAX_SLICES ? MAX_SLICES : papr_cu_count();
         long stages = (M + TN_ROWS - 1) / TN_ROWS;
         int S = (int)(stages < n_cu ? stages : n_cu);                   // one workgroup per CU streams one slice
@@ -1381,12 +1385,17 @@ struct TNH3Queue {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_h3_kernel<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T3_LDS_BYTES);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_h3_kernel<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T3_LDS_BYTES);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_h3_kernel<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T3_LDS_BYTES);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_h3_kernel<true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T3_LDS_BYTES);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_h3_kernel<false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)T3_LDS_BYTES);
         }
         const bool prof = papr_prof_on();
         if (prof) papr_prof_begin2(8, batch.job[0].M, batch.n, 0, bytes, flops, s);
-        if (GEMM_ONE_PRODUCT && half) {
+        if (half == 2) {                            // (f16 rows have one plane: one product -- also behind the parity arithmetic's runs, PAPR_MLP_H3_F16ROWS)
             if (full) gemm_tn_h3_kernel<true, 2><<<dim3(grid), dim3(512), T3_LDS_BYTES, s>>>(batch);
             else gemm_tn_h3_kernel<false, 2><<<dim3(grid), dim3(512), T3_LDS_BYTES, s>>>(batch);
+        } else if (half == 3) {
+            if (full) gemm_tn_h3_kernel<true, 3><<<dim3(grid), dim3(512), T3_LDS_BYTES, s>>>(batch);
+            else gemm_tn_h3_kernel<false, 3><<<dim3(grid), dim3(512), T3_LDS_BYTES, s>>>(batch);
         } else if (GEMM_ONE_PRODUCT) {
             if (full) gemm_tn_h3_kernel<true, 1><<<dim3(grid), dim3(512), T3_LDS_BYTES, s>>>(batch);
             else gemm_tn_h3_kernel<false, 1><<<dim3(grid), dim3(512), T3_LDS_BYTES, s>>>(batch);
@@ -1463,7 +1472,7 @@ static bool layer_rowmax_saved(const papr_layer* layers, int n_layers, int i) {
 // copy of the run's input rows the second half of the run's first output buffer; likewise the gradient-row slots of the
 // backward scratch.  Only the run's last output (forward) / the gradient that leaves the run (backward) remain fp32 rows.
 // mode PAPR_MLP_H1_F32ROWS keeps fp32 rows (a different computation: other bits in the weight gradients; A/B).
-#define H1_HALF_ROWS (!t_h1_f32_rows && one_product_now())
+#define H1_HALF_ROWS ((!t_h1_f32_rows && one_product_now()) || t_h3_f16_rows)
 // forward run [b, e) of a training pass stores f16 rows (the backward pass asks the same question)
 static bool run_half_rows(const papr_layer* layers, int n_layers, int b, int e, const int32_t* ld_out, bool training) {
     if (!H1_HALF_ROWS || !training || e - b < 2) return false;
@@ -1570,7 +1579,7 @@ extern "C" int papr_mlp_fwd(const papr_layer* layers, int n_layers, float* x, in
                 c.sr_hi = q.hi; c.sr_lo = q.lo; c.sr_inv = q.inv; c.sr_max = q.mx; c.sr_ld = q.Kq;
             }
             const bool half_rows = run_half_rows(layers, n_layers, i, e, ld_out, saved != nullptr);
-            if (half_rows) { c.a0_half = reinterpret_cast<_Float16*>(outs[i]) + (size_t)M * ld_out[i]; c.lda0_half = ld_out[i]; }
+            if (half_rows && GEMM_ONE_PRODUCT) { c.a0_half = reinterpret_cast<_Float16*>(outs[i]) + (size_t)M * ld_out[i]; c.lda0_half = ld_out[i]; }      // (PAPR_MLP_H3_F16ROWS: no copy -- the first weight gradient reads the fp32 rows)
             size_t used = 0;
             SplitBatch split = {};
             long long bytes = 4LL * M * L.n_in, flops = 0;
@@ -1833,7 +1842,8 @@ extern "C" int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float*
                 else if (g_half && l >= last) gh = 1;
                 if (x_half && gh) {                  // (a layer whose gradient rows are fp32 -- layer 0 when the launch stops above it -- reads its fp32 input)
                     xh = 1;
-                    if (l == b) { xin = reinterpret_cast<const float*>(reinterpret_cast<const _Float16*>(outs[b]) + (size_t)M * ld_out[b]); ldxin = ld_out[b]; }
+                    if (l == b && !GEMM_ONE_PRODUCT) xh = 0;      // (PAPR_MLP_H3_F16ROWS: the run's input rows have no f16 copy -- G f16, X fp32, gemm_tn_h3_kernel<., 3>)
+                    else if (l == b) { xin = reinterpret_cast<const float*>(reinterpret_cast<const _Float16*>(outs[b]) + (size_t)M * ld_out[b]); ldxin = ld_out[b]; }
                     else { xin = outs[l - 1]; ldxin = ld_out[l - 1]; }
                 }
                 if (int err = wgrad(l, gl, ldl, gm, gh, xh, xin, ldxin)) return err;

@@ -20,7 +20,7 @@ from . import hip
 
 def mlp_mode(one_product, fp32_rows_inside=False):
     """The `mode` argument of papr_mlp_fwd / papr_mlp_bwd (include/papr_hip.h: PAPR_MLP_*) for one call.  The library itself reads no
-    environment: PAPR_GEMM_MODE (h3 default | h1 | layers | dgrad | fwd | f32: A/B and benchmark switch) is THIS module's, and a
+    environment: PAPR_GEMM_MODE (h3 default | h3_f16rows | h1 | layers | dgrad | fwd | f32: A/B and benchmark switch) is THIS module's, and a
     `use_amp: true` model asks for the one-product arithmetic call by call (on top of the default mode only, so that the A/B modes
     stay what they say)."""
     name = os.environ.get("PAPR_GEMM_MODE", "h3")
@@ -171,14 +171,14 @@ def conv3x3_wgrad_rows(d_y, x, want_bias=True, d_y_max=None, x_max=None):
     return d_w.permute(0, 3, 1, 2), d_b
 
 
-_OWN_CONV_WGRAD = os.environ.get("PAPR_UNET_WGRAD", "1") == "1"
-_OWN_WGRAD_MIN_CIN = int(os.environ.get("PAPR_UNET_WGRAD_MIN_CIN", "32"))      # (64: the first layer's weight gradient on MIOpen, A/B)
+from .debug import own_or_raise as _own_or_raise
 
 
 class _Conv3x3Fn(torch.autograd.Function):
     """relu(conv3x3(x) + b) over an NHWC map with the reference's (C_out, C_in, 3, 3) weight.  Forward and data-gradient on
-    papr_conv3x3_fwd, weight gradient on papr_conv3x3_wgrad (PAPR_UNET_WGRAD=0, or channel counts that are not multiples of
-    4: MIOpen through aten.convolution_backward)."""
+    papr_conv3x3_fwd, weight gradient on papr_conv3x3_wgrad.  A gradient the own kernels have no form for (data gradient: output channels not a
+    multiple of 32; weight gradient: channel counts not multiples of 4, fewer than 32 input channels) raises by name; aten.convolution_backward only
+    behind PAPR_DEBUG_TORCH_HEAD=wgrad (papr_amd/debug.py)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, relu):
@@ -194,17 +194,21 @@ class _Conv3x3Fn(torch.autograd.Function):
         if ctx.relu:
             d_y = torch.ops.aten.threshold_backward(d_y, y, 0)
         d_x = d_w = d_b = None
-        own_dx = ctx.needs_input_grad[0] and weight.shape[0] % 32 == 0          # (the kernel's K slabs are 32 channels)
+        want_w = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        shape = "Conv2d(%d, %d, 3x3)" % (weight.shape[1], weight.shape[0])
+        # (the kernel's K slabs are 32 channels)
+        own_dx = ctx.needs_input_grad[0] and _own_or_raise(weight.shape[0] % 32 == 0, "wgrad", "data gradient of " + shape, "output channels a multiple of 32")
         dy_max = None
         if own_dx:
             d_x, dy_max = conv3x3_rows(d_y, weight, None, False, transposed=True, want_max=True)
         lib_dx = ctx.needs_input_grad[0] and not own_dx
         # (the 32-channel first layer has its own tile shape in the kernel: 128 x 32 instead of 128 x 128)
-        own_dw = _OWN_CONV_WGRAD and weight.shape[0] % 4 == 0 and weight.shape[1] % 4 == 0 and weight.shape[1] >= _OWN_WGRAD_MIN_CIN
+        own_dw = want_w and _own_or_raise(weight.shape[0] % 4 == 0 and weight.shape[1] % 4 == 0 and weight.shape[1] >= 32, "wgrad", "weight gradient of " + shape,
+                                          "channel counts multiples of 4 and at least 32 input channels")
         if own_dw:
             d_w, d_b = conv3x3_wgrad_rows(d_y, x, ctx.needs_input_grad[2], _conv_max_ptr(dy_max, x.device) if dy_max else None,
                                           _conv_max_ptr(ctx.x_max, x.device))
-        if ((ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) and not own_dw) or lib_dx:
+        if (want_w and not own_dw) or lib_dx:           # (PAPR_DEBUG_TORCH_HEAD=wgrad only: _own_or_raise has raised otherwise)
             g_x, g_w, g_b = torch.ops.aten.convolution_backward(d_y.permute(0, 3, 1, 2), x.permute(0, 3, 1, 2), weight, [weight.shape[0]],
                                                                 [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [lib_dx, not own_dw, not own_dw])
             if not own_dw:
@@ -963,7 +967,7 @@ class _RenderFn(torch.autograd.Function):
         in_run = plan.k_norm and _SCORES_IN_RUN
         # training: the key embedding stays RAW in memory (its only reader, the tail's backward pass, standardises what it loads): the fused run's
         # last row phase then takes no row statistics.  Only where the whole key MLP is one fused run (every width a multiple of 32, the fused modes)
-        raw_keys = (in_run and keep and _RAW_KEYS and mlp_mode(plan.key.one_product) in (hip.MLP_MODES["h3"], hip.MLP_MODES["h1"], hip.MLP_MODES["h1_f32rows"])
+        raw_keys = (in_run and keep and _RAW_KEYS and mlp_mode(plan.key.one_product) in (hip.MLP_MODES["h3"], hip.MLP_MODES["h1"], hip.MLP_MODES["h1_f32rows"], hip.MLP_MODES["h3_f16rows"])
                     and 2 <= plan.key.n_layer <= 8 and all(L["n_out"] % 32 == 0 and L["n_out"] <= 256 and not L["skip"] for L in plan.key.layers)
                     and plan.key.last_act == hip.ACT["none"])
         k_outs = mlp_forward(plan.key, kw, kb, key_in, M, keep, (plan.key.d_out, eps) if plan.k_norm else None,

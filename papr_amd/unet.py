@@ -11,7 +11,11 @@ come from the producing kernels, skip concatenations are written in place, ReLU 
 PAPR_UNET_NET=0: layer by layer, which other sizes take anyway).  With `use_amp: true` as well: the reference wraps this module in fp16
 autocast there (models/unet.py:212); here the same kernels run with fp32 maps and fp32 accumulation -- on the whole-network path with ONE f16
 product per fp32 product (the reference's operand precision under autocast; PAPR_UNET_AMP_ONE=0: three, as without use_amp), layer by layer
-with three.  PAPR_UNET_AMP=autocast brings torch's autocast back (A/B); on the CPU or with PAPR_UNET_CONV=0 the layers are torch's.
+with three.
+
+No fallback on the device (round 6): a CUDA tensor reaches torch's own layers (nn.Conv2d, MaxPool2d, ConvTranspose2d, autocast) ONLY behind the one debug
+switch PAPR_DEBUG_TORCH_HEAD (papr_amd/debug.py: conv | rest | wgrad | autocast | all, announced on stderr when it engages); a shape outside the own
+kernels' constraints raises NotImplementedError by name.  On the CPU the modules are plain torch: the float64 reference of the GPU tests, not a product path.
 """
 import os
 
@@ -19,18 +23,16 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-_OWN_CONV = os.environ.get("PAPR_UNET_CONV", "1") == "1"
-_AMP_OWN = os.environ.get("PAPR_UNET_AMP", "own") == "own"        # under use_amp: the head on the own kernels (default) or torch's fp16 autocast + MIOpen (A/B)
-_OWN_REST = os.environ.get("PAPR_UNET_REST", "1") == "1"       # (0: pooling, transposed and 1x1 convolutions on torch / MIOpen, A/B)
+from .debug import own_or_raise, torch_head
+
 _WHOLE_NET = os.environ.get("PAPR_UNET_NET", "1") == "1"       # (0: layer by layer -- one autograd function per layer, torch glue between them; A/B)
 _AMP_ONE = os.environ.get("PAPR_UNET_AMP_ONE", "1") == "1"     # under use_amp, whole-network path: one f16 product per fp32 product (0: three, as without use_amp; A/B)
 
 
 class ConvStage(nn.Module):
-    """Conv2d(3x3, padding 1) + ReLU (the reference's DoubleConv with single=True, models/unet.py:16-33).  On the device, in
-    fp32 and with a channels-last map it runs on the split-f16 implicit-GEMM kernels (papr_conv3x3_fwd: forward and
-    data-gradient; papr_conv3x3_wgrad: weight gradient for c_in >= 64); otherwise on torch's convolution.  PAPR_UNET_CONV=0
-    forces the latter (A/B)."""
+    """Conv2d(3x3, padding 1) + ReLU (the reference's DoubleConv with single=True, models/unet.py:16-33).  On the device it runs on the
+    split-f16 implicit-GEMM kernels over the NHWC map (papr_conv3x3_fwd: forward and data-gradient; papr_conv3x3_wgrad: weight gradient);
+    channel counts they have no form for raise.  A CPU tensor takes torch's convolution (the tests' float64 reference)."""
 
     def __init__(self, c_in, c_out):
         super().__init__()
@@ -38,16 +40,32 @@ class ConvStage(nn.Module):
 
     def forward(self, x):
         conv = self.double_conv[0]
-        if (_OWN_CONV and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled() and conv.in_channels % 32 == 0
-                and conv.out_channels % 4 == 0):
+        if _own(x, conv.in_channels % 32 == 0 and conv.out_channels % 32 == 0, "conv", "Conv2d(%d, %d, 3x3)" % (conv.in_channels, conv.out_channels),
+                "input and output channels multiples of 32"):
             from .ops import _Conv3x3Fn
             rows = x.permute(0, 2, 3, 1).contiguous()             # (no copy when the map is channels-last already)
             return _Conv3x3Fn.apply(rows, conv.weight, conv.bias, True).permute(0, 3, 1, 2)
         return self.double_conv(x)
 
 
-def _own_path(x):
-    return _OWN_CONV and _OWN_REST and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled()
+def _plain_f32(x):
+    return x.dtype == torch.float32 and not torch.is_autocast_enabled()
+
+
+def _own(x, ok, part, layer, constraint):
+    """Which way a layer goes.  True: this library's kernel.  False: torch's layer -- for a CPU tensor (the tests' reference, not a product path) and, on the
+    device, ONLY behind PAPR_DEBUG_TORCH_HEAD (papr_amd/debug.py; `autocast` hands every layer over, the reference's arrangement).  A device tensor
+    outside the own kernel's constraints (`ok` false, a dtype other than fp32, a caller's autocast region) raises NotImplementedError by name."""
+    if not x.is_cuda:
+        return False
+    if torch.is_autocast_enabled() and torch_head("autocast"):
+        return False
+    return own_or_raise(_plain_f32(x) and ok, part, "%s on a %s map%s" % (layer, str(x.dtype).replace("torch.", ""), " under autocast" if torch.is_autocast_enabled() else ""),
+                        "fp32 maps outside autocast, " + constraint)
+
+
+def _own_rest(x, ok, layer, constraint):
+    return _own(x, ok, "rest", layer, constraint)
 
 
 class DownStage(nn.Module):
@@ -58,7 +76,8 @@ class DownStage(nn.Module):
         self.maxpool_conv = nn.Sequential(nn.MaxPool2d(2), ConvStage(c_in, c_out))
 
     def forward(self, x):
-        if _own_path(x) and x.shape[1] % 4 == 0 and x.shape[2] >= 2 and x.shape[3] >= 2:
+        if _own_rest(x, x.shape[1] % 4 == 0 and x.shape[2] >= 2 and x.shape[3] >= 2, "MaxPool2d(2) over %s" % (tuple(x.shape),),
+                     "channels a multiple of 4 and a map of at least 2 x 2"):
             from .ops import _MaxPool2Fn
             pooled = _MaxPool2Fn.apply(x.permute(0, 2, 3, 1).contiguous()).permute(0, 3, 1, 2)
             return self.maxpool_conv[1](pooled)
@@ -72,7 +91,8 @@ class UpStage(nn.Module):
         self.conv = ConvStage(c_in, c_out)
 
     def forward(self, low, skip):
-        if _own_path(low) and self.up.in_channels % 64 == 0 and self.up.out_channels % 64 == 0:
+        if _own_rest(low, self.up.in_channels % 64 == 0 and self.up.out_channels % 64 == 0,
+                     "ConvTranspose2d(%d, %d, 2x2)" % (self.up.in_channels, self.up.out_channels), "input and output channels multiples of 64"):
             from .ops import _UpConv2x2Fn                      # (papr_upconv2x2_*: forward and both gradients one launch each)
             low = _UpConv2x2Fn.apply(low.permute(0, 2, 3, 1).contiguous(), self.up.weight, self.up.bias).permute(0, 3, 1, 2)
         else:
@@ -90,7 +110,7 @@ class Head(nn.Module):
 
     def forward(self, x):
         c_in, c_out = self.conv.in_channels, self.conv.out_channels
-        if _own_path(x) and c_out <= 4 and c_in in (32, 64, 128, 256):
+        if _own_rest(x, c_out <= 4 and c_in in (32, 64, 128, 256), "Conv2d(%d, %d, 1x1)" % (c_in, c_out), "at most 4 classes and 32 / 64 / 128 / 256 input channels"):
             from .ops import _Conv1x1Fn
             return _Conv1x1Fn.apply(x.permute(0, 2, 3, 1).contiguous(), self.conv.weight, self.conv.bias).permute(0, 3, 1, 2)
         return self.conv(x)
@@ -106,21 +126,22 @@ class SmallUNet(nn.Module):
         self.up1 = UpStage(512, 256)
         self.up2 = UpStage(256, 128)
         self.outc = Head(128, n_classes)
-        # The feature map arrives as (N, H, W, C) rows; with channels-last weights MIOpen's NHWC kernels take both as they
-        # are (the state dict is unchanged: same keys, shapes and values, only the strides differ).
-        if os.environ.get("PAPR_UNET_CL", "1") == "1":
-            self.to(memory_format=torch.channels_last)
+        # The feature map arrives as (N, H, W, C) rows; channels-last weights are what the own kernels read in place (the state dict is
+        # unchanged: same keys, shapes and values, only the strides differ).
+        self.to(memory_format=torch.channels_last)
 
     def forward(self, x, gamma=None, beta=None):
         # the whole network as one library call each way (papr_small_unet_fwd / _bwd) where its shapes allow: two exact poolings (H, W multiples
         # of 4), input channels a multiple of 32, biases present; otherwise layer by layer below
-        if (_WHOLE_NET and _own_path(x) and not (self.use_amp and not _AMP_OWN) and x.shape[2] % 4 == 0 and x.shape[3] % 4 == 0 and x.shape[2] >= 4
+        on_torch = x.is_cuda and (torch_head("conv") or torch_head("rest") or (self.use_amp and torch_head("autocast")))       # (debug switch: layer by layer below)
+        if (_WHOLE_NET and x.is_cuda and not on_torch and _plain_f32(x) and x.shape[2] % 4 == 0 and x.shape[3] % 4 == 0 and x.shape[2] >= 4
                 and x.shape[3] >= 4 and x.shape[1] % 32 == 0 and self.outc.conv.out_channels <= 4 and x.shape[0] * x.shape[2] * x.shape[3] * 2048 < 2 ** 31):
             from .ops import small_unet_rows
             # use_amp: the reference autocasts this module to fp16 (models/unet.py:212: f16 operands, f16 maps); here f16 OPERANDS (one product per
             # fp32 product, fp32 accumulation) and fp32 maps -- pinned to the reference's own AMP output by G17 (tests/test_hip_amp_golden.py)
             return small_unet_rows(x.permute(0, 2, 3, 1).contiguous(), self, one_product=self.use_amp and _AMP_ONE).permute(0, 3, 1, 2)
-        with torch.autocast(device_type="cuda", dtype=self.amp_dtype, enabled=self.use_amp and x.is_cuda and not _AMP_OWN):
+        # layer by layer: other map sizes on the same kernels (each layer raises by name where its own kernel has no form); a CPU tensor: plain torch
+        with torch.autocast(device_type="cuda", dtype=self.amp_dtype, enabled=self.use_amp and x.is_cuda and torch_head("autocast")):
             x1 = self.inc(x)
             x2 = self.down1(x1)
             x3 = self.down2(x2)

@@ -276,7 +276,9 @@ def p1_stream(acc_u, mode, act):
     return it
 
 
-def p2_stream(acc_u, mode, one=False):
+def p2_stream(acc_u, mode, one=False, hrows=False):
+    """hrows (parity arithmetic only): the rows a training run keeps for its weight gradients leave as f16 rows -- the hi plane's bytes, as in the
+    one-product mode (ChainLayer::c_half) -- instead of fp32 rows; the arithmetic of the run itself (three products, both planes) is untouched."""
     it = []
     PM = G[0:8]
     MX, E, T = G[8], G[9], G[10]
@@ -331,7 +333,7 @@ def p2_stream(acc_u, mode, one=False):
                 it.append(Item("ds_read_b128 %s, %s" % (R[sx & 1], src), lds=("rb", sx), kind="lds"))
                 it.append(Item("global_store_dwordx4 %%[gso], %s, %%[crow0] offset:%d%s" % (R[sx & 1], 512 * sx, STMOD), need=[("rb", sx)], kind="vmem"))
         return it
-    if train:
+    if train and not hrows:
         # ---- the rows: into the wave's own 128 bytes of every plane row (where its split goes afterwards) ...
         for i in range(2):
             for g in range(4):
@@ -373,6 +375,17 @@ def p2_stream(acc_u, mode, one=False):
             it.append(Item("ds_write_b128 %s, %s offset:%d" % (dst, vt(h0, 4), 32768 * i), lds=("plh", i, q), kind="lds"))
             it.append(Item("ds_write_b128 %s, %s offset:%d" % (dst, vt(l0, 4), 32768 * i + 4096), lds=("pll", i, q), kind="lds"))
             it.append(Item("s_nop 1", kind="salu"))          # (a wide store's data registers must not be rewritten right behind it)
+    if train and hrows:
+        # ---- f16 rows for the weight gradients: the hi plane's bytes, read back sixteen rows per instruction (four lanes per row's 64 bytes of this
+        # wave's columns) -- the one-product mode's stores, character for character (rdb / gso / crow0 are the caller's in that mode's form)
+        R = [vt(GB, 4), vt(GB + 4, 4)]
+        for sx in range(4):
+            src = "%[rdb]"
+            if sx:
+                it.append(Item("v_xor_b32 %s, 0x%x, %%[rdb]" % (AD, 528 * sx)))
+                src = AD
+            it.append(Item("ds_read_b128 %s, %s" % (R[sx & 1], src), lds=("rb", sx), kind="lds"))
+            it.append(Item("global_store_dwordx4 %%[gso], %s, %%[crow0] offset:%d%s" % (R[sx & 1], 512 * sx, STMOD), need=[("rb", sx)], kind="vmem"))
     return it
 
 
@@ -396,11 +409,11 @@ class Emit:
         self.lines.pop()
 
 
-def build(tile, mode, act, ld, kcnt=16, one=False):
+def build(tile, mode, act, ld, kcnt=16, one=False, hrows=False):
     acc_t, acc_u = (ACC["X"], ACC["Y"]) if tile == "X" else (ACC["Y"], ACC["X"])
     pro, steps = k_stream_one(acc_t, ld, kcnt) if one else (k_stream_exp(acc_t, ld, kcnt) if (KVAR and kcnt == 16) else k_stream(acc_t, ld, kcnt))
     NM = len(steps)                             # matrix instructions of the statement
-    p1, p2 = p1_stream(acc_u, mode, act), p2_stream(acc_u, mode, one)
+    p1, p2 = p1_stream(acc_u, mode, act), p2_stream(acc_u, mode, one, hrows)
     if ABLATE == "K":                           # (timing experiment, results wrong: the k-loop alone)
         p1, p2 = [], []
     elif ABLATE == "KP1":
@@ -451,7 +464,7 @@ def build(tile, mode, act, ld, kcnt=16, one=False):
     return e.lines
 
 
-def build_pair(mode, act, one=False):
+def build_pair(mode, act, one=False, hrows=False):
     """TWO hot slots in one statement: slot (tile X, step i) and slot (tile Y, step i) -- the two k-loops of a step, the row phases of Y's step i - 1
     and X's step i beside them.  Between two statements every wave spends ~1.7k cycles in compiled C++ (which slot is next, its descriptors, ~40
     lane-derived operands recomputed because nothing lane-derived may live across a statement: at two waves per SIMD every dependent instruction costs
@@ -462,8 +475,8 @@ def build_pair(mode, act, one=False):
     step's weight fragments, the last of which are requested at the very end of tile Y's k-loop (they refill their registers in place) -- between two
     statements the compiled C++ hides that latency, inside one statement it would stand exposed.  Tile Y multiplies with the weights tile X has just
     used: nothing to wait for.  The halves are the single statements' instruction lists, character for character."""
-    a = build("X", mode, act, 0, 16, one)
-    b = build("Y", mode, act, 1, 16, one)
+    a = build("X", mode, act, 0, 16, one, hrows)
+    b = build("Y", mode, act, 1, 16, one, hrows)
     ren = lambda l: l.replace("%[sgn]", "%[sgnb]").replace("%[rmp]", "%[rmpb]").replace("%[crow0]", "%[crow0b]").replace("%[crow1]", "%[crow1b]")
     mid = ["s_waitcnt lgkmcnt(0)", "s_barrier",          # = lds_barrier(): X's step is in its accumulators, Y's rows of the step before are split into its planes
            "v_add_u32 %[pbx], 0x10000, %[pbx]",         # T: tile X -> tile Y
@@ -555,6 +568,14 @@ if __name__ == "__main__":
                     emit("C4F1_%s_%s_%s_%s" % (mode.upper(), act.upper(), tile, "LD" if ld else "NL"), build(tile, mode, act, ld, 16, True))
             for kcnt in (8, 10):
                 emit("C4F1_%s_%s_Y_LD_K%d" % (mode.upper(), act.upper(), kcnt), build("Y", mode, act, 1, kcnt, True))
+            # parity arithmetic, f16 rows for the weight gradients (mode PAPR_MLP_H3_F16ROWS): training forward and data-gradient
+            if mode != "inf":
+                for tile in ("X", "Y"):
+                    for ld in ((0,) if tile == "X" else (0, 1)):
+                        emit("C4FH_%s_%s_%s_%s" % (mode.upper(), act.upper(), tile, "LD" if ld else "NL"), build(tile, mode, act, ld, 16, False, True))
+                for kcnt in (8, 10):
+                    emit("C4FH_%s_%s_Y_LD_K%d" % (mode.upper(), act.upper(), kcnt), build("Y", mode, act, 1, kcnt, False, True))
+                emit("C4F2H_%s_%s" % (mode.upper(), act.upper()), build_pair(mode, act, False, True))
     print("#define C4F_CLOBBERS " + ", ".join('"%s"' % v for v in CLOB_V) + ', "vcc", "memory"')
     print('#define C4F_LD_CLOBBERS "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97"')
     print("#define C4F_AGPRS " + ", ".join('"a%d"' % i for i in range(128)))

@@ -76,3 +76,37 @@ def test_one_product_mode_forms_agree_bit_for_bit(tmp_path):
             continue
         for (k, a), (_, b) in zip(_flat(ref), _flat(res)):
             assert torch.equal(a, b), "%s: %s differs in %d of %d elements" % (name, k, int((a != b).sum()), a.numel())
+
+
+F16ROWS_VARIANTS = [("h3_f16rows generic rows", {"PAPR_C4_GENERIC": "1", "PAPR_GEMM_MODE": "h3_f16rows"}), ("h3_f16rows", {"PAPR_GEMM_MODE": "h3_f16rows"}),
+                    ("h3_f16rows again", {"PAPR_GEMM_MODE": "h3_f16rows"}), ("h3_f16rows single slots", {"PAPR_GEMM_MODE": "h3_f16rows", "PAPR_C4_PAIRS": "0"}),
+                    ("h3_f16rows two-role", {"PAPR_GEMM_MODE": "h3_f16rows", "PAPR_C4_FUSED": "0"})]
+
+
+@pytest.mark.parametrize("M,n,act,dims", [(40000, 5, "relu", ()), (30053, 4, "leakyrelu", (141, 32))])
+def test_f16_rows_mode_is_h3_but_for_the_weight_gradients(tmp_path, M, n, act, dims):
+    """PAPR_MLP_H3_F16ROWS (round 6's gated experiment): the parity arithmetic whose fused runs keep f16 rows for their weight gradients.  Its forms agree
+    bit for bit; against the default mode the run's result, the inference pass and the input gradient are IDENTICAL (the forward and data-gradient
+    arithmetic is untouched), weight and bias gradients carry the f16 rounding of their operands' rows: the measured distance is printed, the bar is the
+    one the default mode's gradients are held to against the reference (rms within 1.5e-4 of the tensor's largest element, tests/conftest.py)."""
+    base = _run(tmp_path, "h3", {}, M, n, act, dims)
+    ref = None
+    for name, env in F16ROWS_VARIANTS:
+        res = _run(tmp_path, name, env, M, n, act, dims)
+        if ref is None:
+            ref = res
+            continue
+        for (k, a), (_, b) in zip(_flat(ref), _flat(res)):
+            assert a.shape == b.shape, (name, k)
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32)), "%s: %s differs in %d of %d elements" % (name, k, int((a.view(torch.int32) != b.view(torch.int32)).sum()), a.numel())
+    for k in ("d_x", "d_x2", "inf"):
+        assert torch.equal(base[k], ref[k]), "%s differs from the default mode's in %d elements" % (k, int((base[k] != ref[k]).sum()))
+    assert torch.equal(base["outs"][-1], ref["outs"][-1])
+    worst = 0.0
+    for k in ("d_ws", "d_bs"):
+        for i, (a, b) in enumerate(zip(base[k], ref[k])):
+            rel = float((a - b).pow(2).mean().sqrt() / a.abs().max().clamp_min(1e-30))
+            worst = max(worst, rel)
+            print("%s[%d]: rms |f16rows - h3| / max |h3| = %.3g" % (k, i, rel))
+            assert rel < 1.5e-4, (k, i, rel)
+    print("worst %.3g" % worst)

@@ -784,7 +784,7 @@ def test_layernorm_affine_fold(n_out, n_in, ld_eff):
         np.testing.assert_allclose(got.grad.cpu().numpy(), ref.grad.numpy(), rtol=0, atol=3e-6 * (1 + ref.grad.abs().max().item()))
 
 
-@pytest.mark.parametrize("B,H,W,c_in,c_out,relu", [(1, 20, 24, 32, 128, True), (2, 9, 7, 64, 36, False), (1, 40, 40, 256, 512, True),
+@pytest.mark.parametrize("B,H,W,c_in,c_out,relu", [(1, 20, 24, 32, 128, True), (2, 9, 7, 64, 96, False), (1, 40, 40, 256, 512, True),
                                                      (1, 13, 130, 128, 128, True)])
 def test_conv3x3_forward_and_gradients_match_torch(B, H, W, c_in, c_out, relu):
     """papr_conv3x3_fwd (forward and, through the flipped weight, data-gradient) against torch.nn.functional.conv2d in fp32
@@ -808,6 +808,38 @@ def test_conv3x3_forward_and_gradients_match_torch(B, H, W, c_in, c_out, relu):
     np.testing.assert_allclose(xd.grad.cpu().permute(0, 3, 1, 2).numpy(), x.grad.numpy(), rtol=0, atol=3e-6 * x.grad.abs().max().item())
     np.testing.assert_allclose(wd.grad.cpu().numpy(), w.grad.numpy(), rtol=0, atol=2e-5 * w.grad.abs().max().item())
     np.testing.assert_allclose(bd.grad.cpu().numpy(), b.grad.numpy(), rtol=0, atol=2e-5 * b.grad.abs().max().item())
+
+
+def test_conv3x3_gradient_without_an_own_form_raises_by_name():
+    """No silent aten / MIOpen fallback in the render head (round 6): the forward kernel takes any output width that is a multiple of 4, the
+    data-gradient kernel needs a multiple of 32 -- a gradient it has no form for raises by name instead of going to aten.convolution_backward
+    (which stays reachable only behind PAPR_DEBUG_TORCH_HEAD=wgrad, papr_amd/debug.py)."""
+    from papr_amd import ops
+    d = dev()
+    x = torch.randn(1, 6, 5, 64, device=d, requires_grad=True)
+    w = torch.randn(36, 64, 3, 3, device=d, requires_grad=True)
+    b = torch.zeros(36, device=d, requires_grad=True)
+    y = ops._Conv3x3Fn.apply(x, w, b, False)
+    assert y.shape == (1, 6, 5, 36)
+    with pytest.raises(NotImplementedError, match="data gradient of Conv2d\\(64, 36, 3x3\\)"):
+        y.sum().backward()
+
+
+def test_small_unet_layer_outside_the_own_kernels_raises_on_the_device():
+    """... and a layer of a head whose shape the own kernels do not cover raises when it meets a device tensor (rounds 3-5: nn.Conv2d / MaxPool2d /
+    ConvTranspose2d took it without a word)."""
+    from papr_amd.unet import ConvStage, DownStage, Head, UpStage
+    d = dev()
+    with pytest.raises(NotImplementedError, match="Conv2d\\(24, 32, 3x3\\)"):
+        ConvStage(24, 32).to(d)(torch.randn(1, 24, 8, 8, device=d))
+    with pytest.raises(NotImplementedError, match="MaxPool2d"):
+        DownStage(6, 32).to(d)(torch.randn(1, 6, 8, 8, device=d))
+    with pytest.raises(NotImplementedError, match="ConvTranspose2d\\(96, 48, 2x2\\)"):
+        UpStage(96, 32).to(d)(torch.randn(1, 96, 4, 4, device=d), torch.randn(1, 48, 8, 8, device=d))
+    with pytest.raises(NotImplementedError, match="Conv2d\\(128, 7, 1x1\\)"):
+        Head(128, 7).to(d)(torch.randn(1, 128, 8, 8, device=d))
+    with pytest.raises(NotImplementedError, match="float16"):
+        ConvStage(32, 32).to(d).half()(torch.randn(1, 32, 8, 8, device=d).half())
 
 
 @pytest.mark.parametrize("B,H,W,C", [(1, 40, 40, 128), (2, 7, 9, 4), (1, 20, 20, 256), (3, 2, 5, 36)])
@@ -1076,7 +1108,7 @@ def test_own_adam_under_a_gradscaler_follows_torchs_scaler_step():
         own_adam.step_scaled(own_opts, own_sc)
 
 
-@pytest.mark.parametrize("mode", ["f32", "fwd", "dgrad", "layers"])
+@pytest.mark.parametrize("mode", ["f32", "fwd", "dgrad", "layers", "h3_f16rows"])
 def test_other_gemm_modes_meet_the_same_mlp_parity(mode):
     """PAPR_GEMM_MODE selects which wide GEMMs use the split-f16 (hi/lo, 3 MFMA) kernels (default `h3`: forward
     layers, data-gradients and weight-gradients); `dgrad` (no weight-gradients), `fwd` (forward only) and `f32`

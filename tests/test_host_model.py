@@ -462,3 +462,56 @@ def test_eval_chunk_policy(monkeypatch):
     monkeypatch.setenv("PAPR_EVAL_CHUNK", "config")
     assert train.eval_chunk(m, 1, 800, 800, 200, 200, cuda) == (200, 200)
 
+
+
+class _FakeDeviceMap:
+    """What the render head's routing looks at of a map: device, dtype, shape (no GPU in the CPU suite)."""
+    is_cuda = True
+
+    def __init__(self, shape, dtype=torch.float32):
+        self.shape, self.dtype = tuple(shape), dtype
+
+
+def test_render_head_has_no_torch_fallback_on_the_device(monkeypatch, capsys):
+    """papr_amd/unet.py: a DEVICE tensor can reach torch's own layers (nn.Conv2d, MaxPool2d, ConvTranspose2d, autocast) only behind the one debug switch
+    PAPR_DEBUG_TORCH_HEAD, which says so once on stderr; a shape the own kernels do not cover raises by name (rounds 3-5: four import-time switches and
+    silent shape tests).  Checked on the routing function every layer goes through, with a stand-in for a device map, and on the module source: every call
+    of a torch layer sits behind that function."""
+    import ast
+    import inspect
+    import papr_amd.debug as dbg
+    import papr_amd.unet as unet
+    monkeypatch.setattr(dbg, "_ON", frozenset())
+    monkeypatch.setattr(dbg, "_said", set())
+    ok_map = _FakeDeviceMap((1, 32, 8, 8))
+    assert unet._own(ok_map, True, "conv", "Conv2d(32, 128, 3x3)", "channels") is True             # the own kernel
+    for bad in (dict(ok=False), dict(ok=True, dtype=torch.float16), dict(ok=True, dtype=torch.float64)):
+        with pytest.raises(NotImplementedError, match="no torch fallback on the device"):
+            unet._own(_FakeDeviceMap((1, 32, 8, 8), bad.get("dtype", torch.float32)), bad["ok"], "rest", "MaxPool2d(2)", "channels")
+    with monkeypatch.context() as mp:                                                                # a caller's (device) autocast region: not silently honoured either
+        mp.setattr(torch, "is_autocast_enabled", lambda *a: True)
+        with pytest.raises(NotImplementedError, match="under autocast"):
+            unet._own(ok_map, True, "conv", "Conv2d(32, 128, 3x3)", "channels")
+    assert unet._own(torch.zeros(1, 32, 8, 8), True, "conv", "Conv2d", "channels") is False          # a CPU tensor: plain torch, the tests' reference
+    assert capsys.readouterr().err == ""
+    # the debug switch: torch, and it says so -- once per part
+    monkeypatch.setattr(dbg, "_ON", frozenset({"rest"}))
+    assert unet._own(ok_map, True, "rest", "MaxPool2d(2)", "channels") is False
+    assert unet._own(ok_map, False, "rest", "MaxPool2d(2)", "channels") is False
+    assert unet._own(ok_map, True, "conv", "Conv2d(32, 128, 3x3)", "channels") is True               # (another part stays on the own kernels)
+    err = capsys.readouterr().err
+    assert err.count("PAPR_DEBUG_TORCH_HEAD") == 1 and "'rest'" in err
+    # the source: a torch layer of the head is only ever called in the branch behind _own / _own_rest, and no other environment switch routes layers
+    src = inspect.getsource(unet)
+    tree = ast.parse(src)
+    for cls in ("ConvStage", "DownStage", "UpStage", "Head"):
+        fwd = next(f for c in tree.body if isinstance(c, ast.ClassDef) and c.name == cls for f in c.body if isinstance(f, ast.FunctionDef) and f.name == "forward")
+        tests = [n for n in ast.walk(fwd) if isinstance(n, ast.If)]
+        assert any(isinstance(t.test, ast.Call) and getattr(t.test.func, "id", "") in ("_own", "_own_rest") for t in tests), cls
+    assert "PAPR_UNET_CONV" not in src and "PAPR_UNET_REST" not in src and 'get("PAPR_UNET_AMP"' not in src
+    with pytest.raises(ValueError):                                                                  # an unknown part is an error, not a no-op
+        monkeypatch.setenv("PAPR_DEBUG_TORCH_HEAD", "convs")
+        import importlib
+        importlib.reload(dbg)
+    monkeypatch.delenv("PAPR_DEBUG_TORCH_HEAD")
+    importlib.reload(dbg)
