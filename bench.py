@@ -123,7 +123,8 @@ def self_launch(args):
     import socket
     import subprocess
     n_vis = torch.cuda.device_count()
-    if n_vis < args.gpus:
+    share = share_one_gpu() and n_vis >= 1
+    if n_vis < args.gpus and not share:
         print("bench.py: --gpus %d but only %d GPU(s) visible here: refusing to print a line for fewer ranks than asked for" % (args.gpus, n_vis), file=sys.stderr)
         return 2
     with socket.socket() as sk:
@@ -132,8 +133,19 @@ def self_launch(args):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     print("bench.py: no launcher environment, starting %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr)
-    r = subprocess.run(cmd, env=child_env(), cwd=ROOT)
+    env = child_env()
+    if share:
+        env["PAPR_DIST_BACKEND"] = "gloo"              # (RCCL refuses two ranks per device)
+        print("bench.py: PAPR_BENCH_SHARE_GPU=1 -- %d ranks on %d GPU(s) over gloo: a TEST of the N > 1 code path, not a measurement" % (args.gpus, n_vis), file=sys.stderr)
+    r = subprocess.run(cmd, env=env, cwd=ROOT)
     return r.returncode
+
+
+def share_one_gpu():
+    """PAPR_BENCH_SHARE_GPU=1 (tests/test_hip_rccl.py only): the ranks of `--gpus N` may share the visible GPU(s), process group gloo -- so that the
+    world > 1 arithmetic of this file (value = world x R x steps / max-over-ranks time, ranks_seen, the relay of rank 0's line and of the exit code
+    through self_launch) runs on a 1-GPU box before the first real multi-GPU run.  The line it prints says so (`test_override`)."""
+    return os.environ.get("PAPR_BENCH_SHARE_GPU", "0") == "1"
 
 
 def psnr_after_steps(args):
@@ -174,6 +186,10 @@ def main():
             print("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks: the two must agree" % (args.gpus, os.environ["WORLD_SIZE"]), file=sys.stderr)
         sys.exit(2)
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if share_one_gpu() and pdist.launched() and torch.cuda.device_count() >= 1:
+        if os.environ.get("PAPR_DIST_BACKEND") != "gloo":
+            raise SystemExit("bench.py: PAPR_BENCH_SHARE_GPU=1 needs PAPR_DIST_BACKEND=gloo (RCCL refuses two ranks per device)")
+        local = local % torch.cuda.device_count()
     if torch.cuda.device_count() <= local:
         print("bench.py: rank with LOCAL_RANK %d but %d GPU(s) visible (the render path has no CPU fallback; one GPU per rank)" % (local, torch.cuda.device_count()), file=sys.stderr)
         sys.exit(2)
@@ -241,10 +257,11 @@ def main():
         recs = hip.profile_collect()
     ranks_seen = 1
     if torch.distributed.is_initialized():
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        cdev = dev if torch.distributed.get_backend() == "nccl" else "cpu"      # (gloo -- PAPR_BENCH_SHARE_GPU -- reduces host tensors)
+        t = torch.tensor([dt], device=cdev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
-        one = torch.ones(1, device=dev, dtype=torch.float64)              # every rank that ran the timed steps adds itself
+        one = torch.ones(1, device=cdev, dtype=torch.float64)             # every rank that ran the timed steps adds itself
         torch.distributed.all_reduce(one, op=torch.distributed.ReduceOp.SUM)
         ranks_seen = int(round(float(one)))
         torch.distributed.barrier()
@@ -382,6 +399,8 @@ def main():
         "metric": "train rays/sec, nerf_synthetic/%s (PAPR), fp32 in/out, GEMM mode '%s'" % (os.path.splitext(os.path.basename(args.scene))[0], args.gemm_mode),
         "value": world * R * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ranks_seen": ranks_seen,
+        **({"test_override": "PAPR_BENCH_SHARE_GPU=1: %d ranks shared %d GPU(s) over gloo -- a test of the N > 1 code path, NOT a measurement" % (world, torch.cuda.device_count())}
+           if share_one_gpu() and world > 1 else {}),
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         # north_star's literal figure: "train rays/sec ... as achieved fraction of the kNN HBM roofline" -- LOGICAL bytes (what an every-point search
         # would read per ray, SURVEY section 8d: 12 P + 12 + 4 k) times the END-TO-END train rays/s of the whole job, over N x the HBM peak.  The

@@ -170,8 +170,9 @@ int papr_qk_bias_bwd(const float* Q, int ldq, int dq, int dm, const float* d_c0,
                      float* d_Q, float* d_wq, const float* d_bq_in, float* d_bq, float* d_bk, void* workspace, papr_stream_t stream);
 
 /* The `mse` loss term (torch.nn.MSELoss() in the reference's BasicLoss, models/__init__.py:8-52): *loss = mean((pred - target)^2) over n numbers and,
- * with grad != NULL, grad[i] = 2 (pred[i] - target[i]) / n -- one launch (ABI 26).  workspace: papr_mse_workspace_bytes() bytes, ZEROED before its first
- * use and then left to the calls (a ticket counter the kernel resets; calls sharing one workspace must run on one stream). */
+ * with grad != NULL, grad[i] = 2 (pred[i] - target[i]) / n -- one kernel launch (ABI 26).  workspace: papr_mse_workspace_bytes() bytes; its ticket counter is
+ * zeroed in-stream in front of every launch (ABI 27: a 4-byte memset -- an aborted launch can no longer poison later calls); calls sharing one workspace
+ * must run on one stream. */
 size_t papr_mse_workspace_bytes(void);
 int papr_mse_fwd(const float* pred, const float* target, int64_t n, float* loss, float* grad, void* workspace, papr_stream_t stream);
 
@@ -511,8 +512,10 @@ int papr_profile_enable(int on);
  *                              statement (ABI 23)
  *   PAPR_SW_C4_PHASE    (6130) the workgroups of a fused run that carry one pair of tiles fewer than the others start late instead of finishing early
  *                              (out of phase with the rest at no cost).  value = 1000 x (the fewest steps a run must have) + (delay per step of the run in
- *                              hundreds of cycles); 0: off
- *   PAPR_SW_C4_WCOPIES  (1)    timing experiment: 2-4 = the workgroups of an XCD read a fused run's weight fragments from that many copies of the planes
+ *                              hundreds of cycles -- shader cycles at 2.1 GHz, waited for on the constant 100 MHz clock since ABI 27: a time, whatever
+ *                              the box's power state); 0: off
+ *   PAPR_SW_C4_WCOPIES  (1)    timing experiment of probe builds (-DC4_X_WCOPIES; the regular library ignores it since ABI 27): 2-4 = the workgroups of
+ *                              an XCD read a fused run's weight fragments from that many copies of the planes
  *   PAPR_SW_C4_SUBPHASE (0)    timing experiment: workgroup b of a fused run starts ((b / 8) % 4) x value cycles late (sub-slot phases inside an XCD) */
 enum { PAPR_SW_C4_GENERIC = 0, PAPR_SW_C4_FUSED = 1, PAPR_SW_C4_EARLY = 2, PAPR_SW_KNN_BLOCKS = 3, PAPR_SW_KNN_T = 4, PAPR_SW_WGRAD_WGS = 5,
        PAPR_SW_NT_VARIANT = 6, PAPR_SW_C4_DMA = 7, PAPR_SW_TN_JOBPAR = 8, PAPR_SW_C4_PAIRS = 9, PAPR_SW_C4_PHASE = 10, PAPR_SW_C4_SUBPHASE = 11, PAPR_SW_C4_WCOPIES = 12, PAPR_SW_COUNT = 13 };

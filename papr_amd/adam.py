@@ -61,14 +61,30 @@ def scaler_supported(scaler):
         from torch.amp.grad_scaler import OptState  # noqa: F401
     except Exception:
         return False
-    return (type(scaler).__module__.startswith("torch.") and hasattr(scaler, "_check_scale_growth_tracker") and hasattr(scaler, "_per_optimizer_states")
-            and hasattr(OptState, "STEPPED") and hasattr(OptState, "UNSCALED"))
+    if not (type(scaler).__module__.startswith("torch.") and hasattr(scaler, "_check_scale_growth_tracker") and hasattr(scaler, "_per_optimizer_states")
+            and hasattr(OptState, "STEPPED") and hasattr(OptState, "UNSCALED") and hasattr(OptState, "READY")):
+        return False
+    # ... and the LAYOUT of a per-optimizer record, which update() reads: a fresh entry of the scaler's own defaultdict must carry the two keys
+    # step_scaled writes (probed on a throw-away key, removed again)
+    probe = object()
+    try:
+        rec = scaler._per_optimizer_states[id(probe)]
+        ok = isinstance(rec, dict) and rec.get("stage") is OptState.READY and isinstance(rec.get("found_inf_per_device"), dict)
+    except Exception:
+        ok = False
+    finally:
+        try:
+            scaler._per_optimizer_states.pop(id(probe), None)
+        except Exception:
+            ok = False
+    return ok
 
 
 def step_scaled(optimizers, scaler):
     """`for opt in optimizers: scaler.step(opt)` (reference models/model.py:439-442) under a live torch.amp.GradScaler, as the same launches as
-    step() plus one pass that looks for non-finite gradients: the kernel divides every gradient by the scaler's scale as it reads it and leaves
-    everything untouched when any gradient of the call overflowed.  The scaler is told what it would have found itself -- found_inf per optimizer,
+    step() plus one pass that looks for non-finite gradients: the kernel divides every gradient by the scaler's scale as it reads it, and an optimizer
+    with a non-finite gradient is skipped WHOLE (parameters, moments, step counters) while the others step -- torch's per-optimizer scaler.step
+    contract, what the reference's loop does.  The scaler is told what it would have found itself -- found_inf per optimizer,
     stage STEPPED -- so that its update() halves / grows the scale exactly as after its own step() (torch/amp/grad_scaler.py: step, update); the
     scale never leaves the device and nothing synchronises."""
     from torch.amp.grad_scaler import OptState

@@ -77,7 +77,9 @@ __device__ __forceinline__ float wave_max(float v) {
 // (zeroed beforehand): a workgroup adds ONE atomicMax of its max |.| (bit pattern) to word (its linear block index mod 256), a consumer wave takes
 // the largest of the 256 (one 16-byte load per lane).  Not one word: same-address atomics are served one at a time at the memory side, ~10 ns each
 // -- 12,800 of them (a wave each of a 3,200-workgroup elementwise launch) made a 7-us kernel a 150-us one, and even one per workgroup of a
-// 1,024-workgroup launch cost 10 us; spread over 256 words the queue per word is four deep.  Every thread of the workgroup must call the writer.
+// 1,024-workgroup launch cost 10 us; spread over 256 words the queue per word is four deep.  Every thread of the workgroup must call the writer
+// (it holds two barriers: an early return of some threads deadlocks); it may be called more than once per kernel (the trailing barrier keeps a second
+// call's writes off the table thread 0 is still reading).
 constexpr int PAPR_SLOT_W = 256;
 __device__ __forceinline__ void papr_wg_max_to_slot(unsigned* slot, float v) {
     __shared__ float papr_wmax[16];
@@ -90,6 +92,7 @@ __device__ __forceinline__ void papr_wg_max_to_slot(unsigned* slot, float v) {
         const unsigned bid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
         if (m > 0.f) atomicMax(slot + (bid & (PAPR_SLOT_W - 1)), __float_as_uint(m));
     }
+    __syncthreads();
 }
 // the maximum a slot holds (n == PAPR_SLOT_W), or the single word a caller of the single-layer entry points supplies (n == 1); in every lane
 __device__ __forceinline__ unsigned papr_slot_max(const unsigned* slot, int n) {

@@ -947,6 +947,9 @@ extern "C" int papr_mse_fwd(const float* pred, const float* target, int64_t n, f
     PAPR_REQUIRE(pred && target && loss && workspace && n >= 1, "papr_mse_fwd: null pointer or empty input");
     long wgs = (n / 4 + 255) / 256;
     wgs = wgs < 1 ? 1 : (wgs > MSE_MAX_WGS ? MSE_MAX_WGS : wgs);
+    // the ticket is zeroed IN the stream in front of every launch (4 bytes): the last workgroup's reset alone would leave a launch that was aborted or
+    // faulted mid-flight behind as a ticket that never reaches the count again -- every later loss on the stream unfinalised, silently
+    PAPR_REQUIRE(hipMemsetAsync(workspace, 0, 4, as_stream(stream)) == hipSuccess, "papr_mse_fwd: memset of the ticket failed");
     mse_fwd_kernel<<<dim3((unsigned)wgs), dim3(256), 0, as_stream(stream)>>>(pred, target, n, loss, grad, static_cast<unsigned*>(workspace),
                                                                             reinterpret_cast<double*>(static_cast<char*>(workspace) + 16));
     PAPR_CHECK_LAUNCH("mse_fwd");

@@ -26,7 +26,7 @@ class _MseFn(torch.autograd.Function):
         pred, target = pred.contiguous(), target.contiguous()
         loss = torch.empty((), device=pred.device, dtype=torch.float32)
         grad = torch.empty_like(pred) if ctx.needs_input_grad[0] else None
-        key = (pred.device.index, torch.cuda.current_stream().cuda_stream)        # (one zero-initialised ticket workspace per device and stream)
+        key = (pred.device.index, torch.cuda.current_stream(pred.device).cuda_stream)        # (one ticket workspace per device and stream -- of pred's device)
         ws = _mse_ws.get(key)
         if ws is None:
             ws = _mse_ws[key] = torch.zeros(hip.lib().papr_mse_workspace_bytes(), device=pred.device, dtype=torch.uint8)

@@ -28,6 +28,8 @@ def mlp_mode(one_product, fp32_rows_inside=False):
         name = "h1"
     if name == "h1" and (os.environ.get("PAPR_H1_ROWS", "") == "f32" or fp32_rows_inside):      # (A/B: fp32 rows between a run and its weight gradients;
         name = "h1_f32rows"                                                                       # fp32_rows_inside: a run whose INNER rows the host reads)
+    if name == "h3_f16rows" and fp32_rows_inside:       # (the same for round 6's f16-rows form of the parity mode: such a run keeps fp32 rows)
+        name = "h3"
     return hip.MLP_MODES[name]
 
 
@@ -1067,8 +1069,13 @@ class _RenderFn(torch.autograd.Function):
                 d_wkb_v = torch.empty((plan.d_model,), device=dev, dtype=torch.float32)
                 ws = torch.empty((lib.papr_qk_bias_bwd_workspace_bytes(plan.qry.d_out) + 3) // 4, device=dev, dtype=torch.float32)
                 bq_ = wqb[0].contiguous()
-                assert d_wqb_a.shape[0] == plan.d_model and bk.shape[0] >= plan.d_model and d_Q.is_contiguous() and d_wq_a.is_contiguous()
-                hip.check(lib.papr_qk_bias_bwd(hip.ptr(Q), Q.shape[1], plan.qry.d_out, plan.d_model, hip.ptr(d_c0), R, hip.ptr(wqw[0]), wqw[0].shape[1],
+                # (raw pointers go in: the preconditions are checked with a raise, not an assert -- `python -O` must not turn a padded or transposed
+                #  W_q into a read with the wrong pitch; the weight's leading dimension is its row stride.  ADVICE r05)
+                wq0 = wqw[0] if wqw[0].stride(1) == 1 else wqw[0].contiguous()
+                if not (d_wqb_a.shape[0] == plan.d_model and bk.shape[0] >= plan.d_model and d_Q.is_contiguous() and d_wq_a.is_contiguous()
+                        and d_wq_a.shape == wq0.shape and Q.stride(1) == 1 and d_Q.shape == Q.shape):
+                    raise RuntimeError("papr_amd: papr_qk_bias_bwd: d_Q / d_W_q must be contiguous and shaped like Q / W_q, b_k at least d_model long")
+                hip.check(lib.papr_qk_bias_bwd(hip.ptr(Q), Q.stride(0), plan.qry.d_out, plan.d_model, hip.ptr(d_c0), R, hip.ptr(wq0), wq0.stride(0),
                                                hip.ptr(bk), hip.ptr(bq_), hip.ptr(d_Q), hip.ptr(d_wq_a), hip.ptr(d_wqb_a), hip.ptr(d_wqb_a), hip.ptr(d_wkb_v),
                                                hip.ptr(ws), hip.stream_ptr()), "papr_qk_bias_bwd")
                 d_wq, d_wqb = [d_wq_a], [d_wqb_a]

@@ -1,10 +1,10 @@
 #!/bin/bash
 # round 6, GPU call 1: the f16-rows experiment of the parity mode (PAPR_MLP_H3_F16ROWS) + where the one-product hot statement's time goes
-O=gpurun_out/r6a; mkdir -p $O
+O=gpurun_out/r6b; mkdir -p $O
 python3 -c "import torch; print(torch.cuda.get_device_name(0))" > $O/box.txt 2>&1
 # 1. the new mode's forms against each other and against h3
 timeout 900 python3 -m pytest tests/test_hip_chain_variants.py -q -m gpu -k "f16_rows" -x -s > $O/variants.txt 2>&1; echo "variants rc $?" >> $O/rc.txt
-timeout 600 python3 -m pytest tests/test_hip_kernels.py -q -m gpu -k "other_gemm_modes and f16rows" -x > $O/modes.txt 2>&1; echo "modes rc $?" >> $O/rc.txt
+timeout 900 python3 -m pytest tests/test_hip_rccl.py tests/test_hip_kernels.py -q -m gpu -k "bench_gpus_2 or without_an_own_form or outside_the_own or small_unet or mse" -x > $O/modes.txt 2>&1; echo "new tests rc $?" >> $O/rc.txt
 # 2. the step: default against the new mode, twice each (same box)
 run() { PAPR_BENCH_LAUNCHES=1 python3 bench.py --steps 20 --warmup 5 --no-amp-line --no-shipped-line --psnr-steps 0 --no-cpu-baseline "$@" 2> $O/l.txt | python3 -c "import sys,json; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('ms_per_step', round(j['ms_per_step'],3), 'final_loss', j['config'].get('final_loss'))"; grep "^kernel  *\(9\|10\|8\) " $O/l.txt | head -12; }
 for i in 1 2; do
@@ -16,12 +16,7 @@ echo "=== amp"; run --amp > $O/bench_amp.txt 2>&1
 PAPR_GEMM_MODE=h3_f16rows timeout 1500 python3 -m pytest tests/test_hip_model.py tests/test_dynamics_golden.py -q -m gpu > $O/goldens_f16rows.txt 2>&1; echo "goldens rc $?" >> $O/rc.txt
 # 4. per-tensor gradient error against the reference goldens, both modes
 for m in h3 h3_f16rows; do PAPR_GEMM_MODE=$m python3 scripts/probes/grad_err.py; done > $O/grad_err.txt 2>&1
-# 5. one-product mode: the hot statement's streams (K alone, K + P1, K + P2, no row stores)
-{ echo "as built:"; PAPR_GEMM_MODE=h1 python3 scripts/probes/chain_bench.py 2>/dev/null
-  for ab in K KP1 KP2 NOST; do echo "abl_$ab:"; PAPR_GEMM_MODE=h1 PAPR_HIP_LIB=$PWD/scripts/probes/bin/libpapr_abl_$ab.so python3 scripts/probes/chain_bench.py 2>/dev/null; done
-  echo "as built, single slots:"; PAPR_C4_PAIRS=0 PAPR_GEMM_MODE=h1 python3 scripts/probes/chain_bench.py 2>/dev/null
-  echo "as built, two-role:"; PAPR_C4_FUSED=0 PAPR_GEMM_MODE=h1 python3 scripts/probes/chain_bench.py 2>/dev/null
-  echo "h3 as built:"; python3 scripts/probes/chain_bench.py 2>/dev/null
-  echo "h3_f16rows as built:"; PAPR_GEMM_MODE=h3_f16rows python3 scripts/probes/chain_bench.py 2>/dev/null
-} > $O/h1_ablate.txt 2>&1
+# 5. the whole GPU suite on the tree as it stands
+timeout 1700 python3 -m pytest tests -q -m gpu -x > $O/suite.txt 2>&1; echo "suite rc $?" >> $O/rc.txt
+tail -3 $O/suite.txt
 cat $O/rc.txt

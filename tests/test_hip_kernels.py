@@ -1108,7 +1108,7 @@ def test_own_adam_under_a_gradscaler_follows_torchs_scaler_step():
         own_adam.step_scaled(own_opts, own_sc)
 
 
-@pytest.mark.parametrize("mode", ["f32", "fwd", "dgrad", "layers", "h3_f16rows"])
+@pytest.mark.parametrize("mode", ["f32", "fwd", "dgrad", "layers"])
 def test_other_gemm_modes_meet_the_same_mlp_parity(mode):
     """PAPR_GEMM_MODE selects which wide GEMMs use the split-f16 (hi/lo, 3 MFMA) kernels (default `h3`: forward
     layers, data-gradients and weight-gradients); `dgrad` (no weight-gradients), `fwd` (forward only) and `f32`

@@ -91,3 +91,30 @@ def test_bench_line_carries_ranks_seen_and_the_logical_knn_fraction():
     e = j["e2e_frac_of_knn_hbm_roofline"]
     assert e["logical"] is True and e["bytes_per_ray"] == 12 * 10000 + 12 + 4 * 20
     assert e["frac"] == pytest.approx(j["value"] * e["bytes_per_ray"] / 8e12, rel=1e-9)
+
+
+def test_bench_gpus_2_walks_the_world_2_branch_on_one_gpu():
+    """`python bench.py --gpus 2` end to end on the one GPU of a test box (the first SCALE run must not be this code's first run):
+    self_launch starts two ranks through torch.distributed.run, PAPR_BENCH_SHARE_GPU=1 (a test-only override of the visible-GPU check) lets them share
+    cuda:0 over gloo; each rank renders its own patches, PAPR.step() averages the gradient bucket, the ranks' times meet in an all-reduce(MAX), rank 0's
+    line is relayed with the launcher's exit code.  The line must say what ran: two ranks, dp2, twice one rank's rays per step over the slowest rank's time."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--profile-steps", "0", "--no-amp-line", "--no-shipped-line",
+           "--psnr-steps", "0", "--no-cpu-baseline"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PAPR_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "PAPR_DIST_BACKEND"):
+        env.pop(k, None)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                       # ONE line: rank 0's
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["ranks_seen"] == 2 and j["config"]["parallelism"] == "dp2" and j["scaling"] == "weak"
+    assert "test_override" in j and "starting 2 ranks" in r.stderr
+    R = j["config"]["global_batch_rays"] // 2
+    assert R == 25600
+    assert abs(j["value"] - 2 * R * 1e3 / j["ms_per_step"]) <= 1e-6 * j["value"]
+    one = _bench({}, launcher=False)
+    assert one["config"]["global_batch_rays"] == R and j["ms_per_step"] > one["ms_per_step"]       # (two ranks took turns on one GPU: slower per step, as it must be)
+    # the exit code of a failing rank comes back through self_launch (here: a scene file that does not exist), and no line is printed
+    bad = subprocess.run(cmd + ["--scene", "nerfsyn/no_such_scene.yml"], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert bad.returncode != 0 and not [l for l in bad.stdout.splitlines() if l.startswith("{")]
