@@ -47,6 +47,9 @@ def parse():
                     help="h3 (default): split-f16 MFMA everywhere, consecutive layers fused into one launch; layers: the same "
                          "arithmetic, one launch per layer; dgrad: forward + data-gradient only; fwd: forward only; f32: fp32 MFMA everywhere; "
                          "h1: h3 with one f16 product per fp32 product in the fused runs (reduced precision, reported as throughput_mode_h1)")
+    ap.add_argument("--h3-rows", default="f16", choices=["f16", "f32"],
+                    help="gemm mode h3: what a fused run keeps for its weight gradients -- f16 (default since round 6, PAPR_MLP_H3_F16ROWS: forward and data-gradient "
+                         "arithmetic unchanged, every golden bar unchanged) or f32 (PAPR_MLP_H3: rounds 1-5; reported as parity_fp32_rows in the default line)")
     ap.add_argument("--no-amp-line", action="store_true", help="skip the second measurement (throughput_mode_h1: a child process in --gemm-mode h1)")
     ap.add_argument("--cpu-rays", type=int, default=32, help="edge of the CPU-baseline patch (32 -> 1,024 rays)")
     ap.add_argument("--cpu-steps", type=int, default=8)
@@ -174,6 +177,7 @@ def psnr_after_steps(args):
 def main():
     args = parse()
     os.environ["PAPR_GEMM_MODE"] = args.gemm_mode       # read by papr_amd/ops.py (mlp_mode) at every call: the `mode` argument of papr_mlp_fwd / _bwd
+    os.environ["PAPR_H3_ROWS"] = args.h3_rows
     from papr_amd import dist as pdist, get_model, get_loss, hip
     from papr_amd.data import SyntheticRayData
     if args.gpus < 1:
@@ -279,7 +283,7 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     traffic_all = json.load(open(tpath)) if os.path.exists(tpath) else {}
     # (the counter passes were run in the parity mode; the one-product modes move f16 rows: traffic null there)
-    traffic_db = traffic_all if (args.gemm_mode != "h1" and not args.amp) else {}
+    traffic_db = traffic_all if (args.gemm_mode != "h1" and not args.amp and args.h3_rows == traffic_all.get("h3_rows", "f32")) else {}
     dt_prof = max(dt_prof, 1e-9)
 
     def mfma_line(kernel, ids, key):
@@ -409,7 +413,9 @@ def main():
                                          "frac": (world * R * args.steps / dt) * (12.0 * P + 12 + 4 * k) / (world * HBM_PEAK_GBS * 1e9),
                                          "note": "value x (12 P + 12 + 4 k) B / (n_gpus x 8 TB/s): end-to-end train throughput priced in the kNN stage's logical HBM bytes; "
                                                  "the step is bound by the embedding MLPs' matrix work (roofline), not by this stream"},
-        "dtype": ("f32" if args.gemm_mode == "f32" else "f32 (wide GEMMs: operands split into f16 hi+lo, 3 MFMA, fp32 accumulate)")
+        "dtype": ("f32" if args.gemm_mode == "f32" else "f32 (wide GEMMs: operands split into f16 hi+lo, 3 MFMA, fp32 accumulate"
+                  + ("; the rows a fused run keeps for its weight gradients are f16 -- each row's hi plane, one product per weight-gradient term, fp32 accumulate: "
+                     "forward, data gradients and rgb parity untouched, gradient bars of the goldens unchanged, tests/test_hip_chain_variants.py" if args.gemm_mode == "h3" and args.h3_rows == "f16" and not args.amp else "") + ")")
                  + ("; use_amp: embedding MLPs one f16 product per fp32 product (PAPR_MLP_H1), GradScaler on, U-Net on the own split-f16 kernels" if args.amp else ""), "data": "synthetic",
         "config": {"workload": "configs/" + args.scene + ": P=%d points, one %dx%d patch (R=%d rays) per rank per step, k=%d, "
                                "U-Net head, MSE loss (LPIPS weight 0: VGG weights unavailable offline), use_amp=%s; "
@@ -449,7 +455,15 @@ def main():
     def chain_of(j):
         return j.get("roofline") if "mlp_chain" in (j.get("roofline") or {}).get("kernel", "") else j.get("roofline_mlp_chain")
 
-    main_line = world == 1 and args.gemm_mode == "h3" and not args.amp
+    main_line = world == 1 and args.gemm_mode == "h3" and not args.amp and args.h3_rows == "f16"
+    if main_line and not args.no_shipped_line:
+        j = child_line(["--h3-rows", "f32"])
+        out["parity_fp32_rows"] = j if "error" in j else {
+            "value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "final_loss": j["config"]["final_loss"], "roofline_mlp_chain": chain_of(j),
+            "note": "PAPR_H3_ROWS=f32 (mode PAPR_MLP_H3): fp32 rows between a fused run and its weight gradients, three f16 products per weight-gradient term -- the "
+                    "default of rounds 1-5.  The headline keeps f16 rows there (PAPR_MLP_H3_F16ROWS): same forward / data-gradient bits, same golden bars "
+                    "(G7 gradients, 3-step trajectory, G15 360 steps), 21,500-step PSNR 24.99 / 28.24 / 28.58 against 24.86 / 27.89 / 28.86 dB over seeds 1-3 "
+                    "(profiles/r06_seed_study/)"}
     if main_line and not args.no_shipped_line:
         # BASELINE configs[1] verbatim: configs/nerfsyn/chair.yml as shipped has use_amp: true
         j = child_line(["--amp"])

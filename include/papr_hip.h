@@ -265,11 +265,15 @@ typedef struct {
  * the library keeps nothing between calls.  A backward call must name the mode of its forward call.
  *   PAPR_MLP_H3      fp32-parity default: wide layers as split-f16 products (hi.hi + hi.lo + lo.hi, fp32 accumulate), runs of layers fused
  *   PAPR_MLP_H1      one f16 product per fp32 product in the fused runs, f16 rows between a run and its weight gradients: the counterpart
- *                    of the reference running its attention block under fp16 autocast (`use_amp: true`, models/attn.py:248)
+ *                    of the reference running its attention block under fp16 autocast (`use_amp: true`, models/attn.py:248).  Since ABI 27 a run
+ *                    carries ONE power-of-two scale per row through all of its layers (chosen from the maximum of the run's input row / top gradient
+ *                    row: [2^6, 2^7), 2^9 of headroom before f16 overflows -- csrc/h3_common.h: one_scale_from_max) instead of one per row and layer;
+ *                    a training call one of whose runs cannot keep f16 rows (skip layers, a middle width that is no multiple of 32) runs in the
+ *                    parity arithmetic as a whole
  *   PAPR_MLP_F32     exact fp32 MFMA everywhere;  PAPR_MLP_FWD / _DGRAD / _LAYERS: A/B steps between F32 and H3 (split-f16 forward only /
  *                    + data-gradient / + weight gradient, one launch per layer)
- *   PAPR_MLP_H1_F32ROWS  H1 with fp32 rows between a run and its weight gradients (ABI 19; before: PAPR_H1_ROWS=f32 in the environment): another
- *                    computation than H1 -- other bits in the weight gradients, inside the same tolerance
+ *   PAPR_MLP_H1_F32ROWS  (ABI 19-26: H1 with fp32 rows between a run and its weight gradients.)  Since ABI 27 the same as PAPR_MLP_H3: what a caller of
+ *                    H1 asks for when it reads a run's inner rows itself (the one-product runs keep f16 rows only)
  *   PAPR_MLP_H3_F16ROWS  (ABI 27; round 6's gated experiment) H3 -- forward and data-gradient bit for bit -- whose fused runs keep the rows their weight
  *                    gradients read as f16 rows (each row's hi plane: the row times a power of two, rounded to f16) instead of fp32 rows: half the bytes
  *                    the runs store and the weight-gradient kernel reads, ONE f16 product per weight-gradient term (fp32 accumulation).  Results of the

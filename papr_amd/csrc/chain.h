@@ -14,7 +14,9 @@ struct ChainLayer {
     long ld_mask;
     unsigned* sign_bits;       // chain_sign_rows(M) x CHAIN_SIGN_WORDS words: forward = written (bit set where the result is > 0), data-gradient = read in place of
                                // mask; or null.  One word per lane and 64-row tile: tile t owns words [512 t, 512 (t + 1)), wave w of the tile words 64 w .. 64 w + 63;
-                               // bit 31 - (16 i + e) of lane (row & 31, h)'s word = column 32 w + 16 h + e of row 32 i + (row & 31) of the tile
+                               // bit 31 - (16 i + e) of lane (row & 31, h)'s word = column 32 w + 16 h + e of row 32 i + (row & 31) of the tile.
+                               // ONE-PRODUCT mode (round 6: the bits come off packed f16 pairs, one instruction per pair): value e = 8 q + 2 j + b of the
+                               // lane's sixteen (q: 16-byte chunk, j: pair, b: half) of row tile i sits at bit (15 - (4 (2 q + i) + j)) + 16 b
     float* C;                  // (M, ldc) result rows, or null when nobody needs them in memory
     long ldc;
     float* rowmax;             // (M) max |.| of every result row, or null
@@ -23,9 +25,11 @@ struct ChainLayer {
     int k1steps;               // = ksteps, or for a skip layer ([previous output | x] as input): the k-steps of the first
                                // segment (a multiple of 4); the remaining ones multiply the run's input rows A0 again
     int act;                   // forward: activation; data-gradient: activation whose derivative is applied
-    int c_half;                // 1 (one_product, not the run's last layer): C receives f16 rows instead of fp32 ones (ldc counts
-                               // halfs) -- the hi plane the next layer multiplies, i.e. each row times the power of two that brings its
-                               // maximum (rowmax, required) into [2^13, 2^14); the weight-gradient kernel reads them back with that scale
+    int c_half;                // 1 (not the run's last layer): C receives f16 rows instead of fp32 ones (ldc counts halfs) -- the hi plane the next
+                               // layer multiplies.  Parity arithmetic (PAPR_MLP_H3_F16ROWS): each row times the power of two that brings ITS maximum
+                               // (rowmax, required) into [2^13, 2^14).  One-product mode: each row times the RUN's scale of that row (h3_common.h:
+                               // one_scale_from_max of the run's input row / top gradient row; rowmax is not written).  The weight-gradient kernel
+                               // reads them back with that scale (gemm.hip: TNH3Args::g_rs / x_rs)
 };
 
 struct ChainArgs {

@@ -527,14 +527,15 @@ int launch_nt(const NTArgs& a, hipStream_t s) {
 //   h1 (PAPR_MLP_H1): h3, and the fused runs (chain4.hip) multiply one f16 product per fp32 product: the throughput mode that stands for
 //   the reference's fp16 autocast of the attention block (models/attn.py:248, `use_amp: true`); own tolerance in the tests.
 static thread_local int t_mode = 4;            // 0 f32, 1 fwd, 2 dgrad, 3 layers, 4 h3, 5 h1
-static thread_local bool t_h1_f32_rows = false;
 static thread_local bool t_h3_f16_rows = false;   // PAPR_MLP_H3_F16ROWS: h3 whose fused runs keep f16 rows for their weight gradients (round 6's gated experiment)
 static inline bool mode_from_arg(int32_t m) {  // false: not a mode of papr_hip.h
-    t_h1_f32_rows = m == PAPR_MLP_H1_F32ROWS;
     t_h3_f16_rows = m == PAPR_MLP_H3_F16ROWS;
     switch (m) { case PAPR_MLP_F32: t_mode = 0; return true; case PAPR_MLP_FWD: t_mode = 1; return true; case PAPR_MLP_DGRAD: t_mode = 2; return true;
                  case PAPR_MLP_LAYERS: t_mode = 3; return true; case PAPR_MLP_H3: case PAPR_MLP_H3_F16ROWS: t_mode = 4; return true;
-                 case PAPR_MLP_H1: case PAPR_MLP_H1_F32ROWS: t_mode = 5; return true; default: return false; }
+                 case PAPR_MLP_H1: t_mode = 5; return true;
+                 // (round 6: the one-product runs carry one scale per row and run and keep f16 rows only; a call that wants fp32 rows between a run and
+                 //  its weight gradients runs in the parity arithmetic)
+                 case PAPR_MLP_H1_F32ROWS: t_mode = 4; return true; default: return false; }
 }
 #define GEMM_MODE t_mode
 #define GEMM_ONE_PRODUCT (t_mode == 5)
@@ -923,12 +924,16 @@ struct TNH3Args {
     long M; long rows_per_slice;
     const float* gmax; const float* xmax;      // per-row max |.| of G and of X
     float* slab; float* bias_slab;
-    int g_half, x_half;                        // (ONE instantiation) the operand is f16 rows, each row scaled by the power of two that
-                                               // scale_from_row_max() makes of its maximum (what the fused-run kernels of the h1 mode
-                                               // store); ldg / ldx then count halfs
+    int g_half, x_half;                        // (ONE instantiation) the operand is f16 rows, each row scaled by the power of two that the fused-run
+                                               // kernel made of the maximum in gmax / xmax; ldg / ldx then count halfs
+    int g_rs, x_rs;                            // which power: 0 = the parity arithmetic's per-layer scale (PAPR_MLP_H3_F16ROWS; h3_scale_from_max), 1 / 2 = the
+                                               // one-product mode's scale per row and RUN, forward / data-gradient clamp (one_scale_from_max): gmax / xmax
+                                               // are then the maxima of the run's top gradient rows / input rows for EVERY layer of the run
 };
-__device__ __forceinline__ float inv_scale_from_row_max(float m) {       // 1 / (the fused-run kernels' row scale), chain4.hip: scale_from_max
+__device__ __forceinline__ float inv_scale_from_row_max(float m, int rs) {       // 1 / (the fused-run kernels' row scale)
     const unsigned bits = __float_as_uint(m);
+    float inv;
+    if (rs) { (void)one_scale_from_max(bits, rs == 2 ? ONE_EMIN_DGRAD : ONE_EMIN_FWD, inv); return inv; }
     const int ea = bits ? (int)((bits >> 23) & 0xff) : 127 + 13;
     return pow2_from_biased(127 - 13 + (ea - 127));
 }
@@ -1070,7 +1075,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_h3_kernel(TNH3Batch batch) {
         for (int r = 0; r < 4; ++r) {
             const long m = mbeg + st * TN_ROWS + 4 * wave + r;
             const bool ok = m < mend;
-            const float ig = gh ? inv_scale_from_row_max(comp4(mg, r)) : 1.f, ix = xh ? inv_scale_from_row_max(comp4(mx, r)) : 1.f;
+            const float ig = gh ? inv_scale_from_row_max(comp4(mg, r), p.g_rs) : 1.f, ix = xh ? inv_scale_from_row_max(comp4(mx, r), p.x_rs) : 1.f;
             sg[r] = ok ? g_scale * ig : 0.f;
             sx[r] = ok ? x_scale * ix : 0.f;
             fg[r] = ok ? ig : 0.f;
@@ -1329,7 +1334,7 @@ struct TNH3Queue {
     hipStream_t s;
     TNH3Queue(void* ws, hipStream_t st) : workspace(ws), s(st) { batch.n = 0; }
     int push(const float* G, long ldg, int N, const float* X, long ldx, int K, long M, const float* gmax, const float* xmax,
-             float* dW, int ldw, float* db, int g_half = 0, int x_half = 0) {
+             float* dW, int ldw, float* db, int g_half = 0, int x_half = 0, int g_rs = 0, int x_rs = 0) {
         PAPR_REQUIRE(N <= SLAB && K <= SLAB, "gemm_tn_h3: N=%d, K=%d exceed %d", N, K, SLAB);
         PAPR_REQUIRE(N % 4 == 0 && K % 4 == 0 && ldg % 4 == 0 && ldx % 4 == 0, "gemm_tn_h3: sizes must be multiples of 4");
         if (M <= 0) return 0;
@@ -1348,7 +1353,7 @@ struct TNH3Queue {
         S = (int)((M + rows_per_slice - 1) / rows_per_slice);
         TNH3Args& a = batch.job[batch.n];
         a.G = G; a.ldg = ldg; a.N = N; a.X = X; a.ldx = ldx; a.K = K; a.M = M; a.rows_per_slice = rows_per_slice;
-        a.gmax = gmax; a.xmax = xmax; a.g_half = g_half; a.x_half = x_half;
+        a.gmax = gmax; a.xmax = xmax; a.g_half = g_half; a.x_half = x_half; a.g_rs = g_rs; a.x_rs = x_rs;
         a.slab = static_cast<float*>(workspace) + (size_t)batch.n * TN_JOB_FLOATS;
         a.bias_slab = a.slab + (size_t)MAX_SLICES * SLAB * SLAB;
         red.job[batch.n] = ReduceJob{a.slab, a.bias_slab, S, N, K, dW, ldw, db};
@@ -1472,15 +1477,29 @@ static bool layer_rowmax_saved(const papr_layer* layers, int n_layers, int i) {
 // copy of the run's input rows the second half of the run's first output buffer; likewise the gradient-row slots of the
 // backward scratch.  Only the run's last output (forward) / the gradient that leaves the run (backward) remain fp32 rows.
 // mode PAPR_MLP_H1_F32ROWS keeps fp32 rows (a different computation: other bits in the weight gradients; A/B).
-#define H1_HALF_ROWS ((!t_h1_f32_rows && one_product_now()) || t_h3_f16_rows)
+#define H1_HALF_ROWS (one_product_now() || t_h3_f16_rows)
 // forward run [b, e) of a training pass stores f16 rows (the backward pass asks the same question)
 static bool run_half_rows(const papr_layer* layers, int n_layers, int b, int e, const int32_t* ld_out, bool training) {
     if (!H1_HALF_ROWS || !training || e - b < 2) return false;
-    for (int l = 0; l < n_layers; ++l) if (layers[l].n_skip > 0) return false;          // (the skip segment's weight gradient reads fp32 rows)
+    for (int l = 0; l < n_layers; ++l) if (layers[l].n_skip > 0) return false;          // (the backward pass cuts its runs at skip layers: the forward run's f16 rows would not line up)
     const int k0pad = (layers[b].n_in + 31) / 32 * 32;
     if (k0pad > ld_out[b]) return false;                                                // the input copy must fit behind outs[b]'s rows
     for (int l = b; l < e - 1; ++l) if (ld_out[l] % 8 || layers[l].n_out % 32) return false;
     return true;
+}
+
+// One-product mode (round 6): its fused runs keep f16 rows only (one scale per row and run: chain4.hip).  A TRAINING call with a run that cannot keep them
+// (skip layers -- the backward pass cuts its runs there --, a middle layer whose width is no multiple of 32, an input copy that does not fit behind the run's
+// first output), and a backward call without the forward pass's saved state, run in the parity arithmetic as a whole -- forward and backward take the same
+// decision from the same arguments.
+static void one_product_or_parity(const papr_layer* layers, int n_layers, const int32_t* ld_out, bool training, bool backward = false) {
+    if (GEMM_ONE_PRODUCT && backward && !training) { t_mode = 4; return; }
+    if (!GEMM_ONE_PRODUCT || !training) return;
+    for (int b = 0; b < n_layers;) {
+        const int e = chain_run_end(layers, n_layers, b, true);
+        if (e - b >= 2) { if (!run_half_rows(layers, n_layers, b, e, ld_out, true)) { t_mode = 4; return; } b = e; }
+        else ++b;
+    }
 }
 
 // pre-split W (N x K, leading dimension ldw) into fragment-order planes at `planes`; returns the halfs used
@@ -1527,6 +1546,7 @@ extern "C" int papr_mlp_fwd(const papr_layer* layers, int n_layers, float* x, in
                             const papr_row_norm* out_norm, void* workspace, int32_t mode, papr_stream_t stream) {
     PAPR_REQUIRE(mode_from_arg(mode), "papr_mlp_fwd: unknown mode %d", mode);
     PAPR_REQUIRE(layers && x && outs && ld_out && n_layers >= 1, "papr_mlp_fwd: bad arguments");
+    one_product_or_parity(layers, n_layers, ld_out, row_absmax != nullptr);
     hipStream_t s = as_stream(stream);
     bool have_amax = false;                 // split-f16 mode: row maxima of the current layer's input are in h3.in()
     bool norm_done = false;
@@ -1557,7 +1577,7 @@ extern "C" int papr_mlp_fwd(const papr_layer* layers, int n_layers, float* x, in
                 c.in_norm_width = in_norm->width; c.in_norm_eps = in_norm->eps; c.in_norm_stats = in_norm->stats;
                 c.in_norm_mean = in_norm->given_mean;
                 c.in_norm_writeback = (row_absmax != nullptr || run_has_skip || e < n_layers) ? 1 : 0;
-                if (c.in_norm_mean == nullptr && !(!GEMM_ONE_PRODUCT && papr_switch(PAPR_SW_C4_DMA))) {
+                if (c.in_norm_mean == nullptr && !(!GEMM_ONE_PRODUCT && !t_h3_f16_rows && papr_switch(PAPR_SW_C4_DMA))) {
                     // nobody gave the statistics: one pass over the rows takes them (the run applies them while it stages the rows); the means go
                     // to the head of the scratch the split-ahead experiment would use
                     float* means = reinterpret_cast<float*>(static_cast<char*>(workspace) + H3Scratch::bytes(M));
@@ -1568,7 +1588,7 @@ extern "C" int papr_mlp_fwd(const papr_layer* layers, int n_layers, float* x, in
             c.rowmax0 = saved ? saved + (size_t)i * M : nullptr;
             c.M = M; c.n_layers = e - i;
             c.one_product = GEMM_ONE_PRODUCT ? 1 : 0;
-            if (!GEMM_ONE_PRODUCT && papr_switch(PAPR_SW_C4_DMA) && c.in_norm_mean == nullptr) {
+            if (!GEMM_ONE_PRODUCT && !t_h3_f16_rows && papr_switch(PAPR_SW_C4_DMA) && c.in_norm_mean == nullptr) {
                 // the run's input rows split ahead of it: the run stages its tiles by LDS-DMA (chain.h: sr_*)
                 SRScratch sr(static_cast<char*>(workspace) + H3Scratch::bytes(M), M);
                 SplitRowsArgs q = {};
@@ -1697,6 +1717,7 @@ extern "C" int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float*
     PAPR_REQUIRE(layers && x && outs && ld_out && d_out && d_weight && d_bias && workspace && n_layers >= 1,
                  "papr_mlp_bwd: bad arguments");
     PAPR_REQUIRE(n_layers == 1 || (scratch0 && scratch1), "papr_mlp_bwd: scratch buffers required");
+    one_product_or_parity(layers, n_layers, ld_out, row_absmax != nullptr, true);
     hipStream_t s = as_stream(stream);
     bool any_skip = false;
     for (int i = 0; i < n_layers; ++i) any_skip |= layers[i].n_skip > 0;
@@ -1733,7 +1754,12 @@ extern "C" int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float*
         }
     }
     TNH3Queue tnq(workspace, s);             // split-f16 weight-gradients collect here; the fp32 kernel shares the workspace, so flush before it
-    auto wgrad = [&](int i, const float* gi, long ldgi, const float* gmax_i, int g_half = 0, int x_half = 0, const float* x_rows = nullptr, long ld_x_rows = 0) -> int {
+    auto wgrad = [&](int i, const float* gi, long ldgi, const float* gmax_i, int g_half = 0, int x_half = 0, const float* x_rows = nullptr, long ld_x_rows = 0,
+                     const float* xmax_run = nullptr) -> int {
+        // (one-product mode, f16 rows: ONE scale per row and run -- the row maxima that stand for it are the run's top gradient rows' (gmax_i: the caller
+        //  passes that table for every layer) and the run's input rows' (xmax_run))
+        const int g_rs = g_half && GEMM_ONE_PRODUCT ? 2 : 0, x_rs = x_half && GEMM_ONE_PRODUCT ? 1 : 0;
+        const float* const xmax_i = xmax_run ? xmax_run : row_absmax + (size_t)i * M;
         const papr_layer& L = layers[i];
         const float* in = x_half ? x_rows : (i == 0 ? x : outs[i - 1]);
         const long ld_in = x_half ? ld_x_rows : (i == 0 ? ldx : ld_out[i - 1]);
@@ -1750,7 +1776,7 @@ extern "C" int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float*
                 float* db = (k0 == 0 && d_bias[i]) ? d_bias[i] + n0 : nullptr;
                 if (h3w) {
                     PAPR_REQUIRE((!g_half && !x_half) || (n0 == 0 && k0 == 0 && nb == L.n_out && kb == L.n_in), "papr_mlp_bwd: layer %d: f16 rows of a blocked weight-gradient", i);
-                    if (int e = tnq.push(gi + n0, ldgi, nb, in + k0, ld_in, kb, M, gmax_i, row_absmax + (size_t)i * M, dw, L.ldw, db, g_half, x_half)) return e;
+                    if (int e = tnq.push(gi + n0, ldgi, nb, in + k0, ld_in, kb, M, gmax_i, xmax_i, dw, L.ldw, db, g_half, x_half, g_rs, x_rs)) return e;
                 } else {
                     PAPR_REQUIRE(!g_half && !x_half, "papr_mlp_bwd: layer %d: f16 rows without the split-f16 weight-gradient", i);
                     if (int e = tnq.flush()) return e;
@@ -1761,8 +1787,9 @@ extern "C" int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float*
             // the skip segment [previous output | x]: dW[:, skip_col ..) = G^T x -- split-f16 like the first segment when the forward
             // run left the maxima of the x rows (row_absmax[0 .. M): a fused run that starts at layer 0), fp32 MFMA otherwise
             if (h3w && L.n_skip <= SLAB && layer_rowmax_saved(layers, n_layers, 0)) {
-                if (int e = tnq.push(gi, ldgi, L.n_out, x, ldx, L.n_skip, M, gmax_i, row_absmax, d_weight[i] + L.skip_col, L.ldw, nullptr)) return e;
+                if (int e = tnq.push(gi, ldgi, L.n_out, x, ldx, L.n_skip, M, gmax_i, row_absmax, d_weight[i] + L.skip_col, L.ldw, nullptr, g_half, 0, g_rs, 0)) return e;
             } else {
+                PAPR_REQUIRE(!g_half, "papr_mlp_bwd: layer %d: f16 gradient rows and a skip segment without the split-f16 weight gradient", i);
                 if (int e = tnq.flush()) return e;
                 if (int e = gemm_tn(gi, ldgi, L.n_out, x, ldx, L.n_skip, M, d_weight[i] + L.skip_col, L.ldw, nullptr, workspace, s)) return e;
             }
@@ -1779,7 +1806,8 @@ extern "C" int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float*
             ChainArgs c = {};
             c.A0 = g; c.lda0 = ldg; c.K0 = L.n_out; c.rowmax0 = runs.gmax[CHAIN_MAX_LAYERS];
             c.M = M; c.one_product = GEMM_ONE_PRODUCT ? 1 : 0;
-            const bool split_ahead = !GEMM_ONE_PRODUCT && papr_switch(PAPR_SW_C4_DMA) != 0;       // (the kernel is launched below, once the run's width is known to be its own)
+            const bool split_ahead = !GEMM_ONE_PRODUCT && !t_h3_f16_rows && papr_switch(PAPR_SW_C4_DMA) != 0;       // (the kernel is launched below, once the run's width is known to be its own;
+                                                                                                                  //  with f16 rows the staging also makes the top rows' f16 copy: not by DMA)
             // h1 mode: f16 rows (see run_half_rows).  x_half: what the forward run stored; g_half: this launch, if it has a layer
             // that is not its last (the copy of the top gradient rows goes behind that layer's rows)
             const bool x_half = run_half_rows(layers, n_layers, b, i + 1, ld_out, row_absmax != nullptr);
@@ -1840,13 +1868,15 @@ extern "C" int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float*
                 const float* xin = nullptr; long ldxin = 0;
                 if (g_half && l == i) { gl = reinterpret_cast<const float*>(c.a0_half); ldl = G_LD; gh = 1; }
                 else if (g_half && l >= last) gh = 1;
+                // (one-product mode: the f16 gradient rows of a run all carry the scale of the run's TOP rows -- their maxima stand for it, chain.h: c_half)
+                if (gh && GEMM_ONE_PRODUCT) gm = runs.gmax[CHAIN_MAX_LAYERS];
                 if (x_half && gh) {                  // (a layer whose gradient rows are fp32 -- layer 0 when the launch stops above it -- reads its fp32 input)
                     xh = 1;
                     if (l == b && !GEMM_ONE_PRODUCT) xh = 0;      // (PAPR_MLP_H3_F16ROWS: the run's input rows have no f16 copy -- G f16, X fp32, gemm_tn_h3_kernel<., 3>)
                     else if (l == b) { xin = reinterpret_cast<const float*>(reinterpret_cast<const _Float16*>(outs[b]) + (size_t)M * ld_out[b]); ldxin = ld_out[b]; }
                     else { xin = outs[l - 1]; ldxin = ld_out[l - 1]; }
                 }
-                if (int err = wgrad(l, gl, ldl, gm, gh, xh, xin, ldxin)) return err;
+                if (int err = wgrad(l, gl, ldl, gm, gh, xh, xin, ldxin, (xh && GEMM_ONE_PRODUCT) ? row_absmax + (size_t)b * M : nullptr)) return err;
             }
             if (int err = tnq.flush()) return err;               // (the next run reuses the gradient-row slots)
             if (b == 0 && d_x && !to_dx) {                       // d_x accumulates (a skip layer wrote into it): separate launch

@@ -27,6 +27,23 @@ __device__ __forceinline__ float h3_scale_from_max(unsigned bits, float& inv) {
     return pow2_from_biased(127 + 13 - (ea - 127));
 }
 
+// One-product mode (round 6): ONE power-of-two scale per row and RUN of layers, chosen from the maximum of the run's input row (forward) or of its
+// top gradient row (data-gradient) and carried through every layer of the run in the "scaled domain" (accumulators, biases times the scale, f16 rows
+// all hold value x scale); only what leaves the run is multiplied by 1 / scale.  The scale brings the row maximum into [2^6, 2^7): 2^9 of headroom
+// above it for the layers' activations / gradients before f16 overflows, full f16 precision down to 2^-20 of it.  The maximum's exponent is clamped
+// from below (biased exponent `emin`): forward rows whose maximum is below 1 are scaled as if it were 1 -- the biases ride in the same scaled
+// domain --, gradient rows down to 2^-40.  The weight-gradient kernel turns the same maximum into the same power of two (gemm.hip).
+#ifndef ONE_TARGET_E_V
+#define ONE_TARGET_E_V 6                       // (probe builds: another target exponent, scripts/probes)
+#endif
+constexpr int ONE_TARGET_E = ONE_TARGET_E_V, ONE_EMIN_FWD = 127, ONE_EMIN_DGRAD = 87;
+__device__ __forceinline__ float one_scale_from_max(unsigned bits, int emin, float& inv) {
+    int ea = (int)((bits >> 23) & 0xff);
+    ea = ea < emin ? emin : ea;
+    inv = pow2_from_biased(ea - ONE_TARGET_E);
+    return pow2_from_biased(254 + ONE_TARGET_E - ea);
+}
+
 // hi = f16(v * s), lo = f16(v * s - hi) for four values; s is a power of two, so v * s is exact and the fused forms
 // below round exactly like the multiply / convert / convert back / subtract / convert sequence they replace:
 // v_fma_mixlo/hi_f16 write one half of a register from an fp32 fma, and take the f16 hi as an operand: 8 instructions

@@ -26,9 +26,13 @@ def mlp_mode(one_product, fp32_rows_inside=False):
     name = os.environ.get("PAPR_GEMM_MODE", "h3")
     if name == "h3" and one_product:
         name = "h1"
+    # round 6: the parity mode's fused runs keep the rows their weight gradients read as f16 rows (PAPR_MLP_H3_F16ROWS: forward and data-gradient
+    # bit for bit those of PAPR_MLP_H3, every golden bar unchanged, 10.4 -> 8.9 ms per step).  PAPR_H3_ROWS=f32: fp32 rows (A/B)
+    if name == "h3" and not fp32_rows_inside and os.environ.get("PAPR_H3_ROWS", "f16") != "f32":
+        name = "h3_f16rows"
     if name == "h1" and (os.environ.get("PAPR_H1_ROWS", "") == "f32" or fp32_rows_inside):      # (A/B: fp32 rows between a run and its weight gradients;
         name = "h1_f32rows"                                                                       # fp32_rows_inside: a run whose INNER rows the host reads)
-    if name == "h3_f16rows" and fp32_rows_inside:       # (the same for round 6's f16-rows form of the parity mode: such a run keeps fp32 rows)
+    if name == "h3_f16rows" and fp32_rows_inside:       # (named explicitly: a run whose inner rows the host reads keeps fp32 rows all the same)
         name = "h3"
     return hip.MLP_MODES[name]
 

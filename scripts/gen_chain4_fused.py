@@ -389,6 +389,95 @@ def p2_stream(acc_u, mode, one=False, hrows=False):
     return it
 
 
+SC_DELTA = 20992          # LDS bytes from a tile's 1 / scale table to its scale table (chain4.hip: C4_OFF_XMAX - C4_OFF_INV; static_assert there)
+
+
+def sign_pos(c, j, h):
+    """bit of chain.h's one-product sign word that holds value (chunk c = 2 q + i, pair j, half h) of a lane: the word collects one packed register
+    per step, t = 4 c + j = 0 .. 15, `word = (word << 1) | (bits 0 and 16 of the step's register)`"""
+    return (15 - (4 * c + j)) + 16 * h
+
+
+def p_stream_one(acc_u, mode, act):
+    """The row phase of the one-product mode (round 6): ONE stream, no barrier.  The run carries one power-of-two scale per ROW (chosen when the tile's
+    input rows are staged: chain4.hip, one_scale_from_max) through all of its layers, so a middle layer's row phase never needs the row's maximum:
+      forward   y s = acc + s b  (acc = s x W^T: one fma per value), packed pairs to f16 (v_cvt_pk_f16_f32, RTNE), ReLU on the f16 bit patterns
+                (v_pk_max_i16 with 0: +0 for everything with the sign bit), sign bits from the packed halfs (v_pk_min_u16 with 1: one instruction
+                per PAIR, in place behind the LDS write), hi plane = the next layer's operand = the f16 row the weight gradient reads;
+      data-gradient  (g s) masked by the sign word in fp32, then the same conversion.
+    96 / 80 vector instructions per statement against 220 / 184 of the per-layer-scale form it replaces, and the eight waves of the workgroup meet only at
+    the end of the slot."""
+    it = []
+    SC = ["v45", "v47"]
+    B = G[0:8]
+    HS = [G[8:12], G[12:16]]
+    fwd = mode != "dgrad"
+    train = mode != "inf"
+    T, T2 = G[0], G[1]                          # (data-gradient: no biases)
+    if fwd:
+        it.append(Item("ds_read_b32 %s, %%[invad] offset:%d" % (SC[0], SC_DELTA), lds=("sc", 0), kind="lds"))
+        it.append(Item("ds_read_b32 %s, %%[invad] offset:%d" % (SC[1], SC_DELTA + 128), lds=("sc", 1), kind="lds"))
+
+    def signs(c):
+        H = HS[c & 1]
+        out = []
+        for j in range(4):
+            if act == "relu":
+                out.append(Item("v_pk_min_u16 %s, %s, %%[k11]" % (H[j], H[j])))      # (k11 = 0x00010001 in a scalar register: an inline 1 reaches the low half only)
+            else:
+                out += [Item("v_pk_min_i16 %s, %s, %%[k11]" % (H[j], H[j])), Item("v_pk_max_i16 %s, %s, 0" % (H[j], H[j]))]
+            out.append(Item("v_lshl_or_b32 %%[word], %%[word], 1, %s" % H[j]))
+        return out
+
+    for q in range(2):
+        if fwd:
+            for gg in range(2):
+                it.append(Item("ds_read_b128 %s, %%[biasad] offset:%d" % (vt(GB + 4 * gg, 4), 32 * q + 16 * gg), lds=("b", q, gg), kind="lds"))
+        for i in range(2):
+            c = 2 * q + i
+            H = HS[c & 1]
+            regs = ["v%d" % (acc_u + 16 * i + 8 * q + e) for e in range(8)]
+            for e in range(8):
+                a = regs[e]
+                if fwd:
+                    it.append(Item("v_fma_f32 %s, %s, %s, %s" % (a, B[e], SC[i], a), need=[("sc", i), ("b", q, e // 4)]))
+                    if act != "relu":
+                        it.append(Item("v_fma_f32 %s, %s, %%[slope], 0" % (H[e // 2], a)))
+                        it.append(Item("v_max_f32 %s, %s, %s" % (a, a, H[e // 2])))
+                else:
+                    it.append(Item("v_bfe_i32 %s, %%[word], %d, 1" % (T, sign_pos(c, e // 2, e & 1))))
+                    if act == "relu":
+                        it.append(Item("v_and_b32 %s, %s, %s" % (a, a, T)))
+                    else:
+                        it.append(Item("v_mul_f32 %s, %%[slope], %s" % (T2, a)))
+                        it.append(Item("v_bfi_b32 %s, %s, %s, %s" % (a, T, a, T2)))
+            for j in range(4):
+                it.append(Item("v_cvt_pk_f16_f32 %s, %s, %s" % (H[j], regs[2 * j], regs[2 * j + 1])))
+            if fwd and act == "relu":
+                for j in range(4):
+                    it.append(Item("v_pk_max_i16 %s, %s, 0" % (H[j], H[j])))
+            it.append(Item("ds_write_b128 %s, %s offset:%d" % ("%[plw2]" if q else "%[plw]", vt(int(H[0][1:]), 4), 32768 * i), lds=("plh", i, q), kind="lds"))
+            if mode == "fwd" and c > 0:        # the sign bits of the chunk BEFORE, in place in its registers (its LDS write is long gone)
+                it += signs(c - 1)
+    if mode == "fwd":
+        it += [Item("s_nop 1", kind="salu")] + signs(3)
+        it += [Item("v_lshrrev_b32 %s, 2, %%[wv]" % SC[1]), Item("global_store_dword %s, %%[word], %%[sgn]" % SC[1], kind="vmem")]
+    if train:
+        # the f16 rows the weight gradient reads (ChainLayer::c_half) ARE the hi plane's bytes: read back sixteen rows per instruction (four lanes per
+        # row's 64 bytes of this wave's columns), stored
+        AD1 = SC[0]
+        R = [vt(GB + 4 * sx, 4) for sx in range(4)]       # (every temporary is free by now: the four reads go out together, the stores follow as the rows arrive)
+        for sx in range(4):
+            src = "%[rdb]"
+            if sx:
+                it.append(Item("v_xor_b32 %s, 0x%x, %%[rdb]" % (AD1, 528 * sx)))
+                src = AD1
+            it.append(Item("ds_read_b128 %s, %s" % (R[sx], src), lds=("rb", sx), kind="lds"))
+        for sx in range(4):
+            it.append(Item("global_store_dwordx4 %%[gso], %s, %%[crow0] offset:%d%s" % (R[sx], 512 * sx, STMOD), need=[("rb", sx)], kind="vmem"))
+    return it
+
+
 class Emit:
     def __init__(self):
         self.lines, self.queue, self.retired = [], [], 0
@@ -413,6 +502,8 @@ def build(tile, mode, act, ld, kcnt=16, one=False, hrows=False):
     acc_t, acc_u = (ACC["X"], ACC["Y"]) if tile == "X" else (ACC["Y"], ACC["X"])
     pro, steps = k_stream_one(acc_t, ld, kcnt) if one else (k_stream_exp(acc_t, ld, kcnt) if (KVAR and kcnt == 16) else k_stream(acc_t, ld, kcnt))
     NM = len(steps)                             # matrix instructions of the statement
+    if one:
+        return build_one(pro, steps, p_stream_one(acc_u, mode, act))
     p1, p2 = p1_stream(acc_u, mode, act), p2_stream(acc_u, mode, one, hrows)
     if ABLATE == "K":                           # (timing experiment, results wrong: the k-loop alone)
         p1, p2 = [], []
@@ -464,6 +555,31 @@ def build(tile, mode, act, ld, kcnt=16, one=False, hrows=False):
     return e.lines
 
 
+def build_one(pro, steps, p):
+    """one-product statement: the k-loop's matrix instructions with the row phase's single stream spread evenly behind them"""
+    NM = len(steps)
+    if ABLATE == "K":
+        p = []
+    e = Emit()
+    for x in pro:
+        e.put(x)
+    head = 4
+    for x in p[:head]:                          # the row phase's first LDS reads ride in front of the first MFMA
+        e.put(x)
+    p = p[head:]
+    for m, (mf, post) in enumerate(steps):
+        e.put(mf)
+        for x in post:
+            e.put(x)
+        take = -(-len(p) // (NM - m))
+        for x in p[:take]:
+            e.put(x)
+        p = p[take:]
+    assert not p
+    e.lines += ["s_nop 15", "s_nop 7"]          # the last results leave the matrix pipe 16 passes after issue
+    return e.lines
+
+
 def build_pair(mode, act, one=False, hrows=False):
     """TWO hot slots in one statement: slot (tile X, step i) and slot (tile Y, step i) -- the two k-loops of a step, the row phases of Y's step i - 1
     and X's step i beside them.  Between two statements every wave spends ~1.7k cycles in compiled C++ (which slot is next, its descriptors, ~40
@@ -483,6 +599,8 @@ def build_pair(mode, act, one=False, hrows=False):
            "v_add_u32 %[stw], 0xffff0000, %[stw]", "v_add_u32 %[rdb], 0xffff0000, %[rdb]", "v_add_u32 %[plw], 0xffff0000, %[plw]",      # U: tile Y -> tile X
            "v_add_u32 %[invad], 0xffffff00, %[invad]",  # U's 1 / scale table (and, through the instructions' offsets, its partial maxima)
            "v_add_u32 %[biasad], %[dbias], %[biasad]"]  # the biases of the layer X has just multiplied
+    if one:
+        mid.append("v_add_u32 %[plw2], 0xffff0000, %[plw2]")
     if mode == "fwd":
         mid.append("v_mov_b32 %[word], 0")
     if mode == "dgrad":                         # the second half's sign word (tile X's, of the layer it has just multiplied) is a second operand

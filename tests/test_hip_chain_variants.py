@@ -21,17 +21,20 @@ import torch
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-VARIANTS = [("generic rows", {"PAPR_C4_GENERIC": "1"}), ("two-role", {"PAPR_C4_FUSED": "0"}), ("fused", {}), ("fused again", {}),
+# (PAPR_H3_ROWS=f32: the parity mode with fp32 rows between a run and its weight gradients, PAPR_MLP_H3 -- the default since round 6 keeps f16 rows, whose
+#  forms are compared by test_f16_rows_mode_is_h3_but_for_the_weight_gradients below)
+F32 = {"PAPR_H3_ROWS": "f32"}
+VARIANTS = [("generic rows", dict(F32, PAPR_C4_GENERIC="1")), ("two-role", dict(F32, PAPR_C4_FUSED="0")), ("fused", dict(F32)), ("fused again", dict(F32)),
             # every hot slot its own statement (the default runs tile Y's step and tile X's next step of a forward run as ONE statement)
-            ("fused, single slots", {"PAPR_C4_PAIRS": "0"}),
+            ("fused, single slots", dict(F32, PAPR_C4_PAIRS="0")),
             # the run takes its input rows split ahead of it (split_rows_kernel) through LDS-DMA instead of splitting them itself while it stages
             # them (registers + vector instructions): the same arithmetic, instruction for instruction
-            ("rows split ahead", {"PAPR_C4_DMA": "1"}), ("rows split ahead, generic rows", {"PAPR_C4_DMA": "1", "PAPR_C4_GENERIC": "1"})]
+            ("rows split ahead", dict(F32, PAPR_C4_DMA="1")), ("rows split ahead, generic rows", dict(F32, PAPR_C4_DMA="1", PAPR_C4_GENERIC="1"))]
 
 
 def _run(tmp_path, name, env, M, n, act, dims=()):
     out = tmp_path / (name.replace(" ", "_") + ".pt")
-    e = {k: v for k, v in os.environ.items() if k not in ("PAPR_C4_GENERIC", "PAPR_C4_FUSED", "PAPR_GEMM_MODE", "PAPR_C4_DMA", "PAPR_C4_PAIRS")}
+    e = {k: v for k, v in os.environ.items() if k not in ("PAPR_C4_GENERIC", "PAPR_C4_FUSED", "PAPR_GEMM_MODE", "PAPR_C4_DMA", "PAPR_C4_PAIRS", "PAPR_H3_ROWS")}
     e.update(env)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "chain_variants_worker.py"), str(out), str(M), str(n), act] + [str(v) for v in dims], env=e, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (name, r.stderr[-2000:])
@@ -78,7 +81,7 @@ def test_one_product_mode_forms_agree_bit_for_bit(tmp_path):
             assert torch.equal(a, b), "%s: %s differs in %d of %d elements" % (name, k, int((a != b).sum()), a.numel())
 
 
-F16ROWS_VARIANTS = [("h3_f16rows generic rows", {"PAPR_C4_GENERIC": "1", "PAPR_GEMM_MODE": "h3_f16rows"}), ("h3_f16rows", {"PAPR_GEMM_MODE": "h3_f16rows"}),
+F16ROWS_VARIANTS = [("h3_f16rows generic rows", {"PAPR_C4_GENERIC": "1", "PAPR_GEMM_MODE": "h3_f16rows"}), ("h3_f16rows", {}),      # ({}: the default IS this mode)
                     ("h3_f16rows again", {"PAPR_GEMM_MODE": "h3_f16rows"}), ("h3_f16rows single slots", {"PAPR_GEMM_MODE": "h3_f16rows", "PAPR_C4_PAIRS": "0"}),
                     ("h3_f16rows two-role", {"PAPR_GEMM_MODE": "h3_f16rows", "PAPR_C4_FUSED": "0"})]
 
@@ -89,7 +92,7 @@ def test_f16_rows_mode_is_h3_but_for_the_weight_gradients(tmp_path, M, n, act, d
     bit for bit; against the default mode the run's result, the inference pass and the input gradient are IDENTICAL (the forward and data-gradient
     arithmetic is untouched), weight and bias gradients carry the f16 rounding of their operands' rows: the measured distance is printed, the bar is the
     one the default mode's gradients are held to against the reference (rms within 1.5e-4 of the tensor's largest element, tests/conftest.py)."""
-    base = _run(tmp_path, "h3", {}, M, n, act, dims)
+    base = _run(tmp_path, "h3", dict(F32), M, n, act, dims)
     ref = None
     for name, env in F16ROWS_VARIANTS:
         res = _run(tmp_path, name, env, M, n, act, dims)

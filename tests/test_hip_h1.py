@@ -2,8 +2,9 @@
 
 The reference's counterpart is `use_amp: true`: ProximityAttention.forward under fp16 autocast (models/attn.py:248), whose Linear
 layers multiply fp16 operands -- 11-bit mantissas, ~1e-3 relative per product.  h1 keeps fp32 accumulation and fp32 rows where a run
-of layers begins and ends, multiplies ONE f16 product per fp32 product with the power-of-two row scales of the parity mode
-(chain4.hip, ONE), and leaves the rows its weight gradients read as f16 (the hi planes it multiplied; PAPR_H1_ROWS=f32: fp32 rows).
+of layers begins and ends, multiplies ONE f16 product per fp32 product with one power-of-two scale per row and run (round 6; chain4.hip, ONE;
+no GradScaler needed: the gradient rows get their scale from their own maxima), and leaves the rows its weight gradients read as f16 (the
+planes it multiplied; PAPR_H1_ROWS=f32: such calls run in the parity arithmetic since round 6).
 Its bar, stated here (measured: 1.3e-4 / 1.7e-3): RGB / fused features within 2e-3 of the fp32 reference's (values of order 1), the
 loss within 1 %, every gradient tensor finite with an rms error below 1 % of the tensor's largest reference entry.  The parity
 mode's own bars (1e-4 / 2e-4) are in tests/test_hip_model.py; bench.py reports this mode as a second line, never as `value`."""
@@ -26,8 +27,9 @@ def _run(tag, out, **extra):
 
 
 def test_h1_f16_rows_and_fp32_rows_both_meet_the_bar_and_differ(tmp_path):
-    """The rows between a fused run and its weight gradients: f16 (default) and fp32 (PAPR_H1_ROWS=f32) are two computations -- different
-    bits in the weight gradients -- that both stay inside the mode's tolerance, with the generic row phases (PAPR_C4_GENERIC=1) as well."""
+    """The one-product runs with their f16 rows (default) and the parity arithmetic the same calls take under PAPR_H1_ROWS=f32 (mode
+    PAPR_MLP_H1_F32ROWS) are two computations -- different bits in the weight gradients -- that both stay inside the mode's tolerance, with the
+    generic row phases (PAPR_C4_GENERIC=1) as well."""
     half = _run("chair1k", tmp_path / "a.json")
     full = _run("chair1k", tmp_path / "b.json", PAPR_H1_ROWS="f32")
     half2 = _run("chair1k", tmp_path / "c.json", PAPR_C4_GENERIC="1")
