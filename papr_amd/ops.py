@@ -871,8 +871,9 @@ class RenderPath:
         # the embedding MLPs multiply ONE f16 product per fp32 product and keep f16 rows for their weight gradients (the library's
         # h1 arithmetic; tolerance in tests/test_hip_h1.py).  PAPR_AMP_MLP=fp32 keeps the parity arithmetic under use_amp.
         self.amp_mlp = bool(cfg.get("use_amp", False)) and os.environ.get("PAPR_AMP_MLP", "h1") == "h1"
-        for spec in (self.key, self.qry, self.val):
-            spec.one_product = self.amp_mlp
+        only = os.environ.get("PAPR_AMP_MLP_ONLY", "key,query,value").split(",")      # (A/B of scripts/probes: which of the three take the one-product arithmetic)
+        for spec, name in ((self.key, "key"), (self.qry, "query"), (self.val, "value")):
+            spec.one_product = self.amp_mlp and name in only
 
     # -------------------------------------------------------------------------------------------
     def feature_desc(self, k):

@@ -69,11 +69,12 @@ def test_fused_run_kernels_agree_bit_for_bit(tmp_path, M, n, act, dims):
             assert same, "%s: %s differs from the generic form in %d of %d elements (max |diff| %g)" % (name, k, int((a != b).sum()), a.numel(), float((a - b).abs().max()))
 
 
-def test_one_product_mode_forms_agree_bit_for_bit(tmp_path):
+@pytest.mark.parametrize("M,n,act,dims", [(40000, 5, "relu", ()), (30053, 4, "leakyrelu", (141, 32))])
+def test_one_product_mode_forms_agree_bit_for_bit(tmp_path, M, n, act, dims):
     """The same for the reduced-precision mode (PAPR_GEMM_MODE=h1: two-role slots; hot and generic row phases)."""
     ref = None
     for name, env in H1_VARIANTS:
-        res = _run(tmp_path, name, env, 40000, 5, "relu")
+        res = _run(tmp_path, name, env, M, n, act, dims)
         if ref is None:
             ref = res
             continue
