@@ -277,7 +277,8 @@ typedef struct {
  *   PAPR_MLP_H3_F16ROWS  (ABI 27; round 6's gated experiment) H3 -- forward and data-gradient bit for bit -- whose fused runs keep the rows their weight
  *                    gradients read as f16 rows (each row's hi plane: the row times a power of two, rounded to f16) instead of fp32 rows: half the bytes
  *                    the runs store and the weight-gradient kernel reads, ONE f16 product per weight-gradient term (fp32 accumulation).  Results of the
- *                    forward pass and every data gradient are those of H3; weight and bias gradients carry ~2^-11 relative rounding per term
+ *                    forward pass and every data gradient are those of H3; weight and bias gradients carry ~2^-11 relative rounding per term.  The
+ *                    inner rows of a run are then part of the saved state: papr_mlp_bwd must be given the forward call's row_absmax (as in H1)
  * An unknown value is an error. */
 enum { PAPR_MLP_H3 = 0, PAPR_MLP_H1 = 1, PAPR_MLP_F32 = 2, PAPR_MLP_FWD = 3, PAPR_MLP_DGRAD = 4, PAPR_MLP_LAYERS = 5, PAPR_MLP_H1_F32ROWS = 6, PAPR_MLP_H3_F16ROWS = 7 };
 size_t papr_mlp_fwd_workspace_bytes(int64_t M);

@@ -546,8 +546,10 @@ def test_mlp_forward_backward_vs_torch(M, d_in, width, d_out, n, act, skips, row
     for i in range(n):
         if wtol is None:
             for got, ref, nm in ((wd[i].grad, ws[i].grad, "dW%d" % i), (bd[i].grad, bs[i].grad, "db%d" % i)):
+                # (one f16 rounding per operand element, 2^-11 relative: with a few hundred rows nothing averages -- 1e-3 rms of the tensor's maximum here; the
+                #  model-level goldens hold the same gradients to 1.5e-4, tests/test_hip_model.py, unchanged)
                 e = (got.cpu() - ref).abs() / (ref.abs().max().item() + 1e-12)
-                assert e.pow(2).mean().sqrt().item() <= 1.5e-4 and e.max().item() <= 2e-3, (nm, e.pow(2).mean().sqrt().item(), e.max().item())
+                assert e.pow(2).mean().sqrt().item() <= 1e-3 and e.max().item() <= 4e-3, (nm, e.pow(2).mean().sqrt().item(), e.max().item())
             continue
         sw = ws[i].grad.abs().max().item() + 1e-12
         np.testing.assert_allclose(wd[i].grad.cpu().numpy(), ws[i].grad.numpy(), rtol=0, atol=wtol * sw, err_msg="dW%d" % i)
@@ -556,7 +558,10 @@ def test_mlp_forward_backward_vs_torch(M, d_in, width, d_out, n, act, skips, row
     sx = x.grad.abs().max().item()
     np.testing.assert_allclose(d_x.cpu()[:, :d_in].numpy(), x.grad.numpy(), rtol=0, atol=3e-5 * sx)
     # without the state of the forward call (row maxima, sign words) the backward pass takes its other route -- fp32
-    # activation rows as masks, fp32 MFMA weight-gradients -- and must land on the same gradients
+    # activation rows as masks, fp32 MFMA weight-gradients -- and must land on the same gradients.  (fp32 rows only: with f16 rows the inner rows
+    # of a fused run ARE part of that state -- include/papr_hip.h, PAPR_MLP_H3_F16ROWS)
+    if rows == "f16":
+        return
     d_ws2, d_bs2, d_x2 = ops.mlp_backward(spec, [w.detach() for w in ew], [b.detach() for b in eb], xd, M, list(outs), gp.to(d), scratch, True)
     torch.cuda.synchronize()
     for i in range(n):
@@ -1133,10 +1138,12 @@ def test_other_gemm_modes_meet_the_same_mlp_parity(mode):
 
 
 @pytest.mark.parametrize("act,skips,hw", [("leakyrelu", [], (20, 13)), ("relu", [1], (8, 8))])
-def test_mlp_generator_matches_torch(act, skips, hw):
+@pytest.mark.parametrize("rows", ["f32", "f16"])
+def test_mlp_generator_matches_torch(act, skips, hw, rows, monkeypatch):
     """MLPGenerator (per-pixel MLP render head, reference models/renderer.py:6-17) on the HIP kernels against the same
     module written with torch ops: forward and all gradients."""
     from papr_amd.unet import MLPGenerator
+    monkeypatch.setenv("PAPR_H3_ROWS", rows)               # (f16: the default -- weight gradients from f16-rounded rows, see test_mlp_forward_backward_vs_torch)
     torch.manual_seed(5)
     gen = MLPGenerator(32, 3, 128, 3, act_type=act, last_act_type="none", skip_layers=skips)
     x = torch.randn(2, 32, *hw, requires_grad=True)
@@ -1161,8 +1168,9 @@ def test_mlp_generator_matches_torch(act, skips, hw):
     (y * w.to(d)).sum().backward()
     np.testing.assert_allclose(y.detach().cpu().numpy(), y_ref.detach().numpy(), rtol=0, atol=2e-5 * max(1.0, y_ref.abs().max().item()))
     got = [p.grad.cpu() for p in gen_d.parameters()] + [xd.grad.cpu()]
-    for g, r in zip(got, ref_grads):
-        np.testing.assert_allclose(g.numpy(), r.numpy(), rtol=0, atol=3e-5 * (r.abs().max().item() + 1e-12))
+    for j, (g, r) in enumerate(zip(got, ref_grads)):
+        wtol = 3e-5 if (rows == "f32" or j == len(got) - 1) else 2e-3      # (the input gradient -- last entry -- is the same computation either way)
+        np.testing.assert_allclose(g.numpy(), r.numpy(), rtol=0, atol=wtol * (r.abs().max().item() + 1e-12))
     with torch.no_grad():                                   # inference route (nothing saved) gives the same numbers
         assert torch.equal(gen_d(xd.detach()), y.detach())
 
