@@ -320,12 +320,20 @@ def main():
         by = float(sum(r[5] for r in rs))
         fl = float(sum(r[6] for r in rs))
         ach = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        wg_prods = 1.0 if (args.amp or args.gemm_mode == "h1" or (args.gemm_mode == "h3" and args.h3_rows == "f16")) else 3.0
         return ms, {"kernel": "gemm_tn_h3_kernel (weight gradients of a fused run in one launch, one slice of the rows per CU, split-f16 MFMA)",
                     "jobs": int(sum(r[2] for r in rs)),
-                    "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                    "bound": "hbm" if wg_prods == 1.0 else "hbm+split", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                     "traffic": traffic_db.get("gemm_tn_h3_bytes_per_launch"), "launches": len(rs),
                     "avg_launch_ms": ms / max(len(rs), 1), "algorithmic_bytes_per_launch": by / max(len(rs), 1),
-                    "fp32_equivalent_tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0, "share_of_step_time": ms / (dt_prof * 1e3)}
+                    "fp32_equivalent_tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0, "share_of_step_time": ms / (dt_prof * 1e3),
+                    # how busy the matrix pipe is beside it: f16 products issued per fp32 product (1 with f16 rows or under use_amp, 3 with fp32 rows) over the dense f16 peak
+                    "products_per_fp32_product": wg_prods, "frac_issued": (wg_prods * fl / (ms * 1e-3) / 1e12 / F16_MFMA_PEAK_TF) if ms > 0 else 0.0,
+                    "note": "bound: with f16 rows (the default since round 6, and under use_amp) the kernel streams 2 B per operand element and nothing else holds it: "
+                            "4.2-4.9 TB/s against the 6.2-6.3 TB/s a pure read of its access pattern reaches (scripts/probes/read_patterns.hip).  With fp32 rows "
+                            "(--h3-rows f32) the in-kernel hi / lo split and the register transpose bind it beside the loads (850 of 980 us remain with the row loads "
+                            "ablated, DESIGN.md Appendix B): `bound` says hbm+split there"
+                    }
 
     def chain_line():
         # fused layer runs (chain4.hip): every fp32 product is three f16 MFMA products, and only the run's input, the
