@@ -117,7 +117,7 @@ class Head(nn.Module):
 
 
 class SmallUNet(nn.Module):
-    def __init__(self, n_channels, n_classes, use_amp=False, amp_dtype=torch.float16):
+    def __init__(self, n_channels, n_classes, use_amp=False, amp_dtype=torch.float16, last_act="none"):
         super().__init__()
         self.use_amp, self.amp_dtype = use_amp, amp_dtype
         self.inc = ConvStage(n_channels, 128)
@@ -126,6 +126,12 @@ class SmallUNet(nn.Module):
         self.up1 = UpStage(512, 256)
         self.up2 = UpStage(256, 128)
         self.outc = Head(128, n_classes)
+        # `small_unet.last_act` (reference models/unet.py:205,253: activation_func(last_act) on the logits, default arguments): the same table as the
+        # model's output activation (papr_amd/activations.py, pinned by G16), an elementwise function of the head's (N, classes, H, W) result --
+        # the state-dict keys are the reference's (`last_act.a` for the names with a shape constant).  (PReLU's 128 channels cannot meet 3 classes in the
+        # reference either.)
+        from .activations import output_activation
+        self.last_act = output_activation(last_act)
         # The feature map arrives as (N, H, W, C) rows; channels-last weights are what the own kernels read in place (the state dict is
         # unchanged: same keys, shapes and values, only the strides differ).
         self.to(memory_format=torch.channels_last)
@@ -139,14 +145,14 @@ class SmallUNet(nn.Module):
             from .ops import small_unet_rows
             # use_amp: the reference autocasts this module to fp16 (models/unet.py:212: f16 operands, f16 maps); here f16 OPERANDS (one product per
             # fp32 product, fp32 accumulation) and fp32 maps -- pinned to the reference's own AMP output by G17 (tests/test_hip_amp_golden.py)
-            return small_unet_rows(x.permute(0, 2, 3, 1).contiguous(), self, one_product=self.use_amp and _AMP_ONE).permute(0, 3, 1, 2)
+            return self.last_act(small_unet_rows(x.permute(0, 2, 3, 1).contiguous(), self, one_product=self.use_amp and _AMP_ONE).permute(0, 3, 1, 2))
         # layer by layer: other map sizes on the same kernels (each layer raises by name where its own kernel has no form); a CPU tensor: plain torch
         with torch.autocast(device_type="cuda", dtype=self.amp_dtype, enabled=self.use_amp and x.is_cuda and torch_head("autocast")):
             x1 = self.inc(x)
             x2 = self.down1(x1)
             x3 = self.down2(x2)
             y = self.up2(self.up1(x3, x2), x1)
-            return self.outc(y)
+            return self.last_act(self.outc(y))
 
 
 class MLPGenerator(nn.Module):
@@ -181,9 +187,10 @@ def get_generator(gcfg, in_c, out_c, use_amp=False, amp_dtype=torch.float16):
     """Counterpart of models/renderer.py:21-34."""
     if gcfg["type"] == "small-unet":
         o = gcfg["small_unet"]
-        if o["bilinear"] or not o["single"] or o["norm"] != "none" or o["affine_layer"] >= 0 or o["last_act"] != "none":
-            raise NotImplementedError("papr_amd: only the shipped small-unet variant (transposed-conv, single, no norm/affine) is built")
-        return SmallUNet(in_c, out_c, use_amp=use_amp, amp_dtype=amp_dtype)
+        if o["bilinear"] or not o["single"] or o["norm"] != "none" or o["affine_layer"] >= 0:
+            raise NotImplementedError("papr_amd: small-unet with bilinear / double-conv / norm / affine_layer is not built (the shipped variant: transposed-conv, "
+                                      "single, no norm, no affine; any last_act)")
+        return SmallUNet(in_c, out_c, use_amp=use_amp, amp_dtype=amp_dtype, last_act=o.get("last_act", "none"))
     if gcfg["type"] == "mlp":
         if "mlp" not in gcfg:
             raise KeyError("models.renderer.generator.mlp: option block missing (the reference reads num_layers, num_channels, "

@@ -515,3 +515,26 @@ def test_render_head_has_no_torch_fallback_on_the_device(monkeypatch, capsys):
         importlib.reload(dbg)
     monkeypatch.delenv("PAPR_DEBUG_TORCH_HEAD")
     importlib.reload(dbg)
+
+
+def test_small_unet_last_act_option():
+    """`models.renderer.generator.small_unet.last_act` (reference models/unet.py:205,253: `activation_func(last_act)` on the logits): any name of the
+    table the model's own output activation uses (G16) -- the head's result through that function, the reference's state-dict keys (`renderer.last_act.a`
+    for the names with a shape constant, none for `none`); the other non-shipped variants (bilinear, double conv, norm, affine) still raise by name."""
+    import torch
+    from papr_amd import get_model
+    from papr_amd.config import deep_merge
+    from papr_amd.unet import SmallUNet
+    gen = lambda o: {"models": {"renderer": {"generator": {"small_unet": o}}}}
+    m = get_model(deep_merge(case_cfg("chair1k"), gen({"last_act": "sigmoid"})), device="cpu")
+    assert not [k for k in m.state_dict() if k.startswith("renderer.last_act")]
+    m2 = get_model(deep_merge(case_cfg("chair1k"), gen({"last_act": "gaussian"})), device="cpu")
+    assert "renderer.last_act.a" in m2.state_dict()
+    torch.manual_seed(0)
+    plain, act = SmallUNet(32, 3), SmallUNet(32, 3, last_act="sigmoid")
+    act.load_state_dict(plain.state_dict())
+    x = torch.randn(1, 32, 8, 12)
+    assert torch.equal(act(x), torch.sigmoid(plain(x)))
+    for o in ({"bilinear": True}, {"single": False}, {"norm": "batch"}, {"affine_layer": 1}):
+        with pytest.raises(NotImplementedError, match="small-unet"):
+            get_model(deep_merge(case_cfg("chair1k"), gen(o)), device="cpu")
