@@ -42,7 +42,9 @@ def test_h1_f16_rows_and_fp32_rows_both_meet_the_bar_and_differ(tmp_path):
     assert abs(half["digest"] - full["digest"]) <= 2e-3 * abs(full["digest"])
 
 
-@pytest.mark.parametrize("tag", ["chair1k", "variants1k"])
+# (round 6: lego1k -- LeakyReLU, and a skip-layer value MLP whose training calls fall back to the parity arithmetic --, half_tiny -- 128-wide middle layers in the
+#  generic slots of the run-scale form --, wn_tiny -- weight-normalised MLPs)
+@pytest.mark.parametrize("tag", ["chair1k", "variants1k", "lego1k", "half_tiny", "wn_tiny"])
 def test_h1_mode_stays_within_the_autocast_tolerance_of_the_reference(tag, tmp_path):
     out = tmp_path / "h1.json"
     env = dict(os.environ, PAPR_GEMM_MODE="h1")
