@@ -1320,6 +1320,176 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_h3_kernel(TNH3Batch batch) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// gemm_tn_tr (round 6): the weight gradient of a full 256 x 256 layer from f16 x f16 rows WITHOUT a pass through registers.
+//   * rows arrive by LDS-DMA (global_load_lds_dwordx4), four 32-row stages in flight (128 KB of the CU's LDS; the register-staged form keeps two,
+//     in registers) -- the kernel is HBM-bound and bytes in flight are what buys bandwidth;
+//   * the matrix operand is 8 CONSECUTIVE ROWS of one column: the transposing LDS read (ds_read_b64_tr_b16: a 16-lane group reads a [4 rows][16 columns]
+//     block, lane c receives column c's four rows) takes it straight out of a ROW-major image.  The image is cut into [32 rows][16 columns] subtiles of
+//     1 KB (a DMA instruction fills one: lane i fetches row i / 2, 16-byte piece i & 1 -- the gather is on the SOURCE side, the destination of an LDS-DMA
+//     instruction is linear), 1,152 bytes apart so that the two subtiles a 32-lane half reads sit on disjoint banks (MI355X guide: conflict-free layout);
+//   * the rows' power-of-two scales differ from row to row and the sum runs over rows: the G fragment is multiplied (packed f16, exact) by
+//     c[m] = (1 / scale_g[m]) (1 / scale_x[m]) / P, P = the largest such product of the slice -- rows far below it underflow, contributing less than the
+//     fp32 rounding of the sum (the same argument as gemm_tn_h3's slice scale); the tile leaves times P.  c and 1 / scale_g (for the bias gradient, taken
+//     from the UN-scaled fragments in fp32) come from a 32-entry table per stage that wave 0 makes a stage ahead from the row maxima, which arrive by DMA too.
+// Same slices, same stage order, same 16-row matrix instructions as gemm_tn_h3_kernel<., 2>: partial tiles in natural order (slab_reduce_kernel<false>).
+constexpr int TR_D = 4;                          // stages in flight
+constexpr int TR_SUB = 1152;                     // bytes from one [32][16] subtile to the next (1,024 + 128: adjacent subtiles on disjoint banks)
+constexpr int TR_OP = 16 * TR_SUB;               // one operand of one stage
+constexpr int TR_STAGE = 2 * TR_OP;              // G | X
+constexpr int TR_OFF_RAW = TR_D * TR_STAGE;      // per stage: max |g| [32] | max |x| [32] floats
+constexpr int TR_OFF_C = TR_OFF_RAW + TR_D * 256;        // per stage: c[32] halfs
+constexpr int TR_OFF_IG = TR_OFF_C + TR_D * 64;          // per stage: 1 / scale_g [32] floats
+constexpr size_t TR_LDS_BYTES = TR_OFF_IG + TR_D * 128;
+typedef __fp16 tr_h4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wint-to-pointer-cast"      // (an LDS address is a 32-bit offset: the host pass of hipcc sees a 64-bit pointer type)
+
+__device__ __forceinline__ void tr_dma16(const void* src, unsigned lds_dst) {       // 64 lanes x 16 bytes -> LDS [lds_dst, +1 KB), lane order
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void tr_dma4(const void* src, unsigned lds_dst) {        // 64 lanes x 4 bytes
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_tn_tr_kernel(TNH3Batch batch) {
+    extern __shared__ __attribute__((aligned(16))) char tr_smem[];
+    __shared__ float red[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave >> 2, wk = wave & 3;
+    const unsigned lds0 = (unsigned)(size_t)tr_smem;
+    const int jb = batch.par ? (int)(blockIdx.x % (unsigned)batch.n) : 0;
+    const long slice = batch.par ? (long)(blockIdx.x / (unsigned)batch.n) : (long)blockIdx.x;
+    const TNH3Args& p = batch.job[jb];
+    const long mbeg = slice * p.rows_per_slice;
+    long mend = mbeg + p.rows_per_slice;
+    if (mend > p.M) mend = p.M;
+    if (mbeg >= mend) return;
+    const int nrows = (int)(mend - mbeg);
+    const int g_rs = p.g_rs, x_rs = p.x_rs;
+
+    // P: the largest (1 / scale_g)(1 / scale_x) of the slice (powers of two: the product and the maximum are exact)
+    float pm = 0.f;
+    for (int m = tid; m < nrows; m += 512) pm = fmaxf(pm, inv_scale_from_row_max(p.gmax[mbeg + m], g_rs) * inv_scale_from_row_max(p.xmax[mbeg + m], x_rs));
+    pm = wave_max(pm);
+    if (lane == 0) red[wave] = pm;
+    __syncthreads();
+    float P = red[0];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) P = fmaxf(P, red[w]);
+    const float Pinv = 1.0f / P;                 // (a power of two)
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    float colsum[4] = {0.f, 0.f, 0.f, 0.f};
+
+    const _Float16* const Gh = reinterpret_cast<const _Float16*>(p.G);
+    const _Float16* const Xh = reinterpret_cast<const _Float16*>(p.X);
+    const long nst = (nrows + TN_ROWS - 1) / TN_ROWS;
+    // the requests of stage st (rows past the slice: the slice's last row again -- their c is 0)
+    auto issue = [&](long st) {
+        const unsigned buf = lds0 + (unsigned)(st % TR_D) * TR_STAGE;
+        if (wave == 0) {
+            int m = (int)st * TN_ROWS + (lane & 31);
+            m = m < nrows ? m : nrows - 1;
+            const float* src = (lane >> 5 ? p.xmax : p.gmax) + mbeg + m;
+            tr_dma4(src, lds0 + TR_OFF_RAW + (unsigned)(st % TR_D) * 256);
+        }
+        int m = (int)st * TN_ROWS + (lane >> 1);
+        m = m < nrows ? m : nrows - 1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = 4 * wave + q, op = idx >> 4, sub = idx & 15;
+            const _Float16* src = (op ? Xh + (mbeg + m) * p.ldx : Gh + (mbeg + m) * p.ldg) + 16 * sub + 8 * (lane & 1);
+            tr_dma16(src, buf + (unsigned)(op * TR_OP + sub * TR_SUB));
+        }
+    };
+    // the factor table of stage st (wave 0, lanes 0 .. 31), from the maxima in LDS
+    auto make_table = [&](long st) {
+        if (wave != 0 || lane >= 32) return;
+        const int b = (int)(st % TR_D);
+        const float* raw = reinterpret_cast<const float*>(tr_smem + TR_OFF_RAW + b * 256);
+        const bool ok = (int)st * TN_ROWS + lane < nrows;
+        const float ig = inv_scale_from_row_max(raw[lane], g_rs), ix = inv_scale_from_row_max(raw[32 + lane], x_rs);
+        reinterpret_cast<_Float16*>(tr_smem + TR_OFF_C + b * 64)[lane] = ok ? (_Float16)(ig * ix * Pinv) : (_Float16)0.f;
+        reinterpret_cast<float*>(tr_smem + TR_OFF_IG + b * 128)[lane] = ok ? ig : 0.f;
+    };
+    for (long st = 0; st < TR_D - 1; ++st) issue(st);
+    if (wave == 0) {
+        asm volatile("s_waitcnt vmcnt(14)" ::: "memory");         // stage 0's maxima (behind them: 4 + 5 + 5 requests of this wave)
+        make_table(0);
+    }
+    // lane-derived LDS offsets of the fragments: 16-lane group g = (lane >> 4) & 1 takes the tile's second subtile, k-group lane >> 5 the rows 8 .. 15 of a k-step
+    const unsigned frag = (unsigned)(((lane >> 4) & 1) * TR_SUB + (8 * (lane >> 5) + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8);
+    for (long st = 0; st < nst; ++st) {
+        if (wave == 0) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");       // stage st's rows and stage st + 1's maxima have landed (behind them: 4 + 5 of this wave's requests)
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        lds_barrier();                               // everybody's requests of stage st are in LDS; everybody is done with stage st - 1
+        issue(st + TR_D - 1);
+        make_table(st + 1);
+        const char* const sb = tr_smem + (st % TR_D) * TR_STAGE;
+        const _Float16* const ctab = reinterpret_cast<const _Float16*>(tr_smem + TR_OFF_C + (st % TR_D) * 64);
+        const float* const igtab = reinterpret_cast<const float*>(tr_smem + TR_OFF_IG + (st % TR_D) * 128);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const half8 cv = *reinterpret_cast<const half8*>(ctab + ks * 16 + 8 * (lane >> 5));
+            half8 xb[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const char* a = sb + TR_OP + (2 * (wk * 2 + j)) * TR_SUB + frag + ks * 512;
+                const tr_h4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) tr_h4*)(unsigned)(size_t)a);
+                const tr_h4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) tr_h4*)(unsigned)(size_t)(a + 128));
+                xb[j] = half8{(_Float16)lo[0], (_Float16)lo[1], (_Float16)lo[2], (_Float16)lo[3], (_Float16)hi[0], (_Float16)hi[1], (_Float16)hi[2], (_Float16)hi[3]};
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const char* a = sb + (2 * (wn * 4 + i)) * TR_SUB + frag + ks * 512;
+                const tr_h4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) tr_h4*)(unsigned)(size_t)a);
+                const tr_h4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) tr_h4*)(unsigned)(size_t)(a + 128));
+                const half8 gr = half8{(_Float16)lo[0], (_Float16)lo[1], (_Float16)lo[2], (_Float16)lo[3], (_Float16)hi[0], (_Float16)hi[1], (_Float16)hi[2], (_Float16)hi[3]};
+                if (wk == 0) {                       // bias gradient: the true values of G, this lane's column, its eight rows of the k-step
+                    const float4 i0 = *reinterpret_cast<const float4*>(igtab + ks * 16 + 8 * (lane >> 5)), i1 = *reinterpret_cast<const float4*>(igtab + ks * 16 + 8 * (lane >> 5) + 4);
+                    colsum[i] = __builtin_fmaf((float)gr[7], i1.w, __builtin_fmaf((float)gr[6], i1.z, __builtin_fmaf((float)gr[5], i1.y, __builtin_fmaf((float)gr[4], i1.x,
+                                __builtin_fmaf((float)gr[3], i0.w, __builtin_fmaf((float)gr[2], i0.z, __builtin_fmaf((float)gr[1], i0.y, __builtin_fmaf((float)gr[0], i0.x, colsum[i]))))))));
+                }
+                const half8 ga = gr * cv;            // (packed f16 multiplies by powers of two)
+                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ga, xb[0], acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ga, xb[1], acc[i][1], 0, 0, 0);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // (the requests past the slice's end)
+    float* out = p.slab + slice * SLAB * SLAB;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int k = (wk * 2 + j) * 32 + (lane & 31);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = (wn * 4 + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                out[n * SLAB + k] = acc[i][j][e] * P;
+            }
+        }
+    if (wk == 0) {                                   // column sums: lane l and lane l + 32 hold the two row groups of column (wn * 4 + i) * 32 + (l & 31)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float other = __shfl_xor(colsum[i], 32);
+            if (lane < 32) p.bias_slab[slice * SLAB + (wn * 4 + i) * 32 + lane] = colsum[i] + other;
+        }
+    }
+}
+#pragma clang diagnostic pop
+
 // dW = G^T X on the split-f16 kernel; gmax / xmax: per-row max |.| of G and X (M floats each).  Jobs queue up and go out
 // TN_BATCH to a launch (flush() at the latest before anything reads a result or reuses the partial-tile workspace).
 constexpr size_t TN_JOB_FLOATS = (size_t)MAX_SLICES * (SLAB * SLAB + SLAB);
@@ -1340,7 +1510,10 @@ struct TNH3Queue {
         if (M <= 0) return 0;
         const bool job_full = N > 131 && K > 131;                       // 128 + 3 < N: all eight tiles live
         PAPR_REQUIRE(g_half || !x_half, "gemm_tn_h3: X f16 rows with G fp32 rows");
-        const int fmt = g_half ? (x_half ? 2 : 3) : 0;
+        // format 4 (round 6): both operands f16 rows of a full 256 x 256 layer with 512-byte rows -- rows by LDS-DMA, operands by the transposing LDS read
+        const bool tr = g_half && x_half && N == SLAB && K == SLAB && ldg == SLAB && ldx == SLAB && papr_switch(PAPR_SW_TN_TR) != 0 &&
+                        (reinterpret_cast<size_t>(G) & 15) == 0 && (reinterpret_cast<size_t>(X) & 15) == 0;
+        const int fmt = tr ? 4 : (g_half ? (x_half ? 2 : 3) : 0);
         // (jobs with and without dead tiles share a launch -- on the instantiation with the tile tests: one launch and one reduction per run
         // instead of two, 0.05 ms per step; a batch of full jobs only keeps the test-free one)
         if (batch.n == TN_BATCH || (batch.n > 0 && fmt != half))
@@ -1395,7 +1568,11 @@ struct TNH3Queue {
         }
         const bool prof = papr_prof_on();
         if (prof) papr_prof_begin2(8, batch.job[0].M, batch.n, 0, bytes, flops, s);
-        if (half == 2) {                            // (f16 rows have one plane: one product -- also behind the parity arithmetic's runs, PAPR_MLP_H3_F16ROWS)
+        if (half == 4) {
+            if (papr_first_on_device(PAPR_ONCE_TN_TR))
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_tr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TR_LDS_BYTES);
+            gemm_tn_tr_kernel<<<dim3(grid), dim3(512), TR_LDS_BYTES, s>>>(batch);
+        } else if (half == 2) {                     // (f16 rows have one plane: one product -- also behind the parity arithmetic's runs, PAPR_MLP_H3_F16ROWS)
             if (full) gemm_tn_h3_kernel<true, 2><<<dim3(grid), dim3(512), T3_LDS_BYTES, s>>>(batch);
             else gemm_tn_h3_kernel<false, 2><<<dim3(grid), dim3(512), T3_LDS_BYTES, s>>>(batch);
         } else if (half == 3) {
@@ -1408,7 +1585,8 @@ struct TNH3Queue {
         else gemm_tn_h3_kernel<false, 0><<<dim3(grid), dim3(512), T3_LDS_BYTES, s>>>(batch);
         if (prof) papr_prof_end(s);
         PAPR_CHECK_LAUNCH("gemm_tn_h3");
-        slab_reduce_kernel<true><<<dim3(SLAB * SLAB / 4 / 16, batch.n), dim3(256), 0, s>>>(red);
+        if (half == 4) slab_reduce_kernel<false><<<dim3(SLAB * SLAB / 4 / 16, batch.n), dim3(256), 0, s>>>(red);      // (natural order: no permutation to undo)
+        else slab_reduce_kernel<true><<<dim3(SLAB * SLAB / 4 / 16, batch.n), dim3(256), 0, s>>>(red);
         PAPR_CHECK_LAUNCH("slab_reduce");
         batch.n = 0; grid = 0; bytes = 0; flops = 0;
         return 0;

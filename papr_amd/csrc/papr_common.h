@@ -16,7 +16,7 @@ int papr_rownorm_stats(const float* x, int64_t rows, int width, int ld, float ep
 int papr_rownorm_apply(float* x, int64_t rows, int width, int ld, const float* stats, const float* mean, papr_stream_t stream);      // rowops.hip
 int papr_cu_count();                       // compute units of the CURRENT device (cached per device id)
 bool papr_first_on_device(int slot);       // true once per (current device, slot): hipFuncSetAttribute calls of a launcher
-enum { PAPR_ONCE_CHAIN4 = 0, PAPR_ONCE_NT_H3, PAPR_ONCE_TN_H3, PAPR_ONCE_CONV, PAPR_ONCE_CONV_WGRAD, PAPR_ONCE_PAIRS, PAPR_ONCE_SLOTS };
+enum { PAPR_ONCE_CHAIN4 = 0, PAPR_ONCE_NT_H3, PAPR_ONCE_TN_H3, PAPR_ONCE_CONV, PAPR_ONCE_CONV_WGRAD, PAPR_ONCE_PAIRS, PAPR_ONCE_TN_TR, PAPR_ONCE_SLOTS };
 
 #define PAPR_REQUIRE(cond, ...)                \
     do {                                       \

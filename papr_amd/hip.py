@@ -18,7 +18,7 @@ EXPECTED_ABI = 27
 MLP_MODES = {"h3": 0, "h1": 1, "f32": 2, "fwd": 3, "dgrad": 4, "layers": 5, "h1_f32rows": 6, "h3_f16rows": 7}
 # process-wide A/B switches of the library (papr_set_switch; PAPR_SW_* in include/papr_hip.h).  The library itself reads no environment:
 # lib() forwards these historical variable names once, when it loads the library (scripts/probes, tests/test_hip_chain_variants.py)
-SWITCHES = {"PAPR_C4_GENERIC": 0, "PAPR_C4_FUSED": 1, "PAPR_C4_EARLY": 2, "PAPR_KNN_BLOCKS": 3, "PAPR_KNN_T": 4, "PAPR_WGRAD_WGS": 5, "PAPR_NT_VARIANT": 6, "PAPR_C4_DMA": 7, "PAPR_TN_JOBPAR": 8, "PAPR_C4_PAIRS": 9, "PAPR_C4_PHASE": 10, "PAPR_C4_SUBPHASE": 11, "PAPR_C4_WCOPIES": 12}
+SWITCHES = {"PAPR_C4_GENERIC": 0, "PAPR_C4_FUSED": 1, "PAPR_C4_EARLY": 2, "PAPR_KNN_BLOCKS": 3, "PAPR_KNN_T": 4, "PAPR_WGRAD_WGS": 5, "PAPR_NT_VARIANT": 6, "PAPR_C4_DMA": 7, "PAPR_TN_JOBPAR": 8, "PAPR_C4_PAIRS": 9, "PAPR_C4_PHASE": 10, "PAPR_C4_SUBPHASE": 11, "PAPR_C4_WCOPIES": 12, "PAPR_TN_TR": 13}
 
 EXPORTS = [
     "papr_abi_version", "papr_last_error", "papr_ray_knn_workspace_bytes", "papr_ray_knn",

@@ -34,7 +34,7 @@ VARIANTS = [("generic rows", dict(F32, PAPR_C4_GENERIC="1")), ("two-role", dict(
 
 def _run(tmp_path, name, env, M, n, act, dims=()):
     out = tmp_path / (name.replace(" ", "_") + ".pt")
-    e = {k: v for k, v in os.environ.items() if k not in ("PAPR_C4_GENERIC", "PAPR_C4_FUSED", "PAPR_GEMM_MODE", "PAPR_C4_DMA", "PAPR_C4_PAIRS", "PAPR_H3_ROWS")}
+    e = {k: v for k, v in os.environ.items() if k not in ("PAPR_C4_GENERIC", "PAPR_C4_FUSED", "PAPR_GEMM_MODE", "PAPR_C4_DMA", "PAPR_C4_PAIRS", "PAPR_H3_ROWS", "PAPR_TN_TR")}
     e.update(env)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "chain_variants_worker.py"), str(out), str(M), str(n), act] + [str(v) for v in dims], env=e, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (name, r.stderr[-2000:])
@@ -103,6 +103,15 @@ def test_f16_rows_mode_is_h3_but_for_the_weight_gradients(tmp_path, M, n, act, d
         for (k, a), (_, b) in zip(_flat(ref), _flat(res)):
             assert a.shape == b.shape, (name, k)
             assert torch.equal(a.view(torch.int32), b.view(torch.int32)), "%s: %s differs in %d of %d elements" % (name, k, int((a.view(torch.int32) != b.view(torch.int32)).sum()), a.numel())
+    # the weight gradients of the full 256 x 256 layers on the LDS-DMA + transposing-read kernel (gemm_tn_tr_kernel, PAPR_TN_TR=1; round 6, not the default:
+    # it measures the same 4.3 TB/s as the register-staged kernel): the same rows, slices and matrix instructions; ONE operand carries both rows' scales
+    # instead of each its own, so the f16 roundings of rows far below the slice's largest differ -- equal to 1e-5 of the tensor's maximum, not bit for bit
+    tr = _run(tmp_path, "h3_f16rows tr", {"PAPR_TN_TR": "1"}, M, n, act, dims)
+    for k in ("d_ws", "d_bs"):
+        for i, (a, b) in enumerate(zip(ref[k], tr[k])):
+            rel = float((a - b).abs().max() / a.abs().max().clamp_min(1e-30))
+            assert rel < 1e-5, (k, i, rel)
+    assert torch.equal(ref["d_x"], tr["d_x"])
     for k in ("d_x", "inf"):                      # (d_x2 / d_ws2 -- a backward pass WITHOUT the forward pass's saved state -- read the inner rows as fp32 masks: not a
                                                   #  path of this mode or of h1, whose inner rows are f16; compared among the mode's own forms above only)
         assert torch.equal(base[k], ref[k]), "%s differs from the default mode's in %d elements" % (k, int((base[k] != ref[k]).sum()))
