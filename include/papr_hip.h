@@ -258,6 +258,11 @@ typedef struct {
      * (papr_attn_tail_bwd: kp_mean).  Why: the run's last row phase then needs no row statistics at all (they were 10-16k cycles per wave of a
      * 40k-cycle slot: every lane took them from eight partial tables), only the dot products' finish does. */
     float* raw_mean;
+    /* in_norm only (ABI 27): 1 = the caller never reads x again (its own backward pass of the norm needs neither x nor the standardised rows -- e.g.
+     * papr_build_features_bwd_pairs with key_mean / key_stats): the call MAY leave x as it is instead of overwriting it with the standardised rows.
+     * It does where its own backward pass does not read them either (PAPR_MLP_H1 training runs: the weight gradient reads the run's f16 copy) --
+     * 246 MB of stores per 512,000 key rows. */
+    int32_t leave_input;
 } papr_row_norm;
 
 /* `mode` of papr_mlp_fwd / papr_mlp_bwd / papr_mlp_bwd_needs_weight_t: which arithmetic and which kernels carry the call.  An argument of

@@ -1777,6 +1777,8 @@ extern "C" int papr_mlp_fwd(const papr_layer* layers, int n_layers, float* x, in
                 c.sr_hi = q.hi; c.sr_lo = q.lo; c.sr_inv = q.inv; c.sr_max = q.mx; c.sr_ld = q.Kq;
             }
             const bool half_rows = run_half_rows(layers, n_layers, i, e, ld_out, saved != nullptr);
+            // (papr_row_norm.leave_input: nobody reads the standardised rows back -- the caller said so, and this mode's weight gradient reads the f16 copy)
+            if (i == 0 && in_norm && in_norm->leave_input && half_rows && GEMM_ONE_PRODUCT && e == n_layers) c.in_norm_writeback = 0;
             if (half_rows && GEMM_ONE_PRODUCT) { c.a0_half = reinterpret_cast<_Float16*>(outs[i]) + (size_t)M * ld_out[i]; c.lda0_half = ld_out[i]; }      // (PAPR_MLP_H3_F16ROWS: no copy -- the first weight gradient reads the fp32 rows)
             size_t used = 0;
             SplitBatch split = {};

@@ -46,7 +46,7 @@ class Layer(C.Structure):
 class RowNorm(C.Structure):
     _fields_ = [("eps", C.c_float), ("width", C.c_int32), ("stats", C.c_void_p),
                 ("dot_rows", C.c_void_p), ("ld_dot", C.c_int32), ("rows_per_dot", C.c_int32), ("dots", C.c_void_p),
-                ("given_mean", C.c_void_p), ("raw_mean", C.c_void_p)]
+                ("given_mean", C.c_void_p), ("raw_mean", C.c_void_p), ("leave_input", C.c_int32)]
 
 
 class ProfileRecord(C.Structure):

@@ -611,7 +611,7 @@ class LayerOutputs(list):
     wkT = None             # (the w_q / w_k run: W_k^T as the forward pass laid it out)
 
 
-def mlp_forward(spec, ws, bs, x, M, keep=True, out_norm=None, in_norm=None, dot_rows=None, rows_per_dot=1, raw_rows=False):
+def mlp_forward(spec, ws, bs, x, M, keep=True, out_norm=None, in_norm=None, dot_rows=None, rows_per_dot=1, raw_rows=False, leave_input=False):
     """Run the chain; returns the list of layer outputs (all kept, or two ping-pong buffers).
     out_norm = (width, eps): the last output comes back row-standardised (LayerNorm core), outs.norm_stats holds
     the (M, 2) statistics papr_rownorm_bwd needs.  in_norm = (width, eps): x is standardised first (outs.in_stats; x itself
@@ -636,6 +636,7 @@ def mlp_forward(spec, ws, bs, x, M, keep=True, out_norm=None, in_norm=None, dot_
         rn_in = hip.RowNorm(in_norm[1], in_norm[0], outs.in_stats.data_ptr())
         if given:
             rn_in.given_mean = given[1].data_ptr()
+        rn_in.leave_input = 1 if leave_input else 0      # (the caller's backward pass of the norm reads neither x nor the standardised rows)
         inorm = C.byref(rn_in)
     if out_norm is not None:
         outs.norm_stats = torch.empty((M, 2), device=dev, dtype=torch.float32)
@@ -979,7 +980,7 @@ class _RenderFn(torch.autograd.Function):
                     and plan.key.last_act == hip.ACT["none"])
         k_outs = mlp_forward(plan.key, kw, kb, key_in, M, keep, (plan.key.d_out, eps) if plan.k_norm else None,
                              ((plan.key_w, eps) + (key_given or ())) if plan.k_norm else None, dot_rows=g if in_run else None, rows_per_dot=k,
-                             raw_rows=raw_keys)
+                             raw_rows=raw_keys, leave_input=bool(plan.k_norm and key_given is not None and _LN_IN_FEATURES))
         K = k_outs[-1]
         kst, qst, kst2, qst2 = k_outs.in_stats, q_outs.in_stats, k_outs.norm_stats, q_outs.norm_stats
         v_outs = mlp_forward(plan.val, vw, vb, val_in, M, keep, (plan.val.d_out, eps) if plan.v_norm else None,
