@@ -1887,17 +1887,42 @@ extern "C" int papr_mlp_bwd_needs_weight_t(const papr_layer* layers, int n_layer
     return 0;
 }
 
+// papr_mlp_bwd's d_out_f16: the top layers are a fused run of the one-product mode with f16 rows (the call as a whole runs in that arithmetic: t_mode is
+// the caller's, one_product_or_parity() applied), no activation behind the last layer, and the launch has a layer that is not its last
+static bool bwd_takes_f16_top(const papr_layer* layers, int n_layers, const int32_t* ld_out, bool need_dx) {
+    if (!GEMM_ONE_PRODUCT || layers[n_layers - 1].act != PAPR_ACT_NONE) return false;
+    int bt = -1;
+    for (int b = 0; b < n_layers;) { const int e = chain_run_end(layers, n_layers, b); if (e - b >= 2) { if (e == n_layers) bt = b; b = e; } else ++b; }
+    if (bt < 0 || !run_half_rows(layers, n_layers, bt, n_layers, ld_out, true)) return false;
+    const int last = bt == 0 ? (need_dx ? 0 : 1) : bt;
+    return (n_layers - 1) - last >= 1;
+}
+
+extern "C" int papr_mlp_bwd_takes_f16_rows(const papr_layer* layers, int n_layers, const int32_t* ld_out, int need_dx, int32_t mode) {
+    if (!layers || !ld_out || n_layers < 1 || !mode_from_arg(mode)) return 0;
+    one_product_or_parity(layers, n_layers, ld_out, true, true);
+    return bwd_takes_f16_top(layers, n_layers, ld_out, need_dx != 0) ? 1 : 0;
+}
+
 extern "C" size_t papr_mlp_bwd_workspace_bytes(int64_t M) { return TN_SLAB_BYTES + H3Scratch::bytes(M) + BwdRunScratch::bytes(M) + SRScratch::reserve(M); }
 
 extern "C" int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float* x, int ldx, int64_t M,
-                            float* const* outs, const int32_t* ld_out, const float* row_absmax, float* d_out,
+                            float* const* outs, const int32_t* ld_out, const float* row_absmax, float* d_out, const papr_f16_rows* d_out_f16,
                             float* scratch0, float* scratch1, int ld_scratch, float* const* d_weight,
                             float* const* d_bias, float* d_x, void* workspace, int32_t mode, papr_stream_t stream) {
     PAPR_REQUIRE(mode_from_arg(mode), "papr_mlp_bwd: unknown mode %d", mode);
-    PAPR_REQUIRE(layers && x && outs && ld_out && d_out && d_weight && d_bias && workspace && n_layers >= 1,
+    PAPR_REQUIRE(layers && x && outs && ld_out && (d_out || d_out_f16) && d_weight && d_bias && workspace && n_layers >= 1,
                  "papr_mlp_bwd: bad arguments");
     PAPR_REQUIRE(n_layers == 1 || (scratch0 && scratch1), "papr_mlp_bwd: scratch buffers required");
     one_product_or_parity(layers, n_layers, ld_out, row_absmax != nullptr, true);
+    if (d_out_f16) {
+        // the top gradient rows as the producer wrote them (papr_f16_rows): what the one-product data-gradient run's staging would have made of fp32 rows
+        const int top_w = layers[n_layers - 1].n_out;
+        PAPR_REQUIRE(bwd_takes_f16_top(layers, n_layers, ld_out, d_x != nullptr) && d_out_f16->hi && d_out_f16->inv && d_out_f16->scale && d_out_f16->max &&
+                     d_out_f16->ld % 32 == 0 && d_out_f16->ld >= (top_w + 31) / 32 * 32,
+                     "papr_mlp_bwd: d_out_f16 needs what papr_mlp_bwd_takes_f16_rows() reports (this call: %s arithmetic) and rows of a multiple of 32 halfs",
+                     GEMM_ONE_PRODUCT ? "one-product" : "parity");
+    }
     hipStream_t s = as_stream(stream);
     bool any_skip = false;
     for (int i = 0; i < n_layers; ++i) any_skip |= layers[i].n_skip > 0;
@@ -1986,6 +2011,7 @@ extern "C" int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float*
             ChainArgs c = {};
             c.A0 = g; c.lda0 = ldg; c.K0 = L.n_out; c.rowmax0 = runs.gmax[CHAIN_MAX_LAYERS];
             c.M = M; c.one_product = GEMM_ONE_PRODUCT ? 1 : 0;
+            const bool top_f16 = d_out_f16 && i == n_layers - 1;     // (validated above: this run takes them)
             const bool split_ahead = !GEMM_ONE_PRODUCT && !t_h3_f16_rows && papr_switch(PAPR_SW_C4_DMA) != 0;       // (the kernel is launched below, once the run's width is known to be its own;
                                                                                                                   //  with f16 rows the staging also makes the top rows' f16 copy: not by DMA)
             // h1 mode: f16 rows (see run_half_rows).  x_half: what the forward run stored; g_half: this launch, if it has a layer
@@ -1994,6 +2020,11 @@ extern "C" int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float*
             const bool g_half = x_half && i - last >= 1;
             auto slot0 = [&](int l) { return l - (b > 0 ? b - 1 : 0); };
             if (g_half) { c.a0_half = reinterpret_cast<_Float16*>(runs.g[slot0(i - 1)]) + (size_t)M * G_LD; c.lda0_half = G_LD; }
+            if (top_f16) {                          // staged by LDS-DMA; the rows are their own f16 copy, their maxima the producer's table
+                PAPR_REQUIRE(g_half, "papr_mlp_bwd: d_out_f16 and a top run without f16 gradient rows");
+                c.A0 = nullptr; c.rowmax0 = nullptr; c.a0_half = nullptr;
+                c.sr_hi = reinterpret_cast<const _Float16*>(d_out_f16->hi); c.sr_lo = nullptr; c.sr_inv = d_out_f16->inv; c.sr_max = d_out_f16->scale; c.sr_ld = d_out_f16->ld;
+            }
             size_t used = 0;
             SplitBatch split = {};
             long long bytes = 4LL * M * L.n_out, flops = 0;
@@ -2041,15 +2072,17 @@ extern "C" int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float*
             for (int l = i; l >= b; --l) {
                 const float* gl = l == i ? g : runs.g[slot(l)];
                 long ldl = l == i ? ldg : G_LD;
-                const float* gm = l == i ? runs.gmax[CHAIN_MAX_LAYERS] : runs.gmax[slot(l)];
+                const float* const gm_top = top_f16 ? d_out_f16->max : runs.gmax[CHAIN_MAX_LAYERS];
+                const float* gm = l == i ? gm_top : runs.gmax[slot(l)];
                 // f16 operands: G_l -- the top rows' copy, or what chain layer l + 1 stored (it is not the launch's last: l >= last);
                 // X_l -- the input copy of the forward run, or what forward layer l - 1 stored
                 int gh = 0, xh = 0;
                 const float* xin = nullptr; long ldxin = 0;
-                if (g_half && l == i) { gl = reinterpret_cast<const float*>(c.a0_half); ldl = G_LD; gh = 1; }
+                if (top_f16 && l == i) { gl = reinterpret_cast<const float*>(d_out_f16->hi); ldl = d_out_f16->ld; gh = 1; }
+                else if (g_half && l == i) { gl = reinterpret_cast<const float*>(c.a0_half); ldl = G_LD; gh = 1; }
                 else if (g_half && l >= last) gh = 1;
                 // (one-product mode: the f16 gradient rows of a run all carry the scale of the run's TOP rows -- their maxima stand for it, chain.h: c_half)
-                if (gh && GEMM_ONE_PRODUCT) gm = runs.gmax[CHAIN_MAX_LAYERS];
+                if (gh && GEMM_ONE_PRODUCT) gm = gm_top;
                 if (x_half && gh) {                  // (a layer whose gradient rows are fp32 -- layer 0 when the launch stops above it -- reads its fp32 input)
                     xh = 1;
                     if (l == b && !GEMM_ONE_PRODUCT) xh = 0;      // (PAPR_MLP_H3_F16ROWS: the run's input rows have no f16 copy -- G f16, X fp32, gemm_tn_h3_kernel<., 3>)

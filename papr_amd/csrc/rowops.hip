@@ -1,6 +1,7 @@
 // Row-wise kernels of the render path: the LayerNorm core and the fused attention tail (K4).
 // Both are HBM-streaming: one wave64 per row / per ray, 16-byte lane loads, shuffle reductions.
 #include "papr_common.h"
+#include "h3_common.h"
 
 namespace {
 
@@ -183,11 +184,25 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(papr_tail_desc d, const f
                                                        float* __restrict__ d_qp, float* __restrict__ d_v,
                                                        float* __restrict__ d_influ, float* __restrict__ d_score_bias,
                                                        float* __restrict__ d_pair_influ, const float* __restrict__ kp_stats,
-                                                       const float* __restrict__ score_bias, const float* __restrict__ kp_mean) {
+                                                       const float* __restrict__ score_bias, const float* __restrict__ kp_mean,
+                                                       papr_f16_rows kp16, papr_f16_rows v16) {
     const int lane = threadIdx.x & 63;
     long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= R) return;
     const int k = d.k;
+    // a gradient row in the one-product data-gradient run's input format (papr_f16_rows; chain4.hip's staging arithmetic: the row times the power of two of
+    // its maximum, one rounding to f16): four values of this lane, the row's maximum `mx` known to every lane that holds a piece of it
+    auto put16 = [&](const papr_f16_rows& o, long row, int col, const float4& val, float mx, bool first) {
+        float inv;
+        const float sc = one_scale_from_max(__float_as_uint(mx), ONE_EMIN_DGRAD, inv);
+        unsigned h01, h23;                              // (the staging code's own instructions: chain4.hip, write_planes)
+        asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h01) : "v"(val.x), "v"(sc));
+        asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h23) : "v"(val.z), "v"(sc));
+        asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h01) : "v"(val.y), "v"(sc));
+        asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h23) : "v"(val.w), "v"(sc));
+        *reinterpret_cast<uint2*>(o.hi + row * o.ld + col) = make_uint2(h01, h23);
+        if (first) { o.inv[row] = inv; o.scale[row] = sc; o.max[row] = mx; }
+    };
     const float inv_sqrt_d = 1.0f / sqrtf((float)(d.scale_dim > 0 ? d.scale_dim : d.d_model));
     float a = lane <= k ? attn[r * (k + 1) + lane] : 0.f;
     float top = lane < k ? a : 0.f;
@@ -206,7 +221,12 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(papr_tail_desc d, const f
             const float tj = __shfl(top, jc, 64);
             const float4 vv = *reinterpret_cast<const float4*>(v + (r * k + jc) * d.ld_v + 4 * c4);
             float part = (gf.x * vv.x + gf.y * vv.y) + (gf.z * vv.z + gf.w * vv.w);
-            if (j < k) *reinterpret_cast<float4*>(d_v + (r * k + j) * d.ld_v + 4 * c4) = make_float4(tj * gf.x, tj * gf.y, tj * gf.z, tj * gf.w);
+            const float4 dv = make_float4(tj * gf.x, tj * gf.y, tj * gf.z, tj * gf.w);
+            if (v16.hi) {                                       // (the row's g4 lanes meet for its maximum)
+                float mx = fmaxf(fmaxf(fabsf(dv.x), fabsf(dv.y)), fmaxf(fabsf(dv.z), fabsf(dv.w)));
+                for (int off = 1; off < g4; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+                if (j < k) put16(v16, r * k + j, 4 * c4, dv, mx, c4 == 0);
+            } else if (j < k) *reinterpret_cast<float4*>(d_v + (r * k + j) * d.ld_v + 4 * c4) = dv;
             for (int off = 1; off < g4; off <<= 1) part += __shfl_xor(part, off, 64);
             const float got = __shfl(part, (lane % rp) * g4, 64);        // lane L = j0 + jl' wants the row of group jl' = L % rp
             if (lane >= j0 && lane < j0 + rp && lane < k) my_dtop = got;
@@ -291,7 +311,10 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(papr_tail_desc d, const f
             } else {
                 o = make_float4(gj * qv.x, gj * qv.y, gj * qv.z, gj * qv.w);
             }
-            *reinterpret_cast<float4*>(d_kp + (r * k + j) * d.ld_kp + c) = o;
+            if (kp16.hi) {                                      // (d_model = 256: the wave holds the whole row)
+                const float mx = wave_max(fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
+                put16(kp16, r * k + j, c, o, mx, lane == 0);
+            } else *reinterpret_cast<float4*>(d_kp + (r * k + j) * d.ld_kp + c) = o;
         }
         *reinterpret_cast<float4*>(d_qp + r * d.ld_qp + c) = acc;
     }
@@ -995,16 +1018,30 @@ extern "C" int papr_attn_tail_bwd(const papr_tail_desc* d, const float* kp, cons
                                   const float* influ, const int32_t* idx, int64_t R, const float* scores,
                                   const float* attn, const float* d_fused, const float* d_attn, float* d_kp,
                                   float* d_qp, float* d_v, float* d_influ, float* d_score_bias, float* d_pair_influ,
-                                  const float* kp_norm_stats, const float* score_bias, const float* kp_mean, papr_stream_t stream) {
+                                  const float* kp_norm_stats, const float* score_bias, const float* kp_mean,
+                                  const papr_f16_rows* d_kp_f16, const papr_f16_rows* d_v_f16, papr_stream_t stream) {
     if (int e = check_tail(d, "papr_attn_tail_bwd")) return e;
     PAPR_REQUIRE(!kp_mean || kp_norm_stats, "papr_attn_tail_bwd: kp_mean (raw kp rows) needs kp_norm_stats");
-    PAPR_REQUIRE(kp && qp && v && influ && idx && scores && attn && d_fused && d_kp && d_qp && d_v && (d_influ || d_pair_influ),
+    PAPR_REQUIRE(kp && qp && v && influ && idx && scores && attn && d_fused && (d_kp || d_kp_f16) && d_qp && (d_v || d_v_f16) && (d_influ || d_pair_influ),
                  "papr_attn_tail_bwd: null pointer");
+    papr_f16_rows kp16 = {}, v16 = {};
+    if (d_kp_f16) {
+        kp16 = *d_kp_f16;
+        PAPR_REQUIRE(kp16.hi && kp16.inv && kp16.scale && kp16.max && d->k <= 63 && d->d_model == 256 && kp16.ld >= 256 && kp16.ld % 32 == 0,
+                     "papr_attn_tail_bwd: d_kp_f16 needs k <= 63, d_model = 256 and rows of at least 256 halfs (a multiple of 32)");
+    }
+    if (d_v_f16) {
+        v16 = *d_v_f16;
+        const int g4 = d->C >> 2;
+        PAPR_REQUIRE(v16.hi && v16.inv && v16.scale && v16.max && d->k <= 63 && (d->C & 3) == 0 && d->ld_v == d->C && g4 >= 1 && g4 <= 32 && 64 % g4 == 0 &&
+                     v16.ld >= d->C && v16.ld % 32 == 0,
+                     "papr_attn_tail_bwd: d_v_f16 needs k <= 63, C = ld_v a multiple of 4 that divides 256, rows of a multiple of 32 halfs");
+    }
     if (R <= 0) return 0;
     const dim3 grid((unsigned)((R + 3) / 4)), block(256);
     if (d->k <= 63)
         tail_bwd_kernel<<<grid, block, 0, as_stream(stream)>>>(*d, kp, qp, v, influ, idx, R, scores, attn, d_fused, d_attn, d_kp, d_qp, d_v, d_influ,
-                                                               d_score_bias, d_pair_influ, kp_norm_stats, score_bias, kp_mean);
+                                                               d_score_bias, d_pair_influ, kp_norm_stats, score_bias, kp_mean, kp16, v16);
     else if (d->k <= 127)
         tail_bwd_wide_kernel<2><<<grid, block, 0, as_stream(stream)>>>(*d, kp, qp, v, influ, idx, R, scores, attn, d_fused, d_attn, d_kp, d_qp, d_v, d_influ,
                                                                        d_score_bias, d_pair_influ, kp_norm_stats, score_bias, kp_mean);

@@ -25,7 +25,7 @@ EXPORTS = [
     "papr_feature_widths", "papr_build_features_fwd", "papr_build_features_bwd", "papr_build_features_bwd_pairs",
     "papr_segment_reduce_workspace_bytes", "papr_segment_reduce", "papr_group_pairs_workspace_bytes", "papr_group_pairs", "papr_points_knn",
     "papr_rownorm_fwd", "papr_rownorm_bwd", "papr_row_dots", "papr_qk_bias_bwd_workspace_bytes", "papr_qk_bias_bwd", "papr_mse_workspace_bytes", "papr_mse_fwd", "papr_ln_fold_fwd", "papr_ln_fold_bwd", "papr_ln_fold_fwd_batch", "papr_ln_fold_bwd_batch", "papr_mlp_fwd_workspace_bytes", "papr_mlp_bwd_workspace_bytes", "papr_mlp_saved_floats", "papr_mlp_bwd_needs_weight_t", "papr_mlp_fwd",
-    "papr_mlp_bwd",
+    "papr_mlp_bwd", "papr_mlp_bwd_takes_f16_rows",
     "papr_attn_tail_fwd", "papr_attn_tail_bwd", "papr_conv3x3_weight_halfs", "papr_conv3x3_workspace_bytes", "papr_conv3x3_fwd", "papr_conv3x3_wgrad_workspace_bytes", "papr_conv3x3_wgrad", "papr_maxpool2_fwd", "papr_maxpool2_bwd", "papr_upconv2x2_fwd", "papr_upconv2x2_dgrad", "papr_upconv2x2_wgrad_workspace_bytes", "papr_upconv2x2_wgrad", "papr_conv1x1_fwd", "papr_conv1x1_bwd_workspace_bytes", "papr_conv1x1_bwd", "papr_small_unet_state_bytes", "papr_small_unet_bwd_workspace_bytes", "papr_small_unet_fwd", "papr_small_unet_bwd", "papr_adam_step", "papr_adam_step_scaled", "papr_composite_fwd", "papr_composite_bwd_workspace_bytes", "papr_composite_bwd", "papr_profile_enable", "papr_profile_collect", "papr_set_switch", "papr_get_switch",
 ]
 
@@ -41,6 +41,11 @@ class Layer(C.Structure):
     _fields_ = [("weight", C.c_void_p), ("weight_t", C.c_void_p), ("bias", C.c_void_p),
                 ("n_in", C.c_int32), ("n_out", C.c_int32), ("ldw", C.c_int32), ("ldwt", C.c_int32),
                 ("n_skip", C.c_int32), ("skip_col", C.c_int32), ("act", C.c_int32)]
+
+
+class F16Rows(C.Structure):
+    """papr_f16_rows: gradient rows in the one-product runs' input format."""
+    _fields_ = [("hi", C.c_void_p), ("inv", C.c_void_p), ("scale", C.c_void_p), ("max", C.c_void_p), ("ld", C.c_int32)]
 
 
 class RowNorm(C.Structure):
@@ -168,10 +173,12 @@ def lib():
     L.papr_mlp_saved_floats.restype = C.c_size_t
     L.papr_mlp_saved_floats.argtypes = [i32, i64]
     L.papr_mlp_fwd.argtypes = [C.POINTER(Layer), i32, vp, i32, i64, C.POINTER(vp), C.POINTER(C.c_int32), vp, C.POINTER(RowNorm), C.POINTER(RowNorm), vp, i32, vp]
-    L.papr_mlp_bwd.argtypes = [C.POINTER(Layer), i32, vp, i32, i64, C.POINTER(vp), C.POINTER(C.c_int32), vp, vp, vp, vp,
+    L.papr_mlp_bwd.argtypes = [C.POINTER(Layer), i32, vp, i32, i64, C.POINTER(vp), C.POINTER(C.c_int32), vp, vp, C.POINTER(F16Rows), vp, vp,
                                i32, C.POINTER(vp), C.POINTER(vp), vp, vp, i32, vp]
+    L.papr_mlp_bwd_takes_f16_rows.argtypes = [C.POINTER(Layer), i32, C.POINTER(C.c_int32), i32, i32]
     L.papr_attn_tail_fwd.argtypes = [C.POINTER(TailDesc), vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp]
-    L.papr_attn_tail_bwd.argtypes = [C.POINTER(TailDesc), vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.papr_attn_tail_bwd.argtypes = [C.POINTER(TailDesc), vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                                     C.POINTER(F16Rows), C.POINTER(F16Rows), vp]
     L.papr_profile_enable.argtypes = [i32]
     L.papr_profile_collect.argtypes = [C.POINTER(ProfileRecord), i32]
     L.papr_set_switch.argtypes = [i32, i32]

@@ -673,9 +673,43 @@ def _workspace(dev, kind, M):
     return buf
 
 
+_TAIL_F16 = os.environ.get("PAPR_TAIL_F16", "1") != "0"        # A/B: one-product mode -- papr_attn_tail_bwd writes the key / value gradient rows as the data-gradient run stages them (papr_f16_rows)
+
+
+TAIL_F16_ROWS_USED = 0       # (tests: counts the row sets handed over that way)
+
+
+class F16Rows:
+    """Device buffers of one papr_f16_rows (include/papr_hip.h) and the struct that points at them."""
+
+    def __init__(self, dev, M, width):
+        ld = (width + 31) // 32 * 32
+        self.hi = torch.empty((M, ld), device=dev, dtype=torch.float16)
+        self.tables = torch.empty((3, M), device=dev, dtype=torch.float32)       # 1 / scale, scale, max |row|
+        self.c = hip.F16Rows(self.hi.data_ptr(), self.tables[0].data_ptr(), self.tables[1].data_ptr(), self.tables[2].data_ptr(), ld)
+
+    def ref(self):
+        return C.byref(self.c)
+
+    def float(self):
+        """The rows as fp32 (tests)."""
+        return self.hi.float() * self.tables[0][:, None]
+
+
+def mlp_backward_takes_f16(spec, ws, bs, need_dx):
+    """True if mlp_backward(..., d_out=F16Rows) is accepted for this chain (papr_mlp_bwd_takes_f16_rows)."""
+    if not _TAIL_F16:
+        return False
+    return bool(hip.lib().papr_mlp_bwd_takes_f16_rows(_layer_table(spec, ws, bs), spec.n_layer, hip.i32_array(spec.ld_out), 1 if need_dx else 0,
+                                                      mlp_mode(spec.one_product, getattr(spec, "fp32_rows_inside", False))))
+
+
 def mlp_backward(spec, ws, bs, x, M, outs, d_out, scratch, need_dx):
-    """Returns (d_ws, d_bs, d_x or None).  d_out is consumed."""
+    """Returns (d_ws, d_bs, d_x or None).  d_out is consumed; an F16Rows instead of a tensor: see mlp_backward_takes_f16."""
     dev = x.device
+    d_out_f16 = None
+    if isinstance(d_out, F16Rows):
+        d_out, d_out_f16 = None, d_out.ref()
     tab = _layer_table(spec, ws, bs)
     if hip.lib().papr_mlp_bwd_needs_weight_t(tab, spec.n_layer, 1 if need_dx else 0, mlp_mode(spec.one_product, getattr(spec, "fp32_rows_inside", False))):     # (fused runs read W^T in place)
         wts = [w.t().contiguous() for w in ws]
@@ -685,7 +719,7 @@ def mlp_backward(spec, ws, bs, x, M, outs, d_out, scratch, need_dx):
     d_x = torch.empty_like(x) if need_dx else None
     hip.check(hip.lib().papr_mlp_bwd(tab, spec.n_layer, hip.ptr(x), x.shape[1], M, hip.ptr_array(outs),
                                      hip.i32_array(spec.ld_out), hip.ptr(getattr(outs, "row_absmax", None)),
-                                     hip.ptr(d_out), hip.ptr(scratch[0]), hip.ptr(scratch[1]),
+                                     hip.ptr(d_out), d_out_f16, hip.ptr(scratch[0]), hip.ptr(scratch[1]),
                                      scratch[0].shape[1], hip.ptr_array(d_ws), hip.ptr_array(d_bs), hip.ptr(d_x),
                                      hip.ptr(_workspace(dev, "bwd", M)), mlp_mode(spec.one_product, getattr(spec, "fp32_rows_inside", False)), hip.stream_ptr()), "papr_mlp_bwd")
     return d_ws, d_bs, d_x
@@ -1033,10 +1067,21 @@ class _RenderFn(torch.autograd.Function):
             V = s["v_aff"][2]                        # (what the tail multiplied: the value out-norm's affine applied)
 
         td = plan.tail_desc(k)
-        d_K = torch.empty_like(K) if K.shape[1] == plan.key.d_out else torch.zeros_like(K)
+        # one-product mode: the key / value gradient rows leave the tail kernel as the data-gradient runs stage them (F16Rows) where kernel and run agree
+        need_pts = ctx.needs_input_grad[6]
+        need_val_dx = need_pts or ctx.needs_input_grad[7]
+        k16 = v16 = None
+        if k <= 63 and K.shape[1] == plan.key.d_out == plan.d_model == 256 and mlp_backward_takes_f16(plan.key, kw, kb, need_pts):
+            k16 = F16Rows(dev, M, 256)
+        if k <= 63 and not plan.v_norm and V.shape[1] == plan.val.d_out and td.C == V.shape[1] and td.C in (4, 8, 16, 32, 64, 128) \
+                and mlp_backward_takes_f16(plan.val, vw, vb, need_val_dx):
+            v16 = F16Rows(dev, M, td.C)
+        global TAIL_F16_ROWS_USED
+        TAIL_F16_ROWS_USED += (k16 is not None) + (v16 is not None)
+        d_K = None if k16 else (torch.empty_like(K) if K.shape[1] == plan.key.d_out else torch.zeros_like(K))
         d_g = torch.empty_like(s["g"])
         d_c0 = torch.empty((R,), device=dev, dtype=torch.float32)
-        d_V = torch.empty_like(V)
+        d_V = None if v16 else torch.empty_like(V)
         # the three per-point gradients share ONE zeroed buffer (points without a pair keep the zeros; one fill launch instead of three):
         # [features | points | influence], the features first so that their rows stay 16-byte aligned
         n_pts = s["P"]
@@ -1055,7 +1100,7 @@ class _RenderFn(torch.autograd.Function):
                                          R, hip.ptr(s["scores"]), hip.ptr(s["attn"]), hip.ptr(d_fused), hip.ptr(d_attn), hip.ptr(d_K),
                                          hip.ptr(d_g), hip.ptr(d_V), None, hip.ptr(d_c0), hip.ptr(pair_influ),
                                          hip.ptr(s["kst2"]) if plan.k_norm else None, hip.ptr(s["c0"]) if plan.k_norm else None,
-                                         hip.ptr(s["k_outs"].norm_mean), hip.stream_ptr()), "papr_attn_tail_bwd")
+                                         hip.ptr(s["k_outs"].norm_mean), k16.ref() if k16 else None, v16.ref() if v16 else None, hip.stream_ptr()), "papr_attn_tail_bwd")
         # backward of g = q' W_k, c0 = q'.b_k: R-row products on the library's GEMMs (rocBLAS / hipBLASLt pick 130-270 us
         # kernels for these 25,600 x 256 shapes; the same work is ~100 us here)
         qp = s["qp"]
@@ -1102,8 +1147,7 @@ class _RenderFn(torch.autograd.Function):
             d_wk = [d_wkT[0].t()]
             d_wkb = [(qp * d_c0[:, None]).sum(0)]               # (two launches, 38 us; torch.mv(qp.t(), d_c0) lands on a 269-us rocBLAS gemv kernel: measured, reverted)
         # key branch
-        need_pts = ctx.needs_input_grad[6]
-        d_kw, d_kb, d_key = mlp_backward(plan.key, kw, kb, s["key_in"], M, s["k_outs"], d_K, scratch, need_pts)
+        d_kw, d_kb, d_key = mlp_backward(plan.key, kw, kb, s["key_in"], M, s["k_outs"], k16 or d_K, scratch, need_pts)
         # the backward pass of the LayerNorm core in front of the key MLP rides in papr_build_features_bwd_pairs where that kernel has the row's
         # statistics from the forward pass (key_given: the default); otherwise one papr_rownorm_bwd pass over the gradient rows
         ln_in_features = plan.k_norm and d_key is not None and s["key_given"] is not None and _LN_IN_FEATURES
@@ -1117,7 +1161,6 @@ class _RenderFn(torch.autograd.Function):
             rownorm_bwd_(d_Q, Q, s["qst2"], plan.qry.d_out, eps)
         d_qw, d_qb, _ = mlp_backward(plan.qry, qw, qb, s["qry_in"], R, s["q_outs"], d_Q, qscratch, False)
         # value branch
-        need_val_dx = need_pts or ctx.needs_input_grad[7]
         d_va = d_vbias = None
         if plan.v_norm:                              # back through the value out-norm: its affine (host glue), then its core
             v_hat, va, _ = s["v_aff"]
@@ -1126,7 +1169,7 @@ class _RenderFn(torch.autograd.Function):
             d_hat = torch.zeros_like(d_V)
             d_hat[:, :plan.val.d_out] = dv * va
             d_V = rownorm_bwd_(d_hat, v_hat, s["v_outs"].norm_stats, plan.val.d_out, eps)
-        d_vw, d_vb, d_val = mlp_backward(plan.val, vw, vb, s["val_in"], M, s["v_outs"], d_V, scratch, need_val_dx)
+        d_vw, d_vb, d_val = mlp_backward(plan.val, vw, vb, s["val_in"], M, s["v_outs"], v16 or d_V, scratch, need_val_dx)
         if plan.v_norm and d_val is not None:        # ... and its in-norm's core (the affine is folded into the first layer's weights)
             rownorm_bwd_(d_val, s["val_in"], s["v_outs"].in_stats, plan.val_w, eps)
         # gather / geometry / encoding backward: per-pair gradient rows, then one segmented sum per point

@@ -52,6 +52,8 @@ def main(tag, out):
     # (a fingerprint of the weight gradients, for the test that the f16-row path and the fp32-row path are two different computations)
     res["digest"] = float(sum(np.abs(named[k[5:]].grad.cpu().numpy().astype(np.float64)).sum() for k in g.files
                               if k.startswith("grad/") and named[k[5:]].grad is not None and "attn" in k))
+    from papr_amd import ops
+    res["tail_f16_rows"] = ops.TAIL_F16_ROWS_USED      # how many gradient-row sets left papr_attn_tail_bwd as papr_f16_rows
     json.dump(res, open(out, "w"))
 
 

@@ -34,7 +34,7 @@ VARIANTS = [("generic rows", dict(F32, PAPR_C4_GENERIC="1")), ("two-role", dict(
 
 def _run(tmp_path, name, env, M, n, act, dims=()):
     out = tmp_path / (name.replace(" ", "_") + ".pt")
-    e = {k: v for k, v in os.environ.items() if k not in ("PAPR_C4_GENERIC", "PAPR_C4_FUSED", "PAPR_GEMM_MODE", "PAPR_C4_DMA", "PAPR_C4_PAIRS", "PAPR_H3_ROWS", "PAPR_TN_TR")}
+    e = {k: v for k, v in os.environ.items() if k not in ("PAPR_C4_GENERIC", "PAPR_C4_FUSED", "PAPR_GEMM_MODE", "PAPR_C4_DMA", "PAPR_C4_PAIRS", "PAPR_H3_ROWS", "PAPR_TN_TR", "PAPR_VARIANT_TOP_F16")}
     e.update(env)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "chain_variants_worker.py"), str(out), str(M), str(n), act] + [str(v) for v in dims], env=e, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (name, r.stderr[-2000:])
@@ -42,7 +42,10 @@ def _run(tmp_path, name, env, M, n, act, dims=()):
 
 
 H1_VARIANTS = [("h1 generic rows", {"PAPR_C4_GENERIC": "1", "PAPR_GEMM_MODE": "h1"}), ("h1", {"PAPR_GEMM_MODE": "h1"}), ("h1 again", {"PAPR_GEMM_MODE": "h1"}),
-               ("h1 single slots", {"PAPR_GEMM_MODE": "h1", "PAPR_C4_PAIRS": "0"})]
+               ("h1 single slots", {"PAPR_GEMM_MODE": "h1", "PAPR_C4_PAIRS": "0"}),
+               # the top gradient rows arrive as papr_f16_rows (as papr_attn_tail_bwd writes them) and are staged by LDS-DMA
+               ("h1 top rows f16", {"PAPR_GEMM_MODE": "h1", "PAPR_VARIANT_TOP_F16": "1"}),
+               ("h1 top rows f16, generic rows", {"PAPR_GEMM_MODE": "h1", "PAPR_VARIANT_TOP_F16": "1", "PAPR_C4_GENERIC": "1"})]
 
 
 def _flat(res):

@@ -37,6 +37,10 @@ def test_h1_f16_rows_and_fp32_rows_both_meet_the_bar_and_differ(tmp_path):
         assert res["rgb"] <= 2e-3
         for name, e in res["grads"].items():
             assert e["finite"] and e["rms_rel"] <= 1e-2, (name, e)
+    # (round 6) the key / value gradient rows leave papr_attn_tail_bwd as papr_f16_rows and are staged by LDS-DMA: the same bits as fp32 rows staged by the run
+    plain = _run("chair1k", tmp_path / "d.json", PAPR_TAIL_F16="0")
+    assert half["tail_f16_rows"] == 2 and plain["tail_f16_rows"] == 0 and full["tail_f16_rows"] == 0
+    assert plain["digest"] == half["digest"] and plain["grads"] == half["grads"], "f16 gradient rows from the tail kernel change the gradients"
     assert half["digest"] != full["digest"], "same weight gradients with f16 and fp32 rows: the f16-row path did not run"
     assert half["digest"] == half2["digest"], "hot and generic row phases store different f16 rows"
     assert abs(half["digest"] - full["digest"]) <= 2e-3 * abs(full["digest"])
