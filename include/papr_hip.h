@@ -265,10 +265,13 @@ typedef struct {
     int32_t leave_input;
 } papr_row_norm;
 
-/* Rows in the one-product runs' input format (ABI 27): hi (M, ld) halfs = row x scale, scale (M) = the power of two that brings the row's maximum into
- * [2^6, 2^7) -- data-gradient rows: exponent clamped at 2^-40 --, inv (M) = 1 / scale, max (M) = max |row|.  ld: halfs per row, a multiple of 32, columns
- * beyond the row's width zero or absent. */
-typedef struct { uint16_t* hi; float* inv; float* scale; float* max; int32_t ld; } papr_f16_rows;
+/* Rows in the fused runs' input format (ABI 27): what a run's staging makes of fp32 rows, written by the producer instead.
+ *   lo == NULL, the one-product runs': hi (M, ld) halfs = row x scale, scale (M) = the power of two that brings the row's maximum into [2^6, 2^7) --
+ *     data-gradient rows: exponent clamped at 2^-40 --, inv (M) = 1 / scale, max (M) = max |row|;
+ *   lo != NULL, the parity runs' (split-f16): scale = the power of two that brings the maximum into [2^13, 2^14) (a zero row: 1), hi = f16(row x scale),
+ *     lo (M, ld) = f16(row x scale - hi).
+ * ld: halfs per row, a multiple of 32, columns beyond the row's width zero or absent. */
+typedef struct { uint16_t* hi; float* inv; float* scale; float* max; int32_t ld; uint16_t* lo; } papr_f16_rows;
 
 /* `mode` of papr_mlp_fwd / papr_mlp_bwd / papr_mlp_bwd_needs_weight_t: which arithmetic and which kernels carry the call.  An argument of
  * every call (ABI 16; before: a thread-local precision setting plus an environment variable read when the library loaded) --
@@ -313,10 +316,10 @@ int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float* x, int ldx
                  float* scratch0, float* scratch1, int ld_scratch, float* const* d_weight,
                  float* const* d_bias, float* d_x, void* workspace, int32_t mode, papr_stream_t stream);
 /* d_out_f16 (ABI 27; optional, then d_out may be NULL): the gradient rows in the one-product runs' input format (papr_attn_tail_bwd writes them so):
- * mode PAPR_MLP_H1 only, the last layers a fused run of at least two layers whose last has no activation, the forward call's row_absmax given, f16 rows
+ * modes PAPR_MLP_H1 (lo == NULL) and PAPR_MLP_H3_F16ROWS (lo != NULL) only, the last layers a fused run of at least two layers whose last has no activation, the forward call's row_absmax given, f16 rows
  * kept by the forward call -- anything else is an error, not a fallback.  The run then stages its tiles by LDS-DMA (no pass over fp32 rows: they do not
- * exist) and the top layer's weight gradient reads the same rows.  papr_mlp_bwd_takes_f16_rows: 1 if a call with these arguments accepts them (the
- * forward call's training state assumed), 0 otherwise -- ask before asking the producer for them. */
+ * exist) and the top layer's weight gradient reads the same rows.  papr_mlp_bwd_takes_f16_rows: 1 if a call with these arguments accepts them in the
+ * one-product form, 2 in the parity form (the forward call's training state assumed), 0 if not at all -- ask before asking the producer for them. */
 int papr_mlp_bwd_takes_f16_rows(const papr_layer* layers, int n_layers, const int32_t* ld_out, int need_dx, int32_t mode);
 
 /* ------------------------------------------------------------------------------------
@@ -364,7 +367,7 @@ int papr_attn_tail_bwd(const papr_tail_desc* d, const float* kp, const float* qp
                        const papr_f16_rows* d_kp_f16, const papr_f16_rows* d_v_f16, papr_stream_t stream);
 /* d_kp_f16 / d_v_f16 (ABI 27; each optional): the gradient rows leave AS THE ONE-PRODUCT DATA-GRADIENT RUN TAKES THEM (papr_f16_rows: 2 bytes per element
  * plus three floats per row) instead of as fp32 rows -- d_kp / d_v may then be NULL.  What papr_mlp_bwd(mode PAPR_MLP_H1, d_out_f16) stages by LDS-DMA
- * without a pass over them; the values are bit for bit what that run would have made of the fp32 rows.  Needs k <= 63, d_model = 256 (d_kp_f16),
+ * without a pass over them (PAPR_MLP_H3_F16ROWS: the split form, lo != NULL); the values are bit for bit what that run would have made of the fp32 rows.  Needs k <= 63, d_model = 256 (d_kp_f16),
  * C = ld_v a multiple of 4 that divides 256 (d_v_f16). */
 /* kp_mean (ABI 25; R*k floats or NULL; needs kp_norm_stats): the kp rows are RAW (papr_row_norm.raw_mean) -- every element read is standardised
  * first, (x - kp_mean[row]) * kp_norm_stats[2 row]. */

@@ -1229,7 +1229,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_h3_kernel(TNH3Batch batch) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (!ONE && on && k1) acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gfl, xh1, acc[i][1], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
+#ifndef TN_ABL_NO_MFMA
                 if (ONE && on && k0) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gfh, xh0, acc[i][0], 0, 0, 0);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
 #ifndef TN_ABL_NO_SPLIT
                 split_hi(j);
@@ -1239,7 +1241,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_h3_kernel(TNH3Batch batch) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (!ONE && on && k1) acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gfh, xl1, acc[i][1], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
+#ifndef TN_ABL_NO_MFMA
                 if (ONE && on && k1) acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gfh, xh1, acc[i][1], 0, 0, 0);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
                 if (!ONE) split_lo(j);
 #ifndef TN_ABL_NO_COLSUM
@@ -1333,9 +1337,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_h3_kernel(TNH3Batch batch) {
 //     fp32 rounding of the sum (the same argument as gemm_tn_h3's slice scale); the tile leaves times P.  c and 1 / scale_g (for the bias gradient, taken
 //     from the UN-scaled fragments in fp32) come from a 32-entry table per stage that wave 0 makes a stage ahead from the row maxima, which arrive by DMA too.
 // Same slices, same stage order, same 16-row matrix instructions as gemm_tn_h3_kernel<., 2>: partial tiles in natural order (slab_reduce_kernel<false>).
-constexpr int TR_D = 4;                          // stages in flight
-constexpr int TR_SUB = 1152;                     // bytes from one [32][16] subtile to the next (1,024 + 128: adjacent subtiles on disjoint banks)
-constexpr int TR_OP = 16 * TR_SUB;               // one operand of one stage
+constexpr int TR_D = 4;                          // stage buffers: one being multiplied, three on their way
+constexpr int TR_PAIR = 1088;                    // bytes from one row pair to the next (2 x 512 + 64: four consecutive pairs sit on the four quarters of the banks)
+constexpr int TR_OP = 16 * TR_PAIR;              // one operand of one stage: pair q = rows q and q + 16 of the stage, 512 bytes each
 constexpr int TR_STAGE = 2 * TR_OP;              // G | X
 constexpr int TR_OFF_RAW = TR_D * TR_STAGE;      // per stage: max |g| [32] | max |x| [32] floats
 constexpr int TR_OFF_C = TR_OFF_RAW + TR_D * 256;        // per stage: c[32] halfs
@@ -1355,6 +1359,13 @@ __device__ __forceinline__ void tr_dma4(const void* src, unsigned lds_dst) {    
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
 }
+__device__ __forceinline__ half8 tr_read8(unsigned a) {     // 8 consecutive rows of this lane's column: two transposing reads of four rows each (four pairs apart)
+    const tr_h4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) tr_h4*)a);
+    const tr_h4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) tr_h4*)(a + 4 * TR_PAIR));
+    return half8{(_Float16)lo[0], (_Float16)lo[1], (_Float16)lo[2], (_Float16)lo[3], (_Float16)hi[0], (_Float16)hi[1], (_Float16)hi[2], (_Float16)hi[3]};
+}
+
+struct TrFrags { half8 x[2]; half8 g[4]; half8 cv; float4 ig0, ig1; };
 
 __global__ __launch_bounds__(512, 2) void gemm_tn_tr_kernel(TNH3Batch batch) {
     extern __shared__ __attribute__((aligned(16))) char tr_smem[];
@@ -1390,12 +1401,14 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_tr_kernel(TNH3Batch batch) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    float colsum[4] = {0.f, 0.f, 0.f, 0.f};
+    float colsum = 0.f;                          // bias gradient: this wave sums G's tile wn * 4 + wk (the four waves of a wn read the same G fragments)
 
     const _Float16* const Gh = reinterpret_cast<const _Float16*>(p.G);
     const _Float16* const Xh = reinterpret_cast<const _Float16*>(p.X);
     const long nst = (nrows + TN_ROWS - 1) / TN_ROWS;
-    // the requests of stage st (rows past the slice: the slice's last row again -- their c is 0)
+    // the requests of stage st (rows past the slice: the slice's last row again -- their c is 0).  One instruction = one row pair = two whole rows of
+    // 512 bytes: lanes 0 .. 31 the 16-byte pieces of row q, lanes 32 .. 63 those of row q + 16 (whole cache lines: the first version of this kernel
+    // gathered 32-byte pieces of 32 rows per instruction, four requests per line, and streamed 5.0 TB/s with the matrix work taken out)
     auto issue = [&](long st) {
         const unsigned buf = lds0 + (unsigned)(st % TR_D) * TR_STAGE;
         if (wave == 0) {
@@ -1404,13 +1417,13 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_tr_kernel(TNH3Batch batch) {
             const float* src = (lane >> 5 ? p.xmax : p.gmax) + mbeg + m;
             tr_dma4(src, lds0 + TR_OFF_RAW + (unsigned)(st % TR_D) * 256);
         }
-        int m = (int)st * TN_ROWS + (lane >> 1);
-        m = m < nrows ? m : nrows - 1;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int idx = 4 * wave + q, op = idx >> 4, sub = idx & 15;
-            const _Float16* src = (op ? Xh + (mbeg + m) * p.ldx : Gh + (mbeg + m) * p.ldg) + 16 * sub + 8 * (lane & 1);
-            tr_dma16(src, buf + (unsigned)(op * TR_OP + sub * TR_SUB));
+            const int idx = 4 * wave + q, op = idx >> 4, pair = idx & 15;
+            int m = (int)st * TN_ROWS + pair + 16 * (lane >> 5);
+            m = m < nrows ? m : nrows - 1;
+            const _Float16* src = (op ? Xh + (mbeg + m) * p.ldx : Gh + (mbeg + m) * p.ldg) + 8 * (lane & 31);
+            tr_dma16(src, buf + (unsigned)(op * TR_OP + pair * TR_PAIR));
         }
     };
     // the factor table of stage st (wave 0, lanes 0 .. 31), from the maxima in LDS
@@ -1423,49 +1436,62 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_tr_kernel(TNH3Batch batch) {
         reinterpret_cast<_Float16*>(tr_smem + TR_OFF_C + b * 64)[lane] = ok ? (_Float16)(ig * ix * Pinv) : (_Float16)0.f;
         reinterpret_cast<float*>(tr_smem + TR_OFF_IG + b * 128)[lane] = ok ? ig : 0.f;
     };
-    for (long st = 0; st < TR_D - 1; ++st) issue(st);
-    if (wave == 0) {
-        asm volatile("s_waitcnt vmcnt(14)" ::: "memory");         // stage 0's maxima (behind them: 4 + 5 + 5 requests of this wave)
-        make_table(0);
-    }
-    // lane-derived LDS offsets of the fragments: 16-lane group g = (lane >> 4) & 1 takes the tile's second subtile, k-group lane >> 5 the rows 8 .. 15 of a k-step
-    const unsigned frag = (unsigned)(((lane >> 4) & 1) * TR_SUB + (8 * (lane >> 5) + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8);
-    for (long st = 0; st < nst; ++st) {
-        if (wave == 0) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");       // stage st's rows and stage st + 1's maxima have landed (behind them: 4 + 5 of this wave's requests)
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        lds_barrier();                               // everybody's requests of stage st are in LDS; everybody is done with stage st - 1
-        issue(st + TR_D - 1);
-        make_table(st + 1);
-        const char* const sb = tr_smem + (st % TR_D) * TR_STAGE;
-        const _Float16* const ctab = reinterpret_cast<const _Float16*>(tr_smem + TR_OFF_C + (st % TR_D) * 64);
-        const float* const igtab = reinterpret_cast<const float*>(tr_smem + TR_OFF_IG + (st % TR_D) * 128);
+    // this lane's corner of a fragment: the 16-lane group (lane >> 4) & 1 takes the tile's columns 16 .. 31, the k-group lane >> 5 the rows 8 .. 15 of a
+    // 16-row k-step; a lane of a group asks for row (lane & 15) >> 2 of four, 8-byte piece lane & 3 of the group's 32 bytes.  Row r of the stage: pair r & 15,
+    // upper half for r >= 16 -- the second k-step of the stage is +512 bytes, tile t +64 t bytes, rows +4 are +4 pairs
+    const unsigned frag = (unsigned)((8 * (lane >> 5) + ((lane & 15) >> 2)) * TR_PAIR + 32 * ((lane >> 4) & 1) + 8 * (lane & 3));
+    const unsigned xfrag = frag + TR_OP + (unsigned)(wk * 2) * 64, gfrag = frag + (unsigned)(wn * 4) * 64;
+    auto read_frags = [&](TrFrags& f, long st, int ks) {
+        const unsigned sb = lds0 + (unsigned)(st % TR_D) * TR_STAGE + (unsigned)ks * 512;
+        f.x[0] = tr_read8(sb + xfrag); f.x[1] = tr_read8(sb + xfrag + 64);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const half8 cv = *reinterpret_cast<const half8*>(ctab + ks * 16 + 8 * (lane >> 5));
-            half8 xb[2];
+        for (int i = 0; i < 4; ++i) f.g[i] = tr_read8(sb + gfrag + 64 * i);
+        f.cv = *reinterpret_cast<const half8*>(tr_smem + TR_OFF_C + (st % TR_D) * 64 + (ks * 16 + 8 * (lane >> 5)) * 2);
+        const float* ig = reinterpret_cast<const float*>(tr_smem + TR_OFF_IG + (st % TR_D) * 128) + ks * 16 + 8 * (lane >> 5);
+        f.ig0 = *reinterpret_cast<const float4*>(ig); f.ig1 = *reinterpret_cast<const float4*>(ig + 4);
+    };
+    auto multiply = [&](const TrFrags& f) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const char* a = sb + TR_OP + (2 * (wk * 2 + j)) * TR_SUB + frag + ks * 512;
-                const tr_h4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) tr_h4*)(unsigned)(size_t)a);
-                const tr_h4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) tr_h4*)(unsigned)(size_t)(a + 128));
-                xb[j] = half8{(_Float16)lo[0], (_Float16)lo[1], (_Float16)lo[2], (_Float16)lo[3], (_Float16)hi[0], (_Float16)hi[1], (_Float16)hi[2], (_Float16)hi[3]};
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const char* a = sb + (2 * (wn * 4 + i)) * TR_SUB + frag + ks * 512;
-                const tr_h4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) tr_h4*)(unsigned)(size_t)a);
-                const tr_h4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) tr_h4*)(unsigned)(size_t)(a + 128));
-                const half8 gr = half8{(_Float16)lo[0], (_Float16)lo[1], (_Float16)lo[2], (_Float16)lo[3], (_Float16)hi[0], (_Float16)hi[1], (_Float16)hi[2], (_Float16)hi[3]};
-                if (wk == 0) {                       // bias gradient: the true values of G, this lane's column, its eight rows of the k-step
-                    const float4 i0 = *reinterpret_cast<const float4*>(igtab + ks * 16 + 8 * (lane >> 5)), i1 = *reinterpret_cast<const float4*>(igtab + ks * 16 + 8 * (lane >> 5) + 4);
-                    colsum[i] = __builtin_fmaf((float)gr[7], i1.w, __builtin_fmaf((float)gr[6], i1.z, __builtin_fmaf((float)gr[5], i1.y, __builtin_fmaf((float)gr[4], i1.x,
-                                __builtin_fmaf((float)gr[3], i0.w, __builtin_fmaf((float)gr[2], i0.z, __builtin_fmaf((float)gr[1], i0.y, __builtin_fmaf((float)gr[0], i0.x, colsum[i]))))))));
-                }
-                const half8 ga = gr * cv;            // (packed f16 multiplies by powers of two)
-                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ga, xb[0], acc[i][0], 0, 0, 0);
-                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ga, xb[1], acc[i][1], 0, 0, 0);
-            }
+        for (int i = 0; i < 4; ++i) {
+            const half8 gr = f.g[i];
+            if (wk == i)                             // bias gradient: the true values of G, this lane's column, its eight rows of the k-step
+                colsum = __builtin_fmaf((float)gr[7], f.ig1.w, __builtin_fmaf((float)gr[6], f.ig1.z, __builtin_fmaf((float)gr[5], f.ig1.y, __builtin_fmaf((float)gr[4], f.ig1.x,
+                         __builtin_fmaf((float)gr[3], f.ig0.w, __builtin_fmaf((float)gr[2], f.ig0.z, __builtin_fmaf((float)gr[1], f.ig0.y, __builtin_fmaf((float)gr[0], f.ig0.x, colsum))))))));
+            const half8 ga = gr * f.cv;              // (packed f16 multiplies by powers of two)
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ga, f.x[0], acc[i][0], 0, 0, 0);
+            acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ga, f.x[1], acc[i][1], 0, 0, 0);
         }
+    };
+    // Schedule: the fragments of a k-step are read while the matrix instructions of the k-step before run (two register sets), and the stage's ONE barrier
+    // stands between its two k-steps: in front of it a wave has read everything of stage st (its buffer goes to the requests of stage st + 4 right
+    // behind the barrier), behind it stage st + 1 is everybody's to read -- requested three stages earlier.
+    //   wave 0's requests, in order: [maxima, 4 x rows] per stage.  In front of the barrier of stage st: the rows of st + 1 (and, wave 0, the maxima
+    //   of st + 2: their table is made behind the barrier and first read behind the NEXT one) have landed when 8 (9) requests are outstanding.
+    issue(0); issue(1); issue(2);
+    if (wave == 0) {
+        asm volatile("s_waitcnt vmcnt(9)" ::: "memory");          // maxima of stages 0 and 1 (behind them: 4 + 5 requests)
+        make_table(0); make_table(1);
+    } else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // rows of stage 0
+    lds_barrier();
+    issue(3);
+    TrFrags fa, fb;
+    read_frags(fa, 0, 0);
+    for (long st = 0; st < nst; ++st) {
+        read_frags(fb, st, 1);
+#ifndef TR_ABL_NO_COMPUTE
+        multiply(fa);
+#endif
+        if (wave == 0) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        lds_barrier();
+#ifndef TR_ABL_NO_DMA
+        issue(st + TR_D);
+#endif
+        make_table(st + 2);
+        read_frags(fa, st + 1, 0);
+#ifndef TR_ABL_NO_COMPUTE
+        multiply(fb);
+#endif
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // (the requests past the slice's end)
     float* out = p.slab + slice * SLAB * SLAB;
@@ -1480,12 +1506,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_tr_kernel(TNH3Batch batch) {
                 out[n * SLAB + k] = acc[i][j][e] * P;
             }
         }
-    if (wk == 0) {                                   // column sums: lane l and lane l + 32 hold the two row groups of column (wn * 4 + i) * 32 + (l & 31)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float other = __shfl_xor(colsum[i], 32);
-            if (lane < 32) p.bias_slab[slice * SLAB + (wn * 4 + i) * 32 + lane] = colsum[i] + other;
-        }
+    {                                                // column sums: lane l and lane l + 32 hold the two row groups of column (wn * 4 + wk) * 32 + (l & 31)
+        const float other = __shfl_xor(colsum, 32);
+        if (lane < 32) p.bias_slab[slice * SLAB + (wn * 4 + wk) * 32 + lane] = colsum + other;
     }
 }
 #pragma clang diagnostic pop
@@ -1887,21 +1910,23 @@ extern "C" int papr_mlp_bwd_needs_weight_t(const papr_layer* layers, int n_layer
     return 0;
 }
 
-// papr_mlp_bwd's d_out_f16: the top layers are a fused run of the one-product mode with f16 rows (the call as a whole runs in that arithmetic: t_mode is
-// the caller's, one_product_or_parity() applied), no activation behind the last layer, and the launch has a layer that is not its last
-static bool bwd_takes_f16_top(const papr_layer* layers, int n_layers, const int32_t* ld_out, bool need_dx) {
-    if (!GEMM_ONE_PRODUCT || layers[n_layers - 1].act != PAPR_ACT_NONE) return false;
+// papr_mlp_bwd's d_out_f16: the top layers are a fused run with f16 rows -- the one-product mode's (1) or PAPR_MLP_H3_F16ROWS' (2: the split form; the
+// call as a whole runs in that arithmetic: t_mode is the caller's, one_product_or_parity() applied) --, no activation behind the last layer, and the
+// launch has a layer that is not its last.  0: the call does not take them.
+static int bwd_takes_f16_top(const papr_layer* layers, int n_layers, const int32_t* ld_out, bool need_dx) {
+    if (!(GEMM_ONE_PRODUCT || t_h3_f16_rows) || layers[n_layers - 1].act != PAPR_ACT_NONE) return 0;
     int bt = -1;
     for (int b = 0; b < n_layers;) { const int e = chain_run_end(layers, n_layers, b); if (e - b >= 2) { if (e == n_layers) bt = b; b = e; } else ++b; }
-    if (bt < 0 || !run_half_rows(layers, n_layers, bt, n_layers, ld_out, true)) return false;
+    if (bt < 0 || !run_half_rows(layers, n_layers, bt, n_layers, ld_out, true)) return 0;
     const int last = bt == 0 ? (need_dx ? 0 : 1) : bt;
-    return (n_layers - 1) - last >= 1;
+    if ((n_layers - 1) - last < 1) return 0;
+    return GEMM_ONE_PRODUCT ? 1 : 2;
 }
 
 extern "C" int papr_mlp_bwd_takes_f16_rows(const papr_layer* layers, int n_layers, const int32_t* ld_out, int need_dx, int32_t mode) {
     if (!layers || !ld_out || n_layers < 1 || !mode_from_arg(mode)) return 0;
     one_product_or_parity(layers, n_layers, ld_out, true, true);
-    return bwd_takes_f16_top(layers, n_layers, ld_out, need_dx != 0) ? 1 : 0;
+    return bwd_takes_f16_top(layers, n_layers, ld_out, need_dx != 0);
 }
 
 extern "C" size_t papr_mlp_bwd_workspace_bytes(int64_t M) { return TN_SLAB_BYTES + H3Scratch::bytes(M) + BwdRunScratch::bytes(M) + SRScratch::reserve(M); }
@@ -1918,10 +1943,11 @@ extern "C" int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float*
     if (d_out_f16) {
         // the top gradient rows as the producer wrote them (papr_f16_rows): what the one-product data-gradient run's staging would have made of fp32 rows
         const int top_w = layers[n_layers - 1].n_out;
-        PAPR_REQUIRE(bwd_takes_f16_top(layers, n_layers, ld_out, d_x != nullptr) && d_out_f16->hi && d_out_f16->inv && d_out_f16->scale && d_out_f16->max &&
+        const int kind = bwd_takes_f16_top(layers, n_layers, ld_out, d_x != nullptr);
+        PAPR_REQUIRE(kind != 0 && (kind == 2) == (d_out_f16->lo != nullptr) && d_out_f16->hi && d_out_f16->inv && d_out_f16->scale && d_out_f16->max &&
                      d_out_f16->ld % 32 == 0 && d_out_f16->ld >= (top_w + 31) / 32 * 32,
-                     "papr_mlp_bwd: d_out_f16 needs what papr_mlp_bwd_takes_f16_rows() reports (this call: %s arithmetic) and rows of a multiple of 32 halfs",
-                     GEMM_ONE_PRODUCT ? "one-product" : "parity");
+                     "papr_mlp_bwd: d_out_f16 needs the form papr_mlp_bwd_takes_f16_rows() reports (this call: %d; lo %s) and rows of a multiple of 32 halfs",
+                     kind, d_out_f16->lo ? "given" : "NULL");
     }
     hipStream_t s = as_stream(stream);
     bool any_skip = false;
@@ -2023,7 +2049,9 @@ extern "C" int papr_mlp_bwd(const papr_layer* layers, int n_layers, const float*
             if (top_f16) {                          // staged by LDS-DMA; the rows are their own f16 copy, their maxima the producer's table
                 PAPR_REQUIRE(g_half, "papr_mlp_bwd: d_out_f16 and a top run without f16 gradient rows");
                 c.A0 = nullptr; c.rowmax0 = nullptr; c.a0_half = nullptr;
-                c.sr_hi = reinterpret_cast<const _Float16*>(d_out_f16->hi); c.sr_lo = nullptr; c.sr_inv = d_out_f16->inv; c.sr_max = d_out_f16->scale; c.sr_ld = d_out_f16->ld;
+                c.sr_hi = reinterpret_cast<const _Float16*>(d_out_f16->hi); c.sr_lo = reinterpret_cast<const _Float16*>(d_out_f16->lo); c.sr_inv = d_out_f16->inv;
+                c.sr_max = GEMM_ONE_PRODUCT ? d_out_f16->scale : d_out_f16->max;       // (the tile's second table: the scale itself in the one-product mode, the maximum in the parity arithmetic)
+                c.sr_ld = d_out_f16->ld;
             }
             size_t used = 0;
             SplitBatch split = {};

@@ -194,6 +194,15 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(papr_tail_desc d, const f
     // its maximum, one rounding to f16): four values of this lane, the row's maximum `mx` known to every lane that holds a piece of it
     auto put16 = [&](const papr_f16_rows& o, long row, int col, const float4& val, float mx, bool first) {
         float inv;
+        if (o.lo) {                                     // the parity runs' split form (gemm.hip: split_rows_kernel)
+            const float sc = h3_scale_from_max(__float_as_uint(mx), inv);
+            half4 hi, lo;
+            split4(val, sc, hi, lo);
+            *reinterpret_cast<half4*>(o.hi + row * o.ld + col) = hi;
+            *reinterpret_cast<half4*>(o.lo + row * o.ld + col) = lo;
+            if (first) { o.inv[row] = inv; o.scale[row] = sc; o.max[row] = mx; }
+            return;
+        }
         const float sc = one_scale_from_max(__float_as_uint(mx), ONE_EMIN_DGRAD, inv);
         unsigned h01, h23;                              // (the staging code's own instructions: chain4.hip, write_planes)
         asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h01) : "v"(val.x), "v"(sc));

@@ -45,7 +45,7 @@ class Layer(C.Structure):
 
 class F16Rows(C.Structure):
     """papr_f16_rows: gradient rows in the one-product runs' input format."""
-    _fields_ = [("hi", C.c_void_p), ("inv", C.c_void_p), ("scale", C.c_void_p), ("max", C.c_void_p), ("ld", C.c_int32)]
+    _fields_ = [("hi", C.c_void_p), ("inv", C.c_void_p), ("scale", C.c_void_p), ("max", C.c_void_p), ("ld", C.c_int32), ("lo", C.c_void_p)]
 
 
 class RowNorm(C.Structure):

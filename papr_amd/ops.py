@@ -682,25 +682,28 @@ TAIL_F16_ROWS_USED = 0       # (tests: counts the row sets handed over that way)
 class F16Rows:
     """Device buffers of one papr_f16_rows (include/papr_hip.h) and the struct that points at them."""
 
-    def __init__(self, dev, M, width):
+    def __init__(self, dev, M, width, split=False):
         ld = (width + 31) // 32 * 32
         self.hi = torch.empty((M, ld), device=dev, dtype=torch.float16)
+        self.lo = torch.empty((M, ld), device=dev, dtype=torch.float16) if split else None      # (the parity runs' form: hi + lo)
         self.tables = torch.empty((3, M), device=dev, dtype=torch.float32)       # 1 / scale, scale, max |row|
-        self.c = hip.F16Rows(self.hi.data_ptr(), self.tables[0].data_ptr(), self.tables[1].data_ptr(), self.tables[2].data_ptr(), ld)
+        self.c = hip.F16Rows(self.hi.data_ptr(), self.tables[0].data_ptr(), self.tables[1].data_ptr(), self.tables[2].data_ptr(), ld,
+                             self.lo.data_ptr() if split else None)
 
     def ref(self):
         return C.byref(self.c)
 
     def float(self):
         """The rows as fp32 (tests)."""
-        return self.hi.float() * self.tables[0][:, None]
+        return (self.hi.float() + (self.lo.float() if self.lo is not None else 0.0)) * self.tables[0][:, None]
 
 
 def mlp_backward_takes_f16(spec, ws, bs, need_dx):
-    """True if mlp_backward(..., d_out=F16Rows) is accepted for this chain (papr_mlp_bwd_takes_f16_rows)."""
+    """Whether mlp_backward(..., d_out=F16Rows) is accepted for this chain (papr_mlp_bwd_takes_f16_rows): 0 no, 1 the one-product form,
+    2 the parity form (F16Rows(..., split=True))."""
     if not _TAIL_F16:
-        return False
-    return bool(hip.lib().papr_mlp_bwd_takes_f16_rows(_layer_table(spec, ws, bs), spec.n_layer, hip.i32_array(spec.ld_out), 1 if need_dx else 0,
+        return 0
+    return int(hip.lib().papr_mlp_bwd_takes_f16_rows(_layer_table(spec, ws, bs), spec.n_layer, hip.i32_array(spec.ld_out), 1 if need_dx else 0,
                                                       mlp_mode(spec.one_product, getattr(spec, "fp32_rows_inside", False))))
 
 
@@ -1071,11 +1074,12 @@ class _RenderFn(torch.autograd.Function):
         need_pts = ctx.needs_input_grad[6]
         need_val_dx = need_pts or ctx.needs_input_grad[7]
         k16 = v16 = None
-        if k <= 63 and K.shape[1] == plan.key.d_out == plan.d_model == 256 and mlp_backward_takes_f16(plan.key, kw, kb, need_pts):
-            k16 = F16Rows(dev, M, 256)
-        if k <= 63 and not plan.v_norm and V.shape[1] == plan.val.d_out and td.C == V.shape[1] and td.C in (4, 8, 16, 32, 64, 128) \
-                and mlp_backward_takes_f16(plan.val, vw, vb, need_val_dx):
-            v16 = F16Rows(dev, M, td.C)
+        if k <= 63 and K.shape[1] == plan.key.d_out == plan.d_model == 256:
+            kind = mlp_backward_takes_f16(plan.key, kw, kb, need_pts)
+            k16 = F16Rows(dev, M, 256, kind == 2) if kind else None
+        if k <= 63 and not plan.v_norm and V.shape[1] == plan.val.d_out and td.C == V.shape[1] and td.C in (4, 8, 16, 32, 64, 128):
+            kind = mlp_backward_takes_f16(plan.val, vw, vb, need_val_dx)
+            v16 = F16Rows(dev, M, td.C, kind == 2) if kind else None
         global TAIL_F16_ROWS_USED
         TAIL_F16_ROWS_USED += (k16 is not None) + (v16 is not None)
         d_K = None if k16 else (torch.empty_like(K) if K.shape[1] == plan.key.d_out else torch.zeros_like(K))

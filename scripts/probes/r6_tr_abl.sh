@@ -1,0 +1,11 @@
+#!/bin/bash
+# what binds gemm_tn_tr_kernel: ablation builds (results wrong), the weight-gradient batch of a 4-layer 256-wide run in mode h1 with PAPR_TN_TR=1
+O=gpurun_out/r6tn; mkdir -p $O
+{ timeout 900 python3 -m pytest tests/test_hip_chain_variants.py -q -m gpu -x -k "f16_rows_mode" 2>&1 | tail -3
+  echo "== register kernel"; PAPR_GEMM_MODE=h1 python3 scripts/probes/chain_bench.py 2>&1 | tail -1
+  for v in "" tr_NO_DMA tr_NO_COMPUTE; do
+    echo "== tr ${v:-as built}"
+    if [ -n "$v" ]; then export PAPR_HIP_LIB=$PWD/scripts/probes/bin/libpapr_$v.so; else unset PAPR_HIP_LIB; fi
+    PAPR_TN_TR=1 PAPR_GEMM_MODE=h1 python3 scripts/probes/chain_bench.py 2>&1 | tail -1
+  done; } > $O/abl_tr2.txt 2>&1
+cat $O/abl_tr2.txt

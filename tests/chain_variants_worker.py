@@ -35,15 +35,11 @@ def main(out, M, n, act, d_in=117, d_out=256):
     rowmax = outs.row_absmax[: n * M].clone()
     top = gp.clone()
     if os.environ.get("PAPR_VARIANT_TOP_F16") == "1":
-        # the top gradient rows handed over as papr_f16_rows (what papr_attn_tail_bwd writes in the one-product mode): the rows times the power of two
-        # of their maximum, rounded once -- what the run's own staging makes of the fp32 rows
-        assert ops.mlp_backward_takes_f16(spec, ws, bs, True), "the run does not take f16 top rows"
-        top = ops.F16Rows(d, M, spec.ld_out[-1])
-        mx = gp.abs().amax(1)
-        e = torch.where(mx > 0, torch.clamp(torch.frexp(mx)[1] - 1, min=-40), torch.full_like(mx, -40, dtype=torch.int32))
-        scale = ((127 + 6 - e).to(torch.int32) << 23).view(torch.float32)                  # 2^(6 - e), exactly
-        top.hi.copy_((gp * scale[:, None]).to(torch.float16))
-        top.tables[0].copy_(1.0 / scale); top.tables[1].copy_(scale); top.tables[2].copy_(mx)
+        # the top gradient rows handed over as papr_f16_rows (what papr_attn_tail_bwd writes): what the run's own staging makes of the fp32 rows
+        import f16_rows
+        kind = ops.mlp_backward_takes_f16(spec, ws, bs, True)
+        assert kind, "the run does not take f16 top rows"
+        top = f16_rows.fill(ops.F16Rows(d, M, spec.ld_out[-1], kind == 2), gp)
     d_ws, d_bs, d_x = ops.mlp_backward(spec, ws, bs, xd, M, outs, top, scratch, True)
     d_ws2, _, d_x2 = ops.mlp_backward(spec, ws, bs, xd, M, list(outs), gp.clone(), scratch, True)      # without the saved state: fp32 masks
     inf = ops.mlp_forward(spec, ws, bs, xd, M, keep=False)[-1].clone()

@@ -87,7 +87,9 @@ def test_one_product_mode_forms_agree_bit_for_bit(tmp_path, M, n, act, dims):
 
 F16ROWS_VARIANTS = [("h3_f16rows generic rows", {"PAPR_C4_GENERIC": "1", "PAPR_GEMM_MODE": "h3_f16rows"}), ("h3_f16rows", {}),      # ({}: the default IS this mode)
                     ("h3_f16rows again", {"PAPR_GEMM_MODE": "h3_f16rows"}), ("h3_f16rows single slots", {"PAPR_GEMM_MODE": "h3_f16rows", "PAPR_C4_PAIRS": "0"}),
-                    ("h3_f16rows two-role", {"PAPR_GEMM_MODE": "h3_f16rows", "PAPR_C4_FUSED": "0"})]
+                    ("h3_f16rows two-role", {"PAPR_GEMM_MODE": "h3_f16rows", "PAPR_C4_FUSED": "0"}),
+                    # the top gradient rows arrive split (papr_f16_rows with a lo plane, as papr_attn_tail_bwd writes them) and are staged by LDS-DMA
+                    ("h3_f16rows top rows split", {"PAPR_VARIANT_TOP_F16": "1"}), ("h3_f16rows top rows split, generic rows", {"PAPR_VARIANT_TOP_F16": "1", "PAPR_C4_GENERIC": "1"})]
 
 
 @pytest.mark.parametrize("M,n,act,dims", [(40000, 5, "relu", ()), (30053, 4, "leakyrelu", (141, 32))])

@@ -704,24 +704,22 @@ def test_attention_tail_forward_backward(R, k, d_model, Cc, act, normalize):
                                            hip.ptr(d_qp), hip.ptr(d_v), hip.ptr(d_inf), hip.ptr(d_sb), None, None, None, None, None, None, hip.stream_ptr()), "tail_bwd")
     torch.cuda.synchronize()
     if d_model == 256 and Cc == 32:
-        # the same gradient rows in the one-product runs' input format (papr_f16_rows): bit for bit the fp32 rows times the power of two of their
-        # maximum (exponent target 6, clamped at 2^-40: h3_common.h), rounded once
+        # the same gradient rows in the fused runs' input format (papr_f16_rows; both forms): bit for bit what the runs' staging makes of the fp32 rows
+        import f16_rows
         from papr_amd import ops
-        k16, v16 = ops.F16Rows(d, R * k, 256), ops.F16Rows(d, R * k, 32)
-        d_qp2 = torch.empty_like(d_qp); d_inf2 = torch.zeros((P, 1), device=d); d_sb2 = torch.empty((R,), device=d)
-        hip.check(hip.lib().papr_attn_tail_bwd(C.byref(td), hip.ptr(kpd), hip.ptr(qpd), hip.ptr(vd), hip.ptr(infd), hip.ptr(idxd), R,
-                                               hip.ptr(scores), hip.ptr(attn), hip.ptr(gf_d), hip.ptr(ga_d), None,
-                                               hip.ptr(d_qp2), None, hip.ptr(d_inf2), hip.ptr(d_sb2), None, None, None, None, k16.ref(), v16.ref(), hip.stream_ptr()), "tail_bwd")
-        torch.cuda.synchronize()
-        assert torch.equal(d_qp2, d_qp) and torch.equal(d_sb2, d_sb)
-        for rows, got in ((d_kp, k16), (d_v[:, :32], v16)):
-            mx = rows.abs().amax(1)
-            e = torch.where(mx > 0, torch.clamp(torch.frexp(mx)[1] - 1, min=-40), torch.full_like(mx, -40, dtype=torch.int32))      # max in [2^e, 2^(e+1)); a zero row: the clamp
-            scale = ((127 + 6 - e).to(torch.int32) << 23).view(torch.float32)              # 2^(6 - e), exactly (torch.ldexp on the device is not)
-            bad = (got.tables[1] != scale).nonzero().flatten()[:5]
-            assert torch.equal(got.tables[2], mx) and torch.equal(got.tables[1], scale), (bad, mx[bad], got.tables[1][bad], scale[bad])
-            assert torch.equal(got.tables[0], 1.0 / scale)
-            assert torch.equal(got.hi, (rows * scale[:, None]).to(torch.float16))
+        for split in (False, True):
+            k16, v16 = ops.F16Rows(d, R * k, 256, split), ops.F16Rows(d, R * k, 32, split)
+            d_qp2 = torch.empty_like(d_qp); d_inf2 = torch.zeros((P, 1), device=d); d_sb2 = torch.empty((R,), device=d)
+            hip.check(hip.lib().papr_attn_tail_bwd(C.byref(td), hip.ptr(kpd), hip.ptr(qpd), hip.ptr(vd), hip.ptr(infd), hip.ptr(idxd), R,
+                                                   hip.ptr(scores), hip.ptr(attn), hip.ptr(gf_d), hip.ptr(ga_d), None,
+                                                   hip.ptr(d_qp2), None, hip.ptr(d_inf2), hip.ptr(d_sb2), None, None, None, None, k16.ref(), v16.ref(), hip.stream_ptr()), "tail_bwd")
+            torch.cuda.synchronize()
+            assert torch.equal(d_qp2, d_qp) and torch.equal(d_sb2, d_sb)
+            for rows, got in ((d_kp, k16), (d_v[:, :32], v16)):
+                hi, lo, inv, scale, mx = f16_rows.expected(rows, split)
+                assert torch.equal(got.tables[2], mx) and torch.equal(got.tables[1], scale) and torch.equal(got.tables[0], inv)
+                assert torch.equal(got.hi, hi) and (not split or torch.equal(got.lo, lo))
+                assert (got.float() - rows).abs().max() <= (2e-7 if split else 1e-3) * rows.abs().max()
 
     tol = lambda ref: 3e-5 * ref.abs().max().item() + 1e-9
     np.testing.assert_allclose(d_kp.cpu().numpy(), kp.grad.reshape(R * k, -1).numpy(), rtol=0, atol=tol(kp.grad))
