@@ -545,9 +545,11 @@ int papr_profile_enable(int on);
  *                              the box's power state); 0: off
  *   PAPR_SW_C4_WCOPIES  (1)    timing experiment of probe builds (-DC4_X_WCOPIES; the regular library ignores it since ABI 27): 2-4 = the workgroups of
  *                              an XCD read a fused run's weight fragments from that many copies of the planes
- *   PAPR_SW_TN_TR       (0)    1: the weight gradients of full 256 x 256 layers from f16 rows on the LDS-DMA + transposing-read kernel (gemm_tn_tr_kernel, ABI 27:
- *                              rows by global_load_lds_dwordx4 four stages deep, operands by ds_read_b64_tr_b16) instead of the register-staged kernel
- *                              (gemm_tn_h3_kernel<., 2>).  Measured equal (4.3 TB/s either way: what binds them is on the memory side, not the operand path)
+ *   PAPR_SW_TN_TR       (1)    1: the weight gradients of full 256 x 256 layers from f16 rows on the LDS-DMA + transposing-read kernel (gemm_tn_tr_kernel, ABI 27:
+ *                              whole rows by global_load_lds_dwordx4 four 32-row stages deep, operands by ds_read_b64_tr_b16, a k-step's fragments read
+ *                              under the matrix instructions of the one before); 0: the register-staged kernel (gemm_tn_h3_kernel<., 2>).  A seven-job
+ *                              launch of the value run 0.86 -> 0.56 + 0.13 ms, the step 8.8-8.9 -> 8.6 ms (same-box A/B); results equal to 1e-5 of a
+ *                              tensor's largest element (one operand carries both rows' scales), not bit for bit
  *   PAPR_SW_C4_SUBPHASE (0)    timing experiment: workgroup b of a fused run starts ((b / 8) % 4) x value cycles late (sub-slot phases inside an XCD) */
 enum { PAPR_SW_C4_GENERIC = 0, PAPR_SW_C4_FUSED = 1, PAPR_SW_C4_EARLY = 2, PAPR_SW_KNN_BLOCKS = 3, PAPR_SW_KNN_T = 4, PAPR_SW_WGRAD_WGS = 5,
        PAPR_SW_NT_VARIANT = 6, PAPR_SW_C4_DMA = 7, PAPR_SW_TN_JOBPAR = 8, PAPR_SW_C4_PAIRS = 9, PAPR_SW_C4_PHASE = 10, PAPR_SW_C4_SUBPHASE = 11, PAPR_SW_C4_WCOPIES = 12, PAPR_SW_TN_TR = 13, PAPR_SW_COUNT = 14 };

@@ -18,7 +18,7 @@ extern "C" int papr_abi_version(void) { return 27; }
 // ---- process-wide switches and per-device caches ------------------------------------------------
 #include <atomic>
 namespace {
-std::atomic<int32_t> g_switch[PAPR_SW_COUNT] = {{0}, {1}, {3}, {1}, {0}, {600}, {0}, {0}, {1}, {1}, {6130}, {0}, {1}, {0}};        // defaults = the product (papr_hip.h: PAPR_SW_*)
+std::atomic<int32_t> g_switch[PAPR_SW_COUNT] = {{0}, {1}, {3}, {1}, {0}, {600}, {0}, {0}, {1}, {1}, {6130}, {0}, {1}, {1}};        // defaults = the product (papr_hip.h: PAPR_SW_*)
 constexpr int MAX_DEVICES = 64;
 std::atomic<int> g_cu[MAX_DEVICES];
 std::atomic<unsigned> g_once[MAX_DEVICES];

@@ -980,8 +980,18 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_h3_kernel(TNH3Batch batch) {
     constexpr bool gh = FMT >= 2, xh = FMT == 2;
 
     // slice scales
+    // (four rows per load: a slice is 2,000-14,000 rows, and one row per thread and trip was 4-28 dependent trips to memory in front of the first stage)
     float gm = 0.f, xm = 0.f;
-    for (long m = mbeg + tid; m < mend; m += 512) { gm = fmaxf(gm, p.gmax[m]); xm = fmaxf(xm, p.xmax[m]); }
+    {
+        const long n4 = (mend - mbeg) >> 2;          // (mbeg is a multiple of the 32-row stage: the tables' float4 are aligned)
+        const float4* g4 = reinterpret_cast<const float4*>(p.gmax + mbeg);
+        const float4* x4 = reinterpret_cast<const float4*>(p.xmax + mbeg);
+        for (long q = tid; q < n4; q += 512) {
+            const float4 a = g4[q], b = x4[q];
+            gm = fmaxf(fmaxf(gm, fmaxf(a.x, a.y)), fmaxf(a.z, a.w)); xm = fmaxf(fmaxf(xm, fmaxf(b.x, b.y)), fmaxf(b.z, b.w));
+        }
+        for (long m = mbeg + 4 * n4 + tid; m < mend; m += 512) { gm = fmaxf(gm, p.gmax[m]); xm = fmaxf(xm, p.xmax[m]); }
+    }
     gm = wave_max(gm); xm = wave_max(xm);
     if (lane == 0) { red[0][wave] = gm; red[1][wave] = xm; }
     __syncthreads();
@@ -1383,15 +1393,28 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_tr_kernel(TNH3Batch batch) {
     const int nrows = (int)(mend - mbeg);
     const int g_rs = p.g_rs, x_rs = p.x_rs;
 
-    // P: the largest (1 / scale_g)(1 / scale_x) of the slice (powers of two: the product and the maximum are exact)
+    // P: the largest (1 / scale_g)(1 / scale_x) of the slice (powers of two: the product and the maximum are exact).  A row that is all zeros on either side
+    // contributes nothing and must not set P: the parity arithmetic gives a zero row the scale 1, far above the 2^-30 ... 2^-10 of real gradient rows -- with
+    // such a row in the slice every real row's factor underflowed (the two-rank test's 16 x 16 images have them: 3 % of a gradient's norm lost)
+    auto pair_weight = [&](float gmx, float xmx) { return (gmx == 0.f || xmx == 0.f) ? 0.f : inv_scale_from_row_max(gmx, g_rs) * inv_scale_from_row_max(xmx, x_rs); };
     float pm = 0.f;
-    for (int m = tid; m < nrows; m += 512) pm = fmaxf(pm, inv_scale_from_row_max(p.gmax[mbeg + m], g_rs) * inv_scale_from_row_max(p.xmax[mbeg + m], x_rs));
+    {
+        const int n4 = nrows >> 2;                   // (four rows per load; mbeg is a multiple of the stage: aligned)
+        const float4* g4 = reinterpret_cast<const float4*>(p.gmax + mbeg);
+        const float4* x4 = reinterpret_cast<const float4*>(p.xmax + mbeg);
+        for (int q = tid; q < n4; q += 512) {
+            const float4 a = g4[q], b = x4[q];
+            pm = fmaxf(fmaxf(pm, fmaxf(pair_weight(a.x, b.x), pair_weight(a.y, b.y))), fmaxf(pair_weight(a.z, b.z), pair_weight(a.w, b.w)));
+        }
+        for (int m = 4 * n4 + tid; m < nrows; m += 512) pm = fmaxf(pm, pair_weight(p.gmax[mbeg + m], p.xmax[mbeg + m]));
+    }
     pm = wave_max(pm);
     if (lane == 0) red[wave] = pm;
     __syncthreads();
     float P = red[0];
 #pragma unroll
     for (int w = 1; w < 8; ++w) P = fmaxf(P, red[w]);
+    P = P > 0.f ? P : 1.f;                       // (a slice of zero rows)
     const float Pinv = 1.0f / P;                 // (a power of two)
 
     f32x16 acc[4][2];
@@ -1433,7 +1456,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_tr_kernel(TNH3Batch batch) {
         const float* raw = reinterpret_cast<const float*>(tr_smem + TR_OFF_RAW + b * 256);
         const bool ok = (int)st * TN_ROWS + lane < nrows;
         const float ig = inv_scale_from_row_max(raw[lane], g_rs), ix = inv_scale_from_row_max(raw[32 + lane], x_rs);
-        reinterpret_cast<_Float16*>(tr_smem + TR_OFF_C + b * 64)[lane] = ok ? (_Float16)(ig * ix * Pinv) : (_Float16)0.f;
+        reinterpret_cast<_Float16*>(tr_smem + TR_OFF_C + b * 64)[lane] = ok ? (_Float16)(pair_weight(raw[lane], raw[32 + lane]) * Pinv) : (_Float16)0.f;
         reinterpret_cast<float*>(tr_smem + TR_OFF_IG + b * 128)[lane] = ok ? ig : 0.f;
     };
     // this lane's corner of a fragment: the 16-lane group (lane >> 4) & 1 takes the tile's columns 16 .. 31, the k-group lane >> 5 the rows 8 .. 15 of a
@@ -1483,7 +1506,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_tr_kernel(TNH3Batch batch) {
 #endif
         if (wave == 0) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#ifndef TR_ABL_NO_BARRIER
         lds_barrier();
+#endif
 #ifndef TR_ABL_NO_DMA
         issue(st + TR_D);
 #endif

@@ -30,7 +30,12 @@ def main(out, M, n, act, d_in=117, d_out=256):
     xp[:, :d_in] = torch.randn(M, d_in, generator=gen)
     xd = xp.to(d)
     outs = ops.mlp_forward(spec, ws, bs, xd, M, keep=True)
-    gp = torch.randn(M, spec.ld_out[-1], generator=gen).to(d)
+    gp = torch.randn(M, spec.ld_out[-1], generator=gen)
+    # gradient rows as a render produces them: magnitudes over many powers of two from row to row, and rows that are all zeros (a zero row among real
+    # ones once set the slice scale of the transposing weight-gradient kernel: every real row's factor underflowed)
+    gp *= torch.exp2(-torch.randint(0, 24, (M, 1), generator=gen).float())
+    gp[torch.rand(M, generator=gen) < 0.05] = 0.0
+    gp = gp.to(d)
     scratch = [torch.empty((M, 256), device=d) for _ in range(2)]
     rowmax = outs.row_absmax[: n * M].clone()
     top = gp.clone()

@@ -108,10 +108,10 @@ def test_f16_rows_mode_is_h3_but_for_the_weight_gradients(tmp_path, M, n, act, d
         for (k, a), (_, b) in zip(_flat(ref), _flat(res)):
             assert a.shape == b.shape, (name, k)
             assert torch.equal(a.view(torch.int32), b.view(torch.int32)), "%s: %s differs in %d of %d elements" % (name, k, int((a.view(torch.int32) != b.view(torch.int32)).sum()), a.numel())
-    # the weight gradients of the full 256 x 256 layers on the LDS-DMA + transposing-read kernel (gemm_tn_tr_kernel, PAPR_TN_TR=1; round 6, not the default:
-    # it measures the same 4.3 TB/s as the register-staged kernel): the same rows, slices and matrix instructions; ONE operand carries both rows' scales
-    # instead of each its own, so the f16 roundings of rows far below the slice's largest differ -- equal to 1e-5 of the tensor's maximum, not bit for bit
-    tr = _run(tmp_path, "h3_f16rows tr", {"PAPR_TN_TR": "1"}, M, n, act, dims)
+    # the weight gradients of the full 256 x 256 layers run on the LDS-DMA + transposing-read kernel (gemm_tn_tr_kernel; round 6, the default since its
+    # second version) -- against the register-staged kernel (PAPR_TN_TR=0): the same rows, slices and matrix instructions; ONE operand carries both rows'
+    # scales instead of each its own, so the f16 roundings of rows far below the slice's largest differ -- equal to 1e-5 of the tensor's maximum, not bit for bit
+    tr = _run(tmp_path, "h3_f16rows register-staged weight gradients", {"PAPR_TN_TR": "0"}, M, n, act, dims)
     for k in ("d_ws", "d_bs"):
         for i, (a, b) in enumerate(zip(ref[k], tr[k])):
             rel = float((a - b).abs().max() / a.abs().max().clamp_min(1e-30))
