@@ -1369,9 +1369,10 @@ __device__ __forceinline__ void tr_dma4(const void* src, unsigned lds_dst) {    
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
 }
+template <int FOUR_ROWS = 4 * TR_PAIR>
 __device__ __forceinline__ half8 tr_read8(unsigned a) {     // 8 consecutive rows of this lane's column: two transposing reads of four rows each (four pairs apart)
     const tr_h4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) tr_h4*)a);
-    const tr_h4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) tr_h4*)(a + 4 * TR_PAIR));
+    const tr_h4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) tr_h4*)(a + FOUR_ROWS));
     return half8{(_Float16)lo[0], (_Float16)lo[1], (_Float16)lo[2], (_Float16)lo[3], (_Float16)hi[0], (_Float16)hi[1], (_Float16)hi[2], (_Float16)hi[3]};
 }
 
@@ -1536,6 +1537,140 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_tr_kernel(TNH3Batch batch) {
         if (lane < 32) p.bias_slab[slice * SLAB + (wn * 4 + wk) * 32 + lane] = colsum + other;
     }
 }
+// The same for a layer with 32 outputs (the value MLP's last layer: G rows of 64 bytes, X rows of 512): one n-tile, wave w the k-tile w -- one matrix
+// instruction per wave and k-step, the kernel is the request stream.  A stage (32 rows) is 18 KB here: EIGHT buffers, seven stages on their way.
+// G's rows arrive 16 to an instruction (lane: row lane >> 2, 16-byte piece lane & 3; waves 0 and 1), row-major at 64 bytes -- four consecutive rows
+// on the four quarters of the banks as they are --, the maxima with wave 2.  One barrier per stage, in front of the stage's reads.
+constexpr int TQ_D = 8;
+constexpr int TQ_XOP = 16 * TR_PAIR, TQ_GOP = 32 * 64;
+constexpr int TQ_STAGE = TQ_XOP + TQ_GOP;
+constexpr int TQ_OFF_RAW = TQ_D * TQ_STAGE;
+constexpr int TQ_OFF_C = TQ_OFF_RAW + TQ_D * 256;
+constexpr int TQ_OFF_IG = TQ_OFF_C + TQ_D * 64;
+constexpr size_t TQ_LDS_BYTES = TQ_OFF_IG + TQ_D * 128;
+
+__global__ __launch_bounds__(512, 2) void gemm_tn_tr_n32_kernel(TNH3Batch batch) {
+    extern __shared__ __attribute__((aligned(16))) char tr_smem[];
+    __shared__ float red[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds0 = (unsigned)(size_t)tr_smem;
+    const int jb = batch.par ? (int)(blockIdx.x % (unsigned)batch.n) : 0;
+    const long slice = batch.par ? (long)(blockIdx.x / (unsigned)batch.n) : (long)blockIdx.x;
+    const TNH3Args& p = batch.job[jb];
+    const long mbeg = slice * p.rows_per_slice;
+    long mend = mbeg + p.rows_per_slice;
+    if (mend > p.M) mend = p.M;
+    if (mbeg >= mend) return;
+    const int nrows = (int)(mend - mbeg);
+    const int g_rs = p.g_rs, x_rs = p.x_rs;
+    auto pair_weight = [&](float gmx, float xmx) { return (gmx == 0.f || xmx == 0.f) ? 0.f : inv_scale_from_row_max(gmx, g_rs) * inv_scale_from_row_max(xmx, x_rs); };
+    float pm = 0.f;
+    {
+        const int n4 = nrows >> 2;
+        const float4* g4 = reinterpret_cast<const float4*>(p.gmax + mbeg);
+        const float4* x4 = reinterpret_cast<const float4*>(p.xmax + mbeg);
+        for (int q = tid; q < n4; q += 512) {
+            const float4 a = g4[q], b = x4[q];
+            pm = fmaxf(fmaxf(pm, fmaxf(pair_weight(a.x, b.x), pair_weight(a.y, b.y))), fmaxf(pair_weight(a.z, b.z), pair_weight(a.w, b.w)));
+        }
+        for (int m = 4 * n4 + tid; m < nrows; m += 512) pm = fmaxf(pm, pair_weight(p.gmax[mbeg + m], p.xmax[mbeg + m]));
+    }
+    pm = wave_max(pm);
+    if (lane == 0) red[wave] = pm;
+    __syncthreads();
+    float P = red[0];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) P = fmaxf(P, red[w]);
+    P = P > 0.f ? P : 1.f;
+    const float Pinv = 1.0f / P;
+
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    float colsum = 0.f;                          // (wave 0)
+    const _Float16* const Gh = reinterpret_cast<const _Float16*>(p.G);
+    const _Float16* const Xh = reinterpret_cast<const _Float16*>(p.X);
+    const long nst = (nrows + TN_ROWS - 1) / TN_ROWS;
+    // a wave's requests of a stage, in order: [G rows (waves 0, 1) or the maxima (wave 2)], two row pairs of X
+    auto issue = [&](long st) {
+        const unsigned buf = lds0 + (unsigned)(st % TQ_D) * TQ_STAGE;
+        if (wave < 2) {
+#ifndef TQ_ABL_NO_G
+            int m = (int)st * TN_ROWS + 16 * wave + (lane >> 2);
+            m = m < nrows ? m : nrows - 1;
+            tr_dma16(Gh + (mbeg + m) * p.ldg + 8 * (lane & 3), buf + (unsigned)(TQ_XOP + wave * 1024));
+#endif
+        } else if (wave == 2) {
+            int m = (int)st * TN_ROWS + (lane & 31);
+            m = m < nrows ? m : nrows - 1;
+#ifndef TQ_ABL_NO_MAXIMA
+            tr_dma4((lane >> 5 ? p.xmax : p.gmax) + mbeg + m, lds0 + TQ_OFF_RAW + (unsigned)(st % TQ_D) * 256);
+#endif
+        }
+#ifdef TQ_ABL_NO_X
+        return;
+#endif
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int pair = 2 * wave + q;
+            int m = (int)st * TN_ROWS + pair + 16 * (lane >> 5);
+            m = m < nrows ? m : nrows - 1;
+            tr_dma16(Xh + (mbeg + m) * p.ldx + 8 * (lane & 31), buf + (unsigned)(pair * TR_PAIR));
+        }
+    };
+    auto make_table = [&](long st) {             // (wave 2, lanes 0 .. 31)
+        if (wave != 2 || lane >= 32) return;
+        const int b = (int)(st % TQ_D);
+        const float* raw = reinterpret_cast<const float*>(tr_smem + TQ_OFF_RAW + b * 256);
+        const bool ok = (int)st * TN_ROWS + lane < nrows;
+        reinterpret_cast<_Float16*>(tr_smem + TQ_OFF_C + b * 64)[lane] = ok ? (_Float16)(pair_weight(raw[lane], raw[32 + lane]) * Pinv) : (_Float16)0.f;
+        reinterpret_cast<float*>(tr_smem + TQ_OFF_IG + b * 128)[lane] = ok ? inv_scale_from_row_max(raw[lane], g_rs) : 0.f;
+    };
+    const unsigned xfrag = (unsigned)((8 * (lane >> 5) + ((lane & 15) >> 2)) * TR_PAIR + 32 * ((lane >> 4) & 1) + 8 * (lane & 3)) + (unsigned)wave * 64;
+    const unsigned gfrag = (unsigned)(TQ_XOP + (8 * (lane >> 5) + ((lane & 15) >> 2)) * 64 + 32 * ((lane >> 4) & 1) + 8 * (lane & 3));
+    for (long st = 0; st < TQ_D - 1; ++st) issue(st);
+    for (long st = 0; st < nst; ++st) {
+        // the stage's own requests have landed when those of the six stages behind it are outstanding (wave 2: and the maxima of the next stage)
+        if (wave < 2) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+        else if (wave == 2) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        if (st == 0) make_table(0);
+        lds_barrier();
+#ifndef TQ_ABL_NO_DMA
+        issue(st + TQ_D - 1);
+#endif
+#ifndef TQ_ABL_NO_TABLE
+        make_table(st + 1);
+#endif
+#ifdef TQ_ABL_NO_COMPUTE
+        continue;
+#endif
+        const unsigned sb = lds0 + (unsigned)(st % TQ_D) * TQ_STAGE;
+        const char* const tb = tr_smem + (st % TQ_D) * 64;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const half8 xb = tr_read8(sb + xfrag + ks * 512);
+            const half8 gr = tr_read8<4 * 64>(sb + gfrag + ks * 16 * 64);
+            const half8 cv = *reinterpret_cast<const half8*>(tb + TQ_OFF_C + (ks * 16 + 8 * (lane >> 5)) * 2);
+            if (wave == 0) {
+                const float* ig = reinterpret_cast<const float*>(tr_smem + TQ_OFF_IG + (st % TQ_D) * 128) + ks * 16 + 8 * (lane >> 5);
+                const float4 i0 = *reinterpret_cast<const float4*>(ig), i1 = *reinterpret_cast<const float4*>(ig + 4);
+                colsum = __builtin_fmaf((float)gr[7], i1.w, __builtin_fmaf((float)gr[6], i1.z, __builtin_fmaf((float)gr[5], i1.y, __builtin_fmaf((float)gr[4], i1.x,
+                         __builtin_fmaf((float)gr[3], i0.w, __builtin_fmaf((float)gr[2], i0.z, __builtin_fmaf((float)gr[1], i0.y, __builtin_fmaf((float)gr[0], i0.x, colsum))))))));
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(gr * cv, xb, acc, 0, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float* out = p.slab + slice * SLAB * SLAB;
+    const int k = wave * 32 + (lane & 31);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) out[((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * SLAB + k] = acc[e] * P;
+    if (wave == 0) {
+        const float other = __shfl_xor(colsum, 32);
+        if (lane < 32) p.bias_slab[slice * SLAB + lane] = colsum + other;
+    }
+}
 #pragma clang diagnostic pop
 
 // dW = G^T X on the split-f16 kernel; gmax / xmax: per-row max |.| of G and X (M floats each).  Jobs queue up and go out
@@ -1561,7 +1696,10 @@ struct TNH3Queue {
         // format 4 (round 6): both operands f16 rows of a full 256 x 256 layer with 512-byte rows -- rows by LDS-DMA, operands by the transposing LDS read
         const bool tr = g_half && x_half && N == SLAB && K == SLAB && ldg == SLAB && ldx == SLAB && papr_switch(PAPR_SW_TN_TR) != 0 &&
                         (reinterpret_cast<size_t>(G) & 15) == 0 && (reinterpret_cast<size_t>(X) & 15) == 0;
-        const int fmt = tr ? 4 : (g_half ? (x_half ? 2 : 3) : 0);
+        // format 5: the same with 32 outputs (G rows of 32 halfs at any stride that keeps them 16-byte aligned)
+        const bool trn = g_half && x_half && N == 32 && K == SLAB && ldx == SLAB && ldg % 8 == 0 && papr_switch(PAPR_SW_TN_TR) != 0 &&
+                         (reinterpret_cast<size_t>(G) & 15) == 0 && (reinterpret_cast<size_t>(X) & 15) == 0;
+        const int fmt = tr ? 4 : (trn ? 5 : (g_half ? (x_half ? 2 : 3) : 0));
         // (jobs with and without dead tiles share a launch -- on the instantiation with the tile tests: one launch and one reduction per run
         // instead of two, 0.05 ms per step; a batch of full jobs only keeps the test-free one)
         if (batch.n == TN_BATCH || (batch.n > 0 && fmt != half))
@@ -1616,10 +1754,13 @@ struct TNH3Queue {
         }
         const bool prof = papr_prof_on();
         if (prof) papr_prof_begin2(8, batch.job[0].M, batch.n, 0, bytes, flops, s);
-        if (half == 4) {
-            if (papr_first_on_device(PAPR_ONCE_TN_TR))
+        if (half == 4 || half == 5) {
+            if (papr_first_on_device(PAPR_ONCE_TN_TR)) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_tr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TR_LDS_BYTES);
-            gemm_tn_tr_kernel<<<dim3(grid), dim3(512), TR_LDS_BYTES, s>>>(batch);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_tr_n32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TQ_LDS_BYTES);
+            }
+            if (half == 4) gemm_tn_tr_kernel<<<dim3(grid), dim3(512), TR_LDS_BYTES, s>>>(batch);
+            else gemm_tn_tr_n32_kernel<<<dim3(grid), dim3(512), TQ_LDS_BYTES, s>>>(batch);
         } else if (half == 2) {                     // (f16 rows have one plane: one product -- also behind the parity arithmetic's runs, PAPR_MLP_H3_F16ROWS)
             if (full) gemm_tn_h3_kernel<true, 2><<<dim3(grid), dim3(512), T3_LDS_BYTES, s>>>(batch);
             else gemm_tn_h3_kernel<false, 2><<<dim3(grid), dim3(512), T3_LDS_BYTES, s>>>(batch);
@@ -1633,7 +1774,7 @@ struct TNH3Queue {
         else gemm_tn_h3_kernel<false, 0><<<dim3(grid), dim3(512), T3_LDS_BYTES, s>>>(batch);
         if (prof) papr_prof_end(s);
         PAPR_CHECK_LAUNCH("gemm_tn_h3");
-        if (half == 4) slab_reduce_kernel<false><<<dim3(SLAB * SLAB / 4 / 16, batch.n), dim3(256), 0, s>>>(red);      // (natural order: no permutation to undo)
+        if (half == 4 || half == 5) slab_reduce_kernel<false><<<dim3(SLAB * SLAB / 4 / 16, batch.n), dim3(256), 0, s>>>(red);      // (natural order: no permutation to undo)
         else slab_reduce_kernel<true><<<dim3(SLAB * SLAB / 4 / 16, batch.n), dim3(256), 0, s>>>(red);
         PAPR_CHECK_LAUNCH("slab_reduce");
         batch.n = 0; grid = 0; bytes = 0; flops = 0;

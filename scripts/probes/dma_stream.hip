@@ -14,12 +14,16 @@ __device__ __forceinline__ void dma16(const void* src, unsigned lds_dst) {
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
 struct Jobs { const char* g[4]; const char* x[4]; int n; };
-template <int ROWS, int DEPTH, int PAT, bool BARRIER>
-__global__ __launch_bounds__(512) void dma_read_jobs(Jobs jobs, long M, int* out) {      // the kernel's job-parallel dealing: workgroup b = slice b / n of job b % n
+__device__ __forceinline__ void dma4(const void* src, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
+}
+template <int ROWS, int DEPTH, int PAT, bool BARRIER, int PITCH = 1024, int MAXIMA = 0>
+__global__ __launch_bounds__(512) void dma_read_jobs(Jobs jobs, long M, int* out, const float* mx = nullptr) {      // the kernel's job-parallel dealing: workgroup b = slice b / n of job b % n
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lds0 = (unsigned)(size_t)smem;
-    constexpr int STAGE = 2 * ROWS * 512;
+    constexpr int STAGE = ROWS * PITCH;
     constexpr int NI = 2 * ROWS / 2 / 8;
     const int jb = blockIdx.x % jobs.n, slice = blockIdx.x / jobs.n, S = gridDim.x / jobs.n;
     const char* G = jobs.g[jb]; const char* X = jobs.x[jb];
@@ -32,12 +36,14 @@ __global__ __launch_bounds__(512) void dma_read_jobs(Jobs jobs, long M, int* out
             const int idx = NI * wave + q, op = idx / (ROWS / 2), pair = idx % (ROWS / 2);
             const int row = PAT == 0 ? pair + (ROWS / 2) * (lane >> 5) : 2 * pair + (lane >> 5);
             const char* src = (op ? X : G) + (s * ROWS + row) * 512 + 16 * (lane & 31);
-            dma16(src, lds0 + (unsigned)((st % DEPTH) * STAGE + idx * 1024));
+            dma16(src, lds0 + (unsigned)((st % DEPTH) * STAGE + idx * PITCH));
         }
+        if (MAXIMA && wave == 0) dma4(mx + s * ROWS + (lane & 31) + (lane >> 5) * M, lds0 + (unsigned)(DEPTH * STAGE + (st % DEPTH) * 256));
     };
     for (long st = s0; st < s0 + DEPTH - 1; ++st) issue(st);
     for (long st = s0; st < s1; ++st) {
-        wait_vm<NI * (DEPTH - 2)>();
+        if (MAXIMA) { if (wave == 0) wait_vm<(NI + 1) * (DEPTH - 2)>(); else wait_vm<NI * (DEPTH - 2)>(); }
+        else wait_vm<NI * (DEPTH - 2)>();
         if (BARRIER) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         issue(st + DEPTH - 1);
     }
@@ -132,6 +138,12 @@ int main() {
         float ms = time_ms([&]() { for (int j = 0; j < nj; ++j) { next(); jobs.g[j] = G; jobs.x[j] = X; } dma_read_jobs<32, 4, 0, true><<<nwg / nj * nj, 512, lds>>>(jobs, M, out); }, 12);
         printf("dma jobs %d nwg %d: %.1f us  %.2f TB/s\n", nj, nwg / nj * nj, ms * 1e3, nj * gb / ms);
     }
+    float* mx; hipMalloc(&mx, 2 * M * 4); hipMemset(mx, 0, 2 * M * 4);
+#define JOBS(PITCH, MAXIMA, NJ, NWG) { Jobs jobs; jobs.n = NJ; const int lds = 4 * 32 * PITCH + 1024; \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&dma_read_jobs<32, 4, 0, true, PITCH, MAXIMA>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+        float ms = time_ms([&]() { for (int j = 0; j < NJ; ++j) { next(); jobs.g[j] = G; jobs.x[j] = X; } dma_read_jobs<32, 4, 0, true, PITCH, MAXIMA><<<NWG, 512, lds>>>(jobs, M, out, mx); }, 12); \
+        printf("dma jobs %d nwg %d pitch %d maxima %d: %.1f us  %.2f TB/s\n", NJ, NWG, PITCH, MAXIMA, ms * 1e3, NJ * gb / ms); }
+    JOBS(1024, 0, 4, 256) JOBS(1088, 0, 4, 256) JOBS(1024, 1, 4, 256) JOBS(1088, 1, 4, 256) JOBS(1152, 0, 4, 256) JOBS(1280, 0, 4, 256)
     DMA(32, 3, 0, true, 256) DMA(32, 2, 0, true, 256)
     DMA(16, 8, 0, true, 256) DMA(16, 8, 1, true, 256)
     DMA(64, 2, 0, true, 256) DMA(64, 2, 1, true, 256)
