@@ -1000,9 +1000,17 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_h3_kernel(TNH3Batch batch) {
     for (int w = 1; w < 8; ++w) { gm = fmaxf(gm, red[0][w]); xm = fmaxf(xm, red[1][w]); }
     const int eg = gm > 0.f ? (int)((__float_as_uint(gm) >> 23) & 0xff) : 127 + 13;
     const int ex = xm > 0.f ? (int)((__float_as_uint(xm) >> 23) & 0xff) : 127 + 13;
-    const float g_scale = 4 * lane < p.N ? pow2_from_biased(127 + 13 - (eg - 127)) : 0.f;     // columns beyond the matrix become zeros
-    const float x_scale = 4 * lane < p.K ? pow2_from_biased(127 + 13 - (ex - 127)) : 0.f;
-    const float g_inv = pow2_from_biased(127 - 13 + (eg - 127)), x_inv = pow2_from_biased(127 - 13 + (ex - 127));
+    float g_scale = 4 * lane < p.N ? pow2_from_biased(127 + 13 - (eg - 127)) : 0.f;     // columns beyond the matrix become zeros
+    float x_scale = 4 * lane < p.K ? pow2_from_biased(127 + 13 - (ex - 127)) : 0.f;
+    float g_inv = pow2_from_biased(127 - 13 + (eg - 127)), x_inv = pow2_from_biased(127 - 13 + (ex - 127));
+    // f16 rows that carry ONE scale per row and RUN (one-product mode, g_rs / x_rs): gmax / xmax are the maxima of the run's TOP gradient rows / INPUT rows,
+    // not of this layer's rows -- which may be up to 2^9 larger in the same scaled domain (that is the run scale's headroom).  A slice scale made from those
+    // maxima overflowed f16 as soon as a trained network's inner gradients outgrew its top gradients eightfold: inf in dW on every step, the GradScaler
+    // halving its scale down to 2^-50, training at a standstill from step ~5,000 of a chair.yml run (found by the round's last 21,500-step run).  The rows
+    // themselves are bounded by f16's own range, so the slice factor is taken from the rows' SCALES: row factor = (1 / scale_row) / (2 max over the slice
+    // of 1 / scale) <= 1/2 -- a power of two times an f16 number that cannot overflow; rows far below the slice's largest lose low bits as before.
+    if (gh && p.g_rs) { const float igm = inv_scale_from_row_max(gm, p.g_rs); g_scale = 4 * lane < p.N ? 0.5f / igm : 0.f; g_inv = 2.f * igm; }
+    if (xh && p.x_rs) { const float ixm = inv_scale_from_row_max(xm, p.x_rs); x_scale = 4 * lane < p.K ? 0.5f / ixm : 0.f; x_inv = 2.f * ixm; }
 
     // which 32-row tiles of the LDS image hold real columns: tile t covers columns 4 (32 (t & 1) + i) + (t >> 1)
     bool live_n[4], live_k[2];

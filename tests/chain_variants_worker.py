@@ -23,7 +23,7 @@ def main(out, M, n, act, d_in=117, d_out=256):
         fi = d_in if i == 0 else width
         fo = d_out if i == n - 1 else width
         w = torch.zeros(fo, spec.layers[i]["n_in"])
-        w[:, :fi] = (torch.rand(fo, fi, generator=gen) * 2 - 1) * (6.0 / (fi + fo)) ** 0.5
+        w[:, :fi] = (torch.rand(fo, fi, generator=gen) * 2 - 1) * (6.0 / (fi + fo)) ** 0.5 * float(os.environ.get("PAPR_VARIANT_GAIN", "1"))
         ws.append(w.to(d))
         bs.append(((torch.rand(fo, generator=gen) * 2 - 1) * 0.1).to(d))
     xp = torch.zeros(M, spec.ld_in)
