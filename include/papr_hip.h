@@ -266,7 +266,7 @@ typedef struct {
 } papr_row_norm;
 
 /* Rows in the fused runs' input format (ABI 27): what a run's staging makes of fp32 rows, written by the producer instead.
- *   lo == NULL, the one-product runs': hi (M, ld) halfs = row x scale, scale (M) = the power of two that brings the row's maximum into [2^6, 2^7) --
+ *   lo == NULL, the one-product runs': hi (M, ld) halfs = row x scale, scale (M) = the power of two that brings the row's maximum into [2^3, 2^4) --
  *     data-gradient rows: exponent clamped at 2^-40 --, inv (M) = 1 / scale, max (M) = max |row|;
  *   lo != NULL, the parity runs' (split-f16): scale = the power of two that brings the maximum into [2^13, 2^14) (a zero row: 1), hi = f16(row x scale),
  *     lo (M, ld) = f16(row x scale - hi).
@@ -280,7 +280,7 @@ typedef struct { uint16_t* hi; float* inv; float* scale; float* max; int32_t ld;
  *   PAPR_MLP_H1      one f16 product per fp32 product in the fused runs, f16 rows between a run and its weight gradients: the counterpart
  *                    of the reference running its attention block under fp16 autocast (`use_amp: true`, models/attn.py:248).  Since ABI 27 a run
  *                    carries ONE power-of-two scale per row through all of its layers (chosen from the maximum of the run's input row / top gradient
- *                    row: [2^6, 2^7), 2^9 of headroom before f16 overflows -- csrc/h3_common.h: one_scale_from_max) instead of one per row and layer;
+ *                    row: [2^3, 2^4), 2^12 of headroom before f16 overflows -- csrc/h3_common.h: one_scale_from_max) instead of one per row and layer;
  *                    a training call one of whose runs cannot keep f16 rows (skip layers, a middle width that is no multiple of 32) runs in the
  *                    parity arithmetic as a whole
  *   PAPR_MLP_F32     exact fp32 MFMA everywhere;  PAPR_MLP_FWD / _DGRAD / _LAYERS: A/B steps between F32 and H3 (split-f16 forward only /

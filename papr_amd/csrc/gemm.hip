@@ -1004,7 +1004,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_h3_kernel(TNH3Batch batch) {
     float x_scale = 4 * lane < p.K ? pow2_from_biased(127 + 13 - (ex - 127)) : 0.f;
     float g_inv = pow2_from_biased(127 - 13 + (eg - 127)), x_inv = pow2_from_biased(127 - 13 + (ex - 127));
     // f16 rows that carry ONE scale per row and RUN (one-product mode, g_rs / x_rs): gmax / xmax are the maxima of the run's TOP gradient rows / INPUT rows,
-    // not of this layer's rows -- which may be up to 2^9 larger in the same scaled domain (that is the run scale's headroom).  A slice scale made from those
+    // not of this layer's rows -- which may be up to 2^12 larger in the same scaled domain (2^9 when this was found) (that is the run scale's headroom).  A slice scale made from those
     // maxima overflowed f16 as soon as a trained network's inner gradients outgrew its top gradients eightfold: inf in dW on every step, the GradScaler
     // halving its scale down to 2^-50, training at a standstill from step ~5,000 of a chair.yml run (found by the round's last 21,500-step run).  The rows
     // themselves are bounded by f16's own range, so the slice factor is taken from the rows' SCALES: row factor = (1 / scale_row) / (2 max over the slice

@@ -10,9 +10,9 @@ def expected(rows, split):
     if split:       # parity: the maximum into [2^13, 2^14); a zero row: scale 1
         e = torch.where(mx > 0, e, torch.full_like(e, 13))
         target = 13
-    else:           # one-product data-gradient rows: into [2^6, 2^7), the exponent clamped at -40 (h3_common.h: ONE_EMIN_DGRAD)
+    else:           # one-product data-gradient rows: into [2^3, 2^4) (h3_common.h: ONE_TARGET_E), the exponent clamped at -40 (ONE_EMIN_DGRAD)
         e = torch.where(mx > 0, torch.clamp(e, min=-40), torch.full_like(e, -40))
-        target = 6
+        target = 3
     scale = ((127 + target - e).to(torch.int32) << 23).view(torch.float32)         # 2^(target - e), exactly (torch.ldexp on the device is not)
     inv = ((127 - target + e).to(torch.int32) << 23).view(torch.float32)
     scaled = rows * scale[:, None]
