@@ -321,7 +321,8 @@ def main():
         fl = float(sum(r[6] for r in rs))
         ach = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         wg_prods = 1.0 if (args.amp or args.gemm_mode == "h1" or (args.gemm_mode == "h3" and args.h3_rows == "f16")) else 3.0
-        return ms, {"kernel": "gemm_tn_h3_kernel (weight gradients of a fused run in one launch, one slice of the rows per CU, split-f16 MFMA)",
+        return ms, {"kernel": "gemm_tn_tr_kernel / gemm_tn_tr_n32_kernel / gemm_tn_h3_kernel (weight gradients of a fused run, one slice of the rows per CU; with f16 rows the full "
+                              "256 x 256 layers by LDS-DMA + transposing LDS reads, first layers and fp32 rows register-staged)",
                     "jobs": int(sum(r[2] for r in rs)),
                     "bound": "hbm" if wg_prods == 1.0 else "hbm+split", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                     "traffic": traffic_db.get("gemm_tn_h3_bytes_per_launch"), "launches": len(rs),
@@ -329,8 +330,9 @@ def main():
                     "fp32_equivalent_tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0, "share_of_step_time": ms / (dt_prof * 1e3),
                     # how busy the matrix pipe is beside it: f16 products issued per fp32 product (1 with f16 rows or under use_amp, 3 with fp32 rows) over the dense f16 peak
                     "products_per_fp32_product": wg_prods, "frac_issued": (wg_prods * fl / (ms * 1e-3) / 1e12 / F16_MFMA_PEAK_TF) if ms > 0 else 0.0,
-                    "note": "bound: with f16 rows (the default since round 6, and under use_amp) the kernel streams 2 B per operand element and nothing else holds it: "
-                            "4.2-4.9 TB/s against the 6.2-6.3 TB/s a pure read of its access pattern reaches (scripts/probes/read_patterns.hip).  With fp32 rows "
+                    "note": "bound: with f16 rows (the default since round 6, and under use_amp) the kernels stream 2 B per operand element: the batches of full layers "
+                            "5.2-5.4 TB/s (gemm_tn_tr_kernel), the launch average lower by the first layers' register-staged launches; the same LDS-DMA request stream alone "
+                            "reaches 6.1 TB/s, a plain-load read of the pattern 6.2 (scripts/probes/dma_stream.hip, read_patterns.hip; DESIGN.md Appendix C6).  With fp32 rows "
                             "(--h3-rows f32) the in-kernel hi / lo split and the register transpose bind it beside the loads (850 of 980 us remain with the row loads "
                             "ablated, DESIGN.md Appendix B): `bound` says hbm+split there"
                     }

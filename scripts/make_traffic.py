@@ -26,7 +26,7 @@ def main(fetch_path, write_path, knn_path=None, insts_path=None):
         calls = sum(f.get(n, (0, 0))[0] for n in names)
         return 1024.0 * sum(total_kb(n) * f.get(n, (0, 0))[0] for n in names) / max(calls, 1)
     chain = [n for n in f if n.startswith("mlp_chain4_kernel")]
-    tn = [n for n in f if n.startswith("gemm_tn_h3_kernel")]
+    tn = [n for n in f if n.startswith("gemm_tn_h3_kernel") or n.startswith("gemm_tn_tr")]       # (round 6: + the LDS-DMA / transposing-read kernels)
     out = {
         "source": "%s + %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bench.py --steps 2 --warmup 1; scripts/make_traffic.py)" % (fetch_path, write_path),
         "correction": "FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B for 16 B/lane streams, MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported (uncalibrated)",
