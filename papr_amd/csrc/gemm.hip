@@ -1386,6 +1386,23 @@ __device__ __forceinline__ half8 tr_read8(unsigned a) {     // 8 consecutive row
 
 struct TrFrags { half8 x[2]; half8 g[4]; half8 cv; float4 ig0, ig1; };
 
+// The factor that carries both rows' scales, in EXPONENTS: (1 / scale_g)(1 / scale_x) is a power of two whose exponent is the sum of two exponents each inside
+// fp32's normal range -- their product is not: the gradient rows of a query MLP late in a run with few points are ~1e-35, the product underflowed, 1 / P
+// became inf and the weight gradients NaN (found by the round's last long lego run: NaN parameters at step 13,904, a memory fault once the neighbour
+// search met NaN coordinates).  A row that is all zeros on either side contributes nothing and must not set the slice's exponent (the parity arithmetic
+// gives a zero row the scale 1, far above the 2^-30 ... 2^-10 of real gradient rows).
+constexpr int TR_EXP_NONE = -100000;
+__device__ __forceinline__ int tr_pow2_exp(float p) { return (int)((__float_as_uint(p) >> 23) & 0xff) - 127; }       // p: a normal power of two
+__device__ __forceinline__ int tr_pair_exp(float gmx, float xmx, int g_rs, int x_rs) {
+    if (gmx == 0.f || xmx == 0.f) return TR_EXP_NONE;
+    return tr_pow2_exp(inv_scale_from_row_max(gmx, g_rs)) + tr_pow2_exp(inv_scale_from_row_max(xmx, x_rs));
+}
+__device__ __forceinline__ float tr_factor(int e, int eP) {          // 2^(e - eP) <= 1 (what f16 cannot hold becomes 0 at the conversion)
+    if (e <= TR_EXP_NONE / 2) return 0.f;
+    const int d = e - eP;
+    return d < -126 ? 0.f : pow2_from_biased(127 + d);
+}
+
 __global__ __launch_bounds__(512, 2) void gemm_tn_tr_kernel(TNH3Batch batch) {
     extern __shared__ __attribute__((aligned(16))) char tr_smem[];
     __shared__ float red[8];
@@ -1405,8 +1422,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_tr_kernel(TNH3Batch batch) {
     // P: the largest (1 / scale_g)(1 / scale_x) of the slice (powers of two: the product and the maximum are exact).  A row that is all zeros on either side
     // contributes nothing and must not set P: the parity arithmetic gives a zero row the scale 1, far above the 2^-30 ... 2^-10 of real gradient rows -- with
     // such a row in the slice every real row's factor underflowed (the two-rank test's 16 x 16 images have them: 3 % of a gradient's norm lost)
-    auto pair_weight = [&](float gmx, float xmx) { return (gmx == 0.f || xmx == 0.f) ? 0.f : inv_scale_from_row_max(gmx, g_rs) * inv_scale_from_row_max(xmx, x_rs); };
-    float pm = 0.f;
+    auto pair_weight = [&](float gmx, float xmx) { return (float)tr_pair_exp(gmx, xmx, g_rs, x_rs); };      // (an exponent; exact as a float)
+    float pm = (float)TR_EXP_NONE;
     {
         const int n4 = nrows >> 2;                   // (four rows per load; mbeg is a multiple of the stage: aligned)
         const float4* g4 = reinterpret_cast<const float4*>(p.gmax + mbeg);
@@ -1420,11 +1437,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_tr_kernel(TNH3Batch batch) {
     pm = wave_max(pm);
     if (lane == 0) red[wave] = pm;
     __syncthreads();
-    float P = red[0];
+    float Pf = red[0];
 #pragma unroll
-    for (int w = 1; w < 8; ++w) P = fmaxf(P, red[w]);
-    P = P > 0.f ? P : 1.f;                       // (a slice of zero rows)
-    const float Pinv = 1.0f / P;                 // (a power of two)
+    for (int w = 1; w < 8; ++w) Pf = fmaxf(Pf, red[w]);
+    const int eP = Pf <= (float)(TR_EXP_NONE / 2) ? 0 : (int)Pf;       // the slice's largest exponent (a slice of zero rows: 0)
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -1465,7 +1481,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_tr_kernel(TNH3Batch batch) {
         const float* raw = reinterpret_cast<const float*>(tr_smem + TR_OFF_RAW + b * 256);
         const bool ok = (int)st * TN_ROWS + lane < nrows;
         const float ig = inv_scale_from_row_max(raw[lane], g_rs), ix = inv_scale_from_row_max(raw[32 + lane], x_rs);
-        reinterpret_cast<_Float16*>(tr_smem + TR_OFF_C + b * 64)[lane] = ok ? (_Float16)(pair_weight(raw[lane], raw[32 + lane]) * Pinv) : (_Float16)0.f;
+        reinterpret_cast<_Float16*>(tr_smem + TR_OFF_C + b * 64)[lane] = ok ? (_Float16)tr_factor(tr_pair_exp(raw[lane], raw[32 + lane], g_rs, x_rs), eP) : (_Float16)0.f;
         reinterpret_cast<float*>(tr_smem + TR_OFF_IG + b * 128)[lane] = ok ? ig : 0.f;
     };
     // this lane's corner of a fragment: the 16-lane group (lane >> 4) & 1 takes the tile's columns 16 .. 31, the k-group lane >> 5 the rows 8 .. 15 of a
@@ -1528,6 +1544,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_tr_kernel(TNH3Batch batch) {
 #endif
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // (the requests past the slice's end)
+    const float P1 = pow2_from_biased(127 + (eP >> 1)), P2 = pow2_from_biased(127 + eP - (eP >> 1));       // 2^eP in two factors, each a normal number
     float* out = p.slab + slice * SLAB * SLAB;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -1537,7 +1554,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_tr_kernel(TNH3Batch batch) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int n = (wn * 4 + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                out[n * SLAB + k] = acc[i][j][e] * P;
+                out[n * SLAB + k] = acc[i][j][e] * P1 * P2;
             }
         }
     {                                                // column sums: lane l and lane l + 32 hold the two row groups of column (wn * 4 + wk) * 32 + (l & 31)
@@ -1571,8 +1588,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_tr_n32_kernel(TNH3Batch batch)
     if (mbeg >= mend) return;
     const int nrows = (int)(mend - mbeg);
     const int g_rs = p.g_rs, x_rs = p.x_rs;
-    auto pair_weight = [&](float gmx, float xmx) { return (gmx == 0.f || xmx == 0.f) ? 0.f : inv_scale_from_row_max(gmx, g_rs) * inv_scale_from_row_max(xmx, x_rs); };
-    float pm = 0.f;
+    auto pair_weight = [&](float gmx, float xmx) { return (float)tr_pair_exp(gmx, xmx, g_rs, x_rs); };      // (an exponent; exact as a float)
+    float pm = (float)TR_EXP_NONE;
     {
         const int n4 = nrows >> 2;
         const float4* g4 = reinterpret_cast<const float4*>(p.gmax + mbeg);
@@ -1586,11 +1603,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_tr_n32_kernel(TNH3Batch batch)
     pm = wave_max(pm);
     if (lane == 0) red[wave] = pm;
     __syncthreads();
-    float P = red[0];
+    float Pf = red[0];
 #pragma unroll
-    for (int w = 1; w < 8; ++w) P = fmaxf(P, red[w]);
-    P = P > 0.f ? P : 1.f;
-    const float Pinv = 1.0f / P;
+    for (int w = 1; w < 8; ++w) Pf = fmaxf(Pf, red[w]);
+    const int eP = Pf <= (float)(TR_EXP_NONE / 2) ? 0 : (int)Pf;
 
     f32x16 acc;
 #pragma unroll
@@ -1631,7 +1647,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_tr_n32_kernel(TNH3Batch batch)
         const int b = (int)(st % TQ_D);
         const float* raw = reinterpret_cast<const float*>(tr_smem + TQ_OFF_RAW + b * 256);
         const bool ok = (int)st * TN_ROWS + lane < nrows;
-        reinterpret_cast<_Float16*>(tr_smem + TQ_OFF_C + b * 64)[lane] = ok ? (_Float16)(pair_weight(raw[lane], raw[32 + lane]) * Pinv) : (_Float16)0.f;
+        reinterpret_cast<_Float16*>(tr_smem + TQ_OFF_C + b * 64)[lane] = ok ? (_Float16)tr_factor(tr_pair_exp(raw[lane], raw[32 + lane], g_rs, x_rs), eP) : (_Float16)0.f;
         reinterpret_cast<float*>(tr_smem + TQ_OFF_IG + b * 128)[lane] = ok ? inv_scale_from_row_max(raw[lane], g_rs) : 0.f;
     };
     const unsigned xfrag = (unsigned)((8 * (lane >> 5) + ((lane & 15) >> 2)) * TR_PAIR + 32 * ((lane >> 4) & 1) + 8 * (lane & 3)) + (unsigned)wave * 64;
@@ -1670,10 +1686,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_tr_n32_kernel(TNH3Batch batch)
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const float P1 = pow2_from_biased(127 + (eP >> 1)), P2 = pow2_from_biased(127 + eP - (eP >> 1));
     float* out = p.slab + slice * SLAB * SLAB;
     const int k = wave * 32 + (lane & 31);
 #pragma unroll
-    for (int e = 0; e < 16; ++e) out[((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * SLAB + k] = acc[e] * P;
+    for (int e = 0; e < 16; ++e) out[((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * SLAB + k] = acc[e] * P1 * P2;
     if (wave == 0) {
         const float other = __shfl_xor(colsum, 32);
         if (lane < 32) p.bias_slab[slice * SLAB + lane] = colsum + other;

@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void ray_knn_kernel(const float4* __restrict__
     }
     // ---- seed rays 1..T-1 with ray 0's neighbours
     {
-        int pi = lane < k ? ks[0].idx : 0;
+        int pi = (lane < k && ks[0].idx >= 0) ? ks[0].idx : 0;         // (a slot nothing entered -- NaN coordinates -- holds -1)
         float sx = points[pi * 3 + 0], sy = points[pi * 3 + 1], sz = points[pi * 3 + 2];
 #pragma unroll
         for (int t = 1; t < T; ++t) {
@@ -262,10 +262,10 @@ __global__ __launch_bounds__(256) void ray_knn_kernel(const float4* __restrict__
         for (int j = 0; j < k; ++j) {
             unsigned dj = (unsigned)__builtin_amdgcn_readlane((int)ks[t].bits, j);
             int ij = __builtin_amdgcn_readlane(ks[t].idx, j);
-            rank += (dj < ks[t].bits || (dj == ks[t].bits && ij < ks[t].idx)) ? 1 : 0;
+            rank += (dj < ks[t].bits || (dj == ks[t].bits && (ij < ks[t].idx || (ij == ks[t].idx && j < lane)))) ? 1 : 0;     // (equal entries: only slots nothing entered, idx -1 -- by lane, so that every output slot is written)
         }
         if (lane < k) {
-            out_idx[r * k + rank] = ks[t].idx;
+            out_idx[r * k + rank] = ks[t].idx < 0 ? 0 : ks[t].idx;      // (a slot no candidate entered -- NaN coordinates: a valid index, as torch.topk of NaN distances gives; -1 sent the gathers out of bounds)
             if (out_dist) out_dist[r * k + rank] = sqrtf(__uint_as_float(ks[t].bits));
         }
     }
@@ -358,13 +358,13 @@ __global__ __launch_bounds__(256) void ray_knn_wide_kernel(const float4* __restr
             const unsigned dj = (unsigned)__builtin_amdgcn_readlane((int)ks.bits[sj], j);
             const int ij = __builtin_amdgcn_readlane(ks.idx[sj], j);
 #pragma unroll
-            for (int s = 0; s < NS; ++s) rank[s] += (dj < ks.bits[s] || (dj == ks.bits[s] && ij < ks.idx[s])) ? 1 : 0;
+            for (int s = 0; s < NS; ++s) rank[s] += (dj < ks.bits[s] || (dj == ks.bits[s] && (ij < ks.idx[s] || (ij == ks.idx[s] && 64 * sj + j < 64 * s + lane)))) ? 1 : 0;      // (equal entries: slots nothing entered -- by position)
         }
     }
 #pragma unroll
     for (int s = 0; s < NS; ++s)
         if (ks.member(s, lane)) {
-            out_idx[r * k + rank[s]] = ks.idx[s];
+            out_idx[r * k + rank[s]] = ks.idx[s] < 0 ? 0 : ks.idx[s];
             if (out_dist) out_dist[r * k + rank[s]] = sqrtf(__uint_as_float(ks.bits[s]));
         }
 }
@@ -639,7 +639,7 @@ __global__ __launch_bounds__(256) void ray_knn_blocks_kernel(const float4* __res
         const float rcp_true = dd > 0.f ? 1.0f / dd : 0.f;
         const bool cold = t == 0;
         if (!cold) {                                // the previous ray's neighbours, at this ray's distances
-            const int pi = lane < k ? ks.idx : 0;
+            const int pi = (lane < k && ks.idx >= 0) ? ks.idx : 0;       // (a slot nothing entered -- NaN coordinates -- holds -1)
             const float d2 = ray_dist2(rk, points[pi * 3 + 0], points[pi * 3 + 1], points[pi * 3 + 2]);
             ks.bits = lane < k ? __float_as_uint(d2) : 0u;
             ks.sort(lane);
@@ -683,7 +683,7 @@ __global__ __launch_bounds__(256) void ray_knn_blocks_kernel(const float4* __res
             }
         }
         if (lane < k) {                             // (the set is ascending in (distance, index))
-            out_idx[r * k + lane] = ks.idx;
+            out_idx[r * k + lane] = ks.idx < 0 ? 0 : ks.idx;
             if (out_dist) out_dist[r * k + lane] = sqrtf(__uint_as_float(ks.bits));
         }
 #ifdef KNN_DEBUG_VISITS

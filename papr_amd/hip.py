@@ -227,9 +227,18 @@ def profile_collect(cap=65536):
     return [(r.kernel, r.M, r.N, r.K, r.ms) + ((r.bytes, r.flops) if r.kernel in (8, 9, 10, 11, 12) else ()) for r in buf[:min(n, cap)]]
 
 
+DEBUG_SYNC = False      # (debugging aid: name every library call on stderr and wait for it -- the last name printed before a GPU fault is the call that faulted;
+                        #  train.py switches it on from step PAPR_DEBUG_SYNC_FROM)
+
+
 def check(code, what):
     if code != 0:
         raise RuntimeError("%s failed (%d): %s" % (what, code, lib().papr_last_error().decode()))
+    if DEBUG_SYNC:
+        import sys
+        sys.stderr.write("papr call: %s\n" % what)
+        sys.stderr.flush()
+        torch.cuda.synchronize()
 
 
 def stream_ptr():

@@ -16,13 +16,16 @@ def main(out, M, n, act, d_in=117, d_out=256):
     from papr_amd import ops
     width = 256
     gen = torch.Generator().manual_seed(M + n)
-    spec = ops.MlpSpec("t", d_in, dict(n_ff_layer=n, d_ff=width, d_ff_out=d_out, norm="none", ff_act=act, ff_last_act="none", skip_layers=[]))
+    skips = [int(v) for v in os.environ.get("PAPR_VARIANT_SKIP", "").split(",") if v]       # (the value MLP of lego.yml: skip_layers [5])
+    spec = ops.MlpSpec("t", d_in, dict(n_ff_layer=n, d_ff=width, d_ff_out=d_out, norm="none", ff_act=act, ff_last_act="none", skip_layers=skips))
     d = torch.device("cuda:0")
     ws, bs = [], []
     for i in range(n):
         fi = d_in if i == 0 else width
         fo = d_out if i == n - 1 else width
-        w = torch.zeros(fo, spec.layers[i]["n_in"])
+        w = torch.zeros(fo, spec.layers[i]["n_in"] + (spec.ld_in if i in skips else 0))
+        if i in skips:      # the skip segment [previous output | x]: columns n_in .. n_in + d_in
+            w[:, spec.layers[i]["n_in"]:spec.layers[i]["n_in"] + d_in] = (torch.rand(fo, d_in, generator=gen) * 2 - 1) * (6.0 / (fi + fo)) ** 0.5
         w[:, :fi] = (torch.rand(fo, fi, generator=gen) * 2 - 1) * (6.0 / (fi + fo)) ** 0.5 * float(os.environ.get("PAPR_VARIANT_GAIN", "1"))
         ws.append(w.to(d))
         bs.append(((torch.rand(fo, generator=gen) * 2 - 1) * 0.1).to(d))
@@ -35,6 +38,7 @@ def main(out, M, n, act, d_in=117, d_out=256):
     # ones once set the slice scale of the transposing weight-gradient kernel: every real row's factor underflowed)
     gp *= torch.exp2(-torch.randint(0, 24, (M, 1), generator=gen).float())
     gp[torch.rand(M, generator=gen) < 0.05] = 0.0
+    gp *= float(os.environ.get("PAPR_VARIANT_GRAD_SCALE", "1"))       # (the query MLP's gradient rows late in a run with few points: ~1e-35)
     gp = gp.to(d)
     scratch = [torch.empty((M, 256), device=d) for _ in range(2)]
     rowmax = outs.row_absmax[: n * M].clone()

@@ -18,7 +18,7 @@ for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden
 
 
 def main(tag, out):
-    assert os.environ.get("PAPR_GEMM_MODE") == "h1"
+    assert os.environ.get("PAPR_GEMM_MODE") == "h1" or os.environ.get("PAPR_WORKER_ANY_MODE") == "1"      # (scripts/probes/r6_det_model.sh runs it in the default mode)
     from conftest import case_cfg, case_rays, golden
     from formula import formula_fill
     from papr_amd import get_model

@@ -34,7 +34,7 @@ VARIANTS = [("generic rows", dict(F32, PAPR_C4_GENERIC="1")), ("two-role", dict(
 
 def _run(tmp_path, name, env, M, n, act, dims=()):
     out = tmp_path / (name.replace(" ", "_") + ".pt")
-    e = {k: v for k, v in os.environ.items() if k not in ("PAPR_C4_GENERIC", "PAPR_C4_FUSED", "PAPR_GEMM_MODE", "PAPR_C4_DMA", "PAPR_C4_PAIRS", "PAPR_H3_ROWS", "PAPR_TN_TR", "PAPR_VARIANT_TOP_F16", "PAPR_VARIANT_GAIN")}
+    e = {k: v for k, v in os.environ.items() if k not in ("PAPR_C4_GENERIC", "PAPR_C4_FUSED", "PAPR_GEMM_MODE", "PAPR_C4_DMA", "PAPR_C4_PAIRS", "PAPR_H3_ROWS", "PAPR_TN_TR", "PAPR_VARIANT_TOP_F16", "PAPR_VARIANT_GAIN", "PAPR_VARIANT_GRAD_SCALE", "PAPR_VARIANT_SKIP")}
     e.update(env)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "chain_variants_worker.py"), str(out), str(M), str(n), act] + [str(v) for v in dims], env=e, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (name, r.stderr[-2000:])
@@ -157,3 +157,21 @@ def test_one_product_data_gradient_run_hands_inf_and_nan_on(tmp_path):
     lines = {l.split(" | ")[0]: l for l in r.stdout.splitlines() if " | " in l}
     for label in ("all inf", "one inf per row", "all nan"):
         assert "d_x finite elements: 0 of" in lines[label], lines[label]
+
+
+# (the parity arithmetic only: a one-product run clamps its gradient rows' scale at 2^-40 -- rows this small vanish there by design, a GradScaler keeps them away)
+@pytest.mark.parametrize("mode", ["h3_f16rows"])
+def test_weight_gradients_of_tiny_gradient_rows_stay_finite(tmp_path, mode):
+    """Gradient rows of ~1e-33 and below (the query MLP late in a run with few points): the transposing weight-gradient kernel's factor (1 / scale_g)(1 / scale_x)
+    leaves fp32's normal range as a product -- it is kept as a sum of exponents.  (Round 6: the product underflowed, its reciprocal was inf, the weight gradients
+    NaN: a lego.yml run's parameters at step 13,904.)  Against the register-staged kernel: finite, and equal to 1e-5 of the largest element."""
+    M, n, act = 20000, 5, "relu"
+    env = {"PAPR_GEMM_MODE": mode, "PAPR_VARIANT_GRAD_SCALE": "1e-33"}
+    tr = _run(tmp_path, mode + " tiny", env, M, n, act)
+    reg = _run(tmp_path, mode + " tiny register-staged", dict(env, PAPR_TN_TR="0"), M, n, act)
+    for k in ("d_ws", "d_bs"):
+        for i, (a, b) in enumerate(zip(reg[k], tr[k])):
+            assert torch.isfinite(b).all() and torch.isfinite(a).all(), (k, i)
+            assert float(a.abs().max()) > 0, (k, i, "the reference itself vanished")
+            rel = float((a - b).abs().max() / a.abs().max())
+            assert rel < 1e-5, (k, i, rel)

@@ -162,6 +162,18 @@ def test_knn_wide_form_exact_ties():
                 assert j - 300 in members, (r, j)
 
 
+@pytest.mark.parametrize("P,k", [(135, 20), (3000, 20), (3000, 100)])
+def test_knn_of_a_cloud_of_nans_returns_indices_inside_the_cloud(P, k):
+    """A training run that has diverged hands the neighbour search NaN coordinates: no candidate ever enters a ray's set.  Every output slot must still hold an
+    index inside the cloud (torch.topk of NaN distances returns some) -- the slots' initial -1 sent the gathers of features_fwd out of bounds: the memory access
+    fault at the end of round 6's long lego run.  All three forms: small cloud, binned cloud, more than 64 neighbours."""
+    pts = torch.full((P, 3), float("nan"))
+    ro, rd, _ = synth_rays(1, 16, 16, seed=3)
+    for cloud in (pts, torch.cat([uniform_points(k // 2, 12.0, seed=1), pts[k // 2:]])):      # all NaN; fewer finite points than k
+        idx, _ = _knn(cloud, ro, rd, k)
+        assert int(idx.min()) >= 0 and int(idx.max()) < P
+
+
 def test_knn_rejects_bad_k():
     from papr_amd import ops
     pts = uniform_points(300, 1.0, seed=0).to(dev())

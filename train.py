@@ -105,6 +105,15 @@ def train_step(step, model, batch, loss_fn, args):
     out = model.last_act(model(rayo, rayd, c2w, step))
     loss = loss_fn(out, tgt)
     model.scaler.scale(loss).backward()
+    nan_from = int(os.environ.get("PAPR_DEBUG_NANCHECK_FROM", "-1"))
+    if 0 <= nan_from <= step and not model.scaler.is_enabled():      # (debugging aid: the first step whose gradients are not finite -- its inputs and the model go to PAPR_DEBUG_DUMP)
+        bad = [n for n, p in model.named_parameters() if p.grad is not None and not torch.isfinite(p.grad).all()]
+        if bad or not torch.isfinite(loss):
+            print("step %d: loss %r, non-finite gradients in %d tensors: %s" % (step, float(loss), len(bad), bad[:8]), flush=True)
+            if os.environ.get("PAPR_DEBUG_DUMP"):
+                torch.save({"step": step, "state": {k: v.detach().cpu() for k, v in model.state_dict().items()}, "batch": [b.detach().cpu() for b in batch],
+                            "grads": {n: p.grad.detach().cpu() for n, p in model.named_parameters() if p.grad is not None}}, os.environ["PAPR_DEBUG_DUMP"])
+            sys.exit(3)
     model.step(step)
     if args.scaler_min_scale > 0 and model.scaler.get_scale() < args.scaler_min_scale:
         model.scaler.update(args.scaler_min_scale)
@@ -189,6 +198,12 @@ def main():
                     slog["events"].append((step, 1, int(n), int(model.points.shape[0])))
         if slog is not None:
             slog["P"].append(int(model.points.shape[0]))
+        if 0 <= int(os.environ.get("PAPR_DEBUG_SYNC_FROM", "-1")) <= step:      # (debugging aid: papr_amd/hip.py: DEBUG_SYNC)
+            from papr_amd import hip as _hip
+            _hip.DEBUG_SYNC = True
+            if os.environ.get("PAPR_DEBUG_DUMP"):       # the step's inputs, overwritten every step: what the faulting step was given
+                torch.save({"step": step, "points": model.points.detach().cpu(), "influ": model.points_influ_scores.detach().cpu(),
+                            "batch": [b.detach().cpu() for b in batch]}, os.environ["PAPR_DEBUG_DUMP"])
         loss = train_step(step, model, batch, loss_fn, args)
         step += 1
         if slog is not None:
