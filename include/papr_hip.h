@@ -47,6 +47,8 @@ const char* papr_last_error(void);
  * Requires 1 <= k <= 256 and k <= P (k <= 63: the tuned forms -- seeded every-point search, binned cloud; 64 <= k <= 256, ABI 25: one ray per wave,
  * the set across several registers per lane, exact in the same total order).  workspace: papr_ray_knn_workspace_bytes(R, P) bytes, contents irrelevant
  * on entry (ray records, the binned copy of the cloud, block bounds, cell counters: all rebuilt by every call).
+ * Points whose coordinates are NaN never enter a set; every out_idx entry is an index in [0, P) all the same (a cloud with fewer than k
+ * finite points fills the rest with point 0 -- torch.topk of NaN distances returns valid indices too; ABI 27, end of round 6).
  */
 size_t papr_ray_knn_workspace_bytes(int64_t R, int64_t P);
 int papr_ray_knn(const float* points, int64_t P, const float* rays_o, const float* rays_d, int64_t R,

@@ -1419,10 +1419,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_tr_kernel(TNH3Batch batch) {
     const int nrows = (int)(mend - mbeg);
     const int g_rs = p.g_rs, x_rs = p.x_rs;
 
-    // P: the largest (1 / scale_g)(1 / scale_x) of the slice (powers of two: the product and the maximum are exact).  A row that is all zeros on either side
-    // contributes nothing and must not set P: the parity arithmetic gives a zero row the scale 1, far above the 2^-30 ... 2^-10 of real gradient rows -- with
-    // such a row in the slice every real row's factor underflowed (the two-rank test's 16 x 16 images have them: 3 % of a gradient's norm lost)
-    auto pair_weight = [&](float gmx, float xmx) { return (float)tr_pair_exp(gmx, xmx, g_rs, x_rs); };      // (an exponent; exact as a float)
+    // eP: the largest exponent of (1 / scale_g)(1 / scale_x) over the slice's rows (tr_pair_exp: kept as exponents; rows that are all zeros on either side do not
+    // count -- with such a row setting it every real row's factor underflowed: the two-rank test's 16 x 16 images have them, 3 % of a gradient's norm was lost)
+    auto pair_exp = [&](float gmx, float xmx) { return (float)tr_pair_exp(gmx, xmx, g_rs, x_rs); };      // (an exponent; exact as a float)
     float pm = (float)TR_EXP_NONE;
     {
         const int n4 = nrows >> 2;                   // (four rows per load; mbeg is a multiple of the stage: aligned)
@@ -1430,9 +1429,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_tr_kernel(TNH3Batch batch) {
         const float4* x4 = reinterpret_cast<const float4*>(p.xmax + mbeg);
         for (int q = tid; q < n4; q += 512) {
             const float4 a = g4[q], b = x4[q];
-            pm = fmaxf(fmaxf(pm, fmaxf(pair_weight(a.x, b.x), pair_weight(a.y, b.y))), fmaxf(pair_weight(a.z, b.z), pair_weight(a.w, b.w)));
+            pm = fmaxf(fmaxf(pm, fmaxf(pair_exp(a.x, b.x), pair_exp(a.y, b.y))), fmaxf(pair_exp(a.z, b.z), pair_exp(a.w, b.w)));
         }
-        for (int m = 4 * n4 + tid; m < nrows; m += 512) pm = fmaxf(pm, pair_weight(p.gmax[mbeg + m], p.xmax[mbeg + m]));
+        for (int m = 4 * n4 + tid; m < nrows; m += 512) pm = fmaxf(pm, pair_exp(p.gmax[mbeg + m], p.xmax[mbeg + m]));
     }
     pm = wave_max(pm);
     if (lane == 0) red[wave] = pm;
@@ -1588,7 +1587,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_tr_n32_kernel(TNH3Batch batch)
     if (mbeg >= mend) return;
     const int nrows = (int)(mend - mbeg);
     const int g_rs = p.g_rs, x_rs = p.x_rs;
-    auto pair_weight = [&](float gmx, float xmx) { return (float)tr_pair_exp(gmx, xmx, g_rs, x_rs); };      // (an exponent; exact as a float)
+    auto pair_exp = [&](float gmx, float xmx) { return (float)tr_pair_exp(gmx, xmx, g_rs, x_rs); };      // (an exponent; exact as a float)
     float pm = (float)TR_EXP_NONE;
     {
         const int n4 = nrows >> 2;
@@ -1596,9 +1595,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_tr_n32_kernel(TNH3Batch batch)
         const float4* x4 = reinterpret_cast<const float4*>(p.xmax + mbeg);
         for (int q = tid; q < n4; q += 512) {
             const float4 a = g4[q], b = x4[q];
-            pm = fmaxf(fmaxf(pm, fmaxf(pair_weight(a.x, b.x), pair_weight(a.y, b.y))), fmaxf(pair_weight(a.z, b.z), pair_weight(a.w, b.w)));
+            pm = fmaxf(fmaxf(pm, fmaxf(pair_exp(a.x, b.x), pair_exp(a.y, b.y))), fmaxf(pair_exp(a.z, b.z), pair_exp(a.w, b.w)));
         }
-        for (int m = 4 * n4 + tid; m < nrows; m += 512) pm = fmaxf(pm, pair_weight(p.gmax[mbeg + m], p.xmax[mbeg + m]));
+        for (int m = 4 * n4 + tid; m < nrows; m += 512) pm = fmaxf(pm, pair_exp(p.gmax[mbeg + m], p.xmax[mbeg + m]));
     }
     pm = wave_max(pm);
     if (lane == 0) red[wave] = pm;
