@@ -131,6 +131,7 @@ def reinit(model, step, fn):
 
 
 def main():
+    sys.stdout.reconfigure(line_buffering=True)      # (a log that goes to a file must end where the run ended: a block-buffered one once hid 4,600 steps in front of a GPU fault)
     cli = parse_args()
     cfg = load_config(cli.opt, overrides=parse_overrides(cli.set))
     if cli.steps > 0:
