@@ -92,7 +92,7 @@ F16ROWS_VARIANTS = [("h3_f16rows generic rows", {"PAPR_C4_GENERIC": "1", "PAPR_G
                     ("h3_f16rows top rows split", {"PAPR_VARIANT_TOP_F16": "1"}), ("h3_f16rows top rows split, generic rows", {"PAPR_VARIANT_TOP_F16": "1", "PAPR_C4_GENERIC": "1"})]
 
 
-@pytest.mark.parametrize("M,n,act,dims", [(40000, 5, "relu", ()), (30053, 4, "leakyrelu", (141, 32)), (45, 3, "leakyrelu", ())])       # (the last: less than a tile, less than a stage of the weight-gradient kernels)
+@pytest.mark.parametrize("M,n,act,dims", [(40000, 5, "relu", ()), (30053, 4, "leakyrelu", (141, 32)), (45, 3, "leakyrelu", ()), (45, 3, "relu", (141, 32))])       # (the last two: less than a tile, less than a stage of the weight-gradient kernels)
 def test_f16_rows_mode_is_h3_but_for_the_weight_gradients(tmp_path, M, n, act, dims):
     """PAPR_MLP_H3_F16ROWS (round 6's gated experiment): the parity arithmetic whose fused runs keep f16 rows for their weight gradients.  Its forms agree
     bit for bit; against the default mode the run's result, the inference pass and the input gradient are IDENTICAL (the forward and data-gradient
