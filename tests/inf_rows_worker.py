@@ -1,6 +1,7 @@
-"""What a one-product data-gradient run makes of top gradient rows that hold inf / nan (the GradScaler's overflow signal must survive): python3 scripts/probes/r6_inf_rows.py"""
+"""What a one-product data-gradient run makes of top gradient rows that hold inf / nan (the GradScaler's overflow signal must survive), in a fresh process
+(the mode is read when the library loads):   python3 tests/inf_rows_worker.py      -- tests/test_hip_chain_variants.py reads the printed lines"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["PAPR_GEMM_MODE"] = "h1"
 import torch
 from papr_amd import ops

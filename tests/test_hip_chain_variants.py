@@ -152,7 +152,7 @@ def test_one_product_weight_gradients_when_inner_rows_outgrow_the_run_scale(tmp_
 def test_one_product_data_gradient_run_hands_inf_and_nan_on(tmp_path):
     """The GradScaler's overflow signal: top gradient rows that hold inf or nan must leave a one-product data-gradient run as non-finite gradients (round 6 tried
     MODE.FP16_OVFL to make rows beyond the run scale's headroom saturate -- it also turned a row of nans into finite numbers; dropped)."""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "probes", "r6_inf_rows.py")], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "inf_rows_worker.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = {l.split(" | ")[0]: l for l in r.stdout.splitlines() if " | " in l}
     for label in ("all inf", "one inf per row", "all nan"):
